@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""
+Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE
+(cics-nd/gptorch v0.3.2, imported read-only from /root/reference) in the build
+container, and check the CPU oracle (oracle/gp_oracle.py) against it.
+
+    python tests/golden/make_golden.py            # everything up to N=8192
+    python tests/golden/make_golden.py --big      # also the N=32768 forward (needs ~40 GB, minutes)
+
+The reference never travels to the GPU box; only the vectors written here do.
+Inputs come from gptorch_amd.rng (deterministic, regenerated bit-for-bit from
+(seed, N, D)), so big cases store scalars + a checksum of the inputs only.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import gptorch  # noqa: E402  (the reference)
+from gptorch import kernels as rk  # noqa: E402
+from gptorch.models import GPR as RefGPR  # noqa: E402
+from gptorch import likelihoods as rl  # noqa: E402
+from gptorch import functions as rf  # noqa: E402
+from gptorch import util as ru  # noqa: E402
+from gptorch import mean_functions as rm  # noqa: E402
+
+from gptorch_amd import rng  # noqa: E402
+from oracle import gp_oracle as orc  # noqa: E402
+
+assert gptorch.__file__.startswith(REF), gptorch.__file__
+
+KERNELS = {"Rbf": rk.Rbf, "Matern52": rk.Matern52, "Matern32": rk.Matern32, "Exp": rk.Exp}
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def ref_model(case, x, y):
+    d = x.shape[1]
+    ls = case["length_scales"]
+    if case["ARD"]:
+        ls = np.asarray(ls, dtype=np.float64) * np.ones(d)
+    kern = KERNELS[case["kind"]](d, variance=case["variance"], length_scales=ls, ARD=case["ARD"])
+    lik = rl.Gaussian(variance=case["noise"])
+    mean = None
+    if case.get("mean") is not None:
+        mean = rm.Constant(y.shape[1], val=torch.tensor(case["mean"], dtype=torch.float64))
+        mean.val.requires_grad_(False)
+    return RefGPR(x, y, kern, likelihood=lik, mean_function=mean)
+
+
+def oracle_model(case, x, y):
+    return orc.GPROracle(x, y, kind=case["kind"], variance=case["variance"],
+                         length_scales=case["length_scales"], noise=case["noise"],
+                         ARD=case["ARD"], mean=case.get("mean"))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+# ----------------------------------------------------------------------------
+def gen_ref_kernel_fixtures(out):
+    """Copy the VALUES of the reference's own kernel fixtures (test/data/kernels)
+    for the stationary kernels on the path, and check reference + oracle on them
+    exactly as test/test_kernels.py:59-127 does."""
+    ddir = os.path.join(REF, "test", "data", "kernels")
+    pack = {}
+    for name in ["x1", "x2", "ard_length_scales"]:
+        pack[name] = np.load(os.path.join(ddir, name + ".npy"))
+    for k in KERNELS:
+        for suffix in ["kx", "kx2", "kdiag", "kx_ard", "kx2_ard", "kdiag_ard"]:
+            pack[f"{k}_{suffix}"] = np.load(os.path.join(ddir, f"{k}_{suffix}.npy"))
+    x1, x2 = torch.tensor(pack["x1"]), torch.tensor(pack["x2"])
+    one = torch.ones(1, dtype=torch.float64)
+    ard = torch.tensor(pack["ard_length_scales"])
+    for k in KERNELS:
+        assert np.allclose(orc.kernel_K(k, x1, None, one, one).numpy(), pack[f"{k}_kx"])
+        assert np.allclose(orc.kernel_K(k, x1, x2, one, one).numpy(), pack[f"{k}_kx2"])
+        assert np.allclose(orc.kernel_K(k, x1, None, one, ard).numpy(), pack[f"{k}_kx_ard"])
+        assert np.allclose(orc.kernel_K(k, x1, x2, one, ard).numpy(), pack[f"{k}_kx2_ard"])
+        assert np.allclose(orc.kernel_Kdiag(x1, one).numpy(), pack[f"{k}_kdiag"])
+    np.savez(os.path.join(out, "ref_kernel_fixtures.npz"), **pack)
+    print("ref kernel fixtures: oracle matches", len(pack), "arrays")
+
+
+def gen_kernel_cases(out):
+    """K(X), K(X,X2), Kdiag from the reference on rng inputs: full matrices at
+    small sizes, 64 sampled entries + Frobenius norm + trace at C1/C2 sizes."""
+    cases = []
+    small = {}
+    rs = np.random.RandomState(7)
+    for kind in ["Rbf", "Matern52", "Matern32", "Exp"]:
+        for (n, m, d, ard) in [(33, 17, 3, False), (70, 129, 5, True), (128, 64, 8, True), (1, 1, 1, False), (200, 1, 2, False)]:
+            x = rng.normal(100 + n, (n, d))
+            x2 = rng.normal(200 + m, (m, d))
+            ls = (0.5 + rng.uniform(300 + d, d)) if ard else np.array([0.8])
+            var = 1.7
+            kern = KERNELS[kind](d, variance=var, length_scales=ls if ard else float(ls[0]), ARD=ard)
+            tx, tx2 = torch.tensor(x), torch.tensor(x2)
+            with torch.no_grad():
+                kx = kern.K(tx).numpy()
+                kx2 = kern.K(tx, tx2).numpy()
+                kd = kern.Kdiag(tx).numpy()
+                okx = orc.kernel_K(kind, tx, None, torch.tensor([var], dtype=torch.float64), torch.tensor(ls)).numpy()
+            assert np.max(np.abs(kx - okx)) < 1e-14
+            key = f"{kind}_{n}_{m}_{d}_{int(ard)}"
+            small[key + "_kx"], small[key + "_kx2"], small[key + "_kdiag"] = kx, kx2, kd
+            cases.append(dict(key=key, kind=kind, n=n, m=m, d=d, ARD=ard, variance=var,
+                              length_scales=ls.tolist(), seed_x=100 + n, seed_x2=200 + m))
+    np.savez_compressed(os.path.join(out, "kernel_small.npz"), **small)
+    sampled = []
+    for (kind, n, d, ls) in [("Rbf", 512, 2, 1.0), ("Rbf", 8192, 8, np.sqrt(8.0)), ("Matern52", 4096, 16, 4.0)]:
+        x = rng.normal(0, (n, d))
+        kern = KERNELS[kind](d, variance=1.0, length_scales=float(ls))
+        with torch.no_grad():
+            kx = kern.K(torch.tensor(x)).numpy()
+        ii = rs.randint(0, n, 64)
+        jj = rs.randint(0, n, 64)
+        ii[:4] = jj[:4]  # a few diagonal entries
+        sampled.append(dict(kind=kind, n=n, d=d, length_scales=float(ls), variance=1.0, seed_x=0,
+                            x_checksum=rng.checksum(x), i=ii.tolist(), j=jj.tolist(),
+                            values=kx[ii, jj].tolist(), frobenius=float(np.linalg.norm(kx)),
+                            trace=float(np.trace(kx)), sum=float(kx.sum())))
+    with open(os.path.join(out, "kernel_cases.json"), "w") as f:
+        json.dump(dict(small=cases, sampled=sampled), f, indent=1)
+    print("kernel cases:", len(cases), "small,", len(sampled), "sampled")
+
+
+LML_CASES = [
+    # name, kind, n, d, dy, variance, length_scales, ARD, noise, mean
+    dict(name="C1_rbf_512_2", kind="Rbf", n=512, d=2, dy=1, variance=1.0, length_scales=1.0, ARD=False, noise=1e-2),
+    dict(name="rbf_300_3_dy2_ard", kind="Rbf", n=300, d=3, dy=2, variance=1.3, length_scales=[0.7, 1.1, 1.9], ARD=True, noise=5e-2),
+    dict(name="m52_300_3_dy2_ard", kind="Matern52", n=300, d=3, dy=2, variance=0.8, length_scales=[0.7, 1.1, 1.9], ARD=True, noise=5e-2),
+    dict(name="rbf_77_1", kind="Rbf", n=77, d=1, dy=1, variance=2.0, length_scales=0.5, ARD=False, noise=1e-3),
+    dict(name="m52_130_4_mean", kind="Matern52", n=130, d=4, dy=3, variance=1.0, length_scales=2.0, ARD=False, noise=1e-1, mean=[0.3, -0.2, 1.0]),
+    dict(name="rbf_1024_8", kind="Rbf", n=1024, d=8, dy=1, variance=1.0, length_scales=float(np.sqrt(8.0)), ARD=False, noise=1e-2),
+    dict(name="rbf_1000_8_ls1", kind="Rbf", n=1000, d=8, dy=1, variance=1.0, length_scales=1.0, ARD=False, noise=1e-2),
+    dict(name="rbf_2048_8", kind="Rbf", n=2048, d=8, dy=1, variance=1.0, length_scales=float(np.sqrt(8.0)), ARD=False, noise=1e-2),
+    dict(name="rbf_4096_8_n1e-4", kind="Rbf", n=4096, d=8, dy=1, variance=1.0, length_scales=float(np.sqrt(8.0)), ARD=False, noise=1e-4),
+    dict(name="m52_1024_16", kind="Matern52", n=1024, d=16, dy=1, variance=1.0, length_scales=4.0, ARD=False, noise=1e-2),
+    dict(name="m52_2048_16_ard", kind="Matern52", n=2048, d=16, dy=2, variance=1.5, length_scales=(3.0 + np.arange(16) / 8.0).tolist(), ARD=True, noise=1e-2),
+    dict(name="m52_4096_16", kind="Matern52", n=4096, d=16, dy=1, variance=1.0, length_scales=4.0, ARD=False, noise=1e-2),
+]
+C2_CASE = dict(name="C2_rbf_8192_8", kind="Rbf", n=8192, d=8, dy=1, variance=1.0, length_scales=float(np.sqrt(8.0)), ARD=False, noise=1e-2)
+C3_CASE = dict(name="C3_m52_32768_16", kind="Matern52", n=32768, d=16, dy=1, variance=1.0, length_scales=4.0, ARD=False, noise=1e-2)
+
+
+def gen_lml(out, big):
+    res = []
+    for case in LML_CASES + [C2_CASE]:
+        x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+        t0 = time.time()
+        m = ref_model(case, x, y)
+        loss = m.loss()
+        assert loss.shape == (1,)
+        grads_wanted = case["n"] <= 4096
+        entry = dict(case)
+        entry["x_checksum"], entry["y_checksum"] = rng.checksum(x), rng.checksum(y)
+        entry["lml"] = float(-loss.item())
+        if grads_wanted:
+            loss.backward()
+            entry["grad_loss"] = {
+                "kernel.variance": m.kernel.variance.grad.numpy().tolist(),
+                "kernel.length_scales": m.kernel.length_scales.grad.numpy().tolist(),
+                "likelihood.variance": m.likelihood.variance.grad.numpy().tolist(),
+            }
+        t_ref = time.time() - t0
+        # oracle vs reference
+        o = oracle_model(case, x, y)
+        if grads_wanted:
+            ol, og = o.loss_and_grads()
+            assert rel(ol.numpy(), loss.detach().numpy()) < 1e-12, (case["name"], ol, loss)
+            for a, b in zip(og, [m.kernel.variance.grad, m.kernel.length_scales.grad, m.likelihood.variance.grad]):
+                assert rel(a.numpy(), b.numpy()) < 1e-10, (case["name"], a, b)
+            if case["kind"] in ("Rbf", "Matern52") and case["n"] <= 1024:
+                lml, gv, gl, gn = orc.lml_closed_form_grads(case["kind"], x, y, case["variance"],
+                                                            case["length_scales"], case["noise"], case.get("mean"))
+                assert rel(-gv.numpy(), m.kernel.variance.grad.numpy()) < 1e-8
+                assert rel(-gl.numpy(), m.kernel.length_scales.grad.numpy()) < 1e-8
+                assert rel(-gn.numpy(), m.likelihood.variance.grad.numpy()) < 1e-8
+        else:
+            with torch.no_grad():
+                ol = o.loss()
+            assert rel(ol.numpy(), loss.detach().numpy()) < 1e-12
+        # predictions at 16 test points (diag + full) -- gpr.py:88-117, base.py:338-360
+        xs = rng.normal(4242, (16, case["d"]))
+        with torch.no_grad():
+            mf, vf = m.predict_f(xs)
+            my, vy = m.predict_y(xs)
+            mfc, cf = m.predict_f(xs, diag=False)
+            myc, cy = m.predict_y(xs, diag=False)
+            omf, ovf = o.predict_f(xs)
+            omy, ocy = o.predict_y(xs, diag=False)
+        assert rel(omf.numpy(), mf) < 1e-10 and rel(ovf.numpy(), vf) < 1e-10
+        assert rel(ocy.numpy(), cy) < 1e-10
+        entry["predict"] = dict(seed_xs=4242, mean_f=mf.tolist(), var_f=vf.tolist(), var_y=vy.tolist(),
+                                cov_f=cf.tolist(), cov_y_diag=np.diag(cy).tolist())
+        res.append(entry)
+        print(f"lml {case['name']}: lml={entry['lml']:.10f} ref_time={t_ref:.2f}s")
+    if big:
+        case = C3_CASE
+        x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+        t0 = time.time()
+        with torch.no_grad():
+            m = ref_model(case, x, y)
+            loss = m.loss()
+        entry = dict(case)
+        entry["x_checksum"], entry["y_checksum"] = rng.checksum(x), rng.checksum(y)
+        entry["lml"] = float(-loss.item())
+        entry["ref_seconds"] = time.time() - t0
+        print(f"lml {case['name']}: lml={entry['lml']:.10f} ref_time={entry['ref_seconds']:.1f}s")
+        with open(os.path.join(out, "lml_c3.json"), "w") as f:
+            json.dump(entry, f, indent=1)
+    with open(os.path.join(out, "lml_cases.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def gen_adam(out):
+    """50-step Adam trajectories (base.py:149-151, 260-269)."""
+    res = []
+    for case in [dict(name="adam_C1_rbf_512_2", kind="Rbf", n=512, d=2, dy=1, variance=1.0, length_scales=1.0, ARD=False, noise=1e-2),
+                 dict(name="adam_m52_1024_16_ard", kind="Matern52", n=1024, d=16, dy=1, variance=1.0, length_scales=4.0, ARD=True, noise=1e-2)]:
+        x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+        m = ref_model(case, x, y)
+        with quiet():
+            losses, _ = m.optimize(method="Adam", max_iter=50, verbose=False)
+        o = oracle_model(case, x, y)
+        ol = o.optimize_adam(50, 0.01)
+        assert rel(ol, losses) < 1e-9, (ol - losses)
+        entry = dict(case)
+        entry["losses"] = losses.tolist()
+        entry["final"] = {
+            "kernel.variance": m.kernel.variance.detach().numpy().tolist(),
+            "kernel.length_scales": m.kernel.length_scales.detach().numpy().tolist(),
+            "likelihood.variance": m.likelihood.variance.detach().numpy().tolist(),
+        }
+        res.append(entry)
+        print(f"adam {case['name']}: {losses[0]:.6f} -> {losses[-1]:.6f}")
+    with open(os.path.join(out, "adam_cases.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def gen_functions(out):
+    """functions.cholesky / trtrs / lt_log_determinant direct (unpinned by the
+    reference's tests -- test_functions.py only imports) + jitter ladder."""
+    res = {}
+    n, k = 96, 5
+    a = rng.normal(11, (n, n))
+    spd = a @ a.T / n + 0.5 * np.eye(n)
+    b = rng.normal(12, (n, k))
+    L = rf.cholesky(torch.tensor(spd))
+    X = rf.trtrs(torch.tensor(b), L)
+    res["spd_seed"], res["b_seed"], res["n"], res["k"] = 11, 12, n, k
+    res["chol_frobenius"] = float(L.norm())
+    res["chol_diag"] = L.diag().tolist()
+    res["logdet"] = float(rf.lt_log_determinant(L))
+    res["trtrs"] = X.tolist()
+    assert rel(orc.cholesky(torch.tensor(spd)).numpy(), L.numpy()) < 1e-14
+    ladder = []
+    dup_x = np.repeat(rng.normal(13, (8, 2)), 2, axis=0)  # duplicate rows -> singular K, noise=0
+    kdup = rk.Rbf(2).K(torch.tensor(dup_x)).detach()
+    for name, mat in [("ones2", torch.tensor([[1.0, 1.0], [1.0, 1.0]], dtype=torch.float64)),
+                      ("indef2", torch.tensor([[1.0, 2.0], [2.0, 1.0]], dtype=torch.float64)),
+                      ("dup_rows_rbf", kdup)]:
+        try:
+            Lr = rf.cholesky(mat)
+            _, rung = orc.cholesky_rung(mat)
+            ladder.append(dict(name=name, ok=True, rung=rung, diag=Lr.diag().tolist()))
+        except RuntimeError as e:
+            ladder.append(dict(name=name, ok=False, error=str(e)))
+    res["ladder"] = ladder
+    res["dup_seed"] = 13
+    with open(os.path.join(out, "functions_cases.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("functions:", [(l["name"], l.get("rung", l.get("error"))) for l in ladder])
+
+
+def gen_api(out):
+    """API behaviours of the shell."""
+    x, y = rng.make_regression(20, 3, 2, seed=5)
+    m = RefGPR(x, y, rk.Rbf(3, ARD=True))
+    names = [(n, bool(p.requires_grad), list(p.shape)) for n, p in m.named_parameters()]
+    m2 = RefGPR(torch.tensor(x), torch.tensor(y), rk.Rbf(3))
+    res = dict(param_names=names,
+               default_noise_numpy=float(m.likelihood.variance.transform().item()),
+               default_noise_tensor=float(m2.likelihood.variance.transform().item()),
+               loss_shape=list(m.loss().shape), seed=5, n=20, d=3, dy=2,
+               loss_default_numpy=float(m.loss().item()))
+    sd = ru.squared_distance(torch.tensor([[0.0], [1.0], [2.0]], dtype=torch.float64) + 1.0 / 65.0,
+                             torch.tensor([[0.0], [2.0], [4.0]], dtype=torch.float64) + 1.0 / 65.0)
+    res["squared_distance_test_util"] = sd.tolist()
+    with open(os.path.join(out, "api_cases.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("api:", names)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
+                 lml=lambda: gen_lml(HERE, args.big), adam=lambda: gen_adam(HERE),
+                 func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE))
+    for k, fn in steps.items():
+        if not args.only or k in args.only.split(","):
+            fn()
