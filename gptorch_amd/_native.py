@@ -1,0 +1,68 @@
+"""
+ctypes binding of libgpnative.so (the C ABI declared in include/gpnative.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+returns a non-zero status the caller gets an exception.  The product path never
+routes through a CPU implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpnative.so")
+
+c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+
+# name -> (restype, argtypes); must list every symbol of include/gpnative.h
+SIGNATURES = {
+    "gpn_version": (c_int, []),
+    "gpn_arch": (ctypes.c_char_p, []),
+    "gpn_last_hip_error": (ctypes.c_char_p, []),
+    "gpn_factor_ld": (c_int64, [c_int64, c_int64]),
+    "gpn_factor_rows": (c_int64, [c_int64, c_int64]),
+    "gpn_winv_bytes": (c_int64, [c_int64]),
+    "gpn_kernel_matrix": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                  c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64]),
+    "gpn_pack_rhs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64]),
+    "gpn_potrf_lower": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "gpn_trtri_diag": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "gpn_trsm_right_lt": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
+    "gpn_lml_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "gpn_gemm_nt": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64,
+                            c_void_p, c_int64, c_double, c_void_p, c_int64, c_int]),
+    "gpn_transpose": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64]),
+    "gpn_copy_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
+    "gpn_row_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+}
+# not part of the public header: debugging switches
+DEBUG_SIGNATURES = {
+    "gpn_debug_set_gemm_variant": (c_int, [c_int]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "libgpnative.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or gptorch_amd/csrc/build.sh). gptorch_amd has no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        detail = lib().gpn_last_hip_error().decode() if status == -100 else ""
+        raise NativeError("%s failed with status %d %s" % (what, status, detail))

@@ -1,0 +1,307 @@
+"""
+Host-side orchestration over the C ABI (include/gpnative.h): turns torch CUDA
+(HIP) tensors into device pointers + the current HIP stream, owns the factor
+buffers, and exposes the differentiable log-marginal-likelihood.
+
+Everything here requires fp64 tensors resident on a HIP device.  There is no
+CPU code path: a CPU tensor raises `NativeError`.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _native
+from ._native import NativeError
+
+KINDS = {"Rbf": 0, "Matern52": 1, "Matern32": 2, "Exp": 3, "Matern12": 3, "SqDist": 4}
+GPN_FULL, GPN_LOWER = 0, 1
+LEAF = 64
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _req(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NativeError(
+                "gptorch_amd runs on an AMD GPU only (no CPU fallback): got a tensor on %s; "
+                "move the model/data with .cuda() first" % t.device)
+        if t.dtype != torch.float64:
+            raise TypeError("gptorch_amd computes in fp64 (gptorch TensorType); got %s" % t.dtype)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------
+# K assembly
+# ----------------------------------------------------------------------------
+def kernel_matrix(kind, X, X2, variance, length_scales, noise=None, out=None, ldk=None, lower=False):
+    """K(X, X2) as a new [n, m] tensor, or written into `out` (leading dim ldk)."""
+    _req(X, X2, variance, length_scales, noise)
+    X = _c(X.detach())
+    n, d = X.shape
+    if X2 is not None:
+        X2 = _c(X2.detach())
+        m = X2.shape[0]
+        if X2.shape[1] != d:
+            raise ValueError("X and X2 must have the same input dimension")
+    else:
+        m = n
+    if out is None:
+        out = torch.empty(n, m, dtype=torch.float64, device=X.device)
+        ldk = m
+    variance, length_scales = _c(variance.detach()), _c(length_scales.detach())
+    noise = None if noise is None else _c(noise.detach())
+    st = _native.lib().gpn_kernel_matrix(
+        _stream(X.device), KINDS[kind], _ptr(X), n, _ptr(X2), m, d, _ptr(variance), _ptr(length_scales),
+        length_scales.numel(), _ptr(noise), GPN_LOWER if lower else GPN_FULL, _ptr(out), ldk)
+    _native.check(st, "gpn_kernel_matrix")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# factor buffers + Cholesky
+# ----------------------------------------------------------------------------
+class Factor:
+    """A factor buffer (see gpnative.h): n x n lower Cholesky factor in the
+    top-left corner of `A` (rows x ld, zero padded), `e` extra rows holding
+    (L^-1 R)^T, and the inverses of the 64x64 diagonal blocks in `winv`."""
+
+    def __init__(self, n, e, device):
+        lib = _native.lib()
+        self.n, self.e = int(n), int(e)
+        self.ld = int(lib.gpn_factor_ld(n, e))
+        self.rows = int(lib.gpn_factor_rows(n, e))
+        self.A = torch.zeros(self.rows, self.ld, dtype=torch.float64, device=device)
+        self.winv = torch.empty(max(1, int(lib.gpn_winv_bytes(n)) // 8), dtype=torch.float64, device=device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=device)
+        self.jitter_rung = -1
+
+    @property
+    def device(self):
+        return self.A.device
+
+    def extra(self):
+        """[e, n] view: (L^-1 R)^T after factorisation."""
+        return self.A[self.n:self.n + self.e, :self.n]
+
+    def lower(self):
+        """n x n copy of L with a zeroed upper triangle (torch.cholesky's output)."""
+        out = torch.empty(self.n, self.n, dtype=torch.float64, device=self.device)
+        if self.n:
+            st = _native.lib().gpn_copy_matrix(_stream(self.device), _ptr(self.A), self.n, self.n, self.ld,
+                                               _ptr(out), self.n, 1)
+            _native.check(st, "gpn_copy_matrix")
+        return out
+
+    def pack_rhs(self, R, M=None):
+        """extra rows <- (R - M)^T, R [n, e]."""
+        _req(R, M)
+        R = _c(R.detach())
+        M = None if M is None else _c(M.detach())
+        if self.e:
+            self.A[self.n:self.n + self.e, self.n:].zero_()   # corner accumulates -alpha alpha^T
+            st = _native.lib().gpn_pack_rhs(_stream(self.device), _ptr(R), _ptr(M), self.n, self.e,
+                                            _ptr(self.A[self.n]), self.ld)
+            _native.check(st, "gpn_pack_rhs")
+
+    def potrf(self):
+        """In-place factorisation; returns the LAPACK-style info (host int; syncs)."""
+        self.info.zero_()
+        st = _native.lib().gpn_potrf_lower(_stream(self.device), _ptr(self.A), self.n, self.e, self.ld,
+                                           _ptr(self.winv), _ptr(self.info))
+        _native.check(st, "gpn_potrf_lower")
+        return int(self.info.item())
+
+    def lml_terms(self):
+        """tensor [3]: sum log L_ii, ||extra||_F^2, LML (gpr.py:63-67)."""
+        out = torch.empty(3, dtype=torch.float64, device=self.device)
+        st = _native.lib().gpn_lml_reduce(_stream(self.device), _ptr(self.A), self.n, self.e, self.ld, _ptr(out))
+        _native.check(st, "gpn_lml_reduce")
+        return out
+
+    def solve_right_lt(self, B, m):
+        """B[m, :n] <- B * L^-T in place; B must be a [rows>=round_up(m,64)?, ld] buffer
+        with ld == self.ld whose padding is zero."""
+        st = _native.lib().gpn_trsm_right_lt(_stream(self.device), _ptr(self.A), self.n, self.ld, _ptr(self.winv),
+                                             _ptr(B), m, B.stride(0))
+        _native.check(st, "gpn_trsm_right_lt")
+        return B
+
+
+JITTER_TRIES = 10  # functions.py:21 max_tries
+
+
+def _ladder(attempt):
+    """functions.py:20-43: plain try, then +10^(-10+i) I for i = 0..9, then
+    RuntimeError("Max tries exceeded.").  `attempt(jitter)` -> info."""
+    if attempt(None) == 0:
+        return -1
+    for i in range(JITTER_TRIES):
+        if attempt(10.0 ** (-JITTER_TRIES + i)) == 0:
+            return i
+    raise RuntimeError("Max tries exceeded.")
+
+
+def cholesky_factor(x, rhs=None):
+    """functions.cholesky (functions.py:46-47) of a dense SPD matrix `x` [n, n];
+    optional rhs [n, k] is forward-substituted on the way (extra rows)."""
+    _req(x, rhs)
+    if x.dim() != 2 or x.shape[0] != x.shape[1]:
+        raise RuntimeError("cholesky: expected a square matrix")
+    n = x.shape[0]
+    e = 0 if rhs is None else rhs.shape[1]
+    f = Factor(n, e, x.device)
+    xs = _c(x.detach())
+
+    def attempt(jitter):
+        if n:
+            st = _native.lib().gpn_copy_matrix(_stream(x.device), _ptr(xs), n, n, n, _ptr(f.A), f.ld, 1)
+            _native.check(st, "gpn_copy_matrix")
+            if jitter is not None:
+                f.A.diagonal()[:n].add_(jitter)
+        if e:
+            f.pack_rhs(rhs)
+        return f.potrf()
+
+    f.jitter_rung = _ladder(attempt)
+    return f
+
+
+def kernel_factor(kind, X, variance, length_scales, noise, R=None, factor=None):
+    """Fused K(X)+noise*I assembly -> Cholesky (+ forward substitution of R).
+    gpr.py:61-62 / 104-106.  Reuses `factor` (same n, e) when given."""
+    _req(X, variance, length_scales, noise, R)
+    n = X.shape[0]
+    e = 0 if R is None else R.shape[1]
+    f = factor if (factor is not None and factor.n == n and factor.e == e and factor.device == X.device) \
+        else Factor(n, e, X.device)
+
+    def attempt(jitter):
+        nz = noise if jitter is None else noise + jitter
+        kernel_matrix(kind, X, None, variance, length_scales, noise=nz, out=f.A, ldk=f.ld, lower=True)
+        if e:
+            f.pack_rhs(R)
+        return f.potrf()
+
+    f.jitter_rung = _ladder(attempt)
+    return f
+
+
+def gemm_nt(A, B, M, N, K, alpha=1.0, beta=0.0, C=None, lower=False):
+    """C[M,N] = alpha*A[M,K]*B[N,K]^T + beta*C (row strides taken from the tensors)."""
+    _req(A, B, C)
+    if C is None:
+        C = torch.empty(M, N, dtype=torch.float64, device=A.device)
+    st = _native.lib().gpn_gemm_nt(_stream(A.device), M, N, K, alpha, _ptr(A), A.stride(0), _ptr(B), B.stride(0),
+                                   beta, _ptr(C), C.stride(0), 1 if lower else 0)
+    _native.check(st, "gpn_gemm_nt")
+    return C
+
+
+def transpose(src):
+    _req(src)
+    src = _c(src.detach())
+    rows, cols = src.shape
+    dst = torch.empty(cols, rows, dtype=torch.float64, device=src.device)
+    st = _native.lib().gpn_transpose(_stream(src.device), _ptr(src), rows, cols, cols, _ptr(dst), rows)
+    _native.check(st, "gpn_transpose")
+    return dst
+
+
+def row_sumsq(A, rows, cols):
+    out = torch.empty(rows, dtype=torch.float64, device=A.device)
+    st = _native.lib().gpn_row_sumsq(_stream(A.device), _ptr(A), rows, cols, A.stride(0), _ptr(out))
+    _native.check(st, "gpn_row_sumsq")
+    return out
+
+
+def padded_like_factor(f, m):
+    """zeroed [round_up(m,64), f.ld] buffer for right-hand sides of solve_right_lt."""
+    return torch.zeros(round_up(max(m, 1), LEAF), f.ld, dtype=torch.float64, device=f.device)
+
+
+def trtrs_lower(b, f):
+    """functions.trtrs(b, L, lower=True) (functions.py:71-76): X = L^-1 b, b [n, k]."""
+    _req(b)
+    n, k = b.shape
+    if n != f.n:
+        raise RuntimeError("trtrs: size mismatch")
+    Bt = padded_like_factor(f, k)
+    if n and k:
+        bs = _c(b.detach())
+        st = _native.lib().gpn_transpose(_stream(b.device), _ptr(bs), n, k, k, _ptr(Bt), f.ld)
+        _native.check(st, "gpn_transpose")
+        f.solve_right_lt(Bt, k)
+    out = torch.empty(n, k, dtype=torch.float64, device=b.device)
+    if n and k:
+        st = _native.lib().gpn_transpose(_stream(b.device), _ptr(Bt), k, n, f.ld, _ptr(out), k)
+        _native.check(st, "gpn_transpose")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# GPR predictive equations (gpr.py:88-117) in transposed storage
+# ----------------------------------------------------------------------------
+def gpr_predict(kind, X, x_new, variance, length_scales, f, diag=True):
+    """Returns (A^T V  [n*, dy],  var) with A = L^-1 K(X, x*), V = L^-1 (Y - m) held
+    in f.extra(); var = rowsumsq-reduced diag [n*] or full K(x*) - A^T A [n*, n*]."""
+    ns = x_new.shape[0]
+    n, dy = f.n, f.e
+    Bt = padded_like_factor(f, ns)
+    kernel_matrix(kind, x_new, X, variance, length_scales, out=Bt, ldk=f.ld)   # K(x*, X) = k_ys^T
+    f.solve_right_lt(Bt, ns)                                                   # A^T = K(x*,X) L^-T
+    kpad = round_up(n, 16)
+    mean = gemm_nt(Bt, f.A[n:], ns, dy, kpad)                                  # A^T V
+    if diag:
+        var = variance.detach().expand(ns) - row_sumsq(Bt, ns, n)              # Kdiag - colsumsq(A)
+    else:
+        var = kernel_matrix(kind, x_new, None, variance, length_scales)
+        gemm_nt(Bt, Bt, ns, ns, kpad, alpha=-1.0, beta=1.0, C=var)
+    return mean, var
+
+
+# ----------------------------------------------------------------------------
+# differentiable LML
+# ----------------------------------------------------------------------------
+class GPRLogLik(torch.autograd.Function):
+    """log p(y | X, theta) of gpr.py:47-67 as one autograd node over the native
+    pipeline  K assembly -> Cholesky (+ fused forward substitution) -> reductions.
+    Inputs are the CONSTRAINED hyper-parameters (1-element / [D] device tensors)
+    and the residual R = y - mean(x); output has shape (1,) like the reference."""
+
+    @staticmethod
+    def forward(ctx, X, R, variance, length_scales, noise, kind, holder):
+        f = kernel_factor(kind, X, variance, length_scales, noise, R=R, factor=holder.get("factor"))
+        holder["factor"] = f
+        terms = f.lml_terms()
+        ctx.kind = kind
+        ctx.factor = f
+        ctx.save_for_backward(X, variance, length_scales, noise)
+        return terms[2:3].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _backward
+        X, variance, length_scales, noise = ctx.saved_tensors
+        g_var, g_ls, g_noise, g_R = _backward.lml_backward(ctx.kind, X, variance, length_scales, noise, ctx.factor)
+        go = grad_out.reshape(())
+        return (None, go * g_R if ctx.needs_input_grad[1] else None, go * g_var, go * g_ls, go * g_noise, None, None)
+
+
+LOG_2PI = math.log(2.0 * math.pi)

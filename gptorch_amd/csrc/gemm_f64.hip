@@ -1,0 +1,242 @@
+// fp64 MFMA "NT" contraction for gfx950:  C = alpha * A * B^T + beta * C
+//   A[M,K], B[N,K], C[M,N] row-major, K contiguous in both operands.
+// This one kernel carries every O(N^3) flop of the path: the SYRK/GEMM trailing
+// updates of the blocked Cholesky, the panel solves (as products with the
+// inverted 64x64 diagonal blocks), the predict-path TRSM and the K^-1 products
+// of the backward.
+//
+// Design (MI355X-first, not a port of anything):
+//  * v_mfma_f64_16x16x4_f64: lane l supplies A[row l&15][k l>>4] and
+//    B[k l>>4][col l&15]; result reg r of lane l is C[(l>>4)+4r][l&15].
+//  * operand tiles are staged global->LDS by LDS-DMA (global_load_lds_dwordx4):
+//    one wave-instruction fills one 1 KiB "fragment block" = 16 rows x 8 k's in
+//    exactly the order the wave later reads it back with ONE ds_read_b128 per
+//    lane (lane-linear => bank-conflict free).  A lane's 16 bytes are the pair
+//    (k=2g, k=2g+1) of its row, g = l>>4, so one b128 read feeds two MFMAs
+//    (first MFMA sums k = {0,2,4,6}, second k = {1,3,5,7}: the k order inside a
+//    K-step is a permutation shared by A and B, so the product is unchanged).
+//  * 128x128 block tile, 4 waves each 64x64 (16 accumulator tiles = 128 VGPRs),
+//    BK = 16, two LDS stages (64 KB) => 2 workgroups per CU, one barrier / K-step.
+//  * blockIdx -> tile: bijective XCD remap (blocks b, b+8 share an XCD/L2) then
+//    grouped ordering (8 tile-rows per group) so the tiles resident on one XCD
+//    share operand panels in its 4 MiB L2; `lower` drops tiles above the diagonal.
+#include "gpn_common.h"
+
+namespace gpn {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  int mt, nt;       // tile counts
+  int lower;
+  double alpha, beta;
+};
+
+constexpr int BK = 16;
+
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, int& ti, int& tj) {
+  // bijective XCD remap: consecutive logical ids land on the same XCD
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int group = 8 * nt;
+  const int g = logical / group;
+  const int first = g * 8;
+  const int gm = min(8, mt - first);
+  const int rem = logical - g * group;
+  ti = first + rem % gm;
+  tj = rem / gm;
+}
+
+template <int BM, int BN, int WM, int WN, bool DMA>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int A_BLOCKS = (BM / 16) * 2, B_BLOCKS = (BN / 16) * 2;
+  constexpr int NBLK = A_BLOCKS + B_BLOCKS;      // 1 KiB fragment blocks per K-step
+  constexpr int PER_WAVE = (NBLK + 3) / 4;
+  constexpr int STAGE = NBLK * 1024;             // bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int ti, tj;
+  tile_of_block(blockIdx.x, gridDim.x, p.mt, p.nt, ti, tj);
+  if (p.lower && tj > ti) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int m0 = ti * BM, n0 = tj * BN;
+  const int mlim = (p.M + 15) & ~15, nlim = (p.N + 15) & ~15;
+
+  // per-lane source offsets inside a fragment block
+  const int frow = lane & 15;
+  const int fk = 2 * (lane >> 4);
+
+  d4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  d2 stage_regs[DMA ? 1 : PER_WAVE];
+
+  // issue the loads of K-step `t` into LDS stage `s` (DMA) or registers (!DMA)
+  auto stage_issue = [&](int t, int s) {
+    const int k0 = t * BK;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int idx = wave + 4 * i;
+      if (idx < NBLK) {
+        const bool isA = idx < A_BLOCKS;
+        const int b = isA ? idx : idx - A_BLOCKS;
+        const int rg = b >> 1, kg8 = b & 1;
+        const int row = (isA ? m0 : n0) + rg * 16;
+        const bool ok = row < (isA ? mlim : nlim);
+        const double* src = (isA ? p.A + (int64_t)(row + frow) * p.lda
+                                 : p.B + (int64_t)(row + frow) * p.ldb) + k0 + kg8 * 8 + fk;
+        if constexpr (DMA) {
+          if (ok) {
+            char* dst = smem + s * STAGE + idx * 1024;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+          }
+        } else {
+          stage_regs[i] = ok ? *reinterpret_cast<const d2*>(src) : d2{0.0, 0.0};
+        }
+      }
+    }
+  };
+  auto stage_commit = [&](int s) {
+    if constexpr (!DMA) {
+#pragma unroll
+      for (int i = 0; i < PER_WAVE; ++i) {
+        const int idx = wave + 4 * i;
+        if (idx < NBLK) *reinterpret_cast<d2*>(smem + s * STAGE + idx * 1024 + lane * 16) = stage_regs[i];
+      }
+    }
+  };
+
+  auto compute = [&](int s) {
+    const char* base = smem + s * STAGE + lane * 16;
+#pragma unroll
+    for (int kg8 = 0; kg8 < 2; ++kg8) {
+      d2 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const d2*>(base + (((wave_m * TM + i) * 2 + kg8) * 1024));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const d2*>(base + ((A_BLOCKS + (wave_n * TN + j) * 2 + kg8) * 1024));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nk = p.K / BK;
+  stage_issue(0, 0);
+  stage_commit(0);
+  __syncthreads();
+  for (int t = 0; t < nk; ++t) {
+    const int s = t & 1;
+    if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
+    compute(s);
+    if (t + 1 < nk) stage_commit(s ^ 1);
+    __syncthreads();  // drains the DMA (vmcnt(0)) and fences reuse of stage s
+  }
+
+  // epilogue: reg r of lane l is C[(l>>4) + 4r][l&15] of its 16x16 tile
+  const int crow = lane >> 4, ccol = lane & 15;
+  const bool diag_tile = p.lower && (ti == tj);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wave_n * WN + j * 16 + ccol;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wave_m * WM + i * 16 + crow + 4 * r;
+        if (row < p.M && col < p.N && (!diag_tile || col <= row)) {
+          double* c = p.C + (int64_t)row * p.ldc + col;
+          double v = p.alpha * acc[i][j][r];
+          if (p.beta != 0.0) v += p.beta * *c;
+          *c = v;
+        }
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool DMA>
+static int launch(hipStream_t s, const GemmArgs& a0) {
+  GemmArgs a = a0;
+  a.mt = (a.M + BM - 1) / BM;
+  a.nt = (a.N + BN - 1) / BN;
+  const int grid = a.mt * a.nt;
+  constexpr int smem = ((BM + BN) / 16) * 2 * 1024 * 2;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+static int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging (debug/A-B)
+
+int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+            const double* A, int64_t lda, const double* B, int64_t ldb,
+            double beta, double* C, int64_t ldc, int lower) {
+  if (M <= 0 || N <= 0) return GPN_OK;
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.mt = a.nt = 0;
+  a.lower = lower;
+  a.alpha = alpha; a.beta = beta;
+  // small problems: 64x64 tiles give 4x the workgroups (latency-bound regime)
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+  const bool small = (N <= 64) || (M <= 64) || tiles128 < 128;
+  if (g_gemm_variant == 0) {
+    return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true>(s, a);
+  }
+  return small ? launch<64, 64, 32, 32, false>(s, a) : launch<128, 128, 64, 64, false>(s, a);
+}
+
+}  // namespace gpn
+
+extern "C" int gpn_debug_set_gemm_variant(int v) {
+  gpn::g_gemm_variant = v;
+  return GPN_OK;
+}
+
+extern "C" int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
+                           const double* A, int64_t lda, const double* B, int64_t ldb,
+                           double beta, double* C, int64_t ldc, int lower) {
+  if (M < 0) return -2;
+  if (N < 0) return -3;
+  if (K < 0 || (K % 16) != 0) return -4;
+  if (lower && M != N) return -13;
+  if ((lda & 1) || (ldb & 1)) return GPN_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GPN_E_ALIGN;
+  if (K == 0) {
+    // C = beta*C: degenerate, not on the hot path
+    return GPN_E_UNSUPPORTED;
+  }
+  return gpn::gemm_nt(static_cast<hipStream_t>(stream), M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower);
+}

@@ -1,0 +1,32 @@
+// Shared host-side helpers for libgpnative (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gpnative.h"
+
+namespace gpn {
+
+constexpr int LEAF = 64;  // diagonal leaf block (potrf+inverse in one workgroup)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+void set_hip_error(hipError_t e, const char* where);
+
+#define GPN_HIP_CHECK(expr)                          \
+  do {                                               \
+    hipError_t _e = (expr);                          \
+    if (_e != hipSuccess) {                          \
+      gpn::set_hip_error(_e, #expr);                 \
+      return GPN_E_HIP;                              \
+    }                                                \
+  } while (0)
+
+#define GPN_LAUNCH_CHECK() GPN_HIP_CHECK(hipGetLastError())
+
+// C = alpha*A*B^T + beta*C, see gpnative.h gpn_gemm_nt.  Internal entry used by
+// the factorisation drivers (no argument validation).
+int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+            const double* A, int64_t lda, const double* B, int64_t ldb,
+            double beta, double* C, int64_t ldc, int lower);
+
+}  // namespace gpn

@@ -1,0 +1,199 @@
+// K assembly: pairwise scaled distances + stationary-kernel epilogue, fused.
+// Replaces util.squared_distance (util.py:73-88), Stationary.squared_dist/dist
+// (kernels.py:149-172), Rbf/Matern52/Matern32/Exp .K (kernels.py:182-222) and the
+// "+ sigma_n^2 I" of GPR._compute_kyy (gpr.py:69-86): the reference makes >= 12
+// N x N passes for this; here the N x N matrix is written exactly once.
+//
+// HBM-bound for small D (8 B written per entry, X tiles come from L2), fp64
+// vector-ALU bound for large D.  64x64 output tile per 256-thread workgroup:
+// the two point blocks (64 x DC coordinates each, pre-divided by ell) are staged
+// in LDS in [coordinate][point] order so that a wave reads 4 row points as one
+// broadcast b128 pair and its 2+2 column points as conflict-free b128s; every
+// thread owns a 4x4 micro-tile laid out so each store instruction writes 256 B
+// contiguous per row (16 lanes x double2).
+#include "gpn_common.h"
+
+namespace gpn {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int KT = 64;   // output tile edge
+constexpr int DC = 16;   // coordinates staged per pass
+
+struct KmatArgs {
+  const double* X;
+  const double* X2;   // == X for the symmetric case
+  const double* variance;
+  const double* ls;
+  const double* noise;  // nullptr => no diagonal add
+  double* K;
+  int64_t ldk;
+  int n, m, d, nls;
+  int symmetric, lower, vec_ok;
+};
+
+template <int KIND>
+__device__ __forceinline__ double kernel_of_r2(double r2, double var) {
+  if constexpr (KIND == GPN_SQDIST) {
+    return r2;                                         // util.py:73-88 (lengthscale-scaled)
+  } else if constexpr (KIND == GPN_RBF) {
+    return var * exp(-0.5 * r2);                       // kernels.py:220-222
+  } else {
+    const double r = sqrt(fmax(r2, 1e-40));            // kernels.py:172
+    if constexpr (KIND == GPN_MATERN52) {
+      const double s5 = 2.23606797749978969641;        // sqrt(5), kernels.py:204-212
+      return var * (1.0 + s5 * r + 5.0 / 3.0 * r * r) * exp(-s5 * r);
+    } else if constexpr (KIND == GPN_MATERN32) {
+      const double r3 = 1.73205080756887729353 * r;    // kernels.py:196-201
+      return var * (1.0 + r3) * exp(-r3);
+    } else {
+      return var * exp(-r);                            // kernels.py:189-190
+    }
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
+  __shared__ __attribute__((aligned(16))) double xs[DC][KT];   // row points
+  __shared__ __attribute__((aligned(16))) double ys[DC][KT];   // column points
+
+  const int tj = blockIdx.x, ti = blockIdx.y;
+  if (p.lower && tj > ti) return;
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int i0 = ti * KT, j0 = tj * KT;
+
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+
+  for (int d0 = 0; d0 < p.d; d0 += DC) {
+    // stage: thread -> (point = tid/4, 4 coordinates), scaled by 1/ell
+    {
+      const int pt = tid >> 2, c4 = (tid & 3) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd = d0 + c4 + c;
+        double vx = 0.0, vy = 0.0;
+        if (dd < p.d) {
+          const double ell = p.ls[p.nls == 1 ? 0 : dd];   // X / ell as kernels.py:154-158
+          if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd] / ell;
+          if (j0 + pt < p.m) vy = p.X2[(int64_t)(j0 + pt) * p.d + dd] / ell;
+        }
+        xs[c4 + c][pt] = vx;
+        ys[c4 + c][pt] = vy;
+      }
+    }
+    __syncthreads();
+    const int dmax = min(DC, p.d - d0);
+    for (int dd = 0; dd < dmax; ++dd) {
+      const d2 xa = *reinterpret_cast<const d2*>(&xs[dd][ty * 4]);
+      const d2 xb = *reinterpret_cast<const d2*>(&xs[dd][ty * 4 + 2]);
+      const d2 ya = *reinterpret_cast<const d2*>(&ys[dd][tx * 2]);
+      const d2 yb = *reinterpret_cast<const d2*>(&ys[dd][32 + tx * 2]);
+      const double xr[4] = {xa.x, xa.y, xb.x, xb.y};
+      const double yc[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double df = xr[a] - yc[b];
+          acc[a][b] = fma(df, df, acc[a][b]);
+        }
+    }
+    __syncthreads();
+  }
+
+  const double var = p.variance[0];
+  const double noise = p.noise ? p.noise[0] : 0.0;
+  const bool add_diag = p.noise != nullptr && p.symmetric;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = i0 + ty * 4 + a;
+    if (row >= p.n) continue;
+    double* krow = p.K + (int64_t)row * p.ldk;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = j0 + h * 32 + tx * 2;
+      double v0 = kernel_of_r2<KIND>(acc[a][2 * h], var);
+      double v1 = kernel_of_r2<KIND>(acc[a][2 * h + 1], var);
+      if (add_diag) {
+        if (row == col) v0 += noise;
+        if (row == col + 1) v1 += noise;
+      }
+      if (p.vec_ok && col + 1 < p.m) {
+        *reinterpret_cast<d2*>(krow + col) = d2{v0, v1};
+      } else {
+        if (col < p.m) krow[col] = v0;
+        if (col + 1 < p.m) krow[col + 1] = v1;
+      }
+    }
+  }
+}
+
+__global__ void pack_rhs_kernel(const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int c = 0; c < dy; ++c) {
+    double v = Y[i * dy + c];
+    if (M) v -= M[i * dy + c];
+    E[(int64_t)c * lde + i] = v;
+  }
+}
+
+}  // namespace gpn
+
+extern "C" int gpn_kernel_matrix(void* stream, int kind, const double* X, int64_t n, const double* X2,
+                                 int64_t m, int d, const double* variance, const double* length_scales,
+                                 int nls, const double* noise, int uplo, double* K, int64_t ldk) {
+  using namespace gpn;
+  if (kind < GPN_RBF || kind > GPN_SQDIST) return -2;
+  if (!X) return -3;
+  if (n < 0) return -4;
+  const bool symmetric = (X2 == nullptr);
+  if (symmetric) m = n;
+  if (m < 0) return -6;
+  if (d <= 0) return -7;
+  if (!variance) return -8;
+  if (!length_scales) return -9;
+  if (nls != 1 && nls != d) return -10;
+  if (uplo != GPN_FULL && uplo != GPN_LOWER) return -12;
+  if (uplo == GPN_LOWER && !symmetric) return -12;
+  if (!K) return -13;
+  if (ldk < m) return -14;
+  if (n == 0 || m == 0) return GPN_OK;
+  KmatArgs a;
+  a.X = X; a.X2 = symmetric ? X : X2;
+  a.variance = variance; a.ls = length_scales; a.noise = noise;
+  a.K = K; a.ldk = ldk;
+  a.n = (int)n; a.m = (int)m; a.d = d; a.nls = nls;
+  a.symmetric = symmetric; a.lower = (uplo == GPN_LOWER);
+  a.vec_ok = ((ldk & 1) == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0);
+  dim3 grid((unsigned)((m + KT - 1) / KT), (unsigned)((n + KT - 1) / KT));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (kind) {
+    case GPN_RBF: hipLaunchKernelGGL(kmat_kernel<GPN_RBF>, grid, dim3(256), 0, s, a); break;
+    case GPN_MATERN52: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN52>, grid, dim3(256), 0, s, a); break;
+    case GPN_MATERN32: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN32>, grid, dim3(256), 0, s, a); break;
+    case GPN_EXP: hipLaunchKernelGGL(kmat_kernel<GPN_EXP>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(kmat_kernel<GPN_SQDIST>, grid, dim3(256), 0, s, a); break;
+  }
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+extern "C" int gpn_pack_rhs(void* stream, const double* Y, const double* M, int64_t n, int dy,
+                            double* E, int64_t lde) {
+  if (!Y) return -2;
+  if (n < 0) return -4;
+  if (dy <= 0) return -5;
+  if (!E) return -6;
+  if (lde < n) return -7;
+  if (n == 0) return GPN_OK;
+  hipLaunchKernelGGL(gpn::pack_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), Y, M, n, dy, E, lde);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}

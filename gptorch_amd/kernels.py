@@ -1,0 +1,191 @@
+"""
+Covariance functions with the call surface of gptorch/kernels.py.
+
+Stationary kernels (Rbf / SquaredExponential, Matern52, Matern32, Exp /
+Matern12) evaluate K(X, X2) in ONE native pass (csrc/kmat.hip): distance,
+length-scale scaling, the kernel's epilogue -- nothing N x M is materialised in
+between (the reference chains >= 8 elementwise N x M passes: util.py:82-88,
+kernels.py:149-222).  Hyper-parameters are exp-transformed Params exactly as in
+kernels.py:116-147, so gradients are w.r.t. the logs.
+"""
+import numpy as np
+import torch
+
+from . import _ops
+from .model import Model
+from .param import Param
+from .settings import DefaultPositiveTransform
+from .util import as_tensor, torch_dtype
+
+
+def _k_shape(X, X2):
+    return (X.size(0),) * 2 if X2 is None else (X.size(0), X2.size(0))
+
+
+class Kernel(Model):
+    """Base class (kernels.py:28-64)."""
+
+    def __init__(self, input_dim):
+        self.input_dim = int(input_dim)
+        super().__init__()
+
+    def __add__(self, other):
+        return Sum(self, other)
+
+    def __mul__(self, other):
+        return Product(self, other)
+
+
+class _StationaryK(torch.autograd.Function):
+    """K(X, X2) with gradients w.r.t. the constrained variance / length-scales
+    (the reference gets these from autograd through its elementwise chain)."""
+
+    @staticmethod
+    def forward(ctx, variance, length_scales, X, X2, kind):
+        K = _ops.kernel_matrix(kind, X, X2, variance, length_scales)
+        ctx.kind = kind
+        ctx.has_x2 = X2 is not None
+        ctx.save_for_backward(variance, length_scales, X, X2 if X2 is not None else X)
+        return K
+
+    @staticmethod
+    def backward(ctx, gK):
+        from . import _backward
+        variance, length_scales, X, X2 = ctx.saved_tensors
+        g_var, g_ls = _backward.kernel_backward(ctx.kind, X, X2 if ctx.has_x2 else None, variance,
+                                                length_scales, gK)
+        return g_var, g_ls, None, None, None
+
+
+class Stationary(Kernel):
+    """Kernels of r = ||(x - x') / ell||; ARD = one length-scale per input
+    dimension (kernels.py:108-179)."""
+
+    _kind = None
+
+    def __init__(self, input_dim, variance=1.0, length_scales=None, ARD=False):
+        super().__init__(input_dim)
+        self.variance = Param(torch.tensor([float(variance)], dtype=torch_dtype),
+                              transform=DefaultPositiveTransform())
+        self.ARD = ARD
+        if ARD:
+            if length_scales is None:
+                length_scales = np.ones(input_dim)
+            elif isinstance(length_scales, np.ndarray):
+                assert len(length_scales) == input_dim
+            else:
+                length_scales = length_scales * np.ones(input_dim)
+            ls = torch.as_tensor(np.asarray(length_scales, dtype=np.float64)).clone()
+        else:
+            ls = torch.tensor([1.0 if length_scales is None else float(length_scales)], dtype=torch_dtype)
+        self.length_scales = Param(ls, transform=DefaultPositiveTransform())
+
+    def K(self, X, X2=None):
+        if isinstance(X, np.ndarray):
+            X = as_tensor(X).to(self.variance.device)
+        if isinstance(X2, np.ndarray):
+            X2 = as_tensor(X2).to(self.variance.device)
+        return _StationaryK.apply(self.variance.transform(), self.length_scales.transform(), X, X2, self._kind)
+
+    def Kdiag(self, X):
+        """variance broadcast to [n] (kernels.py:174-179)."""
+        if isinstance(X, np.ndarray):
+            X = as_tensor(X)
+        return self.variance.transform().expand(X.size(0))
+
+    def squared_dist(self, X, X2):
+        """scaled squared distance (kernels.py:149-159); forward only."""
+        one = torch.ones(1, dtype=torch_dtype, device=X.device)
+        return _ops.kernel_matrix("SqDist", X, X2, one, self.length_scales.transform())
+
+    def dist(self, X, X2):
+        """kernels.py:161-172."""
+        return torch.sqrt(torch.clamp(self.squared_dist(X, X2), min=1e-40))
+
+
+class Rbf(Stationary):
+    """variance * exp(-r^2 / 2) (kernels.py:215-222)."""
+    _kind = "Rbf"
+
+
+SquaredExponential = Rbf
+
+
+class Matern52(Stationary):
+    """variance * (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r) (kernels.py:204-212)."""
+    _kind = "Matern52"
+
+
+class Matern32(Stationary):
+    """variance * (1 + sqrt3 r) exp(-sqrt3 r) (kernels.py:196-201)."""
+    _kind = "Matern32"
+
+
+class Exp(Stationary):
+    """variance * exp(-r) (kernels.py:182-190)."""
+    _kind = "Exp"
+
+
+class Matern12(Exp):
+    pass
+
+
+# ---- combinators and input-independent kernels (thin glue) -----
+class Combination(Kernel):
+    def __init__(self, k1, k2):
+        if not k1.input_dim == k2.input_dim:
+            raise ValueError("Kernels must have same input dimension")
+        super().__init__(k1.input_dim)
+        self.kern1, self.kern2 = k1, k2
+
+
+class Sum(Combination):
+    """kernels.py:286-295."""
+
+    def K(self, X, X2=None):
+        return self.kern1.K(X, X2) + self.kern2.K(X, X2)
+
+    def Kdiag(self, X):
+        return self.kern1.Kdiag(X) + self.kern2.Kdiag(X)
+
+
+class Product(Combination):
+    """kernels.py:298-306."""
+
+    def K(self, X, X2=None):
+        return self.kern1.K(X, X2) * self.kern2.K(X, X2)
+
+    def Kdiag(self, X):
+        return self.kern1.Kdiag(X) * self.kern2.Kdiag(X)
+
+
+class Static(Kernel):
+    """kernels.py:67-80."""
+
+    def __init__(self, input_dim, variance=1.0):
+        super().__init__(input_dim)
+        self.variance = Param(torch.tensor([float(variance)], dtype=torch_dtype),
+                              transform=DefaultPositiveTransform())
+
+    def Kdiag(self, X):
+        return self.variance.transform().expand(X.size(0))
+
+
+class White(Static):
+    """kernels.py:83-92."""
+
+    def K(self, X, X2=None, presliced=False):
+        if X2 is None:
+            return self.variance.transform().expand(X.size(0)).diag()
+        return torch.zeros(*_k_shape(X, X2), dtype=torch_dtype, device=X.device)
+
+
+class Constant(Static):
+    """kernels.py:95-101."""
+
+    def K(self, X, X2=None, presliced=False):
+        return self.variance.transform().expand(*_k_shape(X, X2))
+
+
+class Bias(Constant):
+    pass

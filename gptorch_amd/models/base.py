@@ -1,0 +1,199 @@
+"""
+GPModel: data + kernel + likelihood + mean function, the optimiser loop and the
+public predict API -- behaviour of gptorch/models/base.py (the shell around the
+native hot path; no dense arithmetic happens here).
+"""
+from time import time
+
+import numpy as np
+import torch
+from scipy.optimize import minimize
+
+from .. import likelihoods
+from ..functions import cholesky
+from ..mean_functions import Zero
+from ..model import Model
+from ..util import as_tensor, torch_dtype
+
+
+def input_as_tensor(predict_func):
+    """numpy in -> numpy out, tensor in -> tensor out on the caller's device
+    (base.py:21-55)."""
+
+    def predict(obj, input_new, *args, **kwargs):
+        from_numpy = isinstance(input_new, np.ndarray)
+        if from_numpy:
+            input_new = torch.as_tensor(input_new, dtype=torch_dtype).to(obj.Y.device)
+        else:
+            outside_device = input_new.device
+            input_new = input_new.to(obj.Y.device)
+        out = predict_func(obj, input_new, *args, **kwargs)
+
+        def back(o):
+            return o.detach().cpu().numpy() if from_numpy else o.to(outside_device)
+
+        if isinstance(out, torch.Tensor):
+            return back(out)
+        if isinstance(out, tuple):
+            return tuple(back(o) for o in out)
+        raise NotImplementedError("Unhandled output type {}".format(type(out)))
+
+    return predict
+
+
+_TORCH_DEFAULT_LR = {"SGD": 0.001, "Adam": 0.01, "LBFGS": 1.0, "Adadelta": 1.0, "Adagrad": 0.01,
+                     "Adamax": 0.002, "ASGD": 0.01, "RMSprop": 0.01, "Rprop": 0.01}   # base.py:131-141
+_SCIPY_METHODS = ["CG", "BFGS", "Newton-CG", "Nelder-Mead", "Powell", "L-BFGS-B", "TNC", "COBYLA", "SLSQP",
+                  "dogleg", "trust-ncg"]                                            # base.py:203-215
+
+
+class GPModel(Model):
+    def __init__(self, x, y, kernel, likelihood, mean_function, name="gp"):
+        super().__init__()
+        self.kernel = kernel
+        self.likelihood = likelihood if likelihood is not None else GPModel._init_gaussian_likelihood(y)
+        self.mean_function = mean_function if mean_function is not None else Zero(y.shape[1])
+        x, y = as_tensor(x), as_tensor(y)
+        x.requires_grad_(False)
+        y.requires_grad_(False)
+        self.X, self.Y = x, y
+        self.__class__.__name__ = name
+
+    @property
+    def num_data(self):
+        return self.Y.shape[0]
+
+    @property
+    def input_dimension(self):
+        return self.X.shape[1]
+
+    @property
+    def output_dimension(self):
+        return self.Y.shape[1]
+
+    @staticmethod
+    def _init_gaussian_likelihood(y) -> likelihoods.Gaussian:
+        """0.001 * y.var() -- numpy (ddof=0) for arrays, torch (unbiased) for
+        tensors, as base.py:101-109 behaves."""
+        return likelihoods.Gaussian(variance=float(0.001 * y.var()))
+
+    def _make_optimizer(self, method, parameters, learning_rate):
+        """The nine torch optimisers with the reference's settings (base.py:144-200)."""
+        lr = learning_rate
+        o = torch.optim
+        if method == "SGD":
+            return o.SGD(parameters, lr=lr if lr is not None else 0.01, momentum=0.9)
+        if method == "Adam":
+            return o.Adam(parameters, lr=lr if lr is not None else 0.01)
+        if method == "LBFGS":
+            return o.LBFGS(parameters, lr=1.0 if lr is None else lr, max_iter=5, max_eval=None, tolerance_grad=1e-05,
+                           tolerance_change=1e-09, history_size=50, line_search_fn=None)
+        if method == "Adadelta":
+            return o.Adadelta(parameters, lr=lr, rho=0.9, eps=1e-06, weight_decay=0.00001)
+        if method == "Adagrad":
+            return o.Adagrad(parameters, lr=lr, lr_decay=0, weight_decay=0)
+        if method == "Adamax":
+            return o.Adamax(parameters, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0)
+        if method == "ASGD":
+            return o.ASGD(parameters, lr=lr, lambd=0.0001, alpha=0.75, t0=1000000.0, weight_decay=0)
+        if method == "RMSprop":
+            return o.RMSprop(parameters, lr=lr, alpha=0.99, eps=1e-08, weight_decay=0.00, momentum=0.01, centered=False)
+        if method == "Rprop":
+            return o.Rprop(parameters, lr=lr, etas=(0.5, 1.2), step_sizes=(1e-06, 50))
+        return None
+
+    def optimize(self, method="Adam", max_iter=2000, verbose=True, learning_rate=None):
+        """Minimise loss() over the trainable parameters; returns (losses, seconds)
+        for torch optimisers, the scipy result for scipy methods (base.py:111-296)."""
+        parameters = [p for p in self.parameters() if p.requires_grad]
+        if learning_rate is None and method in _TORCH_DEFAULT_LR:
+            learning_rate = _TORCH_DEFAULT_LR[method]
+        if method in _SCIPY_METHODS:
+            print("Scipy.optimize.minimize...")
+            return self._optimize_scipy(method=method, maxiter=max_iter, disp=verbose)
+        self.optimizer = self._make_optimizer(method, parameters, learning_rate)
+        if self.optimizer is None:
+            raise ValueError("Optimizer %s is not found. Supported: %s and scipy's %s"
+                             % (method, ", ".join(_TORCH_DEFAULT_LR), ", ".join(_SCIPY_METHODS)))
+
+        losses = np.zeros(max_iter)
+        tic = time()
+        print("{}: Start optimizing via {}".format(self.__class__.__name__, method))
+
+        def closure():
+            self.optimizer.zero_grad()
+            loss = self.loss()
+            loss.backward()
+            return loss
+
+        for idx in range(max_iter):
+            if method == "LBFGS":
+                loss = self.optimizer.step(closure)
+                if isinstance(loss, float):  # converged
+                    losses[idx] = loss
+                    losses = losses[0: idx + 1]
+                    break
+                losses[idx] = loss.item()
+            else:
+                loss = closure()
+                self.optimizer.step()
+                losses[idx] = loss.item()
+            if verbose or idx % 20 == 0:
+                print("Iter: %d\tLoss: %s" % (idx, losses[idx]))
+        t = time() - tic
+        print("Optimization time taken: %s s" % t)
+        print("Optimization method: %s" % str(self.optimizer))
+        if len(losses) == max_iter:
+            print("Optimization terminated by reaching the maximum iterations")
+        else:
+            print("Optimization terminated by getting below the tolerant error")
+        return losses, t
+
+    def _optimize_scipy(self, method="L-BFGS-B", tol=None, callback=None, maxiter=1000, disp=True):
+        """scipy.optimize.minimize on the flat raw-parameter vector (base.py:298-320)."""
+        return minimize(fun=self._loss_and_grad, x0=self._get_param_array(), method=method, jac=True, tol=tol,
+                        callback=callback, options=dict(disp=disp, maxiter=maxiter))
+
+    def _predict(self, input_new, diag=True):
+        raise NotImplementedError()
+
+    @input_as_tensor
+    def predict_f(self, input_new, diag=True, **kwargs):
+        """mean and (diag) variance / full covariance of the latent function (base.py:338-346)."""
+        return self._predict(input_new, diag=diag, **kwargs)
+
+    @input_as_tensor
+    def predict_y(self, input_new, diag=True, **kwargs):
+        """... of the observations (base.py:348-360)."""
+        mean_f, cov_f = self._predict(input_new, diag=diag, **kwargs)
+        if diag:
+            return self.likelihood.predict_mean_variance(mean_f, cov_f)
+        return self.likelihood.predict_mean_covariance(mean_f, cov_f)
+
+    def _samples(self, mu, sigma, n_samples):
+        chol_s = cholesky(sigma)
+        return mu + chol_s[None, :, :] @ torch.randn(n_samples, *mu.shape, dtype=torch_dtype, device=chol_s.device)
+
+    @input_as_tensor
+    def predict_f_samples(self, input_new, n_samples=1, **kwargs):
+        """[n_samp, n_test, dy] draws (base.py:362-375)."""
+        mu, sigma = self.predict_f(input_new, diag=False, **kwargs)
+        return self._samples(mu, sigma, n_samples)
+
+    @input_as_tensor
+    def predict_y_samples(self, input_new, n_samples=1, **kwargs):
+        """base.py:377-390."""
+        mu, sigma = self.predict_y(input_new, diag=False, **kwargs)
+        return self._samples(mu, sigma, n_samples)
+
+    def cuda(self):
+        """Moves parameters AND data; returns None like base.py:392-399."""
+        super().cuda()
+        self.X, self.Y = self.X.cuda(), self.Y.cuda()
+
+    def cpu(self):
+        super().cpu()
+        self.X, self.Y = self.X.cpu(), self.Y.cpu()
+
+    def _loss(self, *args, **kwargs):
+        return -(self.log_likelihood(*args, **kwargs) + self.log_prior())

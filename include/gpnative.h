@@ -1,0 +1,139 @@
+/*
+ * gpnative.h -- C ABI of libgpnative.so: the MI355X (gfx950) exact-GP hot path.
+ *
+ * The reference (cics-nd/gptorch v0.3.2) is pure Python over PyTorch ops and has
+ * NO FFI/plugin layer; this header is the boundary a maintainer would bind
+ * (ctypes stub: INTEGRATION.md) underneath the reference's Python call surface.
+ * Each entry point names the reference interface it replaces (file:line relative
+ * to the reference tree).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to row-major fp64 unless noted `host`;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *    nothing synchronises the host (graph-capturable) unless stated;
+ *  - return value: 0 = ok, <0 = -(index of the bad argument) or a GPN_E* code;
+ *    never throws, never allocates device memory: workspaces are sized by the
+ *    *_workspace_bytes queries and owned by the caller;
+ *  - LAPACK-style `info` lives on the device (int32): 0 = ok, j>0 = the leading
+ *    minor of order j is not positive definite (first failing pivot, 1-based).
+ *    The Python shell maps info>0 to the jitter ladder of functions.py:20-43.
+ *
+ * "Factor buffers": dense factorisation kernels work on a caller-owned,
+ * ZERO-INITIALISED buffer `A` of `gpn_factor_rows(n,e)` rows and leading
+ * dimension `lda = gpn_factor_ld(n,e)` (a multiple of 64), holding the n x n
+ * matrix in its top-left corner (lower triangle significant) and `e` optional
+ * "extra rows" n..n+e-1 that are carried through the factorisation: on exit
+ * they hold (L^-1 * R)^T for the right-hand sides R^T stored in them on entry
+ * (forward substitution fused into the panel solves -- this is how
+ * alpha = L^-1 (y - m) of gpr.py:62 is produced without a separate TRSV).
+ */
+#ifndef GPNATIVE_H
+#define GPNATIVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPN_VERSION 1
+
+/* kernel kinds: kernels.py:215-222 (Rbf), 204-212 (Matern52), 196-201 (Matern32), 182-193 (Exp/Matern12) */
+enum { GPN_RBF = 0, GPN_MATERN52 = 1, GPN_MATERN32 = 2, GPN_EXP = 3,
+       GPN_SQDIST = 4 /* util.squared_distance itself (util.py:73-88): K = r^2, variance ignored */ };
+enum { GPN_FULL = 0, GPN_LOWER = 1 };
+
+enum {
+  GPN_OK = 0,
+  GPN_E_HIP = -100,      /* a HIP runtime call failed: see gpn_last_hip_error() */
+  GPN_E_ALIGN = -101,    /* pointer / leading dimension violates an alignment rule */
+  GPN_E_UNSUPPORTED = -102
+};
+
+int gpn_version(void);
+/* name of the gfx target compiled into the library, e.g. "gfx950" */
+const char* gpn_arch(void);
+/* text of the last HIP error seen by this thread ("" if none) */
+const char* gpn_last_hip_error(void);
+
+/* ---- factor-buffer geometry --------------------------------------------- */
+int64_t gpn_factor_ld(int64_t n, int64_t e);    /* round_up(n+e, 64) */
+int64_t gpn_factor_rows(int64_t n, int64_t e);  /* round_up(n+e, 64) + 16 (zero apron) */
+/* bytes of the `winv` workspace (inverses of the 64x64 diagonal leaf blocks) */
+int64_t gpn_winv_bytes(int64_t n);
+
+/* ---- K assembly ------------------------------------------------------------
+ * Replaces util.squared_distance (util.py:73-88), Stationary.squared_dist/dist
+ * (kernels.py:149-172), Rbf.K / Matern52.K / Matern32.K / Exp.K (kernels.py:
+ * 182-222) and, with `noise` != NULL, GPR._compute_kyy (gpr.py:69-86).
+ *   K[i,j] = variance * k(|| (X_i - X2_j) / ell ||)   (+ noise on i==j when X2==NULL)
+ * X[n,d], X2[m,d] (NULL => X2 = X, m ignored) contiguous row-major;
+ * variance[1], length_scales[nls] (nls = 1 or d), noise[1] or NULL: device scalars
+ * in CONSTRAINED space.  uplo = GPN_LOWER (only with X2 == NULL) writes tiles on
+ * or below the diagonal only.  Distances are direct differences (no Gram trick),
+ * so r^2 >= 0 by construction (the clamp of util.py:88 is the identity). */
+int gpn_kernel_matrix(void* stream, int kind,
+                      const double* X, int64_t n, const double* X2, int64_t m, int d,
+                      const double* variance, const double* length_scales, int nls,
+                      const double* noise, int uplo, double* K, int64_t ldk);
+
+/* extra rows of a factor buffer: E[c, i] = Y[i, c] - M[i, c] (M may be NULL),
+ * Y, M [n,dy] row-major contiguous; E = A + n*lda.  (gpr.py:62 `y - mean(x)`) */
+int gpn_pack_rhs(void* stream, const double* Y, const double* M, int64_t n, int dy,
+                 double* E, int64_t lde);
+
+/* ---- Cholesky --------------------------------------------------------------
+ * Replaces functions.cholesky's torch.cholesky call (functions.py:46-47; the
+ * jitter ladder of functions.py:20-43 stays in the Python shell and replays on
+ * info>0).  In-place lower factorisation of the n x n top-left block of the
+ * factor buffer A; the strict upper triangle is neither read nor written.
+ * `winv` (gpn_winv_bytes(n)) receives the inverses of the 64x64 diagonal blocks
+ * of L and must be kept with L for the solves below.  e extra rows are carried
+ * (see header comment).  *info must be 0 on entry. */
+int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
+                    double* winv, int32_t* info);
+
+/* winv <- inverses of the 64x64 diagonal blocks of a GIVEN lower-triangular L
+ * (n x n, row-major, ldl): what functions.trtrs (functions.py:71-76) needs when
+ * its triangular argument did not come from gpn_potrf_lower.  info (may be NULL):
+ * j>0 = zero pivot at column j. */
+int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t ldl, double* winv, int32_t* info);
+
+/* X * L^T = B  in place on B[m,n] (row-major, ldb; rows/ld padded like a factor
+ * buffer), i.e. X^T = L^-1 B^T: functions.trtrs(b, L) (functions.py:71-76) for
+ * b = B^T.  L/winv from gpn_potrf_lower. */
+int gpn_trsm_right_lt(void* stream, const double* L, int64_t n, int64_t ldl,
+                      const double* winv, double* B, int64_t m, int64_t ldb);
+
+/* out[0] = sum_i log L[i,i]  (functions.lt_log_determinant, functions.py:61-68)
+ * out[1] = sum of squares of the e x n extra rows (= ||alpha||_F^2, gpr.py:66)
+ * out[2] = LML of gpr.py:63-67 = -0.5*out[1] - e*out[0] - 0.5*e*n*log(2*pi) */
+int gpn_lml_reduce(void* stream, const double* A, int64_t n, int64_t e, int64_t lda,
+                   double* out3);
+
+/* ---- dense contractions (exposed for tests and for the predict path) -------
+ * C[M,N] = alpha * A[M,K] * B[N,K]^T + beta * C   (all row-major; "NT" form).
+ * lower != 0: square case M == N, only tiles on/below the diagonal are computed
+ * and entries with j > i are not written (SYRK-style trailing update).
+ * Requirements: K % 16 == 0; lda, ldb % 2 == 0; A, B 16-byte aligned; rows of A
+ * (B) readable up to round_up(M,16) (round_up(N,16)). */
+int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
+                const double* A, int64_t lda, const double* B, int64_t ldb,
+                double beta, double* C, int64_t ldc, int lower);
+
+/* ---- small utilities -------------------------------------------------------- */
+/* dst[r, c] = src[c, r] for src[rows, cols] */
+int gpn_transpose(void* stream, const double* src, int64_t rows, int64_t cols, int64_t lds,
+                  double* dst, int64_t ldd);
+/* dst[rows, cols] (ldd) <- src (lds); if tril != 0 entries with c > r are written as 0
+ * (torch.cholesky returns a zeroed upper triangle) */
+int gpn_copy_matrix(void* stream, const double* src, int64_t rows, int64_t cols, int64_t lds,
+                    double* dst, int64_t ldd, int tril);
+/* out[r] = sum_c A[r,c]^2  (the (A*A).sum(0) of gpr.py:109-113 in transposed storage) */
+int gpn_row_sumsq(void* stream, const double* A, int64_t rows, int64_t cols, int64_t lda,
+                  double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPNATIVE_H */

@@ -1,0 +1,63 @@
+"""fp64 MFMA contraction (csrc/gemm_f64.hip) against exact integer data and
+torch.matmul on the same device (checker only)."""
+import pytest
+import torch
+
+from gptorch_amd import _native, _ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _pad_rows(t, mult=16):
+    r = (-t.shape[0]) % mult
+    if r:
+        t = torch.cat([t, torch.zeros(r, t.shape[1], dtype=t.dtype, device=t.device)])
+    return t.contiguous()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(16, 16, 16), (64, 64, 64), (128, 128, 32), (200, 72, 48), (1, 130, 16),
+                                   (333, 257, 80), (512, 384, 256), (1024, 1024, 512)])
+def test_gemm_exact_integers(device, variant, M, N, K):
+    """Small integers: every product and sum is exact in fp64, so the result must be
+    bit-identical whatever the summation order; A != B and asymmetric, which catches
+    row/column swaps in the MFMA fragment maps."""
+    _native.lib().gpn_debug_set_gemm_variant(variant)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+        A = torch.randint(-8, 9, (M, K), generator=g).double().to(device)
+        B = torch.randint(-8, 9, (N, K), generator=g).double().to(device)
+        C0 = torch.randint(-8, 9, (M, N), generator=g).double().to(device)
+        Ap, Bp = _pad_rows(A), _pad_rows(B)
+        C = C0.clone()
+        _ops.gemm_nt(Ap, Bp, M, N, K, alpha=-1.0, beta=1.0, C=C)
+        ref = C0 - A @ B.t()
+        assert torch.equal(C, ref)
+        C2 = _ops.gemm_nt(Ap, Bp, M, N, K)
+        assert torch.equal(C2, A @ B.t())
+    finally:
+        _native.lib().gpn_debug_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("n,K", [(64, 64), (200, 32), (640, 128), (1100, 64)])
+def test_syrk_lower(device, n, K):
+    g = torch.Generator(device="cpu").manual_seed(n + K)
+    P = torch.randint(-5, 6, (n, K), generator=g).double().to(device)
+    C0 = torch.randint(-5, 6, (n, n), generator=g).double().to(device)
+    Pp = _pad_rows(P)
+    C = C0.clone()
+    _ops.gemm_nt(Pp, Pp, n, n, K, alpha=-1.0, beta=1.0, C=C, lower=True)
+    full = C0 - P @ P.t()
+    assert torch.equal(torch.tril(C), torch.tril(full))
+    # strictly-upper entries must be untouched
+    assert torch.equal(torch.triu(C, 1), torch.triu(C0, 1))
+
+
+def test_gemm_random_fp64(device):
+    torch.manual_seed(0)
+    M, N, K = 700, 900, 1024
+    A = torch.randn(M + 4, K, dtype=torch.float64, device=device)
+    B = torch.randn(N + 12, K, dtype=torch.float64, device=device)
+    C = _ops.gemm_nt(A, B, M, N, K)
+    ref = A[:M] @ B[:N].t()
+    assert (C - ref).abs().max().item() < 1e-11

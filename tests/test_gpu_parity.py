@@ -1,0 +1,189 @@
+"""Parity of the HIP path against the CPU oracle and the golden vectors generated
+from the reference (tests/golden/make_golden.py).  Everything goes through the
+C ABI (ctypes) via the gptorch_amd shell."""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import load_json, load_npz
+from gptorch_amd import functions, kernels, likelihoods, mean_functions, rng
+from gptorch_amd.models import GPR
+from oracle import gp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+KERN = {"Rbf": kernels.Rbf, "Matern52": kernels.Matern52, "Matern32": kernels.Matern32, "Exp": kernels.Exp}
+# north_star: LML and predictive mean/var within 1e-8 (fp64)
+TOL_LML = 1e-8
+
+
+def _model(case, device, x=None, y=None):
+    if x is None:
+        x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    d = x.shape[1]
+    ls = case["length_scales"]
+    if case["ARD"]:
+        ls = np.asarray(ls, dtype=np.float64) * np.ones(d)
+    kern = KERN[case["kind"]](d, variance=case["variance"], length_scales=ls, ARD=case["ARD"])
+    mean = None
+    if case.get("mean") is not None:
+        mean = mean_functions.Constant(y.shape[1], val=torch.tensor(case["mean"], dtype=torch.float64))
+        mean.val.requires_grad_(False)
+    m = GPR(x, y, kern, likelihood=likelihoods.Gaussian(variance=case["noise"]), mean_function=mean)
+    m.cuda()
+    return m, x, y
+
+
+# ---- kernels ---------------------------------------------------------------
+def test_reference_kernel_fixtures(device):
+    """The reference's own golden vectors (test/data/kernels/*.npy, checked as in
+    test/test_kernels.py:59-127: K(x1), K(x1,x2), symmetry, transpose, shift, Kdiag, ARD)."""
+    z = load_npz("ref_kernel_fixtures.npz")
+    x1 = torch.tensor(z["x1"], device=device)
+    x2 = torch.tensor(z["x2"], device=device)
+    for name, cls in KERN.items():
+        k = cls(3)
+        k.cuda()
+        kx = k.K(x1).detach().cpu().numpy()
+        assert np.allclose(z[f"{name}_kx"], kx)
+        assert np.allclose(z[f"{name}_kx2"], k.K(x1, x2).detach().cpu().numpy())
+        assert np.allclose(kx.T, kx)
+        assert np.allclose(z[f"{name}_kx2"], k.K(x2, x1).detach().cpu().numpy().T)
+        assert np.allclose(z[f"{name}_kx"], k.K(x1 + 0.34).detach().cpu().numpy())
+        assert np.allclose(z[f"{name}_kdiag"], k.Kdiag(x1).detach().cpu().numpy())
+        ka = cls(3, ARD=True, length_scales=z["ard_length_scales"])
+        ka.cuda()
+        assert np.allclose(z[f"{name}_kx_ard"], ka.K(x1).detach().cpu().numpy())
+        assert np.allclose(z[f"{name}_kx2_ard"], ka.K(x1, x2).detach().cpu().numpy())
+        assert np.allclose(z[f"{name}_kdiag_ard"], ka.Kdiag(x1).detach().cpu().numpy())
+
+
+def test_kernel_small_goldens(device):
+    cases = load_json("kernel_cases.json")["small"]
+    z = load_npz("kernel_small.npz")
+    for c in cases:
+        x = torch.tensor(rng.normal(c["seed_x"], (c["n"], c["d"])), device=device)
+        x2 = torch.tensor(rng.normal(c["seed_x2"], (c["m"], c["d"])), device=device)
+        ls = np.asarray(c["length_scales"])
+        k = KERN[c["kind"]](c["d"], variance=c["variance"], length_scales=ls if c["ARD"] else float(ls[0]),
+                            ARD=c["ARD"])
+        k.cuda()
+        key = c["key"]
+        assert np.max(np.abs(k.K(x).detach().cpu().numpy() - z[key + "_kx"])) < 1e-13, key
+        assert np.max(np.abs(k.K(x, x2).detach().cpu().numpy() - z[key + "_kx2"])) < 1e-13, key
+        assert np.max(np.abs(k.Kdiag(x).detach().cpu().numpy() - z[key + "_kdiag"])) < 1e-15, key
+
+
+def test_kernel_sampled_goldens(device):
+    for c in load_json("kernel_cases.json")["sampled"]:
+        xn = rng.normal(c["seed_x"], (c["n"], c["d"]))
+        assert rng.checksum(xn) == c["x_checksum"]
+        k = KERN[c["kind"]](c["d"], variance=c["variance"], length_scales=c["length_scales"])
+        k.cuda()
+        K = k.K(torch.tensor(xn, device=device)).detach()
+        i, j = torch.tensor(c["i"], device=device), torch.tensor(c["j"], device=device)
+        got = K[i, j].cpu().numpy()
+        assert np.max(np.abs(got - np.asarray(c["values"]))) < 1e-13
+        assert abs(K.norm().item() - c["frobenius"]) < 1e-9 * c["frobenius"]
+        assert abs(K.diagonal().sum().item() - c["trace"]) < 1e-9 * c["trace"]
+        assert (K - K.t()).abs().max().item() == 0.0   # exactly symmetric (direct differences)
+
+
+# ---- functions ---------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 13, 63, 64, 65, 77, 128, 129, 200, 512, 1000, 2048])
+def test_cholesky_vs_oracle(device, n):
+    a = rng.normal(1000 + n, (n, n))
+    spd = a @ a.T / n + 0.5 * np.eye(n)
+    k = 3
+    b = rng.normal(2000 + n, (n, k))
+    L_ref = orc.cholesky(torch.tensor(spd))
+    x_ref = orc.trtrs(torch.tensor(b), L_ref)
+    L = functions.cholesky(torch.tensor(spd, device=device))
+    assert (L.cpu() - L_ref).abs().max().item() < 1e-12
+    assert torch.equal(torch.triu(L, 1), torch.zeros_like(L))
+    x = functions.trtrs(torch.tensor(b, device=device), L)
+    assert (x.cpu() - x_ref).abs().max().item() < 1e-11
+    ld = functions.lt_log_determinant(L)
+    assert abs(ld.item() - orc.lt_log_determinant(L_ref).item()) < 1e-11
+    # trtrs with a triangular matrix that did NOT come from cholesky()
+    L2 = L.clone()
+    x2 = functions.trtrs(torch.tensor(b, device=device), L2)
+    assert (x2.cpu() - x_ref).abs().max().item() < 1e-11
+
+
+def test_functions_golden(device):
+    g = load_json("functions_cases.json")
+    n, k = g["n"], g["k"]
+    a = rng.normal(g["spd_seed"], (n, n))
+    spd = a @ a.T / n + 0.5 * np.eye(n)
+    b = rng.normal(g["b_seed"], (n, k))
+    L = functions.cholesky(torch.tensor(spd, device=device))
+    assert np.max(np.abs(L.diagonal().cpu().numpy() - np.asarray(g["chol_diag"]))) < 1e-13
+    assert abs(L.norm().item() - g["chol_frobenius"]) < 1e-12
+    assert abs(functions.lt_log_determinant(L).item() - g["logdet"]) < 1e-12
+    X = functions.trtrs(torch.tensor(b, device=device), L)
+    assert np.max(np.abs(X.cpu().numpy() - np.asarray(g["trtrs"]))) < 1e-12
+
+
+def test_jitter_ladder(device):
+    """functions.py:20-43 on the reference's behaviours (golden: which rung succeeds)."""
+    g = load_json("functions_cases.json")
+    lad = {l["name"]: l for l in g["ladder"]}
+    ones = torch.tensor([[1.0, 1.0], [1.0, 1.0]], dtype=torch.float64, device=device)
+    L = functions.cholesky(ones)
+    assert L._gpn_factor.jitter_rung == lad["ones2"]["rung"]
+    assert np.allclose(L.diagonal().cpu().numpy(), lad["ones2"]["diag"], rtol=1e-6)
+    with pytest.raises(RuntimeError, match="Max tries exceeded."):
+        functions.cholesky(torch.tensor([[1.0, 2.0], [2.0, 1.0]], dtype=torch.float64, device=device))
+    dup_x = np.repeat(rng.normal(g["dup_seed"], (8, 2)), 2, axis=0)
+    k = kernels.Rbf(2)
+    k.cuda()
+    Kd = k.K(torch.tensor(dup_x, device=device)).detach()
+    L = functions.cholesky(Kd)
+    assert L._gpn_factor.jitter_rung == lad["dup_rows_rbf"]["rung"]
+
+
+# ---- GPR ---------------------------------------------------------------------
+LML = load_json("lml_cases.json")
+
+
+@pytest.mark.parametrize("case", LML, ids=[c["name"] for c in LML])
+def test_lml_and_predict_golden(device, case):
+    m, x, y = _model(case, device)
+    assert rng.checksum(x) == case["x_checksum"] and rng.checksum(y) == case["y_checksum"]
+    loss = m.loss()
+    assert loss.shape == (1,) and loss.is_cuda
+    lml = -loss.item()
+    assert abs(lml - case["lml"]) < TOL_LML * max(1.0, abs(case["lml"]) * 1e-4), (lml, case["lml"])
+    xs = rng.normal(case["predict"]["seed_xs"], (16, case["d"]))
+    p = case["predict"]
+    mf, vf = m.predict_f(xs)
+    assert isinstance(mf, np.ndarray) and mf.shape == (16, case["dy"]) and vf.shape == (16, case["dy"])
+    assert np.max(np.abs(mf - np.asarray(p["mean_f"]))) < 1e-8
+    assert np.max(np.abs(vf - np.asarray(p["var_f"]))) < 1e-8
+    my, vy = m.predict_y(xs)
+    assert np.max(np.abs(vy - np.asarray(p["var_y"]))) < 1e-8
+    mfc, cf = m.predict_f(xs, diag=False)
+    assert cf.shape == (16, 16)
+    assert np.max(np.abs(cf - np.asarray(p["cov_f"]))) < 1e-8
+    myc, cy = m.predict_y(xs, diag=False)
+    assert np.max(np.abs(np.diag(cy) - np.asarray(p["cov_y_diag"]))) < 1e-8
+
+
+def test_loss_api(device):
+    """test/test_models/test_gpr.py:36-51 behaviours."""
+    x, y = rng.make_regression(20, 3, 2, seed=5)
+    m = GPR(x, y, kernels.Rbf(3, ARD=True))
+    m.cuda()
+    loss = m.loss()
+    assert isinstance(loss, torch.Tensor) and loss.ndimension() == 1
+    loss_xy = m.loss(x=torch.tensor(x, device=device), y=torch.tensor(y, device=device))
+    assert loss_xy.item() == loss.item()
+    with pytest.raises(ValueError):
+        m.loss(x=torch.tensor(x[:10], device=device))
+    api = load_json("api_cases.json")
+    assert abs(loss.item() - api["loss_default_numpy"]) < 1e-9
+    mu, var = m._predict(torch.tensor(rng.normal(3, (7, 3)), device=device))
+    assert mu.shape == (7, 2) and var.shape == (7, 2) and mu.is_cuda
+    mu, cov = m._predict(torch.tensor(rng.normal(3, (7, 3)), device=device), diag=False)
+    assert cov.shape == (7, 7)
