@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""
+bench.py -- GP log-marginal-likelihood evaluations / second (BASELINE.json metric).
+
+A "step" is ONE evaluation of the exact-GP log marginal likelihood through the
+gptorch-compatible shell (model.log_likelihood()): fused K(X)+sigma_n^2 I assembly
+-> blocked fp64 MFMA Cholesky with the residual carried as extra rows (forward
+substitution) -> log-det / ||alpha||^2 reduction -> info check (jitter ladder).
+Inputs are resident in HBM before the timed region.
+
+Workload (config.workload): BASELINE.json configs[1] = "C2": GPR + Rbf, N=8192,
+D=8, fp64, synthetic X~N(0,1), y=sin(sum x)+0.1 eps (gptorch_amd.rng, seed 0),
+sigma^2=1, ell=sqrt(D), sigma_n^2=1e-2.  `--workload c3` runs N=32768 D=16 Matern52.
+
+N>1 GPUs: one process per GPU, each evaluates its own independent model
+(hyper-parameter restarts: rank r uses seed r) -- "replicas", no data-path
+collective (multi-GPU); value = all ranks' evaluations / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline     -- the fp64 MFMA contraction kernel (gemm_nt_kernel): algorithmic
+                  flops of the factorisation it carries / summed HIP-event time of its
+                  launches (events on the launch stream, second pass over the same steps)
+  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference path,
+                  oracle/gp_oracle.py) on this box's host cores, rank 0, N=1 only
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "c2": dict(name="C2: GPR+Rbf N=8192 D=8 fp64 LML eval", kind="Rbf", n=8192, d=8, dy=1,
+               variance=1.0, length_scales=float(np.sqrt(8.0)), noise=1e-2),
+    "c3": dict(name="C3: GPR+Matern52 N=32768 D=16 fp64 LML eval", kind="Matern52", n=32768, d=16, dy=1,
+               variance=1.0, length_scales=4.0, noise=1e-2),
+    "c1": dict(name="C1: GPR+Rbf N=512 D=2 fp64 LML eval", kind="Rbf", n=512, d=2, dy=1,
+               variance=1.0, length_scales=1.0, noise=1e-2),
+}
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak (AMD spec; = 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+
+
+def build_model(w, seed, device):
+    from gptorch_amd import kernels, likelihoods, rng
+    from gptorch_amd.models import GPR
+    x, y = rng.make_regression(w["n"], w["d"], w["dy"], seed=seed)
+    kern = getattr(kernels, w["kind"])(w["d"], variance=w["variance"], length_scales=w["length_scales"])
+    m = GPR(x, y, kern, likelihood=likelihoods.Gaussian(variance=w["noise"]))
+    m.cuda()
+    return m, x, y
+
+
+def algorithmic_gemm_flops(n, dy):
+    """Cholesky = N^3/3 flops; everything but the 64x64 diagonal leaves
+    (N/64 * 64^3/3) runs in the contraction kernel, plus the fused solve N^2*dy."""
+    return n ** 3 / 3.0 - n * 64.0 ** 2 / 3.0 + float(n) ** 2 * dy
+
+
+def cpu_baseline(w, x, y, budget_s=25.0):
+    from oracle import gp_oracle as orc
+    o = orc.GPROracle(x, y, kind=w["kind"], variance=w["variance"], length_scales=w["length_scales"], noise=w["noise"])
+    with torch.no_grad():
+        t0 = time.time()
+        o.log_likelihood()          # warm-up
+        first = time.time() - t0
+        reps = int(max(1, min(5, budget_s // max(first, 1e-3) - 1)))
+        times = []
+        for _ in range(reps):
+            t0 = time.time()
+            o.log_likelihood()
+            times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "LML evals/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d full evaluations of the same workload (N=%d, D=%d) after 1 warm-up, median" % (reps, w["n"], w["d"]),
+            "seconds_per_eval": med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from gptorch_amd import _native
+    lib = _native.lib()   # raises if the HIP library is missing: no fallback
+
+    w = WORKLOADS[args.workload]
+    model, x, y = build_model(w, seed=rank, device=device)
+
+    def step():
+        with torch.no_grad():
+            return model.log_likelihood()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    lml = out.item()
+
+    # roofline leg: same steps again with a HIP event pair around every launch of the
+    # contraction kernel (recorded on the stream the kernel is launched on)
+    lib.gpn_profile_enable(1)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    res = (ctypes.c_double * 3)()
+    lib.gpn_profile_collect(res)
+    lib.gpn_profile_enable(0)
+    launches, gemm_ms, exec_flops = res[0], res[1], res[2]
+    alg = algorithmic_gemm_flops(w["n"], w["dy"]) * args.steps
+    achieved = alg / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (fp64 MFMA NT contraction: SYRK/GEMM trailing updates + panel solves)",
+                "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+                "traffic": None,
+                "launches_per_step": launches / args.steps, "avg_launch_us": gemm_ms * 1e3 / max(launches, 1),
+                "algorithmic_flops_per_launch": alg / max(launches, 1),
+                "executed_tflops": exec_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
+                "kernel_ms_per_step": gemm_ms / args.steps}
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "GP log-marginal-likelihood evals/sec (Cholesky+solve) at NxD fp64",
+            "value": world * args.steps / elapsed, "unit": "LML evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w["name"], "N": w["n"], "D": w["d"], "dy": w["dy"], "kernel": w["kind"],
+                       "parallelism": "replicas x%d (independent models, no collective)" % world},
+            "lml": lml,
+            "cholesky_frac_of_fp64_peak": (w["n"] ** 3 / 3.0) / (elapsed / args.steps) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, x, y)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,8 @@ SIGNATURES = {
 # not part of the public header: debugging switches
 DEBUG_SIGNATURES = {
     "gpn_debug_set_gemm_variant": (c_int, [c_int]),
+    "gpn_profile_enable": (c_int, [c_int]),
+    "gpn_profile_collect": (c_int, [ctypes.POINTER(c_double)]),
 }
 
 _lib = None

@@ -191,7 +191,14 @@ static int launch(hipStream_t s, const GemmArgs& a0) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
+  const bool prof = profile_on();
+  if (prof) {
+    // executed flops: tiles actually computed x 2*BM*BN*K
+    const double tiles = a.lower ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt;
+    profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K);
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  if (prof) profile_end(s);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

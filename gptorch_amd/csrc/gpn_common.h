@@ -29,4 +29,8 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
             double beta, double* C, int64_t ldc, int lower);
 
+bool profile_on();
+void profile_begin(hipStream_t s, double flops);
+void profile_end(hipStream_t s);
+
 }  // namespace gpn
