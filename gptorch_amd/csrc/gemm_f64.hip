@@ -40,10 +40,15 @@ struct GemmArgs {
 
 constexpr int BK = 16;
 
-__device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, int& ti, int& tj) {
-  // bijective XCD remap: consecutive logical ids land on the same XCD
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective XCD remap: consecutive logical ids land on the same XCD (blocks b, b+8 share one)
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// full rectangle: groups of 8 tile rows, column-major inside a group
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, int& ti, int& tj) {
+  const int logical = xcd_remap(bid, nwg);
   const int group = 8 * nt;
   const int g = logical / group;
   const int first = g * 8;
@@ -51,6 +56,38 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, 
   const int rem = logical - g * group;
   ti = first + rem % gm;
   tj = rem / gm;
+}
+
+// lower triangle only (grid = mt(mt+1)/2 exactly, so every XCD gets the same
+// number of real tiles): groups of 8 tile rows; group g holds the 8g full columns
+// left of the diagonal super-tile (column-major, 8 per column) followed by the
+// 36 tiles of the diagonal super-tile.  Tiles before group g: 32 g^2 + 4 g.
+__device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, int& ti, int& tj) {
+  const int q = xcd_remap(bid, nwg);
+  const int G = mt >> 3;
+  const int full_total = 32 * G * G + 4 * G;
+  int g, h;
+  if (q < full_total) {
+    g = (int)((sqrt(16.0 + 128.0 * (double)q) - 4.0) * (1.0 / 64.0));
+    while (32 * g * g + 4 * g > q) --g;
+    while (32 * (g + 1) * (g + 1) + 4 * (g + 1) <= q) ++g;
+    h = 8;
+  } else {
+    g = G;
+    h = mt & 7;
+  }
+  int r = q - (32 * g * g + 4 * g);
+  const int left = h * 8 * g;
+  if (r < left) {
+    tj = r / h;
+    ti = 8 * g + r - tj * h;
+  } else {
+    r -= left;
+    int c = 0;
+    while (r >= h - c) { r -= h - c; ++c; }
+    ti = 8 * g + c + r;
+    tj = 8 * g + c;
+  }
 }
 
 template <int BM, int BN, int WM, int WN, bool DMA>
@@ -64,8 +101,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int ti, tj;
-  tile_of_block(blockIdx.x, gridDim.x, p.mt, p.nt, ti, tj);
-  if (p.lower && tj > ti) return;
+  if (p.lower) tile_of_block_lower(blockIdx.x, gridDim.x, p.mt, ti, tj);
+  else tile_of_block(blockIdx.x, gridDim.x, p.mt, p.nt, ti, tj);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -86,30 +123,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
   d2 stage_regs[DMA ? 1 : PER_WAVE];
 
+  // per-wave staging slots: fragment block idx = wave + 4*i; source pointers are
+  // hoisted out of the K loop (only k0 advances)
+  const double* src_base[PER_WAVE];
+  bool src_ok[PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int idx = wave + 4 * i;
+    const bool isA = idx < A_BLOCKS;
+    const int b = isA ? idx : idx - A_BLOCKS;
+    const int rg = b >> 1, kg8 = b & 1;
+    const int row = (isA ? m0 : n0) + rg * 16;
+    src_ok[i] = (idx < NBLK) && row < (isA ? mlim : nlim);
+    src_base[i] = (isA ? p.A + (int64_t)(row + frow) * p.lda : p.B + (int64_t)(row + frow) * p.ldb) + kg8 * 8 + fk;
+  }
+
   // issue the loads of K-step `t` into LDS stage `s` (DMA) or registers (!DMA)
   auto stage_issue = [&](int t, int s) {
     const int k0 = t * BK;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
       const int idx = wave + 4 * i;
-      if (idx < NBLK) {
-        const bool isA = idx < A_BLOCKS;
-        const int b = isA ? idx : idx - A_BLOCKS;
-        const int rg = b >> 1, kg8 = b & 1;
-        const int row = (isA ? m0 : n0) + rg * 16;
-        const bool ok = row < (isA ? mlim : nlim);
-        const double* src = (isA ? p.A + (int64_t)(row + frow) * p.lda
-                                 : p.B + (int64_t)(row + frow) * p.ldb) + k0 + kg8 * 8 + fk;
-        if constexpr (DMA) {
-          if (ok) {
-            char* dst = smem + s * STAGE + idx * 1024;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)src,
-                (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-          }
-        } else {
-          stage_regs[i] = ok ? *reinterpret_cast<const d2*>(src) : d2{0.0, 0.0};
+      const double* src = src_base[i] + k0;
+      if constexpr (DMA) {
+        if (src_ok[i]) {
+          char* dst = smem + s * STAGE + idx * 1024;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)src,
+              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
+      } else {
+        stage_regs[i] = src_ok[i] ? *reinterpret_cast<const d2*>(src) : d2{0.0, 0.0};
       }
     }
   };
@@ -144,16 +188,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     }
   };
 
+  // Software pipeline, one barrier per K-step: the DMA of K-step t+1 is issued at
+  // the top of step t and only waited for at the top of step t+1 -- a full MFMA
+  // block (64 MFMAs x 64 cycles) covers its latency.  sched_barrier keeps the
+  // compiler from hoisting the next barrier (and its vmcnt(0)) above the MFMAs.
   const int nk = p.K / BK;
   stage_issue(0, 0);
   stage_commit(0);
-  __syncthreads();
   for (int t = 0; t < nk; ++t) {
     const int s = t & 1;
+    __syncthreads();  // K-step t has landed (vmcnt(0)); every wave is done reading stage s^1
     if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
     compute(s);
+    __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < nk) stage_commit(s ^ 1);
-    __syncthreads();  // drains the DMA (vmcnt(0)) and fences reuse of stage s
   }
 
   // epilogue: reg r of lane l is C[(l>>4) + 4r][l&15] of its 16x16 tile
@@ -182,7 +230,7 @@ static int launch(hipStream_t s, const GemmArgs& a0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
-  const int grid = a.mt * a.nt;
+  const int grid = a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt;
   constexpr int smem = ((BM + BN) / 16) * 2 * 1024 * 2;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA>;
   static bool attr_set = false;
@@ -216,9 +264,16 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
   a.mt = a.nt = 0;
   a.lower = lower;
   a.alpha = alpha; a.beta = beta;
-  // small problems: 64x64 tiles give 4x the workgroups (latency-bound regime)
-  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-  const bool small = (N <= 64) || (M <= 64) || tiles128 < 128;
+  // Tile choice = fewest "rounds" of resident workgroups.  128x128 tiles: 2 per CU
+  // (64 KB LDS, 214 VGPRs) = 512 slots, 4 work units each; 64x64 tiles: 5 per CU
+  // (32 KB LDS) = 1280 slots, 1 unit each at ~0.85 of the big tile's efficiency.
+  auto tiles = [&](int64_t b) {
+    const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
+    return lower ? mt * (mt + 1) / 2 : mt * nt;
+  };
+  const double t128 = (double)((tiles(128) + 511) / 512) * 8.0;
+  const double t64 = (double)((tiles(64) + 1279) / 1280) * 5.0 / 0.85;
+  const bool small = (N <= 64) || (M <= 64) || t64 < t128;
   if (g_gemm_variant == 0) {
     return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true>(s, a);
   }

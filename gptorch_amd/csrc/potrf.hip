@@ -28,6 +28,13 @@ constexpr int LP = LEAF + 1;  // padded LDS row (doubles)
 // (for info).  Rows/cols >= kb are treated as identity.
 // FACTOR=false: A already holds a lower-triangular L; only the inverse is formed
 // (one workgroup per 64-block: blockIdx.x selects the diagonal block).
+//
+// Right-looking elimination on [A | I] with the whole working set in REGISTERS:
+// the 256 threads form a 16x16 grid, thread (ty,tx) owns A[ty+16a][tx+16b] and
+// W[ty+16a][tx+16b], a,b = 0..3.  Per pivot column j only the (unscaled) column
+// j of A and row j of W cross threads, through a double-buffered 2x64-double LDS
+// broadcast: one barrier per column; every thread derives 1/sqrt(d) itself.
+// Finished columns of L / rows of W are parked in LDS and copied out coalesced.
 template <bool FACTOR>
 __global__ __launch_bounds__(256) void potrf_leaf_kernel(double* A, int64_t lda, int kb_, int col0_,
                                                          double* winv_, int32_t* info, int n_total) {
@@ -39,46 +46,108 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double* A, int64_t lda,
     A += (int64_t)col0 * lda + col0;
     winv += (int64_t)blockIdx.x * LEAF * LEAF;
   }
-  __shared__ double Ls[LEAF * LP];
-  __shared__ double Ws[LEAF * LP];
-  __shared__ int fail;
+  __shared__ double colbuf[2][LEAF];
+  __shared__ double rowbuf[2][LEAF];
+  __shared__ double Lout[LEAF * LP];
+  __shared__ double Wout[LEAF * LP];
   const int tid = threadIdx.x;
-  if (tid == 0) fail = 0;
-  for (int idx = tid; idx < LEAF * LEAF; idx += 256) {
-    const int i = idx >> 6, c = idx & 63;
-    double v = (i == c) ? 1.0 : 0.0;
-    if (i < kb && c <= i) v = A[(int64_t)i * lda + c];
-    Ls[i * LP + c] = v;
-    Ws[i * LP + c] = (i == c) ? 1.0 : 0.0;
-  }
-  __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;
-  for (int j = 0; j < LEAF; ++j) {
-    const double d = Ls[j * LP + j];
-    if (FACTOR ? !(d > 0.0) : (d == 0.0)) {   // LAPACK dpotrf: ajj <= 0 or NaN; dtrtri: zero pivot
-      if (tid == 0) fail = j + 1;
-      break;                     // d is read by all threads from LDS: uniform
+
+  double ar[4][4], wr_[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ty + 16 * a, c = tx + 16 * b;
+      double v = (i == c) ? 1.0 : 0.0;
+      if (i < kb && c <= i) v = A[(int64_t)i * lda + c];
+      ar[a][b] = v;
+      wr_[a][b] = (i == c) ? 1.0 : 0.0;
     }
-    const double s = FACTOR ? sqrt(d) : d;
-    const double inv_s = 1.0 / s;
-    __syncthreads();             // everyone has read d before it is overwritten
-    if (FACTOR && tid < LEAF) {
-      if (tid > j) Ls[tid * LP + j] *= inv_s;
-      else if (tid == j) Ls[j * LP + j] = s;
-    } else if (tid >= LEAF && tid < 2 * LEAF) {
-      const int c = tid - LEAF;
-      if (c <= j) Ws[j * LP + c] *= inv_s;
-    }
-    __syncthreads();
-    // rows i > j: A part (j < c <= i) and inverse part (c <= j) of the rank-1 update
-    for (int i = j + 1 + ty; i < LEAF; i += 16) {
-      const double lij = Ls[i * LP + j];
-      for (int c = tx; c <= i; c += 16) {
-        if (c > j) { if (FACTOR) Ls[i * LP + c] -= lij * Ls[c * LP + j]; }
-        else Ws[i * LP + c] -= lij * Ws[j * LP + c];
+
+  int fail = 0;
+  // broadcast of column 0 / row 0
+  if (tx == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) colbuf[0][ty + 16 * a] = ar[a][0];
+  }
+  if (ty == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) rowbuf[0][tx + 16 * b] = wr_[0][b];
+  }
+
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) {
+    for (int jt = 0; jt < 16; ++jt) {
+      const int j = jb * 16 + jt;
+      const int p = j & 1;
+      __syncthreads();
+      const double d = colbuf[p][j];
+      if (FACTOR ? !(d > 0.0) : (d == 0.0)) {   // LAPACK dpotrf: ajj <= 0 or NaN; dtrtri: zero pivot
+        fail = j + 1;                            // d comes from LDS: uniform across the workgroup
+        break;
+      }
+      const double s = FACTOR ? sqrt(d) : d;
+      const double inv_s = 1.0 / s;
+      double li[4], lc[4], wj[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int i = ty + 16 * a;
+        const double v = colbuf[p][i];
+        li[a] = (i > j) ? (FACTOR ? v * inv_s : v) : 0.0;
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int c = tx + 16 * b;
+        if (FACTOR) lc[b] = (c > j) ? colbuf[p][c] * inv_s : 0.0;
+        wj[b] = (c <= j) ? rowbuf[p][c] * inv_s : 0.0;
+      }
+      // park the finished column of L / row of W
+      if (FACTOR && tx == jt) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int i = ty + 16 * a;
+          if (i > j) Lout[i * LP + j] = li[a];
+          else if (i == j) Lout[i * LP + j] = s;
+        }
+      }
+      if (ty == jt) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int c = tx + 16 * b;
+          if (c <= j) Wout[j * LP + c] = wj[b];
+        }
+      }
+      // rank-1 update of the trailing rows (registers only)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (FACTOR) ar[a][b] = fma(-li[a], lc[b], ar[a][b]);
+          wr_[a][b] = fma(-li[a], wj[b], wr_[a][b]);
+        }
+      // broadcast column j+1 of A / row j+1 of W through the other buffer
+      if (jt < 15) {
+        if (tx == jt + 1) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) colbuf[p ^ 1][ty + 16 * a] = ar[a][jb];
+        }
+        if (ty == jt + 1) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) rowbuf[p ^ 1][tx + 16 * b] = wr_[jb][b];
+        }
+      } else if (jb < 3) {
+        if (tx == 0) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) colbuf[p ^ 1][ty + 16 * a] = ar[a][jb < 3 ? jb + 1 : 3];
+        }
+        if (ty == 0) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) rowbuf[p ^ 1][tx + 16 * b] = wr_[jb < 3 ? jb + 1 : 3][b];
+        }
       }
     }
-    __syncthreads();
+    if (fail) break;
   }
   __syncthreads();
   if (fail) {
@@ -90,8 +159,8 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double* A, int64_t lda,
   for (int idx = tid; idx < LEAF * LEAF; idx += 256) {
     const int i = idx >> 6, c = idx & 63;
     const bool in = (i < kb && c <= i);
-    if (FACTOR && in) A[(int64_t)i * lda + c] = Ls[i * LP + c];
-    winv[idx] = in ? Ws[i * LP + c] : 0.0;
+    if (FACTOR && in) A[(int64_t)i * lda + c] = Lout[i * LP + c];
+    winv[idx] = in ? Wout[i * LP + c] : 0.0;
   }
 }
 
