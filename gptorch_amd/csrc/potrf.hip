@@ -17,11 +17,10 @@
 // "Extra rows" (gpnative.h): rows n..n+e-1 ride along in every panel solve and
 // trailing update of the right spine of the recursion; on exit they hold
 // (L^-1 R)^T -- alpha^T of gpr.py:62 -- for free.
+#include <type_traits>
 #include "gpn_common.h"
 
 namespace gpn {
-
-constexpr int LP = LEAF + 1;  // padded LDS row (doubles)
 
 // One workgroup: L = chol(A[0:kb,0:kb]) in place, W = L^-1 -> winv (64x64, ld 64,
 // zero outside the kb x kb lower triangle).  col0 = global index of column 0
@@ -34,10 +33,23 @@ constexpr int LP = LEAF + 1;  // padded LDS row (doubles)
 // W[ty+16a][tx+16b], a,b = 0..3.  Per pivot column j only the (unscaled) column
 // j of A and row j of W cross threads, through a double-buffered 2x64-double LDS
 // broadcast: one barrier per column; every thread derives 1/sqrt(d) itself.
-// Finished columns of L / rows of W are parked in LDS and copied out coalesced.
-template <bool FACTOR>
+// Finished columns of L / rows of W stay in registers and are stored once at the end.
+#define GPN_STAMP(k)                                                                       \
+  if constexpr (DIAG) {                                                                    \
+    unsigned long long t_;                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    acc_t[k] += t_ - last_t;                                                               \
+    last_t = t_;                                                                           \
+  }
+
+template <bool FACTOR, bool DIAG = false>
 __global__ __launch_bounds__(256) void potrf_leaf_kernel(double* A, int64_t lda, int kb_, int col0_,
-                                                         double* winv_, int32_t* info, int n_total) {
+                                                         double* winv_, int32_t* info, int n_total,
+                                                         unsigned long long* diag = nullptr) {
+  unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, last_t = 0;
+  if constexpr (DIAG) last_t = __builtin_amdgcn_s_memtime();
   int kb = kb_, col0 = col0_;
   double* winv = winv_;
   if constexpr (!FACTOR) {
@@ -48,8 +60,6 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double* A, int64_t lda,
   }
   __shared__ double colbuf[2][LEAF];
   __shared__ double rowbuf[2][LEAF];
-  __shared__ double Lout[LEAF * LP];
-  __shared__ double Wout[LEAF * LP];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
 
@@ -76,92 +86,137 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double* A, int64_t lda,
     for (int b = 0; b < 4; ++b) rowbuf[0][tx + 16 * b] = wr_[0][b];
   }
 
-#pragma unroll
-  for (int jb = 0; jb < 4; ++jb) {
+  // 4 blocks of 16 pivots; the block index is a compile-time constant so that every
+  // register-array subscript below is static (no selects, no scratch)
+  auto pivots16 = [&](auto jb_c) {
+    constexpr int jb = decltype(jb_c)::value;
     for (int jt = 0; jt < 16; ++jt) {
       const int j = jb * 16 + jt;
       const int p = j & 1;
+      GPN_STAMP(4)
       __syncthreads();
+      GPN_STAMP(0)
       const double d = colbuf[p][j];
       if (FACTOR ? !(d > 0.0) : (d == 0.0)) {   // LAPACK dpotrf: ajj <= 0 or NaN; dtrtri: zero pivot
         fail = j + 1;                            // d comes from LDS: uniform across the workgroup
-        break;
+        return;
       }
-      const double s = FACTOR ? sqrt(d) : d;
-      const double inv_s = 1.0 / s;
+      // values every thread needs from column j / row j (all LDS reads issued together)
+      double cl[4], cc[4], rw[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cl[a] = colbuf[p][ty + 16 * a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        cc[b] = colbuf[p][tx + 16 * b];
+        rw[b] = rowbuf[p][tx + 16 * b];
+      }
+      // 1/sqrt(d) by v_rsq_f64 + two Newton steps (the serial chain of the whole
+      // factorisation runs through here: ~6 dependent ops instead of sqrt + divide);
+      // s = d * inv_s is then within 1 ulp of sqrt(d).  trtri mode: inv_s = 1/d.
+      double s, inv_s;
+      if (FACTOR) {
+        double y = __builtin_amdgcn_rsq(d);
+        const double hd = 0.5 * d;
+        y = fma(y, fma(-hd * y, y, 0.5), y);
+        y = fma(y, fma(-hd * y, y, 0.5), y);
+        inv_s = y;
+        s = d * y;
+        s = fma(fma(-s, s, d), 0.5 * y, s);   // one correction of sqrt(d) itself
+      } else {
+        s = d;
+        inv_s = 1.0 / d;
+      }
+      // rows/cols at or before the pivot take no part: blocks a < jb (b < jb) are dead
+      // for the A part, blocks b > jb are dead for the W part -- all decided statically
       double li[4], lc[4], wj[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const int i = ty + 16 * a;
-        const double v = colbuf[p][i];
-        li[a] = (i > j) ? (FACTOR ? v * inv_s : v) : 0.0;
+        if (a < jb) li[a] = 0.0;
+        else if (a == jb) li[a] = (ty > jt) ? (FACTOR ? cl[a] * inv_s : cl[a]) : 0.0;
+        else li[a] = FACTOR ? cl[a] * inv_s : cl[a];
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int c = tx + 16 * b;
-        if (FACTOR) lc[b] = (c > j) ? colbuf[p][c] * inv_s : 0.0;
-        wj[b] = (c <= j) ? rowbuf[p][c] * inv_s : 0.0;
+        if (!FACTOR || b < jb) lc[b] = 0.0;
+        else if (b == jb) lc[b] = (tx > jt) ? cc[b] * inv_s : 0.0;
+        else lc[b] = cc[b] * inv_s;
+        if (b > jb) wj[b] = 0.0;
+        else if (b == jb) wj[b] = (tx <= jt) ? rw[b] * inv_s : 0.0;
+        else wj[b] = rw[b] * inv_s;
       }
-      // park the finished column of L / row of W
-      if (FACTOR && tx == jt) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int i = ty + 16 * a;
-          if (i > j) Lout[i * LP + j] = li[a];
-          else if (i == j) Lout[i * LP + j] = s;
-        }
-      }
-      if (ty == jt) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int c = tx + 16 * b;
-          if (c <= j) Wout[j * LP + c] = wj[b];
-        }
-      }
-      // rank-1 update of the trailing rows (registers only)
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (FACTOR) ar[a][b] = fma(-li[a], lc[b], ar[a][b]);
-          wr_[a][b] = fma(-li[a], wj[b], wr_[a][b]);
-        }
-      // broadcast column j+1 of A / row j+1 of W through the other buffer
+      GPN_STAMP(1)
+      // look-ahead: bring column j+1 of A / row j+1 of W up to date FIRST and publish
+      // them through the other buffer, so the next pivot's chain starts while the bulk
+      // of this rank-1 update is still being issued
       if (jt < 15) {
         if (tx == jt + 1) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a) colbuf[p ^ 1][ty + 16 * a] = ar[a][jb];
+          for (int a = jb; a < 4; ++a)
+            colbuf[p ^ 1][ty + 16 * a] = FACTOR ? fma(-li[a], lc[jb], ar[a][jb]) : ar[a][jb];
         }
         if (ty == jt + 1) {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) rowbuf[p ^ 1][tx + 16 * b] = wr_[jb][b];
+          for (int b = 0; b <= jb; ++b) rowbuf[p ^ 1][tx + 16 * b] = fma(-li[jb], wj[b], wr_[jb][b]);
         }
-      } else if (jb < 3) {
+      } else if constexpr (jb < 3) {
         if (tx == 0) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a) colbuf[p ^ 1][ty + 16 * a] = ar[a][jb < 3 ? jb + 1 : 3];
+          for (int a = jb + 1; a < 4; ++a)
+            colbuf[p ^ 1][ty + 16 * a] = FACTOR ? fma(-li[a], lc[jb + 1], ar[a][jb + 1]) : ar[a][jb + 1];
         }
         if (ty == 0) {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) rowbuf[p ^ 1][tx + 16 * b] = wr_[jb < 3 ? jb + 1 : 3][b];
+          for (int b = 0; b <= jb + 1; ++b) rowbuf[p ^ 1][tx + 16 * b] = fma(-li[jb + 1], wj[b], wr_[jb + 1][b]);
         }
       }
+      GPN_STAMP(2)
+      // finished column j of L / row j of W stay in their owners' registers (the bulk
+      // update below leaves them alone: lc = 0 for c <= j, li = 0 for i <= j)
+      if (FACTOR && tx == jt) {
+        ar[jb][jb] = (ty == jt) ? s : (ty > jt ? li[jb] : ar[jb][jb]);
+#pragma unroll
+        for (int a = jb + 1; a < 4; ++a) ar[a][jb] = li[a];
+      }
+      if (ty == jt) {
+#pragma unroll
+        for (int b = 0; b < jb; ++b) wr_[jb][b] = wj[b];
+        if (tx <= jt) wr_[jb][jb] = wj[jb];
+      }
+      GPN_STAMP(3)
+      // rank-1 update of the trailing rows (registers only; dead blocks skipped statically)
+#pragma unroll
+      for (int a = jb; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (FACTOR && b >= jb) ar[a][b] = fma(-li[a], lc[b], ar[a][b]);
+          if (b <= jb) wr_[a][b] = fma(-li[a], wj[b], wr_[a][b]);
+        }
     }
-    if (fail) break;
-  }
+  };
+  pivots16(std::integral_constant<int, 0>{});
+  if (!fail) pivots16(std::integral_constant<int, 1>{});
+  if (!fail) pivots16(std::integral_constant<int, 2>{});
+  if (!fail) pivots16(std::integral_constant<int, 3>{});
   __syncthreads();
+  if constexpr (DIAG) {
+    GPN_STAMP(5)
+    if ((tid & 63) == 0) for (int k = 0; k < 6; ++k) diag[(tid >> 6) * 6 + k] = acc_t[k];
+  }
   if (fail) {
     if (tid == 0 && info && *info == 0) *info = col0 + fail;
     // leave A untouched; still publish a finite winv so later kernels stay finite
     for (int idx = tid; idx < LEAF * LEAF; idx += 256) winv[idx] = 0.0;
     return;
   }
-  for (int idx = tid; idx < LEAF * LEAF; idx += 256) {
-    const int i = idx >> 6, c = idx & 63;
-    const bool in = (i < kb && c <= i);
-    if (FACTOR && in) A[(int64_t)i * lda + c] = Lout[i * LP + c];
-    winv[idx] = in ? Wout[i * LP + c] : 0.0;
-  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = ty + 16 * a, c = tx + 16 * b;
+      const bool in = (i < kb && c <= i);
+      if (FACTOR && in) A[(int64_t)i * lda + c] = ar[a][b];
+      winv[i * LEAF + c] = in ? wr_[a][b] : 0.0;
+    }
 }
 
 struct Ctx {
@@ -199,8 +254,8 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
 static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   if (c.rc != GPN_OK || n <= 0) return;
   if (n <= LEAF) {
-    hipLaunchKernelGGL(potrf_leaf_kernel<true>, dim3(1), dim3(256), 0, c.s, A, c.lda, (int)n, (int)col0,
-                       c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0);
+    hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(256), 0, c.s, A, c.lda, (int)n, (int)col0,
+                       c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0, nullptr);
     if (hipGetLastError() != hipSuccess) { c.rc = GPN_E_HIP; return; }
     if (e > 0) trsm_rec(c, A + n * c.lda, e, c.lda, A, c.lda, n, col0, c.winv);
     return;
@@ -316,6 +371,17 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
   return c.rc;
 }
 
+// diagnostic build of the leaf with s_memtime stamps: diag[wave*6 + k] = cycles summed
+// over the 64 columns in segment k (0 barrier, 1 pivot+reads, 2 look-ahead publish,
+// 3 park, 4 bulk update, 5 tail).  Not part of the public header.
+extern "C" int gpn_debug_leaf_timing(void* stream, double* A, int64_t lda, double* winv, int32_t* info,
+                                     unsigned long long* diag24) {
+  hipLaunchKernelGGL((potrf_leaf_kernel<true, true>), dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     A, lda, LEAF, 0, winv, info, 0, diag24);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
 extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t ldl, double* winv, int32_t* info) {
   if (!L) return -2;
   if (n < 0) return -3;
@@ -323,8 +389,8 @@ extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t 
   if (!winv) return -5;
   if (n == 0) return GPN_OK;
   const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
-  hipLaunchKernelGGL(potrf_leaf_kernel<false>, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     const_cast<double*>(L), ldl, 0, 0, winv, info, (int)n);
+  hipLaunchKernelGGL((potrf_leaf_kernel<false, false>), dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     const_cast<double*>(L), ldl, 0, 0, winv, info, (int)n, nullptr);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
