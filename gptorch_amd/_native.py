@@ -29,7 +29,13 @@ SIGNATURES = {
     "gpn_trsm_right_lt": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "gpn_lml_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "gpn_gemm_nt": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64,
-                            c_void_p, c_int64, c_double, c_void_p, c_int64, c_int]),
+                            c_void_p, c_int64, c_double, c_void_p, c_int64, c_int, c_int]),
+    "gpn_trtri_upper": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64]),
+    "gpn_grad_work_bytes": (c_int64, [c_int64, c_int64, c_int, c_int]),
+    "gpn_lml_grad": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
+                             c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "gpn_kernel_grad": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "gpn_transpose": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64]),
     "gpn_copy_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "gpn_row_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),

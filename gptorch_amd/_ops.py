@@ -203,13 +203,16 @@ def kernel_factor(kind, X, variance, length_scales, noise, R=None, factor=None):
     return f
 
 
-def gemm_nt(A, B, M, N, K, alpha=1.0, beta=0.0, C=None, lower=False):
+TRI_A_UPPER, TRI_A_LOWER, TRI_B_UPPER, TRI_B_LOWER = 1, 2, 4, 8
+
+
+def gemm_nt(A, B, M, N, K, alpha=1.0, beta=0.0, C=None, lower=False, tri=0):
     """C[M,N] = alpha*A[M,K]*B[N,K]^T + beta*C (row strides taken from the tensors)."""
     _req(A, B, C)
     if C is None:
         C = torch.empty(M, N, dtype=torch.float64, device=A.device)
     st = _native.lib().gpn_gemm_nt(_stream(A.device), M, N, K, alpha, _ptr(A), A.stride(0), _ptr(B), B.stride(0),
-                                   beta, _ptr(C), C.stride(0), 1 if lower else 0)
+                                   beta, _ptr(C), C.stride(0), 1 if lower else 0, tri)
     _native.check(st, "gpn_gemm_nt")
     return C
 

@@ -35,6 +35,7 @@ struct GemmArgs {
   int M, N, K;
   int mt, nt;       // tile counts
   int lower;
+  int tri;          // GPN_TRI_* structure flags: skip the K range where an operand is known zero
   double alpha, beta;
 };
 
@@ -192,10 +193,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   // the top of step t and only waited for at the top of step t+1 -- a full MFMA
   // block (64 MFMAs x 64 cycles) covers its latency.  sched_barrier keeps the
   // compiler from hoisting the next barrier (and its vmcnt(0)) above the MFMAs.
-  const int nk = p.K / BK;
-  stage_issue(0, 0);
-  stage_commit(0);
-  for (int t = 0; t < nk; ++t) {
+  // triangular operands: rows of an upper-triangular operand are zero left of the
+  // diagonal, rows of a lower-triangular one right of it -> clip the K range per tile
+  int k_lo = 0, k_hi = p.K;
+  if (p.tri & GPN_TRI_A_UPPER) k_lo = max(k_lo, m0);
+  if (p.tri & GPN_TRI_B_UPPER) k_lo = max(k_lo, n0);
+  if (p.tri & GPN_TRI_A_LOWER) k_hi = min(k_hi, m0 + BM);
+  if (p.tri & GPN_TRI_B_LOWER) k_hi = min(k_hi, n0 + BN);
+  const int t0 = k_lo / BK;
+  const int nk = max(t0, (k_hi + BK - 1) / BK);
+  if (t0 < nk) {
+    stage_issue(t0, t0 & 1);
+    stage_commit(t0 & 1);
+  }
+  for (int t = t0; t < nk; ++t) {
     const int s = t & 1;
     __syncthreads();  // K-step t has landed (vmcnt(0)); every wave is done reading stage s^1
     if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
@@ -255,7 +266,7 @@ static int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging (de
 
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
-            double beta, double* C, int64_t ldc, int lower) {
+            double beta, double* C, int64_t ldc, int lower, int tri) {
   if (M <= 0 || N <= 0) return GPN_OK;
   GemmArgs a;
   a.A = A; a.B = B; a.C = C;
@@ -263,6 +274,7 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.mt = a.nt = 0;
   a.lower = lower;
+  a.tri = tri;
   a.alpha = alpha; a.beta = beta;
   // Tile choice = fewest "rounds" of resident workgroups.  128x128 tiles: 2 per CU
   // (64 KB LDS, 214 VGPRs) = 512 slots, 4 work units each; 64x64 tiles: 5 per CU
@@ -289,7 +301,7 @@ extern "C" int gpn_debug_set_gemm_variant(int v) {
 
 extern "C" int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
                            const double* A, int64_t lda, const double* B, int64_t ldb,
-                           double beta, double* C, int64_t ldc, int lower) {
+                           double beta, double* C, int64_t ldc, int lower, int tri) {
   if (M < 0) return -2;
   if (N < 0) return -3;
   if (K < 0 || (K % 16) != 0) return -4;
@@ -300,5 +312,6 @@ extern "C" int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double
     // C = beta*C: degenerate, not on the hot path
     return GPN_E_UNSUPPORTED;
   }
-  return gpn::gemm_nt(static_cast<hipStream_t>(stream), M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower);
+  if (tri < 0 || tri > 15) return -14;
+  return gpn::gemm_nt(static_cast<hipStream_t>(stream), M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri);
 }

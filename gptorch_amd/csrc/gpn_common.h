@@ -27,7 +27,7 @@ void set_hip_error(hipError_t e, const char* where);
 // the factorisation drivers (no argument validation).
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
-            double beta, double* C, int64_t ldc, int lower);
+            double beta, double* C, int64_t ldc, int lower, int tri = 0);
 
 bool profile_on();
 void profile_begin(hipStream_t s, double flops);

@@ -1,0 +1,330 @@
+// Hyper-parameter gradients of the kernel matrix contracted with a weight matrix G:
+//     out[0]      = sum_ij G_ij * dK_ij/d(variance)
+//     out[1+d]    = sum_ij G_ij * dK_ij/d(ell_d)        (isotropic: one entry, summed over d)
+//     out[1+nls]  = trace(G)                            (LML mode only: d/d(noise))
+// Two sources of G:
+//   LML mode   -- G = 1/2 (a a^T - dy * Kyy^-1) formed on the fly from the lower
+//                 triangle of Kyy^-1 and a^T [dy, n]  (closed-form backward of
+//                 gpr.py:47-67; the reference gets it from PyTorch's CholeskyBackward /
+//                 TriangularSolveBackward chain at ~2 N^3 flops + dozens of N x N passes);
+//                 only tiles on/below the diagonal are visited, off-diagonal pairs count twice.
+//   dense mode -- G is a given [n, m] matrix (autograd backward of Kernel.K).
+// K and dK/d(theta) are RE-COMPUTED from the points (same staging as kmat.hip), so the
+// sweep reads each G entry exactly once: HBM-bound at 8 B per pair for small D.
+//
+// dK/d(ell_d) = B(r) * s_d / ell_d with s_d = ((x_id - x_jd)/ell_d)^2 and
+//   Rbf: B = K;  Matern52: B = var*(5/3)(1+sqrt5 r)exp(-sqrt5 r);  Matern32: B = 3 var exp(-sqrt3 r);
+//   Exp: B = var*exp(-r)/r (0 where the reference's clamp at 1e-40 kills the gradient).
+// Per-workgroup partial sums go to a workspace and are reduced by a second tiny kernel
+// (deterministic; no float atomics).
+#include "gpn_common.h"
+
+namespace gpn {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int GT = 64;     // tile edge
+constexpr int GDC = 16;    // coordinates per staged chunk
+constexpr int GMAXD = 64;  // max input dimension supported by the register accumulators
+
+struct GradArgs {
+  const double* X;
+  const double* X2;
+  const double* variance;
+  const double* ls;
+  const double* G;      // dense mode: G [n, m]; LML mode: Kinv (lower) [n, n]
+  int64_t ldg;
+  const double* at;     // LML mode: a^T [dy, n]
+  int64_t ldat;
+  double* partial;      // [nblocks, nout]
+  int n, m, d, nls, dy, nout;
+  int tiles_m, tiles_n;
+};
+
+template <int KIND>
+__device__ __forceinline__ void k_and_base(double r2, double var, double& K, double& B) {
+  if constexpr (KIND == GPN_RBF) {
+    K = var * exp(-0.5 * r2);
+    B = K;
+  } else {
+    const bool dead = r2 < 1e-40;                 // kernels.py:172 clamp: no gradient below it
+    const double r = sqrt(fmax(r2, 1e-40));
+    if constexpr (KIND == GPN_MATERN52) {
+      const double s5 = 2.23606797749978969641;
+      const double e = exp(-s5 * r);
+      K = var * (1.0 + s5 * r + 5.0 / 3.0 * r * r) * e;
+      B = dead ? 0.0 : var * (5.0 / 3.0) * (1.0 + s5 * r) * e;
+    } else if constexpr (KIND == GPN_MATERN32) {
+      const double s3 = 1.73205080756887729353;
+      const double e = exp(-s3 * r);
+      K = var * (1.0 + s3 * r) * e;
+      B = dead ? 0.0 : 3.0 * var * e;
+    } else {
+      const double e = exp(-r);
+      K = var * e;
+      B = dead ? 0.0 : var * e / r;
+    }
+  }
+}
+
+// NCH = number of 16-coordinate chunks (d <= 16*NCH); LML = G formed from Kinv + a
+template <int KIND, int NCH, bool LML>
+__global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
+  __shared__ __attribute__((aligned(16))) double xs[NCH * GDC][GT];
+  __shared__ __attribute__((aligned(16))) double ys[NCH * GDC][GT];
+  __shared__ double red[256];
+
+  int ti, tj;
+  if (LML) {
+    // compact lower-triangle enumeration (row-major over the triangle)
+    const int q = blockIdx.x;
+    ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > q) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+    tj = q - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x / p.tiles_n;
+    tj = blockIdx.x - ti * p.tiles_n;
+  }
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int i0 = ti * GT, j0 = tj * GT;
+
+  // stage both point blocks, divided by the length-scales (kernels.py:154-158)
+  for (int idx = tid; idx < NCH * GDC * GT; idx += 256) {
+    const int dd = idx / GT, pt = idx - dd * GT;   // pt fastest: conflict-free LDS writes
+    double vx = 0.0, vy = 0.0;
+    if (dd < p.d) {
+      const double ell = p.ls[p.nls == 1 ? 0 : dd];
+      if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd] / ell;
+      if (j0 + pt < p.m) vy = p.X2[(int64_t)(j0 + pt) * p.d + dd] / ell;
+    }
+    xs[dd][pt] = vx;
+    ys[dd][pt] = vy;
+  }
+  __syncthreads();
+
+  // pass 1: squared distances of the 4x4 micro-tile (rows ty*4+a, cols {2tx,2tx+1,32+2tx,33+2tx})
+  double r2[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+  for (int dd = 0; dd < p.d; ++dd) {
+    const d2 xa = *reinterpret_cast<const d2*>(&xs[dd][ty * 4]);
+    const d2 xb = *reinterpret_cast<const d2*>(&xs[dd][ty * 4 + 2]);
+    const d2 ya = *reinterpret_cast<const d2*>(&ys[dd][tx * 2]);
+    const d2 yb = *reinterpret_cast<const d2*>(&ys[dd][32 + tx * 2]);
+    const double xr[4] = {xa.x, xa.y, xb.x, xb.y};
+    const double yc[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double df = xr[a] - yc[b];
+        r2[a][b] = fma(df, df, r2[a][b]);
+      }
+  }
+
+  // G' = weight * G * B, plus the variance / noise sums
+  const double var = p.variance[0];
+  double gb[4][4];
+  double s_var = 0.0, s_tr = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = i0 + ty * 4 + a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = j0 + (b >> 1) * 32 + tx * 2 + (b & 1);
+      double g = 0.0;
+      if (row < p.n && col < p.m) {
+        if constexpr (LML) {
+          if (col <= row) {
+            double aa = 0.0;
+            for (int c = 0; c < p.dy; ++c) aa = fma(p.at[(int64_t)c * p.ldat + row], p.at[(int64_t)c * p.ldat + col], aa);
+            g = 0.5 * (aa - (double)p.dy * p.G[(int64_t)row * p.ldg + col]);
+            if (col == row) s_tr += g;
+            else g *= 2.0;   // symmetric partner (col, row)
+          }
+        } else {
+          g = p.G[(int64_t)row * p.ldg + col];
+        }
+      }
+      double K, B;
+      k_and_base<KIND>(r2[a][b], var, K, B);
+      s_var = fma(g, K, s_var);
+      gb[a][b] = g * B;
+    }
+  }
+
+  // pass 2: per-dimension sums  S_d = sum G'_ij * s_d
+  double acc[NCH * GDC];
+#pragma unroll
+  for (int dd = 0; dd < NCH * GDC; ++dd) acc[dd] = 0.0;
+#pragma unroll
+  for (int dd = 0; dd < NCH * GDC; ++dd) {
+    if (dd < p.d) {
+      const d2 xa = *reinterpret_cast<const d2*>(&xs[dd][ty * 4]);
+      const d2 xb = *reinterpret_cast<const d2*>(&xs[dd][ty * 4 + 2]);
+      const d2 ya = *reinterpret_cast<const d2*>(&ys[dd][tx * 2]);
+      const d2 yb = *reinterpret_cast<const d2*>(&ys[dd][32 + tx * 2]);
+      const double xr[4] = {xa.x, xa.y, xb.x, xb.y};
+      const double yc[4] = {ya.x, ya.y, yb.x, yb.y};
+      double sacc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double df = xr[a] - yc[b];
+          sacc = fma(gb[a][b], df * df, sacc);
+        }
+      acc[dd] = sacc;
+    }
+  }
+
+  // workgroup reduction of (1 + nls' + 1) values; isotropic sums over d first
+  auto block_sum = [&](double v) -> double {
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) red[tid] += red[tid + s];
+      __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  double* out = p.partial + (int64_t)blockIdx.x * p.nout;
+  const double tv = block_sum(s_var);
+  if (tid == 0) out[0] = tv / var;                         // dK/dvar = K / var
+  if (p.nls == 1) {
+    double s = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < NCH * GDC; ++dd) s += acc[dd];
+    const double t = block_sum(s);
+    if (tid == 0) out[1] = t / p.ls[0];
+  } else {
+#pragma unroll
+    for (int dd = 0; dd < NCH * GDC; ++dd) {
+      if (dd < p.d) {                                       // uniform
+        const double t = block_sum(acc[dd]);
+        if (tid == 0) out[1 + dd] = t / p.ls[dd];
+      }
+    }
+  }
+  if (LML) {
+    const double t = block_sum(s_tr);
+    if (tid == 0) out[1 + p.nls] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partial, int64_t nblocks, int nout, double* out) {
+  __shared__ double red[256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  double s = 0.0;
+  for (int64_t b = tid; b < nblocks; b += 256) s += partial[b * nout + k];
+  red[tid] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) out[k] = red[0];
+}
+
+template <int KIND, bool LML>
+static int launch_sweep(hipStream_t s, const GradArgs& a, int64_t nblocks) {
+  const int nch = (a.d + GDC - 1) / GDC;
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 1, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 2, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 3, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 4, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
+    default: return GPN_E_UNSUPPORTED;
+  }
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+template <bool LML>
+static int dispatch_kind(hipStream_t s, int kind, const GradArgs& a, int64_t nblocks) {
+  switch (kind) {
+    case GPN_RBF: return launch_sweep<GPN_RBF, LML>(s, a, nblocks);
+    case GPN_MATERN52: return launch_sweep<GPN_MATERN52, LML>(s, a, nblocks);
+    case GPN_MATERN32: return launch_sweep<GPN_MATERN32, LML>(s, a, nblocks);
+    case GPN_EXP: return launch_sweep<GPN_EXP, LML>(s, a, nblocks);
+    default: return -2;
+  }
+}
+
+}  // namespace gpn
+
+using namespace gpn;
+
+extern "C" int64_t gpn_grad_work_bytes(int64_t n, int64_t m, int nls, int lml) {
+  const int64_t tm = (n + GT - 1) / GT, tn = (m + GT - 1) / GT;
+  const int64_t blocks = lml ? tm * (tm + 1) / 2 : tm * tn;
+  return blocks * (int64_t)(2 + nls) * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_lml_grad(void* stream, int kind, const double* X, int64_t n, int d,
+                            const double* variance, const double* length_scales, int nls,
+                            const double* Kinv, int64_t ldk, const double* at, int64_t ldat, int dy,
+                            double* work, double* out) {
+  if (!X) return -3;
+  if (n <= 0) return -4;
+  if (d <= 0 || d > GMAXD) return -5;
+  if (!variance) return -6;
+  if (!length_scales) return -7;
+  if (nls != 1 && nls != d) return -8;
+  if (!Kinv) return -9;
+  if (ldk < n) return -10;
+  if (!at) return -11;
+  if (ldat < n) return -12;
+  if (dy <= 0) return -13;
+  if (!work) return -14;
+  if (!out) return -15;
+  GradArgs a;
+  a.X = X; a.X2 = X; a.variance = variance; a.ls = length_scales;
+  a.G = Kinv; a.ldg = ldk; a.at = at; a.ldat = ldat; a.partial = work;
+  a.n = (int)n; a.m = (int)n; a.d = d; a.nls = nls; a.dy = dy; a.nout = 2 + nls;
+  a.tiles_m = a.tiles_n = (int)((n + GT - 1) / GT);
+  const int64_t nblocks = (int64_t)a.tiles_m * (a.tiles_m + 1) / 2;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rc = dispatch_kind<true>(s, kind, a, nblocks);
+  if (rc != GPN_OK) return rc;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)a.nout), dim3(256), 0, s, work, nblocks, a.nout, out);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+extern "C" int gpn_kernel_grad(void* stream, int kind, const double* X, int64_t n, const double* X2, int64_t m, int d,
+                               const double* variance, const double* length_scales, int nls,
+                               const double* G, int64_t ldg, double* work, double* out) {
+  if (!X) return -3;
+  if (n <= 0) return -4;
+  const bool symmetric = (X2 == nullptr);
+  if (symmetric) m = n;
+  if (m <= 0) return -6;
+  if (d <= 0 || d > GMAXD) return -7;
+  if (!variance) return -8;
+  if (!length_scales) return -9;
+  if (nls != 1 && nls != d) return -10;
+  if (!G) return -11;
+  if (ldg < m) return -12;
+  if (!work) return -13;
+  if (!out) return -14;
+  GradArgs a;
+  a.X = X; a.X2 = symmetric ? X : X2; a.variance = variance; a.ls = length_scales;
+  a.G = G; a.ldg = ldg; a.at = nullptr; a.ldat = 0; a.partial = work;
+  a.n = (int)n; a.m = (int)m; a.d = d; a.nls = nls; a.dy = 0; a.nout = 2 + nls;
+  a.tiles_m = (int)((n + GT - 1) / GT);
+  a.tiles_n = (int)((m + GT - 1) / GT);
+  const int64_t nblocks = (int64_t)a.tiles_m * a.tiles_n;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rc = dispatch_kind<false>(s, kind, a, nblocks);
+  if (rc != GPN_OK) return rc;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(1 + nls)), dim3(256), 0, s, work, nblocks, a.nout, out);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}

@@ -270,6 +270,34 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   potrf_rec(c, A21 + h, n - h, e, col0 + h);
 }
 
+// U_ii <- W_ii^T for every 64x64 diagonal block (one workgroup per block)
+__global__ __launch_bounds__(256) void diag_transpose_kernel(const double* winv, double* U, int64_t ldu, int n) {
+  __shared__ double t[LEAF][LEAF + 1];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const double* W = winv + (int64_t)blk * LEAF * LEAF;
+  for (int idx = tid; idx < LEAF * LEAF; idx += 256) t[idx >> 6][idx & 63] = W[idx];
+  __syncthreads();
+  const int kb = min(LEAF, n - blk * LEAF);
+  double* Ub = U + ((int64_t)blk * LEAF) * ldu + blk * LEAF;
+  for (int idx = tid; idx < LEAF * LEAF; idx += 256) {
+    const int i = idx >> 6, c = idx & 63;
+    if (i < kb && c < kb) Ub[(int64_t)i * ldu + c] = t[c][i];
+  }
+}
+
+// U (upper, row-major) <- L^-T by recursion on the block structure:
+//   U12 = -U11 * L21^T * L22^-T : one NT contraction (A = U11 upper: K range clipped)
+//   followed by the in-place right solve with L22 (trsm_rec) -- no new primitive.
+static void trtri_rec(Ctx& c, const double* L, int64_t ldl, double* U, int64_t ldu, int64_t n, int64_t diag0) {
+  if (c.rc != GPN_OK || n <= LEAF) return;
+  const int64_t h = split_point(n);
+  trtri_rec(c, L, ldl, U, ldu, h, diag0);
+  trtri_rec(c, L + h * ldl + h, ldl, U + h * ldu + h, ldu, n - h, diag0 + h);
+  if (c.rc != GPN_OK) return;
+  c.rc = gemm_nt(c.s, h, n - h, h, -1.0, U, ldu, L + h * ldl, ldl, 0.0, U + h, ldu, 0, GPN_TRI_A_UPPER);
+  trsm_rec(c, U + h, h, ldu, L + h * ldl + h, ldl, n - h, diag0 + h, c.winv);
+}
+
 // ---- reductions / utilities -------------------------------------------------
 __global__ __launch_bounds__(256) void lml_reduce_kernel(const double* A, int64_t n, int64_t e, int64_t lda,
                                                          double* out3) {
@@ -408,6 +436,25 @@ extern "C" int gpn_trsm_right_lt(void* stream, const double* L, int64_t n, int64
   if (n == 0 || m == 0) return GPN_OK;
   Ctx c{static_cast<hipStream_t>(stream), ldl, const_cast<double*>(winv), nullptr, GPN_OK};
   trsm_rec(c, B, m, ldb, L, ldl, n, 0, winv);
+  return c.rc;
+}
+
+extern "C" int gpn_trtri_upper(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv,
+                               double* U, int64_t ldu) {
+  if (!L) return -2;
+  if (n < 0) return -3;
+  if (ldl < round_up(n, LEAF) || (ldl % LEAF) != 0) return -4;
+  if (!winv) return -5;
+  if (!U) return -6;
+  if (ldu < round_up(n, LEAF) || (ldu % LEAF) != 0) return -7;
+  if ((reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(U) & 15)) return GPN_E_ALIGN;
+  if (n == 0) return GPN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
+  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb), dim3(256), 0, s, winv, U, ldu, (int)n);
+  GPN_LAUNCH_CHECK();
+  Ctx c{s, ldl, const_cast<double*>(winv), nullptr, GPN_OK};
+  trtri_rec(c, L, ldl, U, ldu, n, 0);
   return c.rc;
 }
 

@@ -117,9 +117,39 @@ int gpn_lml_reduce(void* stream, const double* A, int64_t n, int64_t e, int64_t 
  * and entries with j > i are not written (SYRK-style trailing update).
  * Requirements: K % 16 == 0; lda, ldb % 2 == 0; A, B 16-byte aligned; rows of A
  * (B) readable up to round_up(M,16) (round_up(N,16)). */
+/* tri: structure hints that clip the K range per tile (operand entries in the clipped
+ * range MUST be zero): A_UPPER: A[i,k] = 0 for k < i; A_LOWER: A[i,k] = 0 for k > i
+ * (to tile granularity: k >= 128*ceil((i+1)/128)); likewise for B with its row index j. */
+enum { GPN_TRI_A_UPPER = 1, GPN_TRI_A_LOWER = 2, GPN_TRI_B_UPPER = 4, GPN_TRI_B_LOWER = 8 };
 int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
                 const double* A, int64_t lda, const double* B, int64_t ldb,
-                double beta, double* C, int64_t ldc, int lower);
+                double beta, double* C, int64_t ldc, int lower, int tri);
+
+/* ---- backward of the LML (closed form) ---------------------
+ * U <- L^-T (upper triangular, row-major) into a ZERO-INITIALISED buffer of
+ * gpn_factor_rows(n,0) x ldu (ldu = gpn_factor_ld(n,0)); L/winv from gpn_potrf_lower.
+ * Then Kyy^-1 = U U^T is one SYRK-style gpn_gemm_nt(lower=1, tri=A_UPPER|B_UPPER)
+ * and a = Kyy^-1 (y-m) = U alpha one gpn_gemm_nt(tri=B_UPPER).  Together they replace
+ * PyTorch's CholeskyBackward0 / TriangularSolveBackward0 under gpr.py:47-67. */
+int gpn_trtri_upper(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv,
+                    double* U, int64_t ldu);
+
+/* workspace bytes for the two gradient sweeps below (lml != 0: gpn_lml_grad) */
+int64_t gpn_grad_work_bytes(int64_t n, int64_t m, int nls, int lml);
+
+/* out[0] = dLML/d variance, out[1..nls] = dLML/d length_scales, out[1+nls] = dLML/d noise
+ * (all w.r.t. the CONSTRAINED values) from G = 1/2 (a a^T - dy Kinv), Kinv lower [n,n],
+ * at = a^T [dy, n]; K and dK/dtheta are recomputed from X on the fly (kernels.py:149-222). */
+int gpn_lml_grad(void* stream, int kind, const double* X, int64_t n, int d,
+                 const double* variance, const double* length_scales, int nls,
+                 const double* Kinv, int64_t ldk, const double* at, int64_t ldat, int dy,
+                 double* work, double* out);
+
+/* autograd backward of gpn_kernel_matrix: out[0] = sum G*dK/dvariance,
+ * out[1..nls] = sum G*dK/dlength_scales for a given dense G [n, m]. */
+int gpn_kernel_grad(void* stream, int kind, const double* X, int64_t n, const double* X2, int64_t m, int d,
+                    const double* variance, const double* length_scales, int nls,
+                    const double* G, int64_t ldg, double* work, double* out);
 
 /* ---- small utilities -------------------------------------------------------- */
 /* dst[r, c] = src[c, r] for src[rows, cols] */

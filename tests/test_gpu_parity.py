@@ -196,3 +196,78 @@ def test_loss_api(device):
     assert mu.shape == (7, 2) and var.shape == (7, 2) and mu.is_cuda
     mu, cov = m._predict(torch.tensor(rng.normal(3, (7, 3)), device=device), diag=False)
     assert cov.shape == (7, 7)
+
+
+# ---- backward ------------------------------------------------------------------
+GRAD_CASES = [c for c in LML if "grad_loss" in c]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES, ids=[c["name"] for c in GRAD_CASES])
+def test_loss_gradients_golden(device, case):
+    """d loss / d raw (log) parameters vs autograd through the reference (golden)."""
+    m, x, y = _model(case, device)
+    loss = m.loss()
+    loss.backward()
+    got = {"kernel.variance": m.kernel.variance.grad, "kernel.length_scales": m.kernel.length_scales.grad,
+           "likelihood.variance": m.likelihood.variance.grad}
+    ill = case["name"] in TOL_LML_ILL
+    for name, g in got.items():
+        ref = np.asarray(case["grad_loss"][name])
+        err = np.max(np.abs(g.cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref)))
+        assert err < (1e-5 if ill else 1e-8), (name, g, ref)
+
+
+def test_gradient_wrt_mean_function(device):
+    """dLML/d(y - m) = -a flows into a trainable mean (gpr.py:62 `y - mean_function(x)`)."""
+    x, y = rng.make_regression(90, 2, 2, seed=8)
+    kern = kernels.Matern52(2, length_scales=1.3)
+    mean = mean_functions.Constant(2, val=torch.tensor([0.2, -0.4], dtype=torch.float64))
+    m = GPR(x, y, kern, likelihood=likelihoods.Gaussian(variance=0.1), mean_function=mean)
+    m.cuda()
+    m.loss().backward()
+    o = orc.GPROracle(x, y, kind="Matern52", variance=1.0, length_scales=1.3, noise=0.1, mean=[0.2, -0.4])
+    o.mean_val.requires_grad_(True)
+    o.loss().backward()
+    assert (mean.val.grad.cpu() - o.mean_val.grad).abs().max().item() < 1e-9
+
+
+def test_kernel_matrix_autograd(device):
+    """Kernel.K is differentiable w.r.t. the raw hyper-parameters (dense-G sweep)."""
+    xn, x2n = rng.normal(21, (150, 5)), rng.normal(22, (70, 5))
+    wn = rng.normal(23, (150, 70))
+    ls = 0.5 + rng.uniform(24, 5)
+    for kind in ["Rbf", "Matern52", "Matern32"]:
+        k = KERN[kind](5, variance=1.4, length_scales=ls, ARD=True)
+        k.cuda()
+        K = k.K(torch.tensor(xn, device=device), torch.tensor(x2n, device=device))
+        (K * torch.tensor(wn, device=device)).sum().backward()
+        rv = torch.tensor([np.log(1.4)], dtype=torch.float64, requires_grad=True)
+        rl = torch.tensor(np.log(ls), dtype=torch.float64, requires_grad=True)
+        Ko = orc.kernel_K(kind, torch.tensor(xn), torch.tensor(x2n), rv.exp(), rl.exp())
+        (Ko * torch.tensor(wn)).sum().backward()
+        assert (k.variance.grad.cpu() - rv.grad).abs().max().item() < 1e-10, kind
+        assert (k.length_scales.grad.cpu() - rl.grad).abs().max().item() < 1e-10, kind
+
+
+def test_cholesky_inverse(device):
+    n = 200
+    a = rng.normal(77, (n, n))
+    spd = a @ a.T / n + 0.5 * np.eye(n)
+    L = functions.cholesky(torch.tensor(spd, device=device))
+    inv = functions.cholesky_inverse(L)
+    assert (inv.cpu() - torch.linalg.inv(torch.tensor(spd))).abs().max().item() < 1e-10
+
+
+def test_adam_trajectory_golden(device):
+    """50 Adam steps (base.py:149-151, 260-269): loss trajectory + final parameters."""
+    import contextlib, io
+    for case in load_json("adam_cases.json"):
+        m, x, y = _model(case, device)
+        with contextlib.redirect_stdout(io.StringIO()):
+            losses, _ = m.optimize(method="Adam", max_iter=50, verbose=False)
+        ref = np.asarray(case["losses"])
+        assert losses.shape == (50,)
+        assert np.max(np.abs(losses - ref) / np.maximum(1.0, np.abs(ref))) < 1e-8, case["name"]
+        for name, p in [("kernel.variance", m.kernel.variance), ("kernel.length_scales", m.kernel.length_scales),
+                        ("likelihood.variance", m.likelihood.variance)]:
+            assert np.max(np.abs(p.detach().cpu().numpy() - np.asarray(case["final"][name]))) < 1e-8, (case["name"], name)
