@@ -1,0 +1,74 @@
+"""CPU suite, part 2: the C-ABI shared library loads and exports every symbol that
+include/gpnative.h declares; pure-host entry points and argument validation behave.
+No compute is launched (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from gptorch_amd import _native
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "gpnative.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpn_\w+)\s*\(", text)))
+
+
+def test_library_present_and_loads():
+    assert os.path.exists(_native.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _native.lib()
+    assert lib.gpn_version() == 1
+    assert lib.gpn_arch() == b"gfx950"
+    assert lib.gpn_last_hip_error() == b""
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libgpnative.so does not export %s" % n
+        assert n in _native.SIGNATURES, "gptorch_amd._native has no ctypes signature for %s" % n
+    for n in _native.SIGNATURES:
+        assert n in names, "%s is bound but not declared in include/gpnative.h" % n
+
+
+def test_factor_geometry():
+    lib = _native.lib()
+    for n, e in [(1, 0), (63, 1), (64, 0), (64, 1), (8192, 1), (1000, 3)]:
+        ld, rows = lib.gpn_factor_ld(n, e), lib.gpn_factor_rows(n, e)
+        assert ld % 64 == 0 and ld >= n + e and ld - (n + e) < 64
+        assert rows == ld + 16
+        assert lib.gpn_winv_bytes(n) == ((n + 63) // 64) * 64 * 64 * 8
+    assert lib.gpn_grad_work_bytes(128, 128, 3, 1) == 3 * 5 * 8
+    assert lib.gpn_grad_work_bytes(128, 64, 1, 0) == 2 * 3 * 8
+
+
+def test_argument_validation_without_launch():
+    """bad arguments are rejected with -(argument index) / GPN_E_* before any HIP call."""
+    lib = _native.lib()
+    null = None
+    assert lib.gpn_gemm_nt(null, 16, 16, 10, 1.0, null, 16, null, 16, 0.0, null, 16, 0, 0) == -4     # K % 16
+    assert lib.gpn_gemm_nt(null, 16, 8, 16, 1.0, null, 16, null, 16, 0.0, null, 16, 1, 0) == -13    # lower, M != N
+    assert lib.gpn_gemm_nt(null, 16, 16, 16, 1.0, null, 15, null, 16, 0.0, null, 16, 0, 0) == -101  # odd lda
+    assert lib.gpn_kernel_matrix(null, 9, null, 4, null, 4, 2, null, null, 1, null, 0, null, 4) == -2
+    assert lib.gpn_kernel_matrix(null, 0, null, 4, null, 4, 2, null, null, 1, null, 0, null, 4) == -3
+    assert lib.gpn_potrf_lower(null, null, 4, 0, 64, null, null) == -2
+    assert lib.gpn_trsm_right_lt(null, null, 4, 64, null, null, 1, 64) == -2
+    assert lib.gpn_lml_grad(null, 0, null, 4, 2, null, null, 1, null, 4, null, 4, 1, null, null) == -3
+    # zero-size problems are no-ops that succeed
+    one = ctypes.c_double(0.0)
+    p = ctypes.cast(ctypes.pointer(one), ctypes.c_void_p)
+    assert lib.gpn_potrf_lower(null, p, 0, 0, 64, p, p) == 0
+    assert lib.gpn_transpose(null, p, 0, 0, 0, p, 0) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_native.NativeError, match="no CPU fallback"):
+        _native.lib()

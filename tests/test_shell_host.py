@@ -1,0 +1,220 @@
+"""CPU suite, part 3: host logic of the gptorch-compatible shell (no GPU, no native
+compute).  Where a behaviour needs numbers, the test injects the CPU ORACLE in place
+of the two native-backed GPR methods -- the product never does that itself: on CPU
+tensors it fails loudly (tested below).  Mirrors test/test_models/test_gpr.py,
+test_base.py, test_model.py, test_param.py, test_mean_functions.py, test_base.py
+of the reference."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import gptorch_amd
+from gptorch_amd import kernels, likelihoods, mean_functions, param, rng, settings, util
+from gptorch_amd._native import NativeError
+from gptorch_amd.models import GPR
+from gptorch_amd.models import base as base_mod
+from oracle import gp_oracle as orc
+from tests._util import load_json
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def test_import_does_not_change_default_dtype():
+    """test/test_base.py:10-22."""
+    assert torch.get_default_dtype() == torch.float32
+    assert util.torch_dtype == torch.float64 and util.TensorType is torch.DoubleTensor
+
+
+def test_param_transform_roundtrip():
+    """test/test_param.py:29-54: raw = log(value) under the default positive transform."""
+    p = param.Param(torch.tensor([2.5], dtype=torch.float64), transform=settings.DefaultPositiveTransform())
+    assert abs(p.data.item() - np.log(2.5)) < 1e-15
+    assert abs(p.transform().item() - 2.5) < 1e-15
+    assert p.requires_grad and p.prior is None
+    q = param.Param(torch.tensor([-1.0], dtype=torch.float64))
+    assert q.transform().item() == -1.0
+
+
+def test_as_tensor_types():
+    assert util.as_tensor(np.ones((2, 3), dtype=np.float32)).dtype == torch.float64
+    assert util.as_tensor(torch.ones(2, dtype=torch.float32)).dtype == torch.float64
+    assert util.as_tensor(1.5).shape == (1,)
+    with pytest.raises(TypeError):
+        util.as_tensor("x")
+
+
+def test_mean_functions():
+    z = mean_functions.Zero(2)
+    assert not z.val.requires_grad
+    assert torch.equal(z(torch.randn(5, 3, dtype=torch.float64)), torch.zeros(5, 2, dtype=torch.float64))
+    c = mean_functions.Constant(2, val=torch.tensor([1.0, -2.0], dtype=torch.float64))
+    assert c.val.requires_grad
+    assert torch.equal(c(torch.randn(4, 3, dtype=torch.float64))[3], torch.tensor([1.0, -2.0], dtype=torch.float64))
+    with pytest.raises(ValueError):
+        mean_functions.Constant(3, val=torch.zeros(2, dtype=torch.float64))
+
+
+def test_gpr_init_and_parameter_layout():
+    """test_gpr.py:24-34 + the golden parameter names / default noise."""
+    api = load_json("api_cases.json")
+    x, y = rng.make_regression(api["n"], api["d"], api["dy"], seed=api["seed"])
+    m = GPR(x, y, kernels.Rbf(3, ARD=True))
+    names = [(n, bool(p.requires_grad), list(p.shape)) for n, p in m.named_parameters()]
+    assert names == [tuple(e) if False else (e[0], e[1], e[2]) for e in api["param_names"]]
+    assert abs(m.likelihood.variance.transform().item() - api["default_noise_numpy"]) < 1e-15
+    m2 = GPR(torch.tensor(x), torch.tensor(y), kernels.Rbf(3))
+    assert abs(m2.likelihood.variance.transform().item() - api["default_noise_tensor"]) < 1e-15
+    GPR(x, y, kernels.Rbf(3), mean_function=torch.nn.Linear(3, 2))
+    assert m.num_data == 20 and m.input_dimension == 3 and m.output_dimension == 2
+    assert m.X.dtype == torch.float64 and not m.X.requires_grad
+    assert "kernel" in repr(m) and "variance" in repr(m)
+
+
+def test_kernel_hyperparameter_shapes():
+    k = kernels.Matern52(4, variance=2.0, length_scales=0.5)
+    assert k.variance.shape == (1,) and k.length_scales.shape == (1,) and not k.ARD
+    assert abs(k.length_scales.transform().item() - 0.5) < 1e-15
+    ka = kernels.Rbf(4, ARD=True)
+    assert ka.length_scales.shape == (4,)
+    kb = kernels.Rbf(3, ARD=True, length_scales=np.array([0.25, 0.5, 0.75]))
+    assert np.allclose(kb.length_scales.transform().detach().numpy(), [0.25, 0.5, 0.75])
+    assert kernels.SquaredExponential is kernels.Rbf
+    assert torch.equal(k.Kdiag(torch.zeros(7, 4, dtype=torch.float64)).detach(), torch.full((7,), 2.0, dtype=torch.float64))
+    assert isinstance(k + ka, kernels.Sum) and isinstance(k * ka, kernels.Product)
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    x, y = rng.make_regression(12, 2, 1, seed=1)
+    m = GPR(x, y, kernels.Rbf(2))
+    with pytest.raises(NativeError, match="no CPU fallback"):
+        m.loss()
+    with pytest.raises(NativeError):
+        m.predict_f(x[:3])
+    with pytest.raises(NativeError):
+        kernels.Rbf(2).K(torch.tensor(x))
+    with pytest.raises(NativeError):
+        gptorch_amd.functions.cholesky(torch.eye(3, dtype=torch.float64))
+    with pytest.raises(ValueError):          # size check precedes any native call (gpr.py:56-57)
+        m.loss(x=torch.tensor(x[:5]))
+    with pytest.raises(NotImplementedError):
+        GPR(x, y, kernels.Rbf(2) + kernels.Rbf(2)).loss()
+
+
+def test_jitter_ladder_logic():
+    """functions.py:20-43 replayed by _ops._ladder on the LAPACK-style info."""
+    from gptorch_amd import _ops
+    calls = []
+
+    def attempt_factory(ok_at):
+        def attempt(j):
+            calls.append(j)
+            return 0 if (j is not None and j >= ok_at) else 3
+        return attempt
+    assert _ops._ladder(lambda j: 0) == -1
+    calls.clear()
+    assert _ops._ladder(attempt_factory(1e-7)) == 3
+    assert calls[0] is None and np.allclose(calls[1:], [1e-10, 1e-9, 1e-8, 1e-7])
+    with pytest.raises(RuntimeError, match="Max tries exceeded."):
+        _ops._ladder(lambda j: 1)
+
+
+@pytest.fixture
+def oracle_backed(monkeypatch):
+    """GPR whose two native-backed methods are answered by the CPU oracle (tests only)."""
+    def _o(self):
+        k = self.kernel
+        o = orc.GPROracle(self.X.numpy(), self.Y.numpy(), kind=k._kind, ARD=k.ARD)
+        o.raw_variance, o.raw_length_scales, o.raw_noise = k.variance, k.length_scales, self.likelihood.variance
+        o.mean_val = self.mean_function.val
+        return o
+
+    def log_likelihood(self, x=None, y=None):
+        x = x if x is not None else self.X
+        y = y if y is not None else self.Y
+        if not x.shape[0] == y.shape[0]:
+            raise ValueError("X and Y must have same # data.")
+        return _o(self).log_likelihood(x, y)
+
+    def _predict(self, x_new, diag=True, x=None):
+        return _o(self).predict_f(x_new, diag=diag)
+
+    monkeypatch.setattr(GPR, "log_likelihood", log_likelihood)
+    monkeypatch.setattr(GPR, "_predict", _predict)
+    monkeypatch.setattr(base_mod, "cholesky", orc.cholesky)
+    x, y = rng.make_regression(30, 2, 2, seed=2)
+    return GPR(x, y, kernels.Rbf(2, ARD=True)), x, y
+
+
+def test_loss_and_flat_parameter_glue(oracle_backed):
+    """test/test_model.py:55-115 behaviours on a real model."""
+    m, x, y = oracle_backed
+    loss = m.loss()
+    assert loss.shape == (1,) and m.compute_loss().item() == loss.item()
+    assert m.loss(x=torch.tensor(x), y=torch.tensor(y)).item() == loss.item()
+    p0 = m._get_param_array()
+    assert p0.shape == (4,)                      # variance, 2 length-scales, noise; mean is frozen
+    m._set_parameters(p0 + 0.1)
+    assert np.allclose(m._get_param_array(), p0 + 0.1)
+    with quiet():
+        f, g = m._loss_and_grad(p0)
+    assert isinstance(f, float) and g.shape == (4,) and g.dtype == np.float64 and np.all(np.isfinite(g))
+    assert m.log_prior() == 0.0
+    m.kernel.variance.prior = torch.distributions.Gamma(torch.tensor(2.0, dtype=torch.float64),
+                                                         torch.tensor(1.0, dtype=torch.float64))
+    assert abs(m.log_prior().item() - torch.distributions.Gamma(2.0, 1.0).log_prob(torch.tensor(1.0)).item()) < 1e-6
+    assert abs(m.loss().item() - (loss.item() - m.log_prior().item())) < 1e-12
+
+
+def test_optimize_torch_and_scipy(oracle_backed):
+    """test/test_models/test_base.py:50-53 + return contracts (base.py:288-296, 298-320)."""
+    m, _, _ = oracle_backed
+    with quiet():
+        losses, t = m.optimize(method="Adam", max_iter=3, verbose=False)
+    assert losses.shape == (3,) and t > 0 and losses[2] < losses[0]
+    with quiet():
+        losses, _ = m.optimize(method="LBFGS", max_iter=2, verbose=True)
+    assert len(losses) <= 2
+    with quiet():
+        res = m.optimize(method="L-BFGS-B", max_iter=2)
+    assert hasattr(res, "x") and res.x.shape == (4,)
+    with pytest.raises(ValueError):
+        m.optimize(method="NotAnOptimizer")
+
+
+def test_predict_wrappers(oracle_backed):
+    """test_base.py:83-163: numpy in -> numpy out, tensor in -> tensor out, shapes, + noise."""
+    m, x, _ = oracle_backed
+    xs = rng.normal(4, (7, 2))
+    mu, var = m.predict_f(xs)
+    assert isinstance(mu, np.ndarray) and mu.shape == (7, 2) and var.shape == (7, 2)
+    mu_t, var_t = m.predict_f(torch.tensor(xs))
+    assert isinstance(mu_t, torch.Tensor) and np.allclose(mu_t.detach().numpy(), mu)
+    _, var_y = m.predict_y(xs)
+    assert np.allclose(var_y - var, m.likelihood.variance.transform().item())
+    _, cov = m.predict_f(xs, diag=False)
+    _, cov_y = m.predict_y(xs, diag=False)
+    assert cov.shape == (7, 7) and np.allclose(np.diag(cov_y) - np.diag(cov), m.likelihood.variance.transform().item())
+    torch.manual_seed(0)
+    assert m.predict_f_samples(xs, n_samples=5).shape == (5, 7, 2)
+    assert m.predict_y_samples(torch.tensor(xs), n_samples=3).shape == (3, 7, 2)
+
+
+def test_gaussian_likelihood_known_answer():
+    """test/test_likelihoods.py:45-59: Gaussian.logp known answer."""
+    lik = likelihoods.Gaussian(variance=1.0)
+    lp = lik.logp(torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64))
+    assert abs(lp.item() - (-0.5 * np.log(2 * np.pi))) < 1e-12
+    m, v = lik.predict_mean_variance(torch.zeros(3, 1, dtype=torch.float64), torch.ones(3, 1, dtype=torch.float64))
+    assert torch.allclose(v, torch.full((3, 1), 2.0, dtype=torch.float64))
+
+
+def test_rng_is_deterministic():
+    x, y = rng.make_regression(8192, 8, 1, seed=0)
+    c2 = [c for c in load_json("lml_cases.json") if c["name"] == "C2_rbf_8192_8"][0]
+    assert rng.checksum(x) == c2["x_checksum"] and rng.checksum(y) == c2["y_checksum"]
+    assert abs(x.mean()) < 0.01 and abs(x.std() - 1) < 0.01
