@@ -271,3 +271,19 @@ def test_adam_trajectory_golden(device):
         for name, p in [("kernel.variance", m.kernel.variance), ("kernel.length_scales", m.kernel.length_scales),
                         ("likelihood.variance", m.likelihood.variance)]:
             assert np.max(np.abs(p.detach().cpu().numpy() - np.asarray(case["final"][name]))) < 1e-8, (case["name"], name)
+
+
+def test_block_cyclic_single_rank_native(device):
+    """gptorch_amd/dist.py with the product's NativeTileOps on one GPU (grid 1x1): the same
+    tile code path every rank runs under RCCL; several tiles incl. a ragged last one."""
+    from gptorch_amd import dist as gdist
+    case = [c for c in LML if c["name"] == "rbf_1000_8_ls1"][0]
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    X, Y = torch.tensor(x, device=device), torch.tensor(y, device=device)
+    g = gdist.BlockCyclicGP(X, Y, "Rbf", tile=256)
+    v = torch.tensor([case["variance"]], dtype=torch.float64, device=device)
+    ls = torch.tensor([case["length_scales"]], dtype=torch.float64, device=device)
+    nz = torch.tensor([case["noise"]], dtype=torch.float64, device=device)
+    lml = g.log_likelihood(v, ls, nz, Y)
+    assert g.nt == 4 and g.info == 0
+    assert abs(lml.item() - case["lml"]) < 1e-8

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""2-D block-cyclic LML (gptorch_amd/dist.py) timing.  Single GPU:  python tools/dist_bench.py 16384 16 2048
+8 GPUs:  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/dist_bench.py 65536 32 2048"""
+import os, sys, time
+import torch
+import torch.distributed as dist
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from gptorch_amd import dist as gdist, rng  # noqa: E402
+
+n, d, T = (int(a) for a in (sys.argv[1:4] + ["16384", "16", "2048"][len(sys.argv) - 1:]))
+world = int(os.environ.get("WORLD_SIZE", "1"))
+local = int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+if world > 1:
+    dist.init_process_group("nccl", device_id=dev)
+x, y = rng.make_regression(n, d, 1, seed=0)
+X, Y = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
+g = gdist.BlockCyclicGP(X, Y, "Rbf", tile=T)
+one = torch.ones(1, dtype=torch.float64, device=dev)
+ls = one * float(d) ** 0.5
+for it in range(3):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    lml = g.log_likelihood(one, ls, 0.01 * one, Y)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if g.rank == 0:
+        print("N=%d D=%d T=%d world=%d grid=%dx%d: lml=%.8f  %.1f ms  (%.1f TFLOP/s aggregate on N^3/3)" % (
+            n, d, T, world, g.pr, g.pc, lml.item(), dt * 1e3, n ** 3 / 3 / dt / 1e12), flush=True)
+if world > 1:
+    dist.destroy_process_group()
