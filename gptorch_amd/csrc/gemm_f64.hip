@@ -136,7 +136,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     const int rg = b >> 1, kg8 = b & 1;
     const int row = (isA ? m0 : n0) + rg * 16;
     src_ok[i] = (idx < NBLK) && row < (isA ? mlim : nlim);
-    src_base[i] = (isA ? p.A + (int64_t)(row + frow) * p.lda : p.B + (int64_t)(row + frow) * p.ldb) + kg8 * 8 + fk;
+    // row groups past the operand's end re-read its first row group instead (always
+    // readable; the garbage only reaches output rows/cols that are never stored), so
+    // every wave issues exactly PER_WAVE DMAs per K-step and the counted waits stay exact
+    const int srow = src_ok[i] ? row : 0;
+    src_base[i] = (isA ? p.A + (int64_t)(srow + frow) * p.lda : p.B + (int64_t)(srow + frow) * p.ldb) + kg8 * 8 + fk;
   }
 
   // issue the loads of K-step `t` into LDS stage `s` (DMA) or registers (!DMA)
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       const int idx = wave + 4 * i;
       const double* src = src_base[i] + k0;
       if constexpr (DMA) {
-        if (src_ok[i]) {
+        if (idx < NBLK) {
           char* dst = smem + s * STAGE + idx * 1024;
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)src,
