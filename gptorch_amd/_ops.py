@@ -120,13 +120,14 @@ class Factor:
                                             _ptr(self.A[self.n]), self.ld)
             _native.check(st, "gpn_pack_rhs")
 
-    def potrf(self):
-        """In-place factorisation; returns the LAPACK-style info (host int; syncs)."""
+    def potrf(self, check=True):
+        """In-place factorisation; returns the LAPACK-style info (host int; syncs) or,
+        with check=False, enqueues only and returns None (read self.info later)."""
         self.info.zero_()
         st = _native.lib().gpn_potrf_lower(_stream(self.device), _ptr(self.A), self.n, self.e, self.ld,
                                            _ptr(self.winv), _ptr(self.info))
         _native.check(st, "gpn_potrf_lower")
-        return int(self.info.item())
+        return int(self.info.item()) if check else None
 
     def lml_terms(self):
         """tensor [3]: sum log L_ii, ||extra||_F^2, LML (gpr.py:63-67)."""
@@ -180,6 +181,24 @@ def cholesky_factor(x, rhs=None):
         return f.potrf()
 
     f.jitter_rung = _ladder(attempt)
+    return f
+
+
+def kernel_factor_async(kind, X, variance, length_scales, noise, R=None, factor=None):
+    """kernel_factor without the host read-back of `info`: everything is enqueued on the
+    current stream and the caller inspects f.info afterwards (a non-zero info must be
+    replayed through kernel_factor for the jitter ladder).  Lets several independent
+    models (hyper-parameter restarts) be in flight on different HIP streams."""
+    _req(X, variance, length_scales, noise, R)
+    n = X.shape[0]
+    e = 0 if R is None else R.shape[1]
+    f = factor if (factor is not None and factor.n == n and factor.e == e and factor.device == X.device) \
+        else Factor(n, e, X.device)
+    kernel_matrix(kind, X, None, variance, length_scales, noise=noise, out=f.A, ldk=f.ld, lower=True)
+    if e:
+        f.pack_rhs(R)
+    f.potrf(check=False)
+    f.jitter_rung = -1
     return f
 
 

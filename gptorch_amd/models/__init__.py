@@ -1,3 +1,3 @@
 """GP models (gptorch/models/__init__.py:20-21)."""
 from .base import GPModel  # noqa: F401
-from .gpr import GPR  # noqa: F401
+from .gpr import GPR, batched_log_likelihood  # noqa: F401

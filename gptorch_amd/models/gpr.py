@@ -70,3 +70,33 @@ class GPR(GPModel):
             mean_f = mean + self.mean_function(x_new)
             var_f = v[:, None].expand_as(mean_f) if diag else v
         return mean_f, var_f
+
+
+def batched_log_likelihood(models, streams=None):
+    """log_likelihood() of several INDEPENDENT GPR models (multi-start hyper-parameter
+    search: one model per restart), each enqueued on its own HIP stream so that the
+    latency-bound factorisation chain of one model overlaps the MFMA-bound trailing updates
+    of the others.  No gradients; returns a list of (1,) tensors.  Any model whose
+    factorisation reports info != 0 is re-evaluated through the sequential path (jitter
+    ladder of functions.py:20-43)."""
+    if streams is None:
+        streams = [torch.cuda.Stream(device=m.X.device) for m in models]
+    cur = torch.cuda.current_stream(models[0].X.device)
+    pending = []
+    with torch.no_grad():
+        for m, st in zip(models, streams):
+            k = m._stationary()
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                resid = m.Y - m.mean_function(m.X)
+                f = _ops.kernel_factor_async(k._kind, m.X, k.variance.transform(), k.length_scales.transform(),
+                                             m.likelihood.variance.transform(), R=resid,
+                                             factor=m._holder.get("factor"))
+                m._holder["factor"] = f
+                pending.append((f, f.lml_terms()))
+        for st in streams:
+            cur.wait_stream(st)
+        out = []
+        for m, (f, terms) in zip(models, pending):
+            out.append(terms[2:3] if int(f.info.item()) == 0 else m.log_likelihood())
+    return out
