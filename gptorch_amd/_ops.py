@@ -212,7 +212,12 @@ def kernel_factor(kind, X, variance, length_scales, noise, R=None, factor=None):
         else Factor(n, e, X.device)
 
     def attempt(jitter):
-        nz = noise if jitter is None else noise + jitter
+        if jitter is None:
+            nz = noise
+        elif noise is None:
+            nz = torch.full((1,), jitter, dtype=torch.float64, device=X.device)
+        else:
+            nz = noise + jitter
         kernel_matrix(kind, X, None, variance, length_scales, noise=nz, out=f.A, ldk=f.ld, lower=True)
         if e:
             f.pack_rhs(R)

@@ -1,3 +1,4 @@
 """GP models (gptorch/models/__init__.py:20-21)."""
 from .base import GPModel  # noqa: F401
 from .gpr import GPR, batched_log_likelihood  # noqa: F401
+from .sparse_gpr import VFE  # noqa: F401

@@ -265,3 +265,62 @@ def lml_closed_form_grads(kind, X, Y, variance, length_scales, noise, mean_val=N
     if ls.numel() == 1:
         g_ls = g_ls.sum().reshape(1)
     return lml, g_var, g_ls, g_noise
+
+
+# ----------------------------------------------------------------------------
+# VFE (gptorch/models/sparse_gpr.py:92-195) -- BASELINE config 5, SURVEY 8(f)-1
+# ----------------------------------------------------------------------------
+class VFEOracle:
+    """Titsias' collapsed bound exactly as sparse_gpr.py:108-153 evaluates it (zero mean;
+    note the reference's quirk `err = self.Y`, sparse_gpr.py:125)."""
+
+    def __init__(self, x, y, z, kind="Matern32", variance=1.0, length_scales=1.0, noise=1.0):
+        self.X = torch.as_tensor(np.asarray(x), dtype=DTYPE)
+        self.Y = torch.as_tensor(np.asarray(y), dtype=DTYPE)
+        self.Z = torch.as_tensor(np.asarray(z), dtype=DTYPE)
+        self.kind = kind
+        self.variance = torch.tensor([float(variance)], dtype=DTYPE)
+        self.ls = torch.as_tensor(np.atleast_1d(np.asarray(length_scales, dtype=np.float64)))
+        self.noise = torch.tensor([float(noise)], dtype=DTYPE)
+
+    def K(self, a, b=None):
+        return kernel_K(self.kind, a, b, self.variance, self.ls)
+
+    def _common(self, x):
+        m = self.Z.shape[0]
+        Kuf = self.K(self.Z, x)
+        L = cholesky(self.K(self.Z))
+        A = trtrs(Kuf, L)
+        AAT = A @ A.t() / self.noise
+        B = AAT + torch.eye(m, dtype=DTYPE)
+        LB = cholesky(B)
+        c = trtrs(A @ self.Y, LB) / self.noise
+        return L, A, AAT, LB, c
+
+    def log_likelihood(self):
+        """sparse_gpr.py:108-153."""
+        x = self.X
+        n, d_out = self.Y.shape
+        L, A, AAT, LB, c = self._common(x)
+        elbo = -0.5 * d_out * n * math.log(2 * math.pi)
+        elbo = elbo - d_out * LB.diag().log().sum()
+        elbo = elbo - 0.5 * d_out * n * self.noise.log()
+        elbo = elbo - 0.5 * (self.Y.pow(2).sum() + d_out * kernel_Kdiag(x, self.variance).sum()) / self.noise
+        elbo = elbo + 0.5 * c.pow(2).sum()
+        elbo = elbo + 0.5 * d_out * AAT.diag().sum()
+        return elbo[0]
+
+    def predict_f(self, x_new, diag=True):
+        """sparse_gpr.py:155-195."""
+        x_new = torch.as_tensor(np.asarray(x_new), dtype=DTYPE)
+        L, A, AAT, LB, c = self._common(self.X)
+        Kus = self.K(self.Z, x_new)
+        tmp1 = trtrs(Kus, L)
+        tmp2 = trtrs(tmp1, LB)
+        mean = tmp2.t() @ c
+        if diag:
+            var = (kernel_Kdiag(x_new, self.variance) - tmp1.pow(2).sum(0).squeeze()
+                   + tmp2.pow(2).sum(0).squeeze())[:, None].expand_as(mean)
+        else:
+            var = self.K(x_new) + tmp2.t() @ tmp2 - tmp1.t() @ tmp1
+        return mean, var

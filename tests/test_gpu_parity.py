@@ -287,3 +287,44 @@ def test_block_cyclic_single_rank_native(device):
     lml = g.log_likelihood(v, ls, nz, Y)
     assert g.nt == 4 and g.info == 0
     assert abs(lml.item() - case["lml"]) < 1e-8
+
+
+# ---- VFE (sparse_gpr.py:92-195; BASELINE config 5) -------------------------------
+def test_vfe_reference_known_answer(device):
+    """The reference's own pins: loss == approx(8.842242323920674) and vfe_y_mean/cov.dat
+    (test/test_models/test_sparse_gpr.py:81-142, pytest.approx = rel 1e-6)."""
+    from gptorch_amd.models import VFE
+    z = load_npz("ref_sparse_gpr_fixtures.npz")
+    m = VFE(z["x"], z["y"], kernels.Matern32(1), inducing_points=z["z"], likelihood=likelihoods.Gaussian(variance=1.0),
+            mean_function=mean_functions.Zero(1))
+    m.cuda()
+    loss = m.loss()
+    assert loss.ndimension() == 0 and loss.is_cuda
+    assert loss.item() == pytest.approx(8.842242323920674)
+    assert abs(loss.item() - float(z["vfe_loss_reference_run"][0])) < 1e-9
+    xt = torch.tensor(z["x_test"], device=device)
+    mu, s = m._predict(xt, diag=False)
+    assert mu.cpu().numpy().ravel() == pytest.approx(z["vfe_y_mean"].ravel())
+    assert s.cpu().numpy().ravel() == pytest.approx(z["vfe_y_cov"].ravel())
+    mu_d, s_d = m._predict(xt, diag=True)
+    assert s_d.shape == mu_d.shape
+    assert s_d.cpu().numpy().ravel() == pytest.approx(np.diag(z["vfe_y_cov"]))
+
+
+def test_vfe_medium_golden(device):
+    from gptorch_amd.models import VFE
+    case = load_json("vfe_cases.json")[0]
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    zpts = rng.normal(case["seed_z"], (case["m"], case["d"]))
+    m = VFE(x, y, kernels.Matern52(case["d"], variance=case["variance"], length_scales=case["length_scales"]),
+            inducing_points=zpts, likelihood=likelihoods.Gaussian(variance=case["noise"]),
+            mean_function=mean_functions.Zero(case["dy"]))
+    m.cuda()
+    elbo = m.log_likelihood().item()
+    assert abs(elbo - case["elbo"]) < 1e-8 * abs(case["elbo"]), (elbo, case["elbo"])
+    xs = rng.normal(case["seed_xs"], (16, case["d"]))
+    mu, var = m.predict_f(xs)
+    _, cov = m.predict_f(xs, diag=False)
+    assert np.max(np.abs(mu - np.asarray(case["mean"]))) < 1e-8
+    assert np.max(np.abs(var - np.asarray(case["var"]))) < 1e-8
+    assert np.max(np.abs(cov - np.asarray(case["cov"]))) < 1e-8
