@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the backward / concurrent-restart legs (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,13 +146,50 @@ def main():
     launches, gemm_ms, exec_flops = res[0], res[1], res[2]
     alg = algorithmic_gemm_flops(w["n"], w["dy"]) * args.steps
     achieved = alg / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):   # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
+        traffic = json.load(open(tpath)).get("gemm_bytes_per_launch")
     roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (fp64 MFMA NT contraction: SYRK/GEMM trailing updates + panel solves)",
                 "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
                 "launches_per_step": launches / args.steps, "avg_launch_us": gemm_ms * 1e3 / max(launches, 1),
                 "algorithmic_flops_per_launch": alg / max(launches, 1),
                 "executed_tflops": exec_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0,
                 "kernel_ms_per_step": gemm_ms / args.steps}
+
+    # extra (not part of `value`): one loss()+backward() step -- what Adam (base.py:260-269) pays
+    # per iteration -- and the throughput with 4 independent restarts in flight on 4 HIP streams
+    extra = {}
+    if world == 1 and args.workload != "c3" and not args.no_extras:
+        torch.cuda.synchronize()
+        for _ in range(2):
+            model.zero_grad()
+            model.loss().backward()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nb = max(2, args.steps // 4)
+        for _ in range(nb):
+            model.zero_grad()
+            model.loss().backward()
+        torch.cuda.synchronize()
+        extra["loss_backward_ms"] = (time.perf_counter() - t1) / nb * 1e3
+        from gptorch_amd.models import batched_log_likelihood
+        R = 4
+        models = [model] + [build_model(w, seed=100 + r, device=device)[0] for r in range(R - 1)]
+        streams = [torch.cuda.Stream(device=device) for _ in range(R)]
+        for _ in range(2):
+            batched_log_likelihood(models, streams)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rounds = max(2, args.steps // 4)
+        for _ in range(rounds):
+            batched_log_likelihood(models, streams)
+        torch.cuda.synchronize()
+        extra["concurrent_restarts"] = {"restarts": R, "evals_per_s": R * rounds / (time.perf_counter() - t1),
+                                        "note": "R independent models on R HIP streams (eager launches, host-bound); "
+                                                "not the headline value"}
+        del models
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -167,6 +205,7 @@ def main():
             "cholesky_frac_of_fp64_peak": (w["n"] ** 3 / 3.0) / (elapsed / args.steps) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
             "roofline": roofline,
         }
+        line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, x, y)
         print(json.dumps(line), flush=True)
