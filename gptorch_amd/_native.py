@@ -43,7 +43,6 @@ SIGNATURES = {
 # not part of the public header: debugging switches
 DEBUG_SIGNATURES = {
     "gpn_debug_set_gemm_variant": (c_int, [c_int]),
-    "gpn_debug_leaf_timing": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_profile_enable": (c_int, [c_int]),
     "gpn_profile_collect": (c_int, [ctypes.POINTER(c_double)]),
 }

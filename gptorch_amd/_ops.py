@@ -16,7 +16,7 @@ from ._native import NativeError
 
 KINDS = {"Rbf": 0, "Matern52": 1, "Matern32": 2, "Exp": 3, "Matern12": 3, "SqDist": 4}
 GPN_FULL, GPN_LOWER = 0, 1
-LEAF = 64
+LEAF = 128   # leaf block of the factorisation = padding granule of factor buffers (gpn_common.h)
 
 
 def _ptr(t):

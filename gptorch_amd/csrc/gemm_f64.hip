@@ -270,7 +270,7 @@ static int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging (de
 
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
-            double beta, double* C, int64_t ldc, int lower, int tri) {
+            double beta, double* C, int64_t ldc, int lower, int tri, int inplace) {
   if (M <= 0 || N <= 0) return GPN_OK;
   GemmArgs a;
   a.A = A; a.B = B; a.C = C;
@@ -290,6 +290,12 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
   const double t128 = (double)((tiles(128) + 511) / 512) * 8.0;
   const double t64 = (double)((tiles(64) + 1279) / 1280) * 5.0 / 0.85;
   const bool small = (N <= 64) || (M <= 64) || t64 < t128;
+  if (inplace) {
+    // C aliases A (panel solve against an inverted leaf block): one column tile must cover
+    // the whole N and K extent of its rows -- a workgroup only stores after its last load
+    if (N > 128 || K > 128 || lower) return GPN_E_UNSUPPORTED;
+    return launch<64, 128, 32, 64, true>(s, a);
+  }
   if (g_gemm_variant == 0) {
     return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true>(s, a);
   }
@@ -317,5 +323,5 @@ extern "C" int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double
     return GPN_E_UNSUPPORTED;
   }
   if (tri < 0 || tri > 15) return -14;
-  return gpn::gemm_nt(static_cast<hipStream_t>(stream), M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri);
+  return gpn::gemm_nt(static_cast<hipStream_t>(stream), M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, 0);
 }

@@ -6,7 +6,7 @@
 
 namespace gpn {
 
-constexpr int LEAF = 64;  // diagonal leaf block (potrf+inverse in one workgroup)
+constexpr int LEAF = 128;  // diagonal leaf block (potrf + inverse in one workgroup) = padding granule of factor buffers
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -27,7 +27,7 @@ void set_hip_error(hipError_t e, const char* where);
 // the factorisation drivers (no argument validation).
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
-            double beta, double* C, int64_t ldc, int lower, int tri = 0);
+            double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0);
 
 bool profile_on();
 void profile_begin(hipStream_t s, double flops);

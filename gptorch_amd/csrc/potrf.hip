@@ -2,16 +2,16 @@
 // solves built on it.  Replaces torch.cholesky / torch.triangular_solve under
 // functions.cholesky / functions.trtrs (functions.py:46-47, 71-76).
 //
-// Structure: recursive blocking down to a 64x64 leaf.
+// Structure: recursive blocking down to a 128x128 leaf.
 //   potrf(A):  A11 = potrf(A11);  A21 <- A21 * L11^-T;  A22 -= A21 A21^T;  potrf(A22)
 //   trsm(B,L): B1 <- B1 * L11^-T; B2 -= B1 * L21^T;     B2 <- B2 * L22^-T
 // Every flop outside the 64x64 leaves is an "NT" fp64-MFMA contraction
 // (gemm_f64.hip) whose K extent is as large as the recursion allows, so the
 // N^2 matrix is streamed O(log N) times instead of N/nb times and the trailing
 // updates stay MFMA-bound rather than HBM-bound.  The leaf kernel factors its
-// block AND inverts it in one workgroup (fused right-looking elimination on
-// [A | I] in LDS); panel solves are then products with the stored inverses, done
-// IN PLACE: a 64-column-wide tile covers the whole K and N extent of its rows,
+// block AND inverts it in one workgroup (blocked elimination on [A ; I], see
+// below); panel solves are then products with the stored inverses, done
+// IN PLACE: a LEAF-column-wide tile covers the whole K and N extent of its rows,
 // and a workgroup only stores after its last load.
 //
 // "Extra rows" (gpnative.h): rows n..n+e-1 ride along in every panel solve and
@@ -22,34 +22,32 @@
 
 namespace gpn {
 
-// One workgroup: L = chol(A[0:kb,0:kb]) in place, W = L^-1 -> winv (64x64, ld 64,
-// zero outside the kb x kb lower triangle).  col0 = global index of column 0
-// (for info).  Rows/cols >= kb are treated as identity.
-// FACTOR=false: A already holds a lower-triangular L; only the inverse is formed
-// (one workgroup per 64-block: blockIdx.x selects the diagonal block).
+// ---------------------------------------------------------------------------------
+// Leaf: one workgroup (512 threads, 8 waves) factors a 128x128 diagonal block AND
+// forms its inverse:  L = chol(A[0:kb,0:kb]) in place,  W = L^-1 -> winv (128x128,
+// ld 128, zero outside the kb x kb lower triangle).  Rows/cols >= kb act as identity.
+// FACTOR=false: A already holds a lower-triangular L; only W is formed (blockIdx.x
+// selects the diagonal block).
 //
-// Right-looking elimination on [A | I] with the whole working set in REGISTERS:
-// the 256 threads form a 16x16 grid, thread (ty,tx) owns A[ty+16a][tx+16b] and
-// W[ty+16a][tx+16b], a,b = 0..3.  Per pivot column j only the (unscaled) column
-// j of A and row j of W cross threads, through a double-buffered 2x64-double LDS
-// broadcast: one barrier per column; every thread derives 1/sqrt(d) itself.
-// Finished columns of L / rows of W stay in registers and are stored once at the end.
-#define GPN_STAMP(k)                                                                       \
-  if constexpr (DIAG) {                                                                    \
-    unsigned long long t_;                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    acc_t[k] += t_ - last_t;                                                               \
-    last_t = t_;                                                                           \
-  }
+// Right-looking, blocked by 8 columns, on the stacked matrix [A ; I] (256 x 128): the
+// identity rows are "extra rows" exactly as in the outer algorithm, so they come out as
+// I * L^-T = W^T and the inverse needs no pass of its own.  The whole trailing matrix
+// lives in REGISTERS as 16x16 MFMA accumulator tiles (72 tiles, 9 per wave); per block of
+// 8 pivots:
+//   P0  owners of the current tile column publish the raw 8-column panel to LDS
+//   P1  wave 0 factors the 8x8 diagonal block in-lane (no cross-lane traffic on the
+//       serial pivot chain: rsq + Newton per pivot), publishes L8 and 1/diag
+//   P2  one thread per row solves its 8 panel entries against L8 (forward substitution),
+//       stores them to global (final L / W values) and back to LDS
+//   P3  rank-8 update of every live tile: 2 x v_mfma_f64_16x16x4_f64 per tile
+// 3 barriers per 8 pivots; the panel buffer is double-buffered.
+// ---------------------------------------------------------------------------------
+constexpr int XPS = 9;                 // padded row of the panel buffer (doubles)
 
-template <bool FACTOR, bool DIAG = false>
-__global__ __launch_bounds__(256) void potrf_leaf_kernel(double* A, int64_t lda, int kb_, int col0_,
-                                                         double* winv_, int32_t* info, int n_total,
-                                                         unsigned long long* diag = nullptr) {
-  unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, last_t = 0;
-  if constexpr (DIAG) last_t = __builtin_amdgcn_s_memtime();
+template <bool FACTOR>
+__global__ __launch_bounds__(512) void potrf_leaf_kernel(double* A, int64_t lda, int kb_, int col0_,
+                                                         double* winv_, int32_t* info, int n_total) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
   int kb = kb_, col0 = col0_;
   double* winv = winv_;
   if constexpr (!FACTOR) {
@@ -58,166 +56,173 @@ __global__ __launch_bounds__(256) void potrf_leaf_kernel(double* A, int64_t lda,
     A += (int64_t)col0 * lda + col0;
     winv += (int64_t)blockIdx.x * LEAF * LEAF;
   }
-  __shared__ double colbuf[2][LEAF];
-  __shared__ double rowbuf[2][LEAF];
+  __shared__ double Xp[2][256 * XPS];   // panel rows 0..127: A part, 128..255: identity (-> W^T) part
+  __shared__ double Dg[64 + 8];         // L8 (row-major 8x8) + reciprocal diagonal
+  __shared__ int failflag;
+
   const int tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;      // D-layout: rows lr + 4r, column lc
+  if (tid == 0) failflag = 0;
 
-  double ar[4][4], wr_[4][4];
+  // tile slots: global slot s = wave + 8k (k = 0..8); J = s / 9, idx = s % 9;
+  // idx < 8-J: A-part tile row I = J + idx;  else identity-part tile row I = 8 + (idx - (8-J))
+  int TI[9], TJ[9];
+  d4 acc[9];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int k = 0; k < 9; ++k) {
+    const int s = wave + 8 * k;
+    const int J = s / 9, idx = s - 9 * J;
+    const int I = (idx < 8 - J) ? J + idx : 8 + (idx - (8 - J));
+    TI[k] = I;
+    TJ[k] = J;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = ty + 16 * a, c = tx + 16 * b;
-      double v = (i == c) ? 1.0 : 0.0;
-      if (i < kb && c <= i) v = A[(int64_t)i * lda + c];
-      ar[a][b] = v;
-      wr_[a][b] = (i == c) ? 1.0 : 0.0;
-    }
-
-  int fail = 0;
-  // broadcast of column 0 / row 0
-  if (tx == 0) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a) colbuf[0][ty + 16 * a] = ar[a][0];
-  }
-  if (ty == 0) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) rowbuf[0][tx + 16 * b] = wr_[0][b];
-  }
-
-  // 4 blocks of 16 pivots; the block index is a compile-time constant so that every
-  // register-array subscript below is static (no selects, no scratch)
-  auto pivots16 = [&](auto jb_c) {
-    constexpr int jb = decltype(jb_c)::value;
-    for (int jt = 0; jt < 16; ++jt) {
-      const int j = jb * 16 + jt;
-      const int p = j & 1;
-      GPN_STAMP(4)
-      __syncthreads();
-      GPN_STAMP(0)
-      const double d = colbuf[p][j];
-      if (FACTOR ? !(d > 0.0) : (d == 0.0)) {   // LAPACK dpotrf: ajj <= 0 or NaN; dtrtri: zero pivot
-        fail = j + 1;                            // d comes from LDS: uniform across the workgroup
-        return;
-      }
-      // values every thread needs from column j / row j (all LDS reads issued together)
-      double cl[4], cc[4], rw[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) cl[a] = colbuf[p][ty + 16 * a];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        cc[b] = colbuf[p][tx + 16 * b];
-        rw[b] = rowbuf[p][tx + 16 * b];
-      }
-      // 1/sqrt(d) by v_rsq_f64 + two Newton steps (the serial chain of the whole
-      // factorisation runs through here: ~6 dependent ops instead of sqrt + divide);
-      // s = d * inv_s is then within 1 ulp of sqrt(d).  trtri mode: inv_s = 1/d.
-      double s, inv_s;
-      if (FACTOR) {
-        double y = __builtin_amdgcn_rsq(d);
-        const double hd = 0.5 * d;
-        y = fma(y, fma(-hd * y, y, 0.5), y);
-        y = fma(y, fma(-hd * y, y, 0.5), y);
-        inv_s = y;
-        s = d * y;
-        s = fma(fma(-s, s, d), 0.5 * y, s);   // one correction of sqrt(d) itself
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + lr + 4 * r, col = 16 * J + lc;
+      double v;
+      if (I < 8) {
+        v = (row == col) ? 1.0 : 0.0;
+        if (row < kb && col <= row) v = A[(int64_t)row * lda + col];
       } else {
-        s = d;
-        inv_s = 1.0 / d;
+        v = (row - 128 == col) ? 1.0 : 0.0;
       }
-      // rows/cols at or before the pivot take no part: blocks a < jb (b < jb) are dead
-      // for the A part, blocks b > jb are dead for the W part -- all decided statically
-      double li[4], lc[4], wj[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        if (a < jb) li[a] = 0.0;
-        else if (a == jb) li[a] = (ty > jt) ? (FACTOR ? cl[a] * inv_s : cl[a]) : 0.0;
-        else li[a] = FACTOR ? cl[a] * inv_s : cl[a];
-      }
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (!FACTOR || b < jb) lc[b] = 0.0;
-        else if (b == jb) lc[b] = (tx > jt) ? cc[b] * inv_s : 0.0;
-        else lc[b] = cc[b] * inv_s;
-        if (b > jb) wj[b] = 0.0;
-        else if (b == jb) wj[b] = (tx <= jt) ? rw[b] * inv_s : 0.0;
-        else wj[b] = rw[b] * inv_s;
-      }
-      GPN_STAMP(1)
-      // look-ahead: bring column j+1 of A / row j+1 of W up to date FIRST and publish
-      // them through the other buffer, so the next pivot's chain starts while the bulk
-      // of this rank-1 update is still being issued
-      if (jt < 15) {
-        if (tx == jt + 1) {
-#pragma unroll
-          for (int a = jb; a < 4; ++a)
-            colbuf[p ^ 1][ty + 16 * a] = FACTOR ? fma(-li[a], lc[jb], ar[a][jb]) : ar[a][jb];
-        }
-        if (ty == jt + 1) {
-#pragma unroll
-          for (int b = 0; b <= jb; ++b) rowbuf[p ^ 1][tx + 16 * b] = fma(-li[jb], wj[b], wr_[jb][b]);
-        }
-      } else if constexpr (jb < 3) {
-        if (tx == 0) {
-#pragma unroll
-          for (int a = jb + 1; a < 4; ++a)
-            colbuf[p ^ 1][ty + 16 * a] = FACTOR ? fma(-li[a], lc[jb + 1], ar[a][jb + 1]) : ar[a][jb + 1];
-        }
-        if (ty == 0) {
-#pragma unroll
-          for (int b = 0; b <= jb + 1; ++b) rowbuf[p ^ 1][tx + 16 * b] = fma(-li[jb + 1], wj[b], wr_[jb + 1][b]);
-        }
-      }
-      GPN_STAMP(2)
-      // finished column j of L / row j of W stay in their owners' registers (the bulk
-      // update below leaves them alone: lc = 0 for c <= j, li = 0 for i <= j)
-      if (FACTOR && tx == jt) {
-        ar[jb][jb] = (ty == jt) ? s : (ty > jt ? li[jb] : ar[jb][jb]);
-#pragma unroll
-        for (int a = jb + 1; a < 4; ++a) ar[a][jb] = li[a];
-      }
-      if (ty == jt) {
-#pragma unroll
-        for (int b = 0; b < jb; ++b) wr_[jb][b] = wj[b];
-        if (tx <= jt) wr_[jb][jb] = wj[jb];
-      }
-      GPN_STAMP(3)
-      // rank-1 update of the trailing rows (registers only; dead blocks skipped statically)
-#pragma unroll
-      for (int a = jb; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          if (FACTOR && b >= jb) ar[a][b] = fma(-li[a], lc[b], ar[a][b]);
-          if (b <= jb) wr_[a][b] = fma(-li[a], wj[b], wr_[a][b]);
-        }
+      acc[k][r] = v;
     }
-  };
-  pivots16(std::integral_constant<int, 0>{});
-  if (!fail) pivots16(std::integral_constant<int, 1>{});
-  if (!fail) pivots16(std::integral_constant<int, 2>{});
-  if (!fail) pivots16(std::integral_constant<int, 3>{});
+  }
   __syncthreads();
-  if constexpr (DIAG) {
-    GPN_STAMP(5)
-    if ((tid & 63) == 0) for (int k = 0; k < 6; ++k) diag[(tid >> 6) * 6 + k] = acc_t[k];
-  }
-  if (fail) {
-    if (tid == 0 && info && *info == 0) *info = col0 + fail;
-    // leave A untouched; still publish a finite winv so later kernels stay finite
-    for (int idx = tid; idx < LEAF * LEAF; idx += 256) winv[idx] = 0.0;
-    return;
-  }
+
+  for (int kb8 = 0; kb8 < 16; ++kb8) {
+    const int c0 = kb8 * 8;
+    const int J0 = kb8 >> 1, half = kb8 & 1;
+    double* xp = Xp[kb8 & 1];
+    // ---- P0: publish the raw panel (8 columns of tile column J0) --------------------
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int k = 0; k < 9; ++k) {
+      if (TJ[k] == J0 && (lc >> 3) == half) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int i = ty + 16 * a, c = tx + 16 * b;
-      const bool in = (i < kb && c <= i);
-      if (FACTOR && in) A[(int64_t)i * lda + c] = ar[a][b];
-      winv[i * LEAF + c] = in ? wr_[a][b] : 0.0;
+        for (int r = 0; r < 4; ++r) xp[(16 * TI[k] + lr + 4 * r) * XPS + (lc & 7)] = acc[k][r];
+      }
     }
+    __syncthreads();
+    // ---- P1: 8x8 diagonal block, in-lane, wave 0 ------------------------------------
+    if (wave == 0) {
+      double a[8][8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c <= i; ++c) a[i][c] = xp[(c0 + i) * XPS + c];
+      double invd[8];
+      int fail = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        double d = a[j][j];
+        if (FACTOR) {
+          if (!(d > 0.0)) {              // LAPACK dpotrf: ajj <= 0 or NaN
+            if (!fail) fail = c0 + j + 1;
+            d = 1.0;
+          }
+          double y = __builtin_amdgcn_rsq(d);
+          const double hd = 0.5 * d;
+          y = fma(y, fma(-hd * y, y, 0.5), y);
+          y = fma(y, fma(-hd * y, y, 0.5), y);
+          double sq = d * y;
+          sq = fma(fma(-sq, sq, d), 0.5 * y, sq);
+          a[j][j] = sq;
+          invd[j] = y;
+#pragma unroll
+          for (int i = j + 1; i < 8; ++i) a[i][j] *= y;
+#pragma unroll
+          for (int c = j + 1; c < 8; ++c)
+#pragma unroll
+            for (int i = c; i < 8; ++i) a[i][c] = fma(-a[i][j], a[c][j], a[i][c]);
+        } else {
+          if (d == 0.0) {                // dtrtri: zero pivot
+            if (!fail) fail = c0 + j + 1;
+            d = 1.0;
+          }
+          invd[j] = 1.0 / d;
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int c = 0; c <= i; ++c) Dg[i * 8 + c] = a[i][c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Dg[64 + j] = invd[j];
+        if (fail) failflag = fail;
+      }
+    }
+    __syncthreads();
+    if (failflag) break;                 // uniform
+    // ---- P2: one thread per panel row: forward substitution against L8 ----------------
+    if (tid < 256) {
+      const bool apart = tid < 128;
+      const int rho = apart ? tid : tid - 128;
+      const bool solve = apart ? (FACTOR && tid >= c0 + 8) : (rho <= c0 + 7);
+      const bool diagrow = apart && tid >= c0 && tid < c0 + 8;
+      double x[8];
+      if (solve) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = xp[tid * XPS + c];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          double v = x[c];
+#pragma unroll
+          for (int k2 = 0; k2 < c; ++k2) v = fma(-x[k2], Dg[c * 8 + k2], v);
+          x[c] = v * Dg[64 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xp[tid * XPS + c] = x[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = 0.0;
+      }
+      if (apart) {
+        if (FACTOR && tid < kb) {
+          if (solve) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+              if (c0 + c < kb) A[(int64_t)tid * lda + c0 + c] = x[c];
+          } else if (diagrow) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+              if (c <= tid - c0) A[(int64_t)tid * lda + c0 + c] = Dg[(tid - c0) * 8 + c];
+          }
+        }
+      } else {
+        // W[c0+c][rho] = (W^T)[rho][c0+c]; zeros everywhere else of the 128x128 block
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const bool in = (c0 + c < kb) && (rho < kb);
+          winv[(int64_t)(c0 + c) * LEAF + rho] = in ? x[c] : 0.0;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- P3: rank-8 update of the live tiles -------------------------------------------
+    const int jact = (c0 + 8) >> 4;      // first tile column that still has unfinished columns
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int I = TI[k], J = TJ[k];
+      const bool live = (J >= jact) && (I < 8 ? FACTOR : (I - 8 <= J0));
+      if (live) {                        // wave-uniform
+        const double* pa = xp + (16 * I + lc) * XPS + lr;
+        const double* pb = xp + (16 * J + lc) * XPS + lr;
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[0], pb[0], acc[k], 0, 0, 0);
+        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4], pb[4], acc[k], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  if (failflag) {
+    if (tid == 0 && info && *info == 0) *info = col0 + failflag;
+    // leave the rest of A untouched; publish a finite (zero) winv so later kernels stay finite
+    for (int idx = tid; idx < LEAF * LEAF; idx += 512) winv[idx] = 0.0;
+  }
 }
+
 
 struct Ctx {
   hipStream_t s;
@@ -240,8 +245,8 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
   if (c.rc != GPN_OK || m <= 0 || kb <= 0) return;
   if (kb <= LEAF) {
     const double* W = winv + (diag0 / LEAF) * (LEAF * LEAF);
-    // in place: one 64-wide column tile per row block (see file header)
-    c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0);
+    // in place: one LEAF-wide column tile per row block (see file header)
+    c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, 0, /*inplace=*/1);
     return;
   }
   const int64_t h = split_point(kb);
@@ -254,8 +259,8 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
 static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   if (c.rc != GPN_OK || n <= 0) return;
   if (n <= LEAF) {
-    hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(256), 0, c.s, A, c.lda, (int)n, (int)col0,
-                       c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0, nullptr);
+    hipLaunchKernelGGL(potrf_leaf_kernel<true>, dim3(1), dim3(512), 0, c.s, A, c.lda, (int)n, (int)col0,
+                       c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0);
     if (hipGetLastError() != hipSuccess) { c.rc = GPN_E_HIP; return; }
     if (e > 0) trsm_rec(c, A + n * c.lda, e, c.lda, A, c.lda, n, col0, c.winv);
     return;
@@ -270,18 +275,21 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   potrf_rec(c, A21 + h, n - h, e, col0 + h);
 }
 
-// U_ii <- W_ii^T for every 64x64 diagonal block (one workgroup per block)
+// U_ii <- W_ii^T for every LEAF x LEAF diagonal block
 __global__ __launch_bounds__(256) void diag_transpose_kernel(const double* winv, double* U, int64_t ldu, int n) {
-  __shared__ double t[LEAF][LEAF + 1];
+  // 32x32 sub-tiles through LDS: blockIdx.y enumerates the (LEAF/32)^2 sub-tiles of W
+  __shared__ double t[32][33];
   const int blk = blockIdx.x, tid = threadIdx.x;
+  const int si = blockIdx.y / (LEAF / 32), sj = blockIdx.y % (LEAF / 32);
   const double* W = winv + (int64_t)blk * LEAF * LEAF;
-  for (int idx = tid; idx < LEAF * LEAF; idx += 256) t[idx >> 6][idx & 63] = W[idx];
+  const int tx = tid & 31, ty = tid >> 5;
+  for (int k = ty; k < 32; k += 8) t[k][tx] = W[(si * 32 + k) * LEAF + sj * 32 + tx];
   __syncthreads();
   const int kb = min(LEAF, n - blk * LEAF);
   double* Ub = U + ((int64_t)blk * LEAF) * ldu + blk * LEAF;
-  for (int idx = tid; idx < LEAF * LEAF; idx += 256) {
-    const int i = idx >> 6, c = idx & 63;
-    if (i < kb && c < kb) Ub[(int64_t)i * ldu + c] = t[c][i];
+  for (int k = ty; k < 32; k += 8) {
+    const int i = sj * 32 + k, c = si * 32 + tx;     // U[i][c] = W[c][i]
+    if (i < kb && c < kb) Ub[(int64_t)i * ldu + c] = t[tx][k];
   }
 }
 
@@ -399,17 +407,6 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
   return c.rc;
 }
 
-// diagnostic build of the leaf with s_memtime stamps: diag[wave*6 + k] = cycles summed
-// over the 64 columns in segment k (0 barrier, 1 pivot+reads, 2 look-ahead publish,
-// 3 park, 4 bulk update, 5 tail).  Not part of the public header.
-extern "C" int gpn_debug_leaf_timing(void* stream, double* A, int64_t lda, double* winv, int32_t* info,
-                                     unsigned long long* diag24) {
-  hipLaunchKernelGGL((potrf_leaf_kernel<true, true>), dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     A, lda, LEAF, 0, winv, info, 0, diag24);
-  GPN_LAUNCH_CHECK();
-  return GPN_OK;
-}
-
 extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t ldl, double* winv, int32_t* info) {
   if (!L) return -2;
   if (n < 0) return -3;
@@ -417,8 +414,8 @@ extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t 
   if (!winv) return -5;
   if (n == 0) return GPN_OK;
   const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
-  hipLaunchKernelGGL((potrf_leaf_kernel<false, false>), dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     const_cast<double*>(L), ldl, 0, 0, winv, info, (int)n, nullptr);
+  hipLaunchKernelGGL(potrf_leaf_kernel<false>, dim3(nb), dim3(512), 0, static_cast<hipStream_t>(stream),
+                     const_cast<double*>(L), ldl, 0, 0, winv, info, (int)n);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
@@ -451,7 +448,7 @@ extern "C" int gpn_trtri_upper(void* stream, const double* L, int64_t n, int64_t
   if (n == 0) return GPN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
-  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb), dim3(256), 0, s, winv, U, ldu, (int)n);
+  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb, (LEAF / 32) * (LEAF / 32)), dim3(256), 0, s, winv, U, ldu, (int)n);
   GPN_LAUNCH_CHECK();
   Ctx c{s, ldl, const_cast<double*>(winv), nullptr, GPN_OK};
   trtri_rec(c, L, ldl, U, ldu, n, 0);

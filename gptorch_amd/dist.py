@@ -51,7 +51,7 @@ class NativeTileOps:
 
     def new_tile(self, rows, cols):
         """zeroed factor-style buffer holding a rows x cols tile (ld multiple of 64, +apron)."""
-        return torch.zeros(_ops.round_up(rows, 64) + 16, _ops.round_up(cols, 64), dtype=torch.float64,
+        return torch.zeros(_ops.round_up(rows, _ops.LEAF) + 16, _ops.round_up(cols, _ops.LEAF), dtype=torch.float64,
                            device=self.device)
 
     def kernel_tile(self, kind, Xi, Xj, variance, ls, noise, out):
@@ -60,12 +60,15 @@ class NativeTileOps:
 
     def potrf(self, tile, n):
         """in-place lower Cholesky of tile[:n,:n]; returns (winv, info_tensor)."""
-        winv = torch.empty(_ops.round_up(n, 64) * 64, dtype=torch.float64, device=tile.device)
+        winv = torch.empty(int(_ops._native.lib().gpn_winv_bytes(n)) // 8, dtype=torch.float64, device=tile.device)
         info = torch.zeros(1, dtype=torch.int32, device=tile.device)
         st = _ops._native.lib().gpn_potrf_lower(_ops._stream(tile.device), _ops._ptr(tile), n, 0, tile.stride(0),
                                                 _ops._ptr(winv), _ops._ptr(info))
         _ops._native.check(st, "gpn_potrf_lower")
         return winv, info
+
+    def winv_numel(self, n):
+        return int(_ops._native.lib().gpn_winv_bytes(n)) // 8
 
     def trsm(self, L, winv, n, B, m):
         """B[:m,:n] <- B L^-T."""
@@ -96,7 +99,7 @@ class BlockCyclicGP:
         self.X, self.Y, self.kind = X, Y, kind
         self.n, self.dy = Y.shape
         self.T = int(tile)
-        assert self.T % 64 == 0
+        assert self.T % _ops.LEAF == 0
         self.nt = (self.n + self.T - 1) // self.T
         self.ops = ops if ops is not None else NativeTileOps(X.device)
         self.group = group
@@ -178,7 +181,7 @@ class BlockCyclicGP:
                     info_local = torch.where((info_local == 0) & (bad != 0), bad + k * self.T, info_local)
                 else:
                     Lkk = ops.new_tile(nk, nk)
-                    winv = torch.empty(_ops.round_up(nk, 64) * 64, dtype=torch.float64, device=dev)
+                    winv = torch.empty(self.ops.winv_numel(nk), dtype=torch.float64, device=dev)
                 self._bcast(Lkk, diag_owner, self.col_groups, ck)
                 self._bcast(winv, diag_owner, self.col_groups, ck)
                 # 2. panel solves on my tiles of column k

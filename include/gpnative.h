@@ -20,7 +20,7 @@
  *
  * "Factor buffers": dense factorisation kernels work on a caller-owned,
  * ZERO-INITIALISED buffer `A` of `gpn_factor_rows(n,e)` rows and leading
- * dimension `lda = gpn_factor_ld(n,e)` (a multiple of 64), holding the n x n
+ * dimension `lda = gpn_factor_ld(n,e)` (a multiple of 128), holding the n x n
  * matrix in its top-left corner (lower triangle significant) and `e` optional
  * "extra rows" n..n+e-1 that are carried through the factorisation: on exit
  * they hold (L^-1 * R)^T for the right-hand sides R^T stored in them on entry
@@ -57,9 +57,9 @@ const char* gpn_arch(void);
 const char* gpn_last_hip_error(void);
 
 /* ---- factor-buffer geometry --------------------------------------------- */
-int64_t gpn_factor_ld(int64_t n, int64_t e);    /* round_up(n+e, 64) */
-int64_t gpn_factor_rows(int64_t n, int64_t e);  /* round_up(n+e, 64) + 16 (zero apron) */
-/* bytes of the `winv` workspace (inverses of the 64x64 diagonal leaf blocks) */
+int64_t gpn_factor_ld(int64_t n, int64_t e);    /* round_up(n+e, 128) */
+int64_t gpn_factor_rows(int64_t n, int64_t e);  /* round_up(n+e, 128) + 16 (zero apron) */
+/* bytes of the `winv` workspace (inverses of the 128x128 diagonal leaf blocks) */
 int64_t gpn_winv_bytes(int64_t n);
 
 /* ---- K assembly ------------------------------------------------------------
@@ -87,13 +87,13 @@ int gpn_pack_rhs(void* stream, const double* Y, const double* M, int64_t n, int 
  * jitter ladder of functions.py:20-43 stays in the Python shell and replays on
  * info>0).  In-place lower factorisation of the n x n top-left block of the
  * factor buffer A; the strict upper triangle is neither read nor written.
- * `winv` (gpn_winv_bytes(n)) receives the inverses of the 64x64 diagonal blocks
+ * `winv` (gpn_winv_bytes(n)) receives the inverses of the 128x128 diagonal blocks
  * of L and must be kept with L for the solves below.  e extra rows are carried
  * (see header comment).  *info must be 0 on entry. */
 int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
                     double* winv, int32_t* info);
 
-/* winv <- inverses of the 64x64 diagonal blocks of a GIVEN lower-triangular L
+/* winv <- inverses of the 128x128 diagonal blocks of a GIVEN lower-triangular L
  * (n x n, row-major, ldl): what functions.trtrs (functions.py:71-76) needs when
  * its triangular argument did not come from gpn_potrf_lower.  info (may be NULL):
  * j>0 = zero pivot at column j. */

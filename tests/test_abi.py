@@ -41,9 +41,9 @@ def test_factor_geometry():
     lib = _native.lib()
     for n, e in [(1, 0), (63, 1), (64, 0), (64, 1), (8192, 1), (1000, 3)]:
         ld, rows = lib.gpn_factor_ld(n, e), lib.gpn_factor_rows(n, e)
-        assert ld % 64 == 0 and ld >= n + e and ld - (n + e) < 64
+        assert ld % 128 == 0 and ld >= n + e and ld - (n + e) < 128
         assert rows == ld + 16
-        assert lib.gpn_winv_bytes(n) == ((n + 63) // 64) * 64 * 64 * 8
+        assert lib.gpn_winv_bytes(n) == ((n + 127) // 128) * 128 * 128 * 8
     assert lib.gpn_grad_work_bytes(128, 128, 3, 1) == 3 * 5 * 8
     assert lib.gpn_grad_work_bytes(128, 64, 1, 0) == 2 * 3 * 8
 
@@ -57,13 +57,13 @@ def test_argument_validation_without_launch():
     assert lib.gpn_gemm_nt(null, 16, 16, 16, 1.0, null, 15, null, 16, 0.0, null, 16, 0, 0) == -101  # odd lda
     assert lib.gpn_kernel_matrix(null, 9, null, 4, null, 4, 2, null, null, 1, null, 0, null, 4) == -2
     assert lib.gpn_kernel_matrix(null, 0, null, 4, null, 4, 2, null, null, 1, null, 0, null, 4) == -3
-    assert lib.gpn_potrf_lower(null, null, 4, 0, 64, null, null) == -2
-    assert lib.gpn_trsm_right_lt(null, null, 4, 64, null, null, 1, 64) == -2
+    assert lib.gpn_potrf_lower(null, null, 4, 0, 128, null, null) == -2
+    assert lib.gpn_trsm_right_lt(null, null, 4, 128, null, null, 1, 128) == -2
     assert lib.gpn_lml_grad(null, 0, null, 4, 2, null, null, 1, null, 4, null, 4, 1, null, null) == -3
     # zero-size problems are no-ops that succeed
     one = ctypes.c_double(0.0)
     p = ctypes.cast(ctypes.pointer(one), ctypes.c_void_p)
-    assert lib.gpn_potrf_lower(null, p, 0, 0, 64, p, p) == 0
+    assert lib.gpn_potrf_lower(null, p, 0, 0, 128, p, p) == 0
     assert lib.gpn_transpose(null, p, 0, 0, 0, p, 0) == 0
 
 

@@ -19,7 +19,7 @@ class CpuTileOps:
     """torch-CPU stand-in for NativeTileOps (same contract)."""
 
     def new_tile(self, rows, cols):
-        return torch.zeros((rows + 63) // 64 * 64 + 16, (cols + 63) // 64 * 64, dtype=torch.float64)
+        return torch.zeros((rows + 127) // 128 * 128 + 16, (cols + 127) // 128 * 128, dtype=torch.float64)
 
     def kernel_tile(self, kind, Xi, Xj, variance, ls, noise, out):
         K = orc.kernel_K(kind, Xi, Xj, variance, ls)
@@ -34,6 +34,9 @@ class CpuTileOps:
         if int(inf) == 0:
             tile[:n, :n] = L
         return torch.zeros(1, dtype=torch.float64), info
+
+    def winv_numel(self, n):
+        return 1
 
     def trsm(self, L, winv, n, B, m):
         B[:m, :n] = torch.linalg.solve_triangular(L[:n, :n], B[:m, :n].t(), upper=False).t()
@@ -79,8 +82,8 @@ def _worker(rank, world, port, n, d, dy, tile, kind, noise, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,tile,dy,kind", [(2, 300, 64, 1, "Rbf"), (4, 450, 128, 2, "Matern52"),
-                                                    (2, 129, 64, 1, "Rbf"), (4, 64, 64, 1, "Rbf")])
+@pytest.mark.parametrize("world,n,tile,dy,kind", [(2, 300, 128, 1, "Rbf"), (4, 700, 128, 2, "Matern52"),
+                                                    (2, 129, 128, 1, "Rbf"), (4, 128, 128, 1, "Rbf")])
 def test_block_cyclic_lml_matches_oracle(tmp_path, world, n, tile, dy, kind):
     out = str(tmp_path / "lml.npy")
     mp.spawn(_worker, args=(world, _free_port(), n, 3, dy, tile, kind, 0.05, out), nprocs=world, join=True)
@@ -97,8 +100,8 @@ def test_grid_and_ownership():
     assert gdist.choose_grid(1) == (1, 1) and gdist.choose_grid(2) == (1, 2)
     assert gdist.choose_grid(4) == (2, 2) and gdist.choose_grid(8) == (2, 4)
     x, y = rng.make_regression(200, 2, 1, seed=0)
-    g = gdist.BlockCyclicGP(torch.tensor(x), torch.tensor(y), "Rbf", tile=64, ops=CpuTileOps())
-    assert g.nt == 4 and g.rows_of(3) == 8 and g.rows_of(4) == 1
+    g = gdist.BlockCyclicGP(torch.tensor(x), torch.tensor(y), "Rbf", tile=128, ops=CpuTileOps())
+    assert g.nt == 2 and g.rows_of(1) == 72 and g.rows_of(2) == 1
     one = torch.ones(1, dtype=torch.float64)
     lml = g.log_likelihood(one, one, 0.1 * one, torch.tensor(y))      # world_size 1 path
     o = orc.GPROracle(x, y, kind="Rbf", noise=0.1)
