@@ -91,7 +91,7 @@ __device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, in
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
@@ -206,17 +206,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   if (p.tri & GPN_TRI_B_LOWER) k_hi = min(k_hi, n0 + BN);
   const int t0 = k_lo / BK;
   const int nk = max(t0, (k_hi + BK - 1) / BK);
-  if (t0 < nk) {
-    stage_issue(t0, t0 & 1);
-    stage_commit(t0 & 1);
-  }
-  for (int t = t0; t < nk; ++t) {
-    const int s = t & 1;
-    __syncthreads();  // K-step t has landed (vmcnt(0)); every wave is done reading stage s^1
-    if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
-    compute(s);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nk) stage_commit(s ^ 1);
+  if constexpr (NS == 2) {
+    if (t0 < nk) {
+      stage_issue(t0, t0 & 1);
+      stage_commit(t0 & 1);
+    }
+    for (int t = t0; t < nk; ++t) {
+      const int s = t & 1;
+      __syncthreads();  // K-step t has landed (vmcnt(0)); every wave is done reading stage s^1
+      if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
+      compute(s);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nk) stage_commit(s ^ 1);
+    }
+  } else {
+    // Deep LDS-DMA ring for latency-bound launches (few, small workgroups): NS-1 K-steps
+    // stay in flight; the wait for step t is a COUNTED vmcnt that leaves the younger steps
+    // outstanding, then a raw s_barrier (a __syncthreads() would drain the ring: vmcnt(0)).
+    // Every wave issues exactly PER_WAVE DMAs per K-step, so the count is exact.
+    static_assert(DMA, "the ring is LDS-DMA only");
+    static_assert(NBLK % 4 == 0, "equal DMA count per wave");
+    constexpr int AHEAD = NS - 1;
+    for (int t = t0; t < min(nk, t0 + AHEAD); ++t) stage_issue(t, (t - t0) % NS);
+    for (int t = t0; t < nk; ++t) {
+      const int slot = (t - t0) % NS;
+      if (t + AHEAD <= nk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE * (AHEAD - 1)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (t + AHEAD < nk) stage_issue(t + AHEAD, (t - t0 + AHEAD) % NS);   // slot last read in step t-1
+      compute(slot);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // epilogue: reg r of lane l is C[(l>>4) + 4r][l&15] of its 16x16 tile
@@ -240,14 +263,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2>
 static int launch(hipStream_t s, const GemmArgs& a0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
   const int grid = a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt;
-  constexpr int smem = ((BM + BN) / 16) * 2 * 1024 * 2;
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA>;
+  constexpr int smem = ((BM + BN) / 16) * 2 * 1024 * NS;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS>;
   static bool attr_set = false;
   if (!attr_set) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -294,7 +317,12 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
     if (N > 128 || K > 128 || lower) return GPN_E_UNSUPPORTED;
-    return launch<64, 128, 32, 64, true>(s, a);
+    return g_gemm_variant == 2 ? launch<64, 128, 32, 64, true>(s, a) : launch<32, 128, 16, 64, true, 4>(s, a);
+  }
+  if (g_gemm_variant == 0 && tiles(64) <= 64) {
+    // a handful of workgroups: per-CU MFMA rate and DMA latency are the limits -> 4x more,
+    // 4x smaller workgroups (32x32 tiles) with 8 K-steps of LDS-DMA in flight
+    return launch<32, 32, 16, 16, true, 8>(s, a);
   }
   if (g_gemm_variant == 0) {
     return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true>(s, a);
