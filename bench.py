@@ -59,9 +59,9 @@ def build_model(w, seed, device):
 
 
 def algorithmic_gemm_flops(n, dy):
-    """Cholesky = N^3/3 flops; everything but the 64x64 diagonal leaves
-    (N/64 * 64^3/3) runs in the contraction kernel, plus the fused solve N^2*dy."""
-    return n ** 3 / 3.0 - n * 64.0 ** 2 / 3.0 + float(n) ** 2 * dy
+    """Cholesky = N^3/3 flops; everything but the 128x128 diagonal leaves
+    (N/128 * 128^3/3) runs in the contraction kernel, plus the fused solve N^2*dy."""
+    return n ** 3 / 3.0 - n * 128.0 ** 2 / 3.0 + float(n) ** 2 * dy
 
 
 def cpu_baseline(w, x, y, budget_s=25.0):
