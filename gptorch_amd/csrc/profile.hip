@@ -53,3 +53,12 @@ extern "C" int gpn_profile_collect(double* out3_host) {
   g_recs.clear();
   return GPN_OK;
 }
+
+// Experimental: a stream restricted to a subset of the 256 CUs (hipExtStreamCreateWithCUMask).
+// mask_words = 8 x uint32 (bit i = CU i enabled).  Returns the hipStream_t through *out.
+extern "C" int gpn_debug_masked_stream(const uint32_t* mask_words, int nwords, void** out) {
+  hipStream_t s;
+  GPN_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask_words));
+  *out = s;
+  return GPN_OK;
+}

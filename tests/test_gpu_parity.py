@@ -334,3 +334,78 @@ def test_vfe_medium_golden(device):
     assert np.max(np.abs(mu - np.asarray(case["mean"]))) < 1e-8
     assert np.max(np.abs(var - np.asarray(case["var"]))) < 1e-8
     assert np.max(np.abs(cov - np.asarray(case["cov"]))) < 1e-8
+
+
+# ---- edge cases -------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,dy", [(1, 1, 1), (2, 3, 1), (127, 2, 3), (128, 2, 1), (129, 4, 2), (255, 1, 1),
+                                     (256, 3, 4), (257, 2, 1), (383, 5, 1), (640, 2, 130)])
+def test_gpr_ragged_sizes_vs_oracle(device, n, d, dy):
+    """sizes around the 128 leaf / padding boundaries, several outputs (extra rows crossing a
+    padding granule when n + dy passes a multiple of 128), tiny problems."""
+    x, y = rng.make_regression(n, d, dy, seed=n)
+    m = GPR(x, y, kernels.Matern52(d, variance=1.1, length_scales=0.9), likelihood=likelihoods.Gaussian(variance=0.07))
+    m.cuda()
+    o = orc.GPROracle(x, y, kind="Matern52", variance=1.1, length_scales=0.9, noise=0.07)
+    loss = m.loss()
+    loss.backward()
+    ol, og = o.loss_and_grads()
+    assert abs(loss.item() - ol.item()) < 1e-9 * max(1.0, abs(ol.item()))
+    for g, ref in zip([m.kernel.variance.grad, m.kernel.length_scales.grad, m.likelihood.variance.grad], og):
+        assert (g.cpu() - ref).abs().max().item() < 1e-8 * max(1.0, ref.abs().max().item())
+    xs = rng.normal(n + 1, (5, d))
+    mu, var = m.predict_y(xs)
+    with torch.no_grad():
+        omu, ovar = o.predict_y(xs)
+    assert np.max(np.abs(mu - omu.numpy())) < 1e-9 and np.max(np.abs(var - ovar.numpy())) < 1e-9
+
+
+def test_predict_samples_and_factor_cache(device):
+    """predict_*_samples shapes (test_base.py:134-163); the factor cache is invalidated when a
+    hyper-parameter changes (the reference re-factorises every call, gpr.py:104)."""
+    x, y = rng.make_regression(150, 2, 2, seed=4)
+    m = GPR(x, y, kernels.Rbf(2, length_scales=0.8), likelihood=likelihoods.Gaussian(variance=0.05))
+    m.cuda()
+    xs = rng.normal(5, (9, 2))
+    torch.manual_seed(0)
+    assert m.predict_f_samples(xs, n_samples=4).shape == (4, 9, 2)
+    assert m.predict_y_samples(torch.tensor(xs, device=device), n_samples=3).shape == (3, 9, 2)
+    mu1, _ = m.predict_f(xs)
+    f1 = m._predict_cache[1]
+    mu1b, _ = m.predict_f(xs)
+    assert m._predict_cache[1] is f1 and np.array_equal(mu1, mu1b)
+    with torch.no_grad():
+        m.kernel.length_scales.data += 0.3
+    mu2, _ = m.predict_f(xs)
+    assert m._predict_cache[1] is not f1
+    o = orc.GPROracle(x, y, kind="Rbf", length_scales=0.8 * np.exp(0.3), noise=0.05)
+    with torch.no_grad():
+        omu, _ = o.predict_f(xs)
+    assert np.max(np.abs(mu2 - omu.numpy())) < 1e-9
+
+
+def test_sum_product_kernels(device):
+    """kernels.py:286-306 combinators on the native stationary kernels (test_kernels.py:39-57)."""
+    z = load_npz("ref_kernel_fixtures.npz")
+    x1 = torch.tensor(z["x1"], device=device)
+    k1, k2 = kernels.Rbf(3), kernels.Matern32(3)
+    ks, kp = k1 + k2, k1 * k2
+    ks.cuda(); kp.cuda()
+    assert np.allclose(ks.K(x1).detach().cpu().numpy(), z["Rbf_kx"] + z["Matern32_kx"])
+    assert np.allclose(kp.K(x1).detach().cpu().numpy(), z["Rbf_kx"] * z["Matern32_kx"])
+    assert np.allclose(ks.Kdiag(x1).detach().cpu().numpy(), 2.0)
+    w = kernels.White(3, variance=0.3)
+    w.cuda()
+    assert np.allclose(w.K(x1).detach().cpu().numpy(), 0.3 * np.eye(4))
+
+
+def test_batched_restarts_match_sequential(device):
+    from gptorch_amd.models import batched_log_likelihood
+    ms = []
+    for r in range(3):
+        x, y = rng.make_regression(700, 3, 1, seed=10 + r)
+        m = GPR(x, y, kernels.Rbf(3, length_scales=1.0 + 0.2 * r), likelihood=likelihoods.Gaussian(variance=0.02))
+        m.cuda()
+        ms.append(m)
+    seq = [m.log_likelihood().item() for m in ms]
+    bat = [t.item() for t in batched_log_likelihood(ms)]
+    assert seq == bat
