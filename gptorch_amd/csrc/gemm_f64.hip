@@ -91,7 +91,7 @@ __device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, in
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     }
   };
 
-  auto compute = [&](int s) {
+  // BLOW: B is lower-triangular (panel solve against an inverted leaf block, B[j][k] = 0 for
+  // k > j): a 16-column tile needs no K beyond its last column -- skipped per (tile, 8-k group)
+  auto compute = [&](int s, int k0) {
     const char* base = smem + s * STAGE + lane * 16;
 #pragma unroll
     for (int kg8 = 0; kg8 < 2; ++kg8) {
@@ -183,20 +185,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         b[j] = *reinterpret_cast<const d2*>(base + ((A_BLOCKS + (wave_n * TN + j) * 2 + kg8) * 1024));
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+      if constexpr (BLOW) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          if (k0 + kg8 * 8 > n0 + wave_n * WN + j * 16 + 15) continue;   // wave-uniform
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          }
         }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          }
+      }
     }
   };
 
-  // Software pipeline, one barrier per K-step: the DMA of K-step t+1 is issued at
-  // the top of step t and only waited for at the top of step t+1 -- a full MFMA
-  // block (64 MFMAs x 64 cycles) covers its latency.  sched_barrier keeps the
-  // compiler from hoisting the next barrier (and its vmcnt(0)) above the MFMAs.
   // triangular operands: rows of an upper-triangular operand are zero left of the
   // diagonal, rows of a lower-triangular one right of it -> clip the K range per tile
   int k_lo = 0, k_hi = p.K;
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       const int s = t & 1;
       __syncthreads();  // K-step t has landed (vmcnt(0)); every wave is done reading stage s^1
       if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
-      compute(s);
+      compute(s, t * BK);
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < nk) stage_commit(s ^ 1);
     }
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       }
       __builtin_amdgcn_s_barrier();
       if (t + AHEAD < nk) stage_issue(t + AHEAD, (t - t0 + AHEAD) % NS);   // slot last read in step t-1
-      compute(slot);
+      compute(slot, t * BK);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -263,14 +273,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
 static int launch(hipStream_t s, const GemmArgs& a0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
   const int grid = a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt;
   constexpr int smem = ((BM + BN) / 16) * 2 * 1024 * NS;
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS>;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
   static bool attr_set = false;
   if (!attr_set) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -317,7 +327,8 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
     if (N > 128 || K > 128 || lower) return GPN_E_UNSUPPORTED;
-    return g_gemm_variant == 2 ? launch<64, 128, 32, 64, true>(s, a) : launch<32, 128, 16, 64, true, 4>(s, a);
+    if (g_gemm_variant == 2) return launch<64, 128, 32, 64, true>(s, a);
+    return (tri & GPN_TRI_B_LOWER) ? launch<32, 128, 16, 64, true, 4, true>(s, a) : launch<32, 128, 16, 64, true, 4>(s, a);
   }
   if (g_gemm_variant == 0 && tiles(64) <= 64) {
     // a handful of workgroups: per-CU MFMA rate and DMA latency are the limits -> 4x more,

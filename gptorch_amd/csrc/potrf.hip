@@ -246,7 +246,7 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
   if (kb <= LEAF) {
     const double* W = winv + (diag0 / LEAF) * (LEAF * LEAF);
     // in place: one LEAF-wide column tile per row block (see file header)
-    c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, 0, /*inplace=*/1);
+    c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
     return;
   }
   const int64_t h = split_point(kb);
