@@ -92,17 +92,24 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the backward / concurrent-restart legs (profiling runs)")
+    ap.add_argument("--test-shared-gpu", action="store_true",
+                    help="(testing the multi-rank control flow on a 1-GPU box) every rank uses cuda:0, gloo collectives")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    if args.test_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.test_shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from gptorch_amd import _native
     lib = _native.lib()   # raises if the HIP library is missing: no fallback
@@ -129,7 +136,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.test_shared_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     lml = out.item()
