@@ -48,8 +48,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // full rectangle: groups of 8 tile rows, column-major inside a group
-__device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, int& ti, int& tj) {
-  const int logical = xcd_remap(bid, nwg);
+// `spread`: K-clipped (triangular-operand) launches have very unequal work per tile row, so
+// their tiles are dealt round-robin over the XCDs (plain blockIdx order) instead of in
+// contiguous per-XCD chunks: balance beats L2 locality there.
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, bool spread, int& ti, int& tj) {
+  const int logical = spread ? bid : xcd_remap(bid, nwg);
   const int group = 8 * nt;
   const int g = logical / group;
   const int first = g * 8;
@@ -63,8 +66,8 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, 
 // number of real tiles): groups of 8 tile rows; group g holds the 8g full columns
 // left of the diagonal super-tile (column-major, 8 per column) followed by the
 // 36 tiles of the diagonal super-tile.  Tiles before group g: 32 g^2 + 4 g.
-__device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, int& ti, int& tj) {
-  const int q = xcd_remap(bid, nwg);
+__device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bool spread, int& ti, int& tj) {
+  const int q = spread ? bid : xcd_remap(bid, nwg);
   const int G = mt >> 3;
   const int full_total = 32 * G * G + 4 * G;
   int g, h;
@@ -102,8 +105,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int ti, tj;
-  if (p.lower) tile_of_block_lower(blockIdx.x, gridDim.x, p.mt, ti, tj);
-  else tile_of_block(blockIdx.x, gridDim.x, p.mt, p.nt, ti, tj);
+  const bool spread = (p.tri & (GPN_TRI_A_UPPER | GPN_TRI_A_LOWER | GPN_TRI_B_UPPER)) != 0;
+  if (p.lower) tile_of_block_lower(blockIdx.x, gridDim.x, p.mt, spread, ti, tj);
+  else tile_of_block(blockIdx.x, gridDim.x, p.mt, p.nt, spread, ti, tj);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
