@@ -109,10 +109,10 @@ def kernel_K(kind, X, X2, variance, length_scales):
         return variance * torch.exp(-r2 / 2.0)
     r = scaled_dist(X, X2, length_scales)
     if kind == "Matern52":
-        s5 = torch.tensor([math.sqrt(5.0)], dtype=DTYPE)
+        s5 = torch.tensor([math.sqrt(5.0)], dtype=DTYPE).to(r.device)   # kernels.py:207
         return variance * (1.0 + s5 * r + 5.0 / 3.0 * r * r) * torch.exp(-s5 * r)
     if kind == "Matern32":
-        r3 = torch.tensor([math.sqrt(3.0)], dtype=DTYPE) * r
+        r3 = torch.tensor([math.sqrt(3.0)], dtype=DTYPE).to(r.device) * r   # kernels.py:199-200
         return variance * (1.0 + r3) * torch.exp(-r3)
     if kind in ("Exp", "Matern12"):
         return variance * torch.exp(-r)
