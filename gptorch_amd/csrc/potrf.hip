@@ -23,7 +23,7 @@
 namespace gpn {
 
 // ---------------------------------------------------------------------------------
-// Leaf: one workgroup (512 threads, 8 waves) factors a 128x128 diagonal block AND
+// Leaf: one workgroup (576 threads, 9 waves) factors a 128x128 diagonal block AND
 // forms its inverse:  L = chol(A[0:kb,0:kb]) in place,  W = L^-1 -> winv (128x128,
 // ld 128, zero outside the kb x kb lower triangle).  Rows/cols >= kb act as identity.
 // FACTOR=false: A already holds a lower-triangular L; only W is formed (blockIdx.x
@@ -32,22 +32,38 @@ namespace gpn {
 // Right-looking, blocked by 8 columns, on the stacked matrix [A ; I] (256 x 128): the
 // identity rows are "extra rows" exactly as in the outer algorithm, so they come out as
 // I * L^-T = W^T and the inverse needs no pass of its own.  The whole trailing matrix
-// lives in REGISTERS as 16x16 MFMA accumulator tiles (72 tiles, 9 per wave); per block of
-// 8 pivots:
-//   P0  owners of the current tile column publish the raw 8-column panel to LDS
-//   P1  wave 0 factors the 8x8 diagonal block in-lane (no cross-lane traffic on the
-//       serial pivot chain: rsq + Newton per pivot), publishes L8 and 1/diag
-//   P2  one thread per row solves its 8 panel entries against L8 (forward substitution),
-//       stores them to global (final L / W values) and back to LDS
-//   P3  rank-8 update of every live tile: 2 x v_mfma_f64_16x16x4_f64 per tile
+// lives in REGISTERS as 16x16 MFMA accumulator tiles.
+//
+// Roles.  Waves 0..7 are TILE waves: wave w owns A-part tile row w (tiles (w,J), J <= w) and
+// identity-part tile row w (tiles (8+w,J), J >= w) -- always 9 tiles, in static slots
+// (slot J for the A tile of column J, slot J+1 for the identity tile of column J).  Wave 8 is
+// the PIVOT wave.  Per block of 8 pivots (panel p), with look-ahead:
+//   A  tile waves: rank-8 update with panel p of tile column `jact` only (the column the next
+//      panel lives in), then publish the next raw 8-column panel to LDS
+//   B  pivot wave: 8x8 diagonal block of panel p+1, one row per lane, broadcasts through
+//      v_readlane only (no LDS / barrier on the serial pivot chain: rsq + 2 Newton per pivot)
+//      tile waves: the rest of the rank-8 update with panel p (2 MFMAs per live tile)
+//   C  waves 0..3, one thread per row: forward substitution of panel p+1 against L8;
+//      waves 4..7, one thread per row: panel p's final values (L rows / W^T rows) LDS -> global
 // 3 barriers per 8 pivots; the panel buffer is double-buffered.
 // ---------------------------------------------------------------------------------
 constexpr int XPS = 9;                 // padded row of the panel buffer (doubles)
+constexpr int LEAF_THREADS = 576;
 
-template <bool FACTOR>
-__global__ __launch_bounds__(512) void potrf_leaf_kernel(double* A, int64_t lda, int kb_, int col0_,
-                                                         double* winv_, int32_t* info, int n_total) {
+#define GPN_STAMP(k)                                                            \
+  if constexpr (DIAG) {                                                         \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                 \
+    acc_t[k] += t_ - last_t;                                                    \
+    last_t = t_;                                                                \
+  }
+
+template <bool FACTOR, bool DIAG = false>
+__global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int64_t lda, int kb_, int col0_,
+                                                                  double* winv_, int32_t* info, int n_total,
+                                                                  unsigned long long* diag = nullptr) {
   typedef double d4 __attribute__((ext_vector_type(4)));
+  unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_t = 0;
+  if constexpr (DIAG) last_t = __builtin_amdgcn_s_memtime();
   int kb = kb_, col0 = col0_;
   double* winv = winv_;
   if constexpr (!FACTOR) {
@@ -62,167 +78,244 @@ __global__ __launch_bounds__(512) void potrf_leaf_kernel(double* A, int64_t lda,
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7 tile waves, 8 pivot wave
+  const bool tilewave = wave < 8;
+  const int w = wave & 7;
   const int lr = lane >> 4, lc = lane & 15;      // D-layout: rows lr + 4r, column lc
   if (tid == 0) failflag = 0;
+  if (!tilewave) __builtin_amdgcn_s_setprio(3);   // the pivot chain must not queue behind tile-wave VALU work
 
-  // tile slots: global slot s = wave + 8k (k = 0..8); J = s / 9, idx = s % 9;
-  // idx < 8-J: A-part tile row I = J + idx;  else identity-part tile row I = 8 + (idx - (8-J))
-  int TI[9], TJ[9];
+  // slot J (J = 0..7): A tile (w, J), used when J <= w; slot J+1: identity tile (8+w, J), used
+  // when J >= w.  (slot w holds the A diagonal tile, slot w+1 the identity diagonal tile.)
   d4 acc[9];
+  if (tilewave) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int s = wave + 8 * k;
-    const int J = s / 9, idx = s - 9 * J;
-    const int I = (idx < 8 - J) ? J + idx : 8 + (idx - (8 - J));
-    TI[k] = I;
-    TJ[k] = J;
+    for (int q = 0; q < 9; ++q) {
+      const bool isA = q <= w;
+      const int J = isA ? q : q - 1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * I + lr + 4 * r, col = 16 * J + lc;
-      double v;
-      if (I < 8) {
-        v = (row == col) ? 1.0 : 0.0;
-        if (row < kb && col <= row) v = A[(int64_t)row * lda + col];
-      } else {
-        v = (row - 128 == col) ? 1.0 : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + lr + 4 * r, col = 16 * J + lc;   // row within its part
+        double v;
+        if (isA) {
+          v = (row == col) ? 1.0 : 0.0;
+          if (row < kb && col <= row) v = A[(int64_t)row * lda + col];
+        } else {
+          v = (row == col) ? 1.0 : 0.0;
+        }
+        acc[q][r] = v;
       }
-      acc[k][r] = v;
     }
   }
+
+  // raw 8-column panel (tile column Jp, half hp) -> LDS
+  auto publish = [&](double* xp, int Jp, int hp) {
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+      if (J == Jp && (lc >> 3) == hp) {
+        if (J <= w) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xp[(16 * w + lr + 4 * r) * XPS + (lc & 7)] = acc[J][r];
+        }
+        if (J >= w) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xp[(128 + 16 * w + lr + 4 * r) * XPS + (lc & 7)] = acc[J + 1][r];
+        }
+      }
+    }
+  };
+
+  // rank-8 update with the solved panel in xp of the tile columns J in [jlo, jhi]
+  auto update = [&](const double* xp, int jlo, int jhi, int J0) {
+    const bool idlive = w <= J0;                 // identity rows 16w.. have met the pivots yet?
+    const double* pa = xp + (16 * w + lc) * XPS + lr;
+    double a0 = 0.0, a1 = 0.0, i0 = 0.0, i1 = 0.0;
+    if (FACTOR) { a0 = -pa[0]; a1 = -pa[4]; }
+    if (idlive) { i0 = -pa[128 * XPS]; i1 = -pa[128 * XPS + 4]; }
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+      if (J >= jlo && J <= jhi) {                // wave-uniform
+        const double* pb = xp + (16 * J + lc) * XPS + lr;
+        const double b0 = pb[0], b1 = pb[4];
+        if (FACTOR && J <= w) {
+          acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[J], 0, 0, 0);
+          acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[J], 0, 0, 0);
+        }
+        if (idlive && J >= w) {
+          acc[J + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(i0, b0, acc[J + 1], 0, 0, 0);
+          acc[J + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(i1, b1, acc[J + 1], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // P1 (pivot wave): lane i holds row i of the 8x8 diagonal block
+  auto pivot_block = [&](const double* xp, int c0) {
+    const int li = lane & 7;
+    double a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = xp[(c0 + li) * XPS + c];
+    double invd[8];
+    int fail = 0;
+    auto bcast = [](double v, int src) -> double {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+      const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+      return __hiloint2double(hi, lo);
+    };
+    // dn = this lane's candidate for the NEXT pivot (its own diagonal entry after the current
+    // rank-1 update): the serial chain is  readlane(d) -> rsq -> one cubic refinement ->
+    // l = a*y -> dn = a' - l*l -> readlane ...;  everything else hangs off it
+    double dn = a[0];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double d = bcast(dn, j);
+      if (FACTOR) {
+        if (!(d > 0.0)) {              // LAPACK dpotrf: ajj <= 0 or NaN
+          if (!fail) fail = c0 + j + 1;
+          d = 1.0;
+        }
+        // y = d^-1/2: v_rsq_f64 seed (~2^-26) + ONE cubically convergent step
+        //   e = 1 - d y^2;  y <- y (1 + e/2 + 3 e^2/8)     (error ~ e^3: far below 2^-53)
+        double y = __builtin_amdgcn_rsq(d);
+        const double e = fma(-d * y, y, 1.0);
+        y = fma(y, e * fma(e, 0.375, 0.5), y);
+        invd[j] = y;
+        const double l = a[j] * y;     // L[i][j] in lane i (i > j)
+        if (j < 7) dn = fma(-l, l, a[j + 1]);   // own-lane diagonal: no broadcast on the chain
+#pragma unroll
+        for (int c = j + 1; c < 8; ++c) a[c] = fma(-l, bcast(l, c), a[c]);
+        double sq = d * y;             // sqrt(d), off the critical chain
+        sq = fma(fma(-sq, sq, d), 0.5 * y, sq);
+        a[j] = (li == j) ? sq : l;
+      } else {
+        d = bcast(a[j], j);
+        if (d == 0.0) {                // dtrtri: zero pivot
+          if (!fail) fail = c0 + j + 1;
+          d = 1.0;
+        }
+        invd[j] = 1.0 / d;
+      }
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c <= lane) Dg[lane * 8 + c] = a[c];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Dg[64 + j] = invd[j];
+      if (fail) failflag = fail;
+    }
+  };
+
+  // P2 (threads 0..255 = waves 0..3): forward substitution of one panel row against L8;
+  // the solved row goes back to LDS (the pivot wave streams it to global one phase later)
+  auto solve_rows = [&](double* xp, int c0) {
+    if (tid >= 256) return;
+    const bool apart = tid < 128;
+    const int rho = apart ? tid : tid - 128;
+    const bool solve = apart ? (FACTOR && tid >= c0 + 8) : (rho <= c0 + 7);
+    if (solve) {
+      double x[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] = xp[tid * XPS + c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        double v = x[c];
+#pragma unroll
+        for (int k2 = 0; k2 < c; ++k2) v = fma(-x[k2], Dg[c * 8 + k2], v);
+        x[c] = v * Dg[64 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xp[tid * XPS + c] = x[c];
+    } else if (!apart) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xp[tid * XPS + c] = 0.0;     // W^T rows not reached yet: zeros
+    } else if (FACTOR && tid >= c0 && tid < c0 + 8) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xp[tid * XPS + c] = (c <= tid - c0) ? Dg[(tid - c0) * 8 + c] : 0.0;   // L8 itself
+    }
+  };
+
+  // final values of panel (c0) from LDS to global, one row per thread, by waves 4..7 (idle
+  // while waves 0..3 solve the next panel):  A rows t >= c0 -> A[t][c0..c0+7];
+  // identity rows rho -> winv[c0+c][rho] (zeros beyond kb / above the diagonal)
+  auto store_panel = [&](const double* xp, int c0) {
+    const int t = tid - 256;                     // 0..255
+    if (t < 0 || t >= 256) return;
+    if (t < 128) {
+      if (FACTOR && t >= c0 && t < kb) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c0 + c < kb && c0 + c <= t) A[(int64_t)t * lda + c0 + c] = xp[t * XPS + c];
+      }
+    } else {
+      const int rho = t - 128;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bool in = (c0 + c < kb) && (rho < kb) && (rho <= c0 + c);
+        winv[(int64_t)(c0 + c) * LEAF + rho] = in ? xp[t * XPS + c] : 0.0;
+      }
+    }
+  };
+
+  // ---- prologue: panel 0 ------------------------------------------------------------------
+  if (tilewave) publish(Xp[0], 0, 0);
+  __syncthreads();
+  if (!tilewave) pivot_block(Xp[0], 0);
+  __syncthreads();
+  if (!failflag) solve_rows(Xp[0], 0);
   __syncthreads();
 
-  for (int kb8 = 0; kb8 < 16; ++kb8) {
+  // ---- main loop --------------------------------------------------------------------------
+  int done = 0;
+  for (int kb8 = 0; kb8 < 16 && !failflag; ++kb8) {
     const int c0 = kb8 * 8;
-    const int J0 = kb8 >> 1, half = kb8 & 1;
-    double* xp = Xp[kb8 & 1];
-    // ---- P0: publish the raw panel (8 columns of tile column J0) --------------------
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      if (TJ[k] == J0 && (lc >> 3) == half) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xp[(16 * TI[k] + lr + 4 * r) * XPS + (lc & 7)] = acc[k][r];
+    const int J0 = kb8 >> 1;
+    const int jact = (c0 + 8) >> 4;          // tile column of the NEXT panel (8 when none)
+    const int halfn = (kb8 + 1) & 1;
+    double* cur = Xp[kb8 & 1];
+    double* nxt = Xp[(kb8 + 1) & 1];
+    GPN_STAMP(0)
+    // A
+    if (tilewave) {
+      if (kb8 < 15) {
+        update(cur, jact, jact, J0);
+        publish(nxt, jact, halfn);
       }
     }
+    done = kb8 + 1;
+    if (kb8 == 15) break;
+    GPN_STAMP(1)
     __syncthreads();
-    // ---- P1: 8x8 diagonal block, in-lane, wave 0 ------------------------------------
-    if (wave == 0) {
-      double a[8][8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int c = 0; c <= i; ++c) a[i][c] = xp[(c0 + i) * XPS + c];
-      double invd[8];
-      int fail = 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        double d = a[j][j];
-        if (FACTOR) {
-          if (!(d > 0.0)) {              // LAPACK dpotrf: ajj <= 0 or NaN
-            if (!fail) fail = c0 + j + 1;
-            d = 1.0;
-          }
-          double y = __builtin_amdgcn_rsq(d);
-          const double hd = 0.5 * d;
-          y = fma(y, fma(-hd * y, y, 0.5), y);
-          y = fma(y, fma(-hd * y, y, 0.5), y);
-          double sq = d * y;
-          sq = fma(fma(-sq, sq, d), 0.5 * y, sq);
-          a[j][j] = sq;
-          invd[j] = y;
-#pragma unroll
-          for (int i = j + 1; i < 8; ++i) a[i][j] *= y;
-#pragma unroll
-          for (int c = j + 1; c < 8; ++c)
-#pragma unroll
-            for (int i = c; i < 8; ++i) a[i][c] = fma(-a[i][j], a[c][j], a[i][c]);
-        } else {
-          if (d == 0.0) {                // dtrtri: zero pivot
-            if (!fail) fail = c0 + j + 1;
-            d = 1.0;
-          }
-          invd[j] = 1.0 / d;
-        }
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int c = 0; c <= i; ++c) Dg[i * 8 + c] = a[i][c];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Dg[64 + j] = invd[j];
-        if (fail) failflag = fail;
-      }
-    }
+    GPN_STAMP(2)
+    // B
+    if (tilewave) update(cur, jact + 1, 7, J0);
+    else pivot_block(nxt, c0 + 8);
+    GPN_STAMP(3)
     __syncthreads();
-    if (failflag) break;                 // uniform
-    // ---- P2: one thread per panel row: forward substitution against L8 ----------------
-    if (tid < 256) {
-      const bool apart = tid < 128;
-      const int rho = apart ? tid : tid - 128;
-      const bool solve = apart ? (FACTOR && tid >= c0 + 8) : (rho <= c0 + 7);
-      const bool diagrow = apart && tid >= c0 && tid < c0 + 8;
-      double x[8];
-      if (solve) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = xp[tid * XPS + c];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          double v = x[c];
-#pragma unroll
-          for (int k2 = 0; k2 < c; ++k2) v = fma(-x[k2], Dg[c * 8 + k2], v);
-          x[c] = v * Dg[64 + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) xp[tid * XPS + c] = x[c];
-      } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = 0.0;
-      }
-      if (apart) {
-        if (FACTOR && tid < kb) {
-          if (solve) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-              if (c0 + c < kb) A[(int64_t)tid * lda + c0 + c] = x[c];
-          } else if (diagrow) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-              if (c <= tid - c0) A[(int64_t)tid * lda + c0 + c] = Dg[(tid - c0) * 8 + c];
-          }
-        }
-      } else {
-        // W[c0+c][rho] = (W^T)[rho][c0+c]; zeros everywhere else of the 128x128 block
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const bool in = (c0 + c < kb) && (rho < kb);
-          winv[(int64_t)(c0 + c) * LEAF + rho] = in ? x[c] : 0.0;
-        }
-      }
-    }
+    GPN_STAMP(4)
+    if (failflag) break;                     // uniform
+    // C
+    solve_rows(nxt, c0 + 8);
+    store_panel(cur, c0);
+    GPN_STAMP(5)
     __syncthreads();
-    // ---- P3: rank-8 update of the live tiles -------------------------------------------
-    const int jact = (c0 + 8) >> 4;      // first tile column that still has unfinished columns
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int I = TI[k], J = TJ[k];
-      const bool live = (J >= jact) && (I < 8 ? FACTOR : (I - 8 <= J0));
-      if (live) {                        // wave-uniform
-        const double* pa = xp + (16 * I + lc) * XPS + lr;
-        const double* pb = xp + (16 * J + lc) * XPS + lr;
-        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[0], pb[0], acc[k], 0, 0, 0);
-        acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4], pb[4], acc[k], 0, 0, 0);
-      }
-    }
+    GPN_STAMP(6)
   }
+  if constexpr (DIAG) {
+    GPN_STAMP(7)
+    if (lane == 0) for (int k = 0; k < 8; ++k) diag[wave * 8 + k] = acc_t[k];
+  }
+  if (!failflag) store_panel(Xp[1], 120);     // last panel (kb8 = 15 lives in buffer 1)
   __syncthreads();
   if (failflag) {
     if (tid == 0 && info && *info == 0) *info = col0 + failflag;
     // leave the rest of A untouched; publish a finite (zero) winv so later kernels stay finite
-    for (int idx = tid; idx < LEAF * LEAF; idx += 512) winv[idx] = 0.0;
+    for (int idx = tid; idx < LEAF * LEAF; idx += LEAF_THREADS) winv[idx] = 0.0;
   }
+  (void)done;
 }
-
 
 struct Ctx {
   hipStream_t s;
@@ -259,8 +352,8 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
 static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   if (c.rc != GPN_OK || n <= 0) return;
   if (n <= LEAF) {
-    hipLaunchKernelGGL(potrf_leaf_kernel<true>, dim3(1), dim3(512), 0, c.s, A, c.lda, (int)n, (int)col0,
-                       c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0);
+    hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, A, c.lda, (int)n, (int)col0,
+                       c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0, nullptr);
     if (hipGetLastError() != hipSuccess) { c.rc = GPN_E_HIP; return; }
     if (e > 0) trsm_rec(c, A + n * c.lda, e, c.lda, A, c.lda, n, col0, c.winv);
     return;
@@ -407,6 +500,17 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
   return c.rc;
 }
 
+// diagnostic build of the leaf with s_memtime stamps (not part of the public header):
+// diag[wave*8 + k] = cycles summed over the pivot blocks in segment k
+// (0 loop top, 1 phase A, 2 barrier, 3 phase B, 4 barrier, 5 phase C, 6 barrier, 7 tail)
+extern "C" int gpn_debug_leaf_timing(void* stream, double* A, int64_t lda, double* winv, int32_t* info,
+                                     unsigned long long* diag72) {
+  hipLaunchKernelGGL((potrf_leaf_kernel<true, true>), dim3(1), dim3(LEAF_THREADS), 0, static_cast<hipStream_t>(stream),
+                     A, lda, LEAF, 0, winv, info, 0, diag72);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
 extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t ldl, double* winv, int32_t* info) {
   if (!L) return -2;
   if (n < 0) return -3;
@@ -414,8 +518,8 @@ extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t 
   if (!winv) return -5;
   if (n == 0) return GPN_OK;
   const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
-  hipLaunchKernelGGL(potrf_leaf_kernel<false>, dim3(nb), dim3(512), 0, static_cast<hipStream_t>(stream),
-                     const_cast<double*>(L), ldl, 0, 0, winv, info, (int)n);
+  hipLaunchKernelGGL((potrf_leaf_kernel<false, false>), dim3(nb), dim3(LEAF_THREADS), 0, static_cast<hipStream_t>(stream),
+                     const_cast<double*>(L), ldl, 0, 0, winv, info, (int)n, nullptr);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
