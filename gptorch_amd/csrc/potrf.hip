@@ -73,7 +73,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     winv += (int64_t)blockIdx.x * LEAF * LEAF;
   }
   __shared__ double Xp[2][256 * XPS];   // panel rows 0..127: A part, 128..255: identity (-> W^T) part
-  __shared__ double Dg[64 + 8];         // L8 (row-major 8x8) + reciprocal diagonal
+  __shared__ double Dg[64];             // L8 (row-major 8x8), for the output rows
+  __shared__ double Ds[64];             // L8 scaled by 1/diag (diagonal slot: 1/diag), for the row solves
   __shared__ int failflag;
 
   const int tid = threadIdx.x;
@@ -149,12 +150,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     }
   };
 
-  // P1 (pivot wave): lane i holds row i of the 8x8 diagonal block
+  // P1 (pivot wave): ONE ELEMENT PER LANE -- lane 8i+c holds D[i][c] of the 8x8 diagonal block.
+  // Per pivot j the serial chain is  readlane(d) -> v_rsq_f64 -> one cubic refinement ->
+  // l = a*y -> DPP shift -> d' = a' - l*l -> readlane;  the rank-1 update of the other 63
+  // elements is one masked FMA whose operands arrive through the LDS crossbar (ds_swizzle row
+  // broadcast, ds_bpermute transpose-gather) and never sits on the chain.
   auto pivot_block = [&](const double* xp, int c0) {
-    const int li = lane & 7;
-    double a[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) a[c] = xp[(c0 + li) * XPS + c];
+    const int pi = lane >> 3, pc = lane & 7;
+    double a = xp[(c0 + pi) * XPS + pc];
     double invd[8];
     int fail = 0;
     auto bcast = [](double v, int src) -> double {
@@ -162,50 +165,71 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
       const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
       return __hiloint2double(hi, lo);
     };
-    // dn = this lane's candidate for the NEXT pivot (its own diagonal entry after the current
-    // rank-1 update): the serial chain is  readlane(d) -> rsq -> one cubic refinement ->
-    // l = a*y -> dn = a' - l*l -> readlane ...;  everything else hangs off it
-    double dn = a[0];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      double d = bcast(dn, j);
+    const int gather = ((pc << 3)) << 2;        // byte address of lane (pc, j) minus 4*j, for ds_bpermute
+    double dn = a;                              // candidate next pivot (valid in the diagonal lanes)
+    auto shr1 = [](double v) -> double {        // value of lane-1 (DPP row_shr:1; neighbours share a 16-lane row)
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, false);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x111, 0xf, 0xf, false);
+      return __hiloint2double(hi, lo);
+    };
+    double aleft = shr1(a);
+    auto pivot = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      double d = bcast(dn, 9 * j);
       if (FACTOR) {
         if (!(d > 0.0)) {              // LAPACK dpotrf: ajj <= 0 or NaN
           if (!fail) fail = c0 + j + 1;
           d = 1.0;
         }
-        // y = d^-1/2: v_rsq_f64 seed (~2^-26) + ONE cubically convergent step
-        //   e = 1 - d y^2;  y <- y (1 + e/2 + 3 e^2/8)     (error ~ e^3: far below 2^-53)
-        double y = __builtin_amdgcn_rsq(d);
-        const double e = fma(-d * y, y, 1.0);
-        y = fma(y, e * fma(e, 0.375, 0.5), y);
+        // y = d^-1/2: v_rsq_f64 seed y0 + ONE cubically convergent step
+        //   e = 1 - d y0^2;  y = y0 (1 + e p),  p = 1/2 + 3e/8.
+        // Dependent fp64 ops cost ~38 cycles each on this chip, so the chain is kept to
+        //   readlane -> rsq -> {d*y0, aleft*y0} -> e -> {p, (aleft*y0)*e} -> l' -> d' :
+        // everything is expressed as x*y0*(1 + e p) so that no product waits for the refined y.
+        const double y0 = __builtin_amdgcn_rsq(d);
+        const double aly = aleft * y0;          // diagonal lane (j+1,j+1): L[j+1][j] before refinement
+        const double ay0 = a * y0;
+        const double e = fma(-d * y0, y0, 1.0);
+        const double p = fma(e, 0.375, 0.5);
+        const double ldiag = fma(aly * e, p, aly);
+        dn = fma(-ldiag, ldiag, a);             // next pivot candidate (valid in lane 9(j+1))
+        const double y = fma(y0 * e, p, y0);
         invd[j] = y;
-        const double l = a[j] * y;     // L[i][j] in lane i (i > j)
-        if (j < 7) dn = fma(-l, l, a[j + 1]);   // own-lane diagonal: no broadcast on the chain
-#pragma unroll
-        for (int c = j + 1; c < 8; ++c) a[c] = fma(-l, bcast(l, c), a[c]);
-        double sq = d * y;             // sqrt(d), off the critical chain
+        const double ay = fma(ay0 * e, p, ay0); // column j lanes: L[i][j]
+        // rank-1 update of the trailing elements (c > j): a -= L[i][j] * L[c][j]
+        constexpr int pat = (j << 5) | 0x18;    // ds_swizzle bit-mode: src = (lane & 0x18) | j  -> lane (i, j)
+        const double li = __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(ay), pat),
+                                           __builtin_amdgcn_ds_swizzle(__double2loint(ay), pat));
+        const double lcj = __hiloint2double(__builtin_amdgcn_ds_bpermute(gather + 4 * j, __double2hiint(ay)),
+                                            __builtin_amdgcn_ds_bpermute(gather + 4 * j, __double2loint(ay)));
+        double sq = d * y;                      // sqrt(d), off the critical chain
         sq = fma(fma(-sq, sq, d), 0.5 * y, sq);
-        a[j] = (li == j) ? sq : l;
+        if (pc > j) a = fma(-li, lcj, a);
+        else if (pc == j) a = (pi == j) ? sq : ay;
+        aleft = shr1(a);                        // left neighbour's (updated) entry, for the next pivot
       } else {
-        d = bcast(a[j], j);
+        d = bcast(a, 9 * j);
         if (d == 0.0) {                // dtrtri: zero pivot
           if (!fail) fail = c0 + j + 1;
           d = 1.0;
         }
         invd[j] = 1.0 / d;
       }
-    }
-    if (lane < 8) {
+    };
+    pivot(std::integral_constant<int, 0>{}); pivot(std::integral_constant<int, 1>{});
+    pivot(std::integral_constant<int, 2>{}); pivot(std::integral_constant<int, 3>{});
+    pivot(std::integral_constant<int, 4>{}); pivot(std::integral_constant<int, 5>{});
+    pivot(std::integral_constant<int, 6>{}); pivot(std::integral_constant<int, 7>{});
+    // publish L8 (for the output rows) and, for the row solves, L8 scaled by its reciprocal
+    // diagonal: x[c] = r[c]/L[c][c] - sum_k x[k] (L[c][k]/L[c][c]) has ONE dependent op per column
+    double myinv = invd[0];
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (c <= lane) Dg[lane * 8 + c] = a[c];
+    for (int j = 1; j < 8; ++j) myinv = (pi == j) ? invd[j] : myinv;
+    if (pc <= pi) {
+      Dg[pi * 8 + pc] = a;
+      Ds[pi * 8 + pc] = (pc == pi) ? myinv : a * myinv;
     }
-    if (lane == 0) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Dg[64 + j] = invd[j];
-      if (fail) failflag = fail;
-    }
+    if (lane == 0 && fail) failflag = fail;
   };
 
   // P2 (threads 0..255 = waves 0..3): forward substitution of one panel row against L8;
@@ -221,10 +245,10 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
       for (int c = 0; c < 8; ++c) x[c] = xp[tid * XPS + c];
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        double v = x[c];
+        double v = x[c] * Ds[c * 8 + c];
 #pragma unroll
-        for (int k2 = 0; k2 < c; ++k2) v = fma(-x[k2], Dg[c * 8 + k2], v);
-        x[c] = v * Dg[64 + c];
+        for (int k2 = 0; k2 < c; ++k2) v = fma(-x[k2], Ds[c * 8 + k2], v);
+        x[c] = v;
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) xp[tid * XPS + c] = x[c];
