@@ -56,6 +56,15 @@ def lml_backward(kind, X, variance, length_scales, noise, f):
     return out[0:1], out[1:1 + nls], out[1 + nls:2 + nls], -a_t.t().contiguous()
 
 
+def _rowmajor(t):
+    """a 2-D tensor usable as a row-major matrix with a leading dimension (no copy for
+    row-slices / column-prefixes of a wider buffer)."""
+    t = t.detach()
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
 def kernel_backward(kind, X, X2, variance, length_scales, gK):
     """-> (sum gK*dK/dvariance [1], sum gK*dK/dlength_scales [nls])."""
     _req(X, X2, variance, length_scales, gK)
@@ -65,7 +74,7 @@ def kernel_backward(kind, X, X2, variance, length_scales, gK):
     X2c = None if X2 is None else _c(X2.detach())
     m = n if X2c is None else X2c.shape[0]
     nls = length_scales.numel()
-    g = _c(gK.detach())
+    g = _rowmajor(gK)
     work = torch.empty(max(1, int(lib.gpn_grad_work_bytes(n, m, nls, 0)) // 8), dtype=torch.float64, device=X.device)
     out = torch.empty(1 + nls, dtype=torch.float64, device=X.device)
     st = lib.gpn_kernel_grad(_stream(X.device), _ops.KINDS[kind], _ptr(Xc), n, _ptr(X2c), m, d,
@@ -73,6 +82,28 @@ def kernel_backward(kind, X, X2, variance, length_scales, gK):
                              _ptr(g), g.stride(0), _ptr(work), _ptr(out))
     _native.check(st, "gpn_kernel_grad")
     return out[0:1], out[1:1 + nls]
+
+
+def kernel_backward_x2(kind, X, X2, variance, length_scales, gK, scale=1.0, out=None):
+    """-> d sum(gK * K(X, X2)) / dX2  [m, d]  (out given: accumulated into it).
+    gK is [n, m]; for dX pass (X2, X, gK^T); for a symmetric K(Z, Z) with symmetric gK pass
+    X = X2 = Z and scale = 2."""
+    _req(X, X2, variance, length_scales, gK)
+    lib = _native.lib()
+    Xc, X2c = _c(X.detach()), _c(X2.detach())
+    n, d = Xc.shape
+    m = X2c.shape[0]
+    nls = length_scales.numel()
+    g = _rowmajor(gK)
+    work = torch.empty(max(1, int(lib.gpn_grad_x2_work_bytes(n, m, d)) // 8), dtype=torch.float64, device=X.device)
+    acc = 1
+    if out is None:
+        out, acc = torch.empty(m, d, dtype=torch.float64, device=X.device), 0
+    st = lib.gpn_kernel_grad_x2(_stream(X.device), _ops.KINDS[kind], _ptr(Xc), n, _ptr(X2c), m, d,
+                                _ptr(_c(variance.detach())), _ptr(_c(length_scales.detach())), nls,
+                                _ptr(g), g.stride(0), float(scale), acc, _ptr(work), _ptr(out))
+    _native.check(st, "gpn_kernel_grad_x2")
+    return out
 
 
 def potri_full(f):

@@ -257,9 +257,163 @@ static int dispatch_kind(hipStream_t s, int kind, const GradArgs& a, int64_t nbl
   }
 }
 
+// ---- gradient w.r.t. the points of the second argument --------------------------------
+//     out[j, c] = scale * sum_i G[i, j] * dK(x_i, z_j)/dz_jc ,   dK/dz_c = B(r) (x_c - z_c)/ell_c^2
+// (what autograd returns for X2 through kernels.py:149-222; used for the inducing points Z
+// of sparse_gpr.py:126-129).  One workgroup owns 64 columns j and a slab of rows i: the
+// wave index is the row phase, the lane is the column, so every G row segment is one
+// coalesced 512-byte read and x_i is an LDS broadcast.  Slab partial sums go to the
+// workspace [slabs, m, d]; a second kernel adds them up in a fixed order (deterministic).
+struct GradX2Args {
+  const double* X;
+  const double* X2;
+  const double* variance;
+  const double* ls;
+  const double* G;
+  int64_t ldg;
+  double* partial;   // [slabs, m, d]
+  int n, m, d, nls, slab_rows;
+};
+
+template <int KIND, int DMAX>
+__global__ __launch_bounds__(256) void grad_x2_kernel(GradX2Args p) {
+  __shared__ double xs[GT][DMAX];          // x_i / ell for the current 64 rows (read as a broadcast)
+  __shared__ double red[4][GDC][GT];       // phase reduction, 16 coordinates at a time
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, ph = tid >> 6;
+  const int j0 = blockIdx.x * GT, col = j0 + lane;
+  const int r_begin = blockIdx.y * p.slab_rows;
+  const int r_end = min(p.n, r_begin + p.slab_rows);
+  const double var = p.variance[0];
+
+  double z[DMAX], acc[DMAX];
+#pragma unroll
+  for (int c = 0; c < DMAX; ++c) {
+    acc[c] = 0.0;
+    z[c] = (c < p.d && col < p.m) ? p.X2[(int64_t)col * p.d + c] / p.ls[p.nls == 1 ? 0 : c] : 0.0;
+  }
+
+  for (int i0 = r_begin; i0 < r_end; i0 += GT) {
+    __syncthreads();
+    for (int idx = tid; idx < GT * DMAX; idx += 256) {
+      const int pt = idx / DMAX, c = idx - pt * DMAX;
+      double v = 0.0;
+      if (c < p.d && i0 + pt < r_end) v = p.X[(int64_t)(i0 + pt) * p.d + c] / p.ls[p.nls == 1 ? 0 : c];
+      xs[pt][c] = v;
+    }
+    __syncthreads();
+    const int lim = min(GT, r_end - i0);
+    for (int ii = ph; ii < lim; ii += 4) {
+      const double g = (col < p.m) ? p.G[(int64_t)(i0 + ii) * p.ldg + col] : 0.0;
+      double df[DMAX];
+      double r2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c) {
+        df[c] = xs[ii][c] - z[c];
+        r2 = fma(df[c], df[c], r2);
+      }
+      double K, B;
+      k_and_base<KIND>(r2, var, K, B);
+      const double w = g * B;
+#pragma unroll
+      for (int c = 0; c < DMAX; ++c) acc[c] = fma(w, df[c], acc[c]);
+    }
+  }
+
+  // add the four row phases, 16 coordinates per round
+  for (int cb = 0; cb < DMAX; cb += GDC) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < GDC; ++c) red[ph][c][lane] = acc[cb + c];   // cb uniform, unrolled
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < GDC / 4; ++q) {
+      const int c = ph * (GDC / 4) + q;
+      if (cb + c < p.d && col < p.m) {
+        const double t = (red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]);
+        p.partial[((int64_t)blockIdx.y * p.m + col) * p.d + cb + c] = t / p.ls[p.nls == 1 ? 0 : cb + c];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void grad_x2_reduce_kernel(const double* partial, int slabs, int64_t md, double scale,
+                                                             int accumulate, double* out) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= md) return;
+  double s = 0.0;
+  for (int b = 0; b < slabs; ++b) s += partial[(int64_t)b * md + k];
+  out[k] = (accumulate ? out[k] : 0.0) + scale * s;
+}
+
+static int x2_slabs(int64_t n, int64_t m) {
+  const int64_t col_tiles = (m + GT - 1) / GT, row_tiles = (n + GT - 1) / GT;
+  int64_t slabs = (1024 + col_tiles - 1) / col_tiles;   // aim for >= 1024 workgroups
+  if (slabs > row_tiles) slabs = row_tiles;
+  if (slabs < 1) slabs = 1;
+  return (int)slabs;
+}
+
+template <int KIND>
+static int launch_x2(hipStream_t s, const GradX2Args& a, dim3 grid) {
+  if (a.d <= 16) hipLaunchKernelGGL((grad_x2_kernel<KIND, 16>), grid, dim3(256), 0, s, a);
+  else if (a.d <= 32) hipLaunchKernelGGL((grad_x2_kernel<KIND, 32>), grid, dim3(256), 0, s, a);
+  else if (a.d <= 64) hipLaunchKernelGGL((grad_x2_kernel<KIND, 64>), grid, dim3(256), 0, s, a);
+  else return GPN_E_UNSUPPORTED;
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
 }  // namespace gpn
 
 using namespace gpn;
+
+extern "C" int64_t gpn_grad_x2_work_bytes(int64_t n, int64_t m, int d) {
+  if (n <= 0 || m <= 0 || d <= 0) return 0;
+  return (int64_t)x2_slabs(n, m) * m * d * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_kernel_grad_x2(void* stream, int kind, const double* X, int64_t n, const double* X2, int64_t m, int d,
+                                  const double* variance, const double* length_scales, int nls,
+                                  const double* G, int64_t ldg, double scale, int accumulate,
+                                  double* work, double* out) {
+  if (!X) return -3;
+  if (n <= 0) return -4;
+  if (!X2) return -5;
+  if (m <= 0) return -6;
+  if (d <= 0 || d > GMAXD) return -7;
+  if (!variance) return -8;
+  if (!length_scales) return -9;
+  if (nls != 1 && nls != d) return -10;
+  if (!G) return -11;
+  if (ldg < m) return -12;
+  if (!work) return -15;
+  if (!out) return -16;
+  GradX2Args a;
+  a.X = X; a.X2 = X2; a.variance = variance; a.ls = length_scales; a.G = G; a.ldg = ldg; a.partial = work;
+  a.n = (int)n; a.m = (int)m; a.d = d; a.nls = nls;
+  const int slabs = x2_slabs(n, m);
+  const int64_t row_tiles = (n + GT - 1) / GT;
+  a.slab_rows = (int)((row_tiles + slabs - 1) / slabs) * GT;
+  const int used = (int)((n + a.slab_rows - 1) / a.slab_rows);   // <= slabs
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((m + GT - 1) / GT), (unsigned)used);
+  int rc;
+  switch (kind) {
+    case GPN_RBF: rc = launch_x2<GPN_RBF>(s, a, grid); break;
+    case GPN_MATERN52: rc = launch_x2<GPN_MATERN52>(s, a, grid); break;
+    case GPN_MATERN32: rc = launch_x2<GPN_MATERN32>(s, a, grid); break;
+    case GPN_EXP: rc = launch_x2<GPN_EXP>(s, a, grid); break;
+    default: return -2;
+  }
+  if (rc != GPN_OK) return rc;
+  const int64_t md = m * (int64_t)d;
+  hipLaunchKernelGGL(grad_x2_reduce_kernel, dim3((unsigned)((md + 255) / 256)), dim3(256), 0, s, work, used, md, scale,
+                     accumulate, out);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
 
 extern "C" int64_t gpn_grad_work_bytes(int64_t n, int64_t m, int nls, int lml) {
   const int64_t tm = (n + GT - 1) / GT, tn = (m + GT - 1) / GT;

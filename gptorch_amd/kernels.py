@@ -37,8 +37,9 @@ class Kernel(Model):
 
 
 class _StationaryK(torch.autograd.Function):
-    """K(X, X2) with gradients w.r.t. the constrained variance / length-scales
-    (the reference gets these from autograd through its elementwise chain)."""
+    """K(X, X2) with gradients w.r.t. the constrained variance / length-scales and, when
+    asked for, the points themselves (the reference gets these from autograd through its
+    elementwise chain, util.py:73-88 / kernels.py:149-222)."""
 
     @staticmethod
     def forward(ctx, variance, length_scales, X, X2, kind):
@@ -54,7 +55,15 @@ class _StationaryK(torch.autograd.Function):
         variance, length_scales, X, X2 = ctx.saved_tensors
         g_var, g_ls = _backward.kernel_backward(ctx.kind, X, X2 if ctx.has_x2 else None, variance,
                                                 length_scales, gK)
-        return g_var, g_ls, None, None, None
+        g_x = g_x2 = None
+        if ctx.needs_input_grad[2]:
+            # rows of X enter as the first argument (and, for K(X), also as the second)
+            g_x = _backward.kernel_backward_x2(ctx.kind, X2, X, variance, length_scales, _ops.transpose(gK))
+            if not ctx.has_x2:
+                _backward.kernel_backward_x2(ctx.kind, X, X, variance, length_scales, gK, out=g_x)
+        if ctx.has_x2 and ctx.needs_input_grad[3]:
+            g_x2 = _backward.kernel_backward_x2(ctx.kind, X, X2, variance, length_scales, gK)
+        return g_var, g_ls, g_x, g_x2, None
 
 
 class Stationary(Kernel):

@@ -1,29 +1,47 @@
 """
 Sparse GP regression: VFE (Titsias' collapsed bound), gptorch/models/sparse_gpr.py:22-195,
-BASELINE config 5 / SURVEY 8(f)-1.  Forward (ELBO) and predict are composed from the
-native primitives; everything N-sized lives in transposed storage so that every
-contraction is the NT fp64-MFMA form:
+BASELINE config 5 / SURVEY 8(f)-1 (N = 1e6 points, M = 4096 inducing points).
 
-    A^T = K(x, Z) L^-T            [N, M]   right-solve  (gpn_trsm_right_lt)
-    A   = (A^T)^T                 [M, N]   HBM-bound transpose
-    B   = A A^T / s2 + I          [M, M]   SYRK (lower) straight into a factor buffer
-    c   = LB^-1 (A err) / s2               carried as the factor's extra rows
+Forward.  Everything N-sized is STREAMED in row chunks of x (CHUNK_ROWS at a time), so the
+M x N matrices Kuf / A of the reference are never held -- only two chunk-sized scratch
+buffers and a handful of M x M matrices live in HBM -- and every contraction is the NT
+fp64-MFMA form of the library:
 
-Status: evaluation and prediction only -- the hyper-parameter / inducing-point gradients
-of the bound are not implemented natively yet, so the tensors returned here carry no
-autograd graph (`optimize()` on a VFE model raises).  SVGP / FITC (sparse_gpr.py:76-90,
-198-381) are out of scope.
+    per chunk c:  A_c^T = K(x_c, Z) L^-T        [nc, M]  assembly + in-place right-solve
+                  A_c   = (A_c^T)^T             [M, nc]  HBM-bound transpose
+                  AAT  += A_c A_c^T / s2        [M, M]   SYRK (lower), beta = 1
+                  Aerr += A_c err_c             [M, dy]
+    then          B = AAT + I = LB LB^T, with (Aerr)^T carried as the factor's extra rows,
+                  so c * s2 = LB^-1 Aerr falls out of the factorisation.
+
+Backward (closed form, verified against autograd through the reference's op chain in
+tests/golden/make_golden.py; the reference gets it from autograd through two Cholesky
+backwards and two M x N triangular-solve backwards).  With p = dy, s = s2,
+beta = B^-1 A err / s, gamma = L^-T beta:
+
+    dF/dKuu = L^-T [ p/2 (2I - B^-1 - B) - 1/2 beta beta^T ] L^-1                (M x M)
+    dF/dKuf = 1/s ( P Kuf + gamma err^T ),  P = L^-T [ p (I - B^-1) - beta beta^T ] L^-1
+    dF/ds   = p/(2s) (M - tr B^-1) - |c|^2/s + beta^T (B - I) beta/(2s) - p tr(AAT)/(2s)
+              - p N/(2s) + (|err|^2 + p tr Kff)/(2 s^2),        dF/dvar += -p N/(2s)
+
+so the N-sized part is ONE dense [nc, M] x [M, M] contraction per chunk (no solve), followed
+by the HBM-bound sweeps that contract dF/dKuf with dK/dtheta (gpn_kernel_grad) and dK/dZ
+(gpn_kernel_grad_x2).  Forward + backward cost 4 N M^2 flops instead of holding 2 x 33 GB.
+
+SVGP / FITC (sparse_gpr.py:76-90, 198-381) are out of scope.
 """
 import math
 
 import numpy as np
 import torch
 
-from .. import _ops
+from .. import _backward, _ops
 from ..mean_functions import Zero
 from ..param import Param
 from ..util import as_tensor
 from .base import GPModel
+
+CHUNK_ROWS = 65536   # rows of x per streamed chunk (scratch: 2 x CHUNK_ROWS x ld(M) x 8 B)
 
 
 class _InducingPointsGP(GPModel):
@@ -49,6 +67,161 @@ class _InducingPointsGP(GPModel):
         return self.Z.shape[0]
 
 
+def _zeros(rows, cols, device):
+    return torch.zeros(rows, cols, dtype=torch.float64, device=device)
+
+
+def _chunks(n, nc):
+    for c0 in range(0, n, nc):
+        yield c0, min(nc, n - c0)
+
+
+class _State:
+    """what one evaluation of the bound leaves behind (all M-sized)."""
+    __slots__ = ("f_uu", "fB", "AAT", "Aerr", "s2", "tr", "terms", "n")
+
+
+def _vfe_forward(kind, x, err, Z, var, ls, s2):
+    """streamed evaluation of sparse_gpr.py:126-137 -> _State."""
+    dev = x.device
+    n, dy = err.shape
+    m = Z.shape[0]
+    st = _State()
+    st.n, st.s2 = n, s2
+    st.f_uu = f_uu = _ops.kernel_factor(kind, Z, var, ls, None)          # L = chol(K(Z)) (+ladder)
+    fB = _ops.Factor(m, dy, dev)
+    st.AAT = AAT = torch.zeros_like(fB.A)
+    mp = _ops.round_up(m, 16)
+    Aerr = _zeros(mp, dy, dev)
+    nc = min(_ops.round_up(n, _ops.LEAF), _ops.round_up(CHUNK_ROWS, _ops.LEAF))
+    At = _zeros(nc + 16, f_uu.ld, dev)                                     # K(x_c, Z) -> A_c^T
+    A = _zeros(mp, nc, dev)
+    errT = _zeros(_ops.round_up(dy, 16), nc, dev)
+    lib, stream = _ops._native.lib(), _ops._stream(dev)
+    for c0, r in _chunks(n, nc):
+        if r < nc:                                                         # ragged tail: stale entries -> 0
+            At.zero_(), A.zero_(), errT.zero_()
+        _ops.kernel_matrix(kind, x[c0:c0 + r], Z, var, ls, out=At, ldk=f_uu.ld)
+        f_uu.solve_right_lt(At, r)                                         # A_c^T = Kuf_c^T L^-T
+        _ops._native.check(lib.gpn_transpose(stream, _ops._ptr(At), r, m, At.stride(0), _ops._ptr(A), nc),
+                           "gpn_transpose")
+        errT[:dy, :r] = err[c0:c0 + r].t()
+        kp = _ops.round_up(r, 16)
+        first = 0.0 if c0 == 0 else 1.0
+        _ops.gemm_nt(A, A, m, m, kp, alpha=1.0 / s2, beta=first, C=AAT, lower=True)
+        _ops.gemm_nt(A, errT, m, dy, kp, beta=first, C=Aerr)
+    st.Aerr = Aerr[:m]
+    st.tr = AAT.diagonal()[:m].sum()
+
+    def attempt(jitter):
+        fB.A.copy_(AAT)
+        fB.A.diagonal()[:m].add_(1.0 if jitter is None else 1.0 + jitter)  # B = AAT + I
+        fB.pack_rhs(st.Aerr)
+        return fB.potrf()
+    _ops._ladder(attempt)
+    st.fB = fB
+    st.terms = fB.lml_terms()            # [sum log LB_ii, || LB^-1 A err ||^2 = s2^2 |c|^2, ...]
+    return st
+
+
+def _sandwich(U, W, m):
+    """U W U^T for upper-triangular U = L^-T and dense symmetric W (zero-padded buffers)."""
+    kp = _ops.round_up(m, 16)
+    T = torch.zeros_like(U)
+    _ops.gemm_nt(U, W, m, m, kp, C=T, tri=_ops.TRI_A_UPPER)              # T = U W   (W = W^T)
+    R = torch.zeros_like(U)
+    _ops.gemm_nt(T, U, m, m, kp, C=R, tri=_ops.TRI_B_UPPER)              # R = T U^T
+    return R
+
+
+def _vfe_backward(kind, x, err, Z, var, ls, st):
+    """-> dF/d(variance [1], length_scales [nls], noise [1], Z [M, D]) for the CONSTRAINED values."""
+    dev = x.device
+    n, p = err.shape
+    m, s = Z.shape[0], st.s2
+    f_uu, fB = st.f_uu, st.fB
+    mp, pp = _ops.round_up(m, 16), _ops.round_up(p, 16)
+    U = _backward._upper_inverse(f_uu)                                     # L^-T
+    UB = _backward._upper_inverse(fB)                                      # LB^-T
+    Binv = _backward._kinv_lower(fB, UB)[:m, :m]
+    Binv = torch.tril(Binv) + torch.tril(Binv, -1).t()
+    Bd = torch.tril(st.AAT[:m, :m]) + torch.tril(st.AAT[:m, :m], -1).t()
+    Bd.diagonal().add_(1.0)
+    eye = torch.eye(m, dtype=torch.float64, device=dev)
+    # beta^T = c^T LB^-1: the extra rows hold (LB^-1 A err)^T = s c^T
+    bt = _zeros(pp, f_uu.ld, dev)
+    _ops.gemm_nt(fB.A[m:], UB, p, m, mp, alpha=1.0 / s, C=bt, tri=_ops.TRI_B_UPPER)
+    beta = _zeros(mp, pp, dev)
+    beta[:m, :p] = bt[:p, :m].t()
+    bbT = _ops.gemm_nt(beta, beta, m, m, pp)
+    W = torch.zeros_like(U)
+    W[:m, :m] = p * (eye - Binv) - bbT
+    P = _sandwich(U, W, m)                                                 # s * dF/dKuf = P Kuf + gamma err^T
+    W[:m, :m] = 0.5 * p * (2.0 * eye - Binv - Bd) - 0.5 * bbT
+    Guu = _sandwich(U, W, m)                                               # dF/dKuu
+    gt = _ops.gemm_nt(bt, U, p, m, mp, tri=_ops.TRI_B_UPPER)              # gamma^T = beta^T L^-1
+
+    # K(Z, Z) part
+    g_var, g_ls = _backward.kernel_backward(kind, Z, None, var, ls, Guu[:m, :m])
+    g_var, g_ls = g_var.clone(), g_ls.clone()
+    g_Z = _backward.kernel_backward_x2(kind, Z, Z, var, ls, Guu[:m, :m], scale=2.0)
+
+    # K(x, Z) part, streamed:  G_c = 1/s [K(x_c, Z) | err_c] [P | gamma]^T
+    ldk = mp + pp
+    Bq = _zeros(mp, ldk, dev)
+    Bq[:m, :m] = P[:m, :m]
+    Bq[:m, mp:mp + p] = gt[:p, :m].t()
+    nc = min(_ops.round_up(n, _ops.LEAF), _ops.round_up(CHUNK_ROWS, _ops.LEAF))
+    Kx = _zeros(nc + 16, ldk, dev)
+    G = torch.empty(nc, mp, dtype=torch.float64, device=dev)
+    for c0, r in _chunks(n, nc):
+        xc = x[c0:c0 + r]
+        _ops.kernel_matrix(kind, xc, Z, var, ls, out=Kx, ldk=ldk)
+        Kx[:r, mp:mp + p] = err[c0:c0 + r]
+        _ops.gemm_nt(Kx, Bq, r, m, ldk, alpha=1.0 / s, C=G)
+        gv, gl = _backward.kernel_backward(kind, xc, Z, var, ls, G[:r, :m])
+        g_var += gv
+        g_ls += gl
+        _backward.kernel_backward_x2(kind, xc, Z, var, ls, G[:r, :m], out=g_Z)
+
+    g_var = g_var - 0.5 * p * n / s                                        # tr Kff = N * variance
+    c2 = st.terms[1] / (s * s)
+    b = beta[:m, :p]
+    quad = (b * st.Aerr).sum() / s - (b * b).sum()                         # beta^T (B - I) beta
+    g_noise = (0.5 * p / s) * (m - Binv.diagonal().sum()) - c2 / s + 0.5 * quad / s - 0.5 * p * st.tr / s \
+        - 0.5 * p * n / s + 0.5 * (err.pow(2).sum() + p * n * var[0]) / (s * s)
+    return g_var, g_ls, g_noise.reshape(1), g_Z
+
+
+class _VFEBound(torch.autograd.Function):
+    """The collapsed bound as one autograd node over (variance, length_scales, noise, Z)."""
+
+    @staticmethod
+    def forward(ctx, variance, length_scales, noise, Z, kind, x, err, holder):
+        s2 = float(noise.item())
+        st = _vfe_forward(kind, x, err, Z.detach(), variance.detach(), length_scales.detach(), s2)
+        n, p = err.shape
+        elbo = -0.5 * p * n * math.log(2.0 * math.pi)
+        elbo = elbo - p * st.terms[0]
+        elbo = elbo - 0.5 * p * n * math.log(s2)
+        elbo = elbo - 0.5 * (err.pow(2).sum() + p * n * variance.detach()[0]) / s2   # Kdiag = variance
+        elbo = elbo + 0.5 * st.terms[1] / (s2 * s2)                     # c = LB^-1 (A err) / s2
+        elbo = elbo + 0.5 * p * st.tr
+        ctx.kind, ctx.x, ctx.err, ctx.st = kind, x, err, st
+        ctx.save_for_backward(variance, length_scales, Z)
+        holder["state"] = st
+        return elbo
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        variance, length_scales, Z = ctx.saved_tensors
+        g_var, g_ls, g_noise, g_Z = _vfe_backward(ctx.kind, ctx.x, ctx.err, Z.detach(), variance.detach(),
+                                                  length_scales.detach(), ctx.st)
+        g = grad_out
+        return (g * g_var, g * g_ls.reshape(length_scales.shape), g * g_noise, g * g_Z,
+                None, None, None, None)
+
+
 class VFE(_InducingPointsGP):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -61,42 +234,13 @@ class VFE(_InducingPointsGP):
             raise NotImplementedError("gptorch_amd.VFE supports the native stationary kernels")
         return k
 
-    def _common(self, x):
-        """-> (f_uu, At [N, M] padded, fB (factor of B carrying c*s2), s2, trace(AAT))."""
+    def _bound(self, x):
         k = self._kind()
-        with torch.no_grad():
-            var, ls = k.variance.transform(), k.length_scales.transform()
-            s2 = float(self.likelihood.variance.transform().item())
-            Z, err = self.Z.detach(), self.Y          # sparse_gpr.py:125 quirk: err = self.Y
-            n, dy = err.shape
-            m = Z.shape[0]
-            f_uu = _ops.kernel_factor(k._kind, Z, var, ls, None)                       # L = chol(K(Z)) (+ladder)
-            At = _ops.padded_like_factor(f_uu, n)                                      # [N, M]
-            _ops.kernel_matrix(k._kind, x, Z, var, ls, out=At, ldk=f_uu.ld)            # K(x, Z) = Kuf^T
-            f_uu.solve_right_lt(At, n)                                                 # A^T = Kuf^T L^-T
-            kp = _ops.round_up(n, 16)
-            A = torch.zeros(_ops.round_up(m, 16), kp, dtype=torch.float64, device=x.device)
-            _ops._native.check(_ops._native.lib().gpn_transpose(_ops._stream(x.device), _ops._ptr(At), n, m, At.stride(0),
-                                                                 _ops._ptr(A), kp), "gpn_transpose")
-            errT = torch.zeros(_ops.round_up(dy, 16), kp, dtype=torch.float64, device=x.device)
-            errT[:dy, :n] = err.t()
-            Aerr = _ops.gemm_nt(A, errT, m, dy, kp)                                    # A err  [M, dy]
-
-            def attempt(jitter):
-                fB = _ops.Factor(m, dy, x.device)
-                _ops.gemm_nt(A, A, m, m, kp, alpha=1.0 / s2, C=fB.A, lower=True)       # AAT / s2 (lower)
-                tr = fB.A.diagonal()[:m].sum()
-                fB.A.diagonal()[:m].add_(1.0 if jitter is None else 1.0 + jitter)      # B = AAT + I
-                fB.pack_rhs(Aerr)
-                return fB, tr, fB.potrf()
-            fB, tr, info = attempt(None)
-            i = 0
-            while info != 0:
-                if i >= _ops.JITTER_TRIES:
-                    raise RuntimeError("Max tries exceeded.")
-                fB, tr, info = attempt(10.0 ** (-_ops.JITTER_TRIES + i))
-                i += 1
-        return f_uu, At, fB, s2, tr
+        holder = {}
+        elbo = _VFEBound.apply(k.variance.transform(), k.length_scales.transform(),
+                               self.likelihood.variance.transform(), self.Z, k._kind, x,
+                               self.Y, holder)                           # sparse_gpr.py:125 quirk: err = self.Y
+        return elbo, holder["state"]
 
     def log_likelihood(self, x=None, y=None):
         """variational lower bound, sparse_gpr.py:108-153 (0-dim tensor)."""
@@ -104,25 +248,15 @@ class VFE(_InducingPointsGP):
         y = y if y is not None else self.Y
         if not x.shape[0] == y.shape[0]:
             raise ValueError("X and Y must have same # data.")
-        k = self._kind()
-        f_uu, At, fB, s2, tr = self._common(x)
-        n, d_out = self.Y.shape
-        terms = fB.lml_terms()                       # [sum log LB_ii, || LB^-1 A err ||^2, ...]
-        with torch.no_grad():
-            elbo = -0.5 * d_out * n * math.log(2.0 * math.pi)
-            elbo = elbo - d_out * terms[0]
-            elbo = elbo - 0.5 * d_out * n * math.log(s2)
-            elbo = elbo - 0.5 * (self.Y.pow(2).sum() + d_out * k.Kdiag(x).sum()) / s2
-            elbo = elbo + 0.5 * terms[1] / (s2 * s2)          # c = LB^-1 (A err) / s2
-            elbo = elbo + 0.5 * d_out * tr
-        return elbo
+        return self._bound(x)[0]
 
     def _predict(self, x_new, diag=True, x=None):
         """sparse_gpr.py:155-195."""
         x = x if x is not None else self.X
         k = self._kind()
-        f_uu, At, fB, s2, tr = self._common(x)
         with torch.no_grad():
+            _, st = self._bound(x)
+            f_uu, fB, s2 = st.f_uu, st.fB, st.s2
             var, ls = k.variance.transform(), k.length_scales.transform()
             ns, m, dy = x_new.shape[0], self.Z.shape[0], self.Y.shape[1]
             T1 = _ops.padded_like_factor(f_uu, ns)                                    # tmp1^T = K(x*, Z) L^-T

@@ -151,6 +151,19 @@ int gpn_kernel_grad(void* stream, int kind, const double* X, int64_t n, const do
                     const double* variance, const double* length_scales, int nls,
                     const double* G, int64_t ldg, double* work, double* out);
 
+/* autograd backward of gpn_kernel_matrix w.r.t. the POINTS of the second argument
+ * (what the reference gets from autograd through util.py:73-88 / kernels.py:149-222, e.g.
+ * for the inducing points Z in sparse_gpr.py:126-129):
+ *     out[j, c] (+)= scale * sum_i G[i, j] * dK(x_i, z_j)/dz_jc      out [m, d] contiguous
+ * accumulate != 0 adds to out.  For the gradient w.r.t. X pass G^T with the roles swapped;
+ * for a symmetric K(Z, Z) with symmetric G pass X = X2 = Z and scale = 2.
+ * work: gpn_grad_x2_work_bytes(n, m, d) bytes. */
+int64_t gpn_grad_x2_work_bytes(int64_t n, int64_t m, int d);
+int gpn_kernel_grad_x2(void* stream, int kind, const double* X, int64_t n, const double* X2, int64_t m, int d,
+                       const double* variance, const double* length_scales, int nls,
+                       const double* G, int64_t ldg, double scale, int accumulate,
+                       double* work, double* out);
+
 /* ---- small utilities -------------------------------------------------------- */
 /* dst[r, c] = src[c, r] for src[rows, cols] */
 int gpn_transpose(void* stream, const double* src, int64_t rows, int64_t cols, int64_t lds,

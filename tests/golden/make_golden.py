@@ -333,8 +333,45 @@ def gen_sparse(out):
     oo = orc.VFEOracle(x, y, z, "Matern52", case["variance"], case["length_scales"], case["noise"])
     assert abs(oo.log_likelihood().item() - case["elbo"]) < 1e-9 * abs(case["elbo"])
     case.update(seed_z=55, seed_xs=56, mean=mu.tolist(), var=var.tolist(), cov=cov.tolist())
+
+    def ref_grads(model):
+        """gradients of the reference's loss w.r.t. its RAW parameters (autograd through
+        sparse_gpr.py:108-153), checked against the oracle's autograd."""
+        model.zero_grad()
+        model.loss().backward()
+        return dict(g_variance=model.kernel.variance.grad.tolist(),
+                    g_length_scales=model.kernel.length_scales.grad.tolist(),
+                    g_noise=model.likelihood.variance.grad.tolist(), g_Z=model.Z.grad.tolist())
+    mm = VFE(x, y, rk.Matern52(case["d"], variance=case["variance"], length_scales=case["length_scales"]),
+             inducing_points=z, likelihood=rl.Gaussian(variance=case["noise"]), mean_function=rm.Zero(case["dy"]))
+    case.update(ref_grads(mm))        # fresh model: _predict freezes Z (sparse_gpr.py:165)
+    cases = [case]
+    # ARD Rbf, ragged sizes, dy = 1, + a 5-step Adam trajectory with Z trainable
+    c2 = dict(n=2500, d=3, dy=1, m=150, kind="Rbf", variance=0.8, length_scales=[0.5, 0.7, 0.9], noise=0.1,
+              seed_z=57, seed_xs=58)
+    x, y = rng.make_regression(c2["n"], c2["d"], c2["dy"], seed=0)
+    z = rng.normal(57, (c2["m"], c2["d"]))
+
+    def build():
+        return VFE(x, y, rk.Rbf(c2["d"], variance=c2["variance"], length_scales=np.array(c2["length_scales"]),
+                                ARD=True),
+                   inducing_points=z.copy(), likelihood=rl.Gaussian(variance=c2["noise"]), mean_function=rm.Zero(1))
+    m2 = build()
+    with torch.no_grad():
+        c2["elbo"] = float(m2.log_likelihood().item())
+        xs = rng.normal(58, (16, c2["d"]))
+        mu, var = m2._predict(torch.tensor(xs))
+        _, cov = m2._predict(torch.tensor(xs), diag=False)
+    c2.update(mean=mu.tolist(), var=var.tolist(), cov=cov.tolist())
+    m2 = build()          # _predict froze Z (sparse_gpr.py:165); start again for the gradients
+    c2.update(ref_grads(m2))
+    m3 = build()
+    losses, _ = m3.optimize(method="Adam", max_iter=5, verbose=False, learning_rate=0.01)
+    c2["adam_losses"] = [float(v) for v in losses]
+    c2["adam_final_Z_sum"] = float(m3.Z.detach().sum().item())
+    cases.append(c2)
     with open(os.path.join(out, "vfe_cases.json"), "w") as f:
-        json.dump([case], f, indent=1)
+        json.dump(cases, f, indent=1)
     print("sparse: VFE known answer reproduced (8.842242323920674); medium elbo %.8f" % case["elbo"])
 
 

@@ -255,6 +255,33 @@ def test_kernel_matrix_autograd(device):
         assert (k.length_scales.grad.cpu() - rl.grad).abs().max().item() < 1e-10, kind
 
 
+@pytest.mark.parametrize("kind", ["Rbf", "Matern52", "Matern32", "Exp"])
+@pytest.mark.parametrize("n,m,d,ard", [(150, 70, 5, True), (64, 64, 1, False), (333, 129, 20, True), (40, 200, 40, False)])
+def test_kernel_matrix_point_gradients(device, kind, n, m, d, ard):
+    """Kernel.K is differentiable w.r.t. the POINTS too (gpn_kernel_grad_x2), as the reference
+    is through util.py:73-88 -- K(X, X2) w.r.t. both arguments and K(X) w.r.t. X."""
+    xn, x2n = rng.normal(31, (n, d)), rng.normal(32, (m, d))
+    wn, wsn = rng.normal(33, (n, m)), rng.normal(34, (n, n))
+    ls = 0.8 * np.sqrt(d) * (0.5 + rng.uniform(35, d)) if ard else 0.8 * np.sqrt(d)
+    k = KERN[kind](d, variance=1.4, length_scales=ls, ARD=ard)
+    k.cuda()
+    X = torch.tensor(xn, device=device, requires_grad=True)
+    X2 = torch.tensor(x2n, device=device, requires_grad=True)
+    (k.K(X, X2) * torch.tensor(wn, device=device)).sum().backward()
+    Xs = torch.tensor(xn, device=device, requires_grad=True)
+    (k.K(Xs) * torch.tensor(wsn, device=device)).sum().backward()
+    Xo, X2o, Xso = [torch.tensor(a, requires_grad=True) for a in (xn, x2n, xn)]
+    var, lso = torch.tensor([1.4], dtype=torch.float64), torch.tensor(np.atleast_1d(ls), dtype=torch.float64)
+    (orc.kernel_K(kind, Xo, X2o, var, lso) * torch.tensor(wn)).sum().backward()
+    (orc.kernel_K(kind, Xso, None, var, lso) * torch.tensor(wsn)).sum().backward()
+    # Exp: the reference's own K(X) gradient carries ~1e-7 of noise at the cusp (Gram-trick
+    # rounding on the diagonal divided by sqrt(1e-16)); the native gradient is exactly 0 there
+    tol = 1e-6 if kind == "Exp" else 1e-10
+    for got, ref in [(X.grad, Xo.grad), (X2.grad, X2o.grad), (Xs.grad, Xso.grad)]:
+        err, scale = (got.cpu() - ref).abs().max().item(), max(1.0, ref.abs().max().item())
+        assert err < tol * scale, (kind, err, scale)
+
+
 def test_cholesky_inverse(device):
     n = 200
     a = rng.normal(77, (n, n))
@@ -334,6 +361,74 @@ def test_vfe_medium_golden(device):
     assert np.max(np.abs(mu - np.asarray(case["mean"]))) < 1e-8
     assert np.max(np.abs(var - np.asarray(case["var"]))) < 1e-8
     assert np.max(np.abs(cov - np.asarray(case["cov"]))) < 1e-8
+
+
+def _vfe_case_model(case):
+    from gptorch_amd.models import VFE
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    zpts = rng.normal(case["seed_z"], (case["m"], case["d"]))
+    ls = case["length_scales"]
+    ard = isinstance(ls, list)
+    m = VFE(x, y, KERN[case["kind"]](case["d"], variance=case["variance"],
+                                     length_scales=np.asarray(ls) if ard else ls, ARD=ard),
+            inducing_points=zpts, likelihood=likelihoods.Gaussian(variance=case["noise"]),
+            mean_function=mean_functions.Zero(case["dy"]))
+    m.cuda()
+    return m
+
+
+def _vfe_grads(m):
+    m.zero_grad()
+    loss = m.loss()
+    loss.backward()
+    return loss.item(), [m.kernel.variance.grad.cpu().numpy().ravel(), m.kernel.length_scales.grad.cpu().numpy().ravel(),
+                         m.likelihood.variance.grad.cpu().numpy().ravel(), m.Z.grad.cpu().numpy()]
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_vfe_gradients_golden(device, idx):
+    """loss().backward() of the collapsed bound vs the reference's autograd (raw parameters
+    and the inducing points), incl. prediction goldens for the second case."""
+    case = load_json("vfe_cases.json")[idx]
+    m = _vfe_case_model(case)
+    loss, got = _vfe_grads(m)
+    assert abs(-loss - case["elbo"]) < 1e-8 * abs(case["elbo"])
+    ref = [np.asarray(case[k]) for k in ("g_variance", "g_length_scales", "g_noise", "g_Z")]
+    for g, r in zip(got, ref):
+        assert np.abs(g.reshape(r.shape) - r).max() < 1e-7 * np.abs(r).max(), (g, r)
+    xs = rng.normal(case["seed_xs"], (16, case["d"]))
+    mu, var = m.predict_f(xs)
+    _, cov = m.predict_f(xs, diag=False)
+    assert np.max(np.abs(mu - np.asarray(case["mean"]))) < 1e-8
+    assert np.max(np.abs(var - np.asarray(case["var"]))) < 1e-8
+    assert np.max(np.abs(cov - np.asarray(case["cov"]))) < 1e-8
+    assert m.Z.requires_grad          # unlike sparse_gpr.py:165 predicting does not freeze Z
+
+
+def test_vfe_streamed_chunks_match(device, monkeypatch):
+    """the N-sized work is streamed in row chunks: 5 ragged chunks == one chunk."""
+    from gptorch_amd.models import sparse_gpr
+    case = load_json("vfe_cases.json")[1]
+    m = _vfe_case_model(case)
+    loss1, g1 = _vfe_grads(m)
+    monkeypatch.setattr(sparse_gpr, "CHUNK_ROWS", 512)
+    loss2, g2 = _vfe_grads(m)
+    assert abs(loss1 - loss2) < 1e-11 * abs(loss1)
+    for a, b in zip(g1, g2):
+        assert np.abs(a - b).max() < 1e-9 * np.abs(a).max()
+    xs = rng.normal(case["seed_xs"], (16, case["d"]))
+    mu, _ = m.predict_f(xs)
+    assert np.max(np.abs(mu - np.asarray(case["mean"]))) < 1e-8
+
+
+def test_vfe_adam_trajectory(device):
+    """5 Adam steps on all of (variance, length_scales, noise, Z) vs the reference's run."""
+    case = load_json("vfe_cases.json")[1]
+    m = _vfe_case_model(case)
+    losses, _ = m.optimize(method="Adam", max_iter=5, verbose=False, learning_rate=0.01)
+    ref = np.asarray(case["adam_losses"])
+    assert np.abs(np.asarray(losses) - ref).max() < 1e-7 * np.abs(ref).max()
+    assert abs(m.Z.detach().sum().item() - case["adam_final_Z_sum"]) < 1e-7
 
 
 # ---- edge cases -------------------------------------------------------------------

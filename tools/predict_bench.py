@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""GPU-box tool: predict path timing at the bench workload (C2: N*=1024 test points)."""
+import os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from gptorch_amd import rng  # noqa: E402
+w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
+ns = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+m, _, _ = bench.build_model(w, 0, torch.device("cuda:0"))
+xs = torch.tensor(rng.normal(77, (ns, w["d"])), device="cuda:0")
+
+
+def t(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def cold():
+    m._predict_cache = None
+    return m.predict_y(xs)
+
+
+print("%s N*=%d: predict_y diag, factor cached   %.3f ms" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+print("%s N*=%d: predict_y full cov, cached      %.3f ms" % (w["name"][:2], ns, t(lambda: m.predict_y(xs, diag=False))))
+print("%s N*=%d: predict_y diag, incl. re-factor %.3f ms (the reference re-factorises every call)" % (w["name"][:2], ns, t(cold)))
