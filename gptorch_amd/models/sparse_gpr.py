@@ -28,6 +28,12 @@ so the N-sized part is ONE dense [nc, M] x [M, M] contraction per chunk (no solv
 by the HBM-bound sweeps that contract dF/dKuf with dK/dtheta (gpn_kernel_grad) and dK/dZ
 (gpn_kernel_grad_x2).  Forward + backward cost 4 N M^2 flops instead of holding 2 x 33 GB.
 
+Why the forward keeps the N-sized solve: A A^T = L^-1 (Kuf Kfu) L^-T would halve the forward
+flops (no N x M TRSM), but only the Gram form A A^T of a COMPUTED A is positive semi-definite
+by construction; the sandwich loses definiteness by ~eps |Kuf|^2 / lambda_min(Kuu), and at
+config 5 (4096 inducing points, Kuu at the edge of the jitter ladder) chol(B) then fails on
+every rung.  Measured, not assumed (round 1).
+
 SVGP / FITC (sparse_gpr.py:76-90, 198-381) are out of scope.
 """
 import math
