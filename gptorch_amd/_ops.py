@@ -14,7 +14,7 @@ import torch
 from . import _native
 from ._native import NativeError
 
-KINDS = {"Rbf": 0, "Matern52": 1, "Matern32": 2, "Exp": 3, "Matern12": 3, "SqDist": 4}
+KINDS = {"Rbf": 0, "Matern52": 1, "Matern32": 2, "Exp": 3, "Matern12": 3, "SqDist": 4, "Periodic": 5}
 GPN_FULL, GPN_LOWER = 0, 1
 LEAF = 128   # leaf block of the factorisation = padding granule of factor buffers (gpn_common.h)
 

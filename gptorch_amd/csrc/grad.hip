@@ -14,7 +14,8 @@
 //
 // dK/d(ell_d) = B(r) * s_d / ell_d with s_d = ((x_id - x_jd)/ell_d)^2 and
 //   Rbf: B = K;  Matern52: B = var*(5/3)(1+sqrt5 r)exp(-sqrt5 r);  Matern32: B = 3 var exp(-sqrt3 r);
-//   Exp: B = var*exp(-r)/r (0 where the reference's clamp at 1e-40 kills the gradient).
+//   Exp: B = var*exp(-r)/r (0 where the reference's clamp at 1e-40 kills the gradient);
+//   Periodic (var*cos r): B = var*sin(r)/r.
 // Per-workgroup partial sums go to a workspace and are reduced by a second tiny kernel
 // (deterministic; no float atomics).
 #include "gpn_common.h"
@@ -59,6 +60,9 @@ __device__ __forceinline__ void k_and_base(double r2, double var, double& K, dou
       const double e = exp(-s3 * r);
       K = var * (1.0 + s3 * r) * e;
       B = dead ? 0.0 : 3.0 * var * e;
+    } else if constexpr (KIND == GPN_PERIODIC) {
+      K = var * cos(r);
+      B = dead ? 0.0 : var * sin(r) / r;
     } else {
       const double e = exp(-r);
       K = var * e;
@@ -253,6 +257,7 @@ static int dispatch_kind(hipStream_t s, int kind, const GradArgs& a, int64_t nbl
     case GPN_MATERN52: return launch_sweep<GPN_MATERN52, LML>(s, a, nblocks);
     case GPN_MATERN32: return launch_sweep<GPN_MATERN32, LML>(s, a, nblocks);
     case GPN_EXP: return launch_sweep<GPN_EXP, LML>(s, a, nblocks);
+    case GPN_PERIODIC: return launch_sweep<GPN_PERIODIC, LML>(s, a, nblocks);
     default: return -2;
   }
 }
@@ -404,6 +409,7 @@ extern "C" int gpn_kernel_grad_x2(void* stream, int kind, const double* X, int64
     case GPN_MATERN52: rc = launch_x2<GPN_MATERN52>(s, a, grid); break;
     case GPN_MATERN32: rc = launch_x2<GPN_MATERN32>(s, a, grid); break;
     case GPN_EXP: rc = launch_x2<GPN_EXP>(s, a, grid); break;
+    case GPN_PERIODIC: rc = launch_x2<GPN_PERIODIC>(s, a, grid); break;
     default: return -2;
   }
   if (rc != GPN_OK) return rc;

@@ -46,6 +46,8 @@ __device__ __forceinline__ double kernel_of_r2(double r2, double var) {
     } else if constexpr (KIND == GPN_MATERN32) {
       const double r3 = 1.73205080756887729353 * r;    // kernels.py:196-201
       return var * (1.0 + r3) * exp(-r3);
+    } else if constexpr (KIND == GPN_PERIODIC) {
+      return var * cos(r);                             // kernels.py:228-235
     } else {
       return var * exp(-r);                            // kernels.py:189-190
     }
@@ -149,7 +151,7 @@ extern "C" int gpn_kernel_matrix(void* stream, int kind, const double* X, int64_
                                  int64_t m, int d, const double* variance, const double* length_scales,
                                  int nls, const double* noise, int uplo, double* K, int64_t ldk) {
   using namespace gpn;
-  if (kind < GPN_RBF || kind > GPN_SQDIST) return -2;
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
   if (!X) return -3;
   if (n < 0) return -4;
   const bool symmetric = (X2 == nullptr);
@@ -178,6 +180,7 @@ extern "C" int gpn_kernel_matrix(void* stream, int kind, const double* X, int64_
     case GPN_MATERN52: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN52>, grid, dim3(256), 0, s, a); break;
     case GPN_MATERN32: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN32>, grid, dim3(256), 0, s, a); break;
     case GPN_EXP: hipLaunchKernelGGL(kmat_kernel<GPN_EXP>, grid, dim3(256), 0, s, a); break;
+    case GPN_PERIODIC: hipLaunchKernelGGL(kmat_kernel<GPN_PERIODIC>, grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(kmat_kernel<GPN_SQDIST>, grid, dim3(256), 0, s, a); break;
   }
   GPN_LAUNCH_CHECK();

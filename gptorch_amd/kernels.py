@@ -140,6 +140,88 @@ class Matern12(Exp):
 
 
 # ---- combinators and input-independent kernels (thin glue) -----
+class Periodic(Stationary):
+    """variance * cos(r) (kernels.py:228-235)."""
+    _kind = "Periodic"
+
+
+class _LinearK(torch.autograd.Function):
+    """K = (X * v) X2^T (kernels.py:258-262) as one NT fp64-MFMA contraction over the
+    (zero-padded) input dimension; backward = three more contractions of the same form."""
+
+    @staticmethod
+    def forward(ctx, v, X, X2):
+        n, d = X.shape
+        other = X if X2 is None else X2
+        m = other.shape[0]
+        dp = _ops.round_up(d, 16)
+        A = torch.zeros(_ops.round_up(n, 16), dp, dtype=torch_dtype, device=X.device)
+        B = torch.zeros(_ops.round_up(m, 16), dp, dtype=torch_dtype, device=X.device)
+        A[:n, :d] = X.detach() * v.detach()
+        B[:m, :d] = other.detach()
+        ctx.save_for_backward(v, X, other)
+        ctx.symmetric = X2 is None
+        return _ops.gemm_nt(A, B, n, m, dp)
+
+    @staticmethod
+    def backward(ctx, gK):
+        v, X, other = ctx.saved_tensors
+        n, d = X.shape
+        m = other.shape[0]
+        dev = X.device
+        # G X2 [n, d] and G^T X [m, d]: NT contractions against the transposed point blocks
+        mp, np_, dp = _ops.round_up(m, 16), _ops.round_up(n, 16), _ops.round_up(d, 16)
+        G = torch.zeros(np_, mp, dtype=torch_dtype, device=dev)
+        G[:n, :m] = gK
+        Ot = torch.zeros(dp, mp, dtype=torch_dtype, device=dev)
+        Ot[:d, :m] = other.detach().t()
+        GX2 = _ops.gemm_nt(G, Ot, n, d, mp)                                # (G X2)[i, c]
+        g_v = g_x = g_x2 = None
+        if ctx.needs_input_grad[0]:
+            g_v = (X.detach() * GX2).sum(0)
+            if v.numel() == 1:
+                g_v = g_v.sum().reshape(1)
+        need_x2 = (not ctx.symmetric and ctx.needs_input_grad[2]) or (ctx.symmetric and ctx.needs_input_grad[1])
+        if need_x2:
+            Gt = torch.zeros(mp, np_, dtype=torch_dtype, device=dev)
+            Gt[:m, :n] = gK.t()
+            Xt = torch.zeros(dp, np_, dtype=torch_dtype, device=dev)
+            Xt[:d, :n] = (X.detach() * v.detach()).t()
+            GtX = _ops.gemm_nt(Gt, Xt, m, d, np_)                          # (G^T (X v))[j, c]
+        if ctx.needs_input_grad[1]:
+            g_x = GX2 * v.detach()
+            if ctx.symmetric:
+                g_x = g_x + GtX
+        if not ctx.symmetric and ctx.needs_input_grad[2]:
+            g_x2 = GtX
+        return g_v, g_x, g_x2
+
+
+class Linear(Kernel):
+    """kernels.py:238-265: K = (X * variance) X2^T with one variance per input when ARD."""
+
+    def __init__(self, input_dim, variance=1.0, ARD=None):
+        super().__init__(input_dim)
+        if ARD is None:
+            ARD = np.asarray(variance).squeeze().shape != ()
+        variance = variance * np.ones(input_dim)
+        if variance.shape != (input_dim,):
+            raise ValueError("shape of possibly-ARD param does not match input_dim")
+        self.ARD = ARD
+        self.variance = Param(torch.as_tensor(np.asarray(variance, dtype=np.float64)).clone(),
+                              transform=DefaultPositiveTransform())
+
+    def K(self, X, X2=None):
+        if isinstance(X, np.ndarray):
+            X = as_tensor(X).to(self.variance.device)
+        if isinstance(X2, np.ndarray):
+            X2 = as_tensor(X2).to(self.variance.device)
+        return _LinearK.apply(self.variance.transform(), X, X2)
+
+    def Kdiag(self, X):
+        return torch.sum(X * X * self.variance.transform(), 1)
+
+
 class Combination(Kernel):
     def __init__(self, k1, k2):
         if not k1.input_dim == k2.input_dim:

@@ -40,7 +40,8 @@ extern "C" {
 
 /* kernel kinds: kernels.py:215-222 (Rbf), 204-212 (Matern52), 196-201 (Matern32), 182-193 (Exp/Matern12) */
 enum { GPN_RBF = 0, GPN_MATERN52 = 1, GPN_MATERN32 = 2, GPN_EXP = 3,
-       GPN_SQDIST = 4 /* util.squared_distance itself (util.py:73-88): K = r^2, variance ignored */ };
+       GPN_SQDIST = 4 /* util.squared_distance itself (util.py:73-88): K = r^2, variance ignored */,
+       GPN_PERIODIC = 5 /* kernels.py:228-235: variance * cos(r) */ };
 enum { GPN_FULL = 0, GPN_LOWER = 1 };
 
 enum {

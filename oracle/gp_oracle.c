@@ -31,7 +31,8 @@ static void scaled_sqdist(const double* x, int n, const double* x2, int m, int d
     free(xs); free(ys);
 }
 
-/* kind: 0 Rbf (kernels.py:215-222), 1 Matern52 (204-212), 2 Matern32 (196-201), 3 Exp (182-190) */
+/* kind: 0 Rbf (kernels.py:215-222), 1 Matern52 (204-212), 2 Matern32 (196-201), 3 Exp (182-190),
+ * 5 Periodic (228-235) */
 int gpo_kernel_matrix(int kind, const double* x, int n, const double* x2, int m, int d,
                       double variance, const double* ls, int nls, double* K) {
     scaled_sqdist(x, n, x2, m, d, ls, nls, K);
@@ -41,6 +42,7 @@ int gpo_kernel_matrix(int kind, const double* x, int n, const double* x2, int m,
         double r = sqrt(r2 < 1e-40 ? 1e-40 : r2);                       /* kernels.py:172 */
         if (kind == 1) { double s5 = sqrt(5.0); K[t] = variance * (1.0 + s5 * r + 5.0 / 3.0 * r * r) * exp(-s5 * r); }
         else if (kind == 2) { double r3 = sqrt(3.0) * r; K[t] = variance * (1.0 + r3) * exp(-r3); }
+        else if (kind == 5) K[t] = variance * cos(r);
         else K[t] = variance * exp(-r);
     }
     return 0;

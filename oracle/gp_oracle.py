@@ -103,7 +103,7 @@ def scaled_dist(X, X2, length_scales):
 
 def kernel_K(kind, X, X2, variance, length_scales):
     """Rbf: kernels.py:215-222; Matern52: 204-212; Matern32: 196-201;
-    Exp/Matern12: 182-193."""
+    Exp/Matern12: 182-193; Periodic: 228-235."""
     if kind == "Rbf":
         r2 = scaled_squared_dist(X, X2, length_scales)
         return variance * torch.exp(-r2 / 2.0)
@@ -116,7 +116,19 @@ def kernel_K(kind, X, X2, variance, length_scales):
         return variance * (1.0 + r3) * torch.exp(-r3)
     if kind in ("Exp", "Matern12"):
         return variance * torch.exp(-r)
+    if kind == "Periodic":
+        return variance * torch.cos(r)                                   # kernels.py:228-235
     raise ValueError(kind)
+
+
+def linear_K(X, X2, variance):
+    """kernels.py:258-262 (variance: one per input dimension)."""
+    return torch.mm(X * variance, (X if X2 is None else X2).t())
+
+
+def linear_Kdiag(X, variance):
+    """kernels.py:264-265."""
+    return torch.sum(X * X * variance, 1)
 
 
 def kernel_Kdiag(X, variance):

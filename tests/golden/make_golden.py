@@ -41,7 +41,8 @@ from oracle import gp_oracle as orc  # noqa: E402
 
 assert gptorch.__file__.startswith(REF), gptorch.__file__
 
-KERNELS = {"Rbf": rk.Rbf, "Matern52": rk.Matern52, "Matern32": rk.Matern32, "Exp": rk.Exp}
+KERNELS = {"Rbf": rk.Rbf, "Matern52": rk.Matern52, "Matern32": rk.Matern32, "Exp": rk.Exp, "Periodic": rk.Periodic}
+STATIC_KERNELS = ["White", "Constant", "Bias", "Linear", "Matern12"]   # fixtures only (no ARD set)
 
 
 def quiet():
@@ -85,9 +86,15 @@ def gen_ref_kernel_fixtures(out):
     for k in KERNELS:
         for suffix in ["kx", "kx2", "kdiag", "kx_ard", "kx2_ard", "kdiag_ard"]:
             pack[f"{k}_{suffix}"] = np.load(os.path.join(ddir, f"{k}_{suffix}.npy"))
+    for k in STATIC_KERNELS:
+        for suffix in ["kx", "kx2", "kdiag"]:
+            pack[f"{k}_{suffix}"] = np.load(os.path.join(ddir, f"{k}_{suffix}.npy"))
     x1, x2 = torch.tensor(pack["x1"]), torch.tensor(pack["x2"])
     one = torch.ones(1, dtype=torch.float64)
     ard = torch.tensor(pack["ard_length_scales"])
+    assert np.allclose(orc.linear_K(x1, None, torch.ones(3, dtype=torch.float64)).numpy(), pack["Linear_kx"])
+    assert np.allclose(orc.linear_K(x1, x2, torch.ones(3, dtype=torch.float64)).numpy(), pack["Linear_kx2"])
+    assert np.allclose(orc.linear_Kdiag(x1, torch.ones(3, dtype=torch.float64)).numpy(), pack["Linear_kdiag"])
     for k in KERNELS:
         assert np.allclose(orc.kernel_K(k, x1, None, one, one).numpy(), pack[f"{k}_kx"])
         assert np.allclose(orc.kernel_K(k, x1, x2, one, one).numpy(), pack[f"{k}_kx2"])
@@ -104,7 +111,7 @@ def gen_kernel_cases(out):
     cases = []
     small = {}
     rs = np.random.RandomState(7)
-    for kind in ["Rbf", "Matern52", "Matern32", "Exp"]:
+    for kind in ["Rbf", "Matern52", "Matern32", "Exp", "Periodic"]:
         for (n, m, d, ard) in [(33, 17, 3, False), (70, 129, 5, True), (128, 64, 8, True), (1, 1, 1, False), (200, 1, 2, False)]:
             x = rng.normal(100 + n, (n, d))
             x2 = rng.normal(200 + m, (m, d))
@@ -122,6 +129,14 @@ def gen_kernel_cases(out):
             small[key + "_kx"], small[key + "_kx2"], small[key + "_kdiag"] = kx, kx2, kd
             cases.append(dict(key=key, kind=kind, n=n, m=m, d=d, ARD=ard, variance=var,
                               length_scales=ls.tolist(), seed_x=100 + n, seed_x2=200 + m))
+    for (n, m, d) in [(33, 17, 3), (70, 129, 20)]:
+        x, x2 = rng.normal(100 + n, (n, d)), rng.normal(200 + m, (m, d))
+        v = 0.5 + rng.uniform(400 + d, d)
+        kern = rk.Linear(d, variance=v)
+        with torch.no_grad():
+            small[f"Linear_{n}_{m}_{d}_kx"] = kern.K(torch.tensor(x)).numpy()
+            small[f"Linear_{n}_{m}_{d}_kx2"] = kern.K(torch.tensor(x), torch.tensor(x2)).numpy()
+            small[f"Linear_{n}_{m}_{d}_kdiag"] = kern.Kdiag(torch.tensor(x)).numpy()
     np.savez_compressed(os.path.join(out, "kernel_small.npz"), **small)
     sampled = []
     for (kind, n, d, ls) in [("Rbf", 512, 2, 1.0), ("Rbf", 8192, 8, np.sqrt(8.0)), ("Matern52", 4096, 16, 4.0)]:

@@ -12,7 +12,8 @@ from oracle import gp_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-KERN = {"Rbf": kernels.Rbf, "Matern52": kernels.Matern52, "Matern32": kernels.Matern32, "Exp": kernels.Exp}
+KERN = {"Rbf": kernels.Rbf, "Matern52": kernels.Matern52, "Matern32": kernels.Matern32, "Exp": kernels.Exp,
+        "Periodic": kernels.Periodic}
 # north_star: LML and predictive mean/var within 1e-8 (fp64).  The one deliberately
 # ill-conditioned case (sigma_n^2 = 1e-4, cond(Kyy) ~ 1e8, |LML| ~ 1e6) is sensitive at the
 # 1e-5 level to 1e-16 perturbations of K: the reference path itself moves by 3.9e-6 when its
@@ -242,7 +243,7 @@ def test_kernel_matrix_autograd(device):
     xn, x2n = rng.normal(21, (150, 5)), rng.normal(22, (70, 5))
     wn = rng.normal(23, (150, 70))
     ls = 0.5 + rng.uniform(24, 5)
-    for kind in ["Rbf", "Matern52", "Matern32"]:
+    for kind in ["Rbf", "Matern52", "Matern32", "Periodic"]:
         k = KERN[kind](5, variance=1.4, length_scales=ls, ARD=True)
         k.cuda()
         K = k.K(torch.tensor(xn, device=device), torch.tensor(x2n, device=device))
@@ -255,7 +256,7 @@ def test_kernel_matrix_autograd(device):
         assert (k.length_scales.grad.cpu() - rl.grad).abs().max().item() < 1e-10, kind
 
 
-@pytest.mark.parametrize("kind", ["Rbf", "Matern52", "Matern32", "Exp"])
+@pytest.mark.parametrize("kind", ["Rbf", "Matern52", "Matern32", "Exp", "Periodic"])
 @pytest.mark.parametrize("n,m,d,ard", [(150, 70, 5, True), (64, 64, 1, False), (333, 129, 20, True), (40, 200, 40, False)])
 def test_kernel_matrix_point_gradients(device, kind, n, m, d, ard):
     """Kernel.K is differentiable w.r.t. the POINTS too (gpn_kernel_grad_x2), as the reference
@@ -491,6 +492,40 @@ def test_sum_product_kernels(device):
     w = kernels.White(3, variance=0.3)
     w.cuda()
     assert np.allclose(w.K(x1).detach().cpu().numpy(), 0.3 * np.eye(4))
+
+
+def test_static_and_linear_kernel_fixtures(device):
+    """White / Constant / Bias / Linear / Matern12 against the reference's own .npy fixtures
+    (test/test_kernels.py:127-187), Linear also on rng inputs with ARD variances + autograd."""
+    z = load_npz("ref_kernel_fixtures.npz")
+    x1, x2 = torch.tensor(z["x1"], device=device), torch.tensor(z["x2"], device=device)
+    for name in ["White", "Constant", "Bias", "Linear", "Matern12"]:
+        k = getattr(kernels, name)(3)
+        k.cuda()
+        assert np.allclose(z[name + "_kx"], k.K(x1).detach().cpu().numpy()), name
+        assert np.allclose(z[name + "_kx2"], k.K(x1, x2).detach().cpu().numpy()), name
+        assert np.allclose(z[name + "_kdiag"], k.Kdiag(x1).detach().cpu().numpy()), name
+    zs = load_npz("kernel_small.npz")
+    for (n, m, d) in [(33, 17, 3), (70, 129, 20)]:
+        xn, x2n = rng.normal(100 + n, (n, d)), rng.normal(200 + m, (m, d))
+        v = 0.5 + rng.uniform(400 + d, d)
+        k = kernels.Linear(d, variance=v)
+        k.cuda()
+        X = torch.tensor(xn, device=device, requires_grad=True)
+        X2 = torch.tensor(x2n, device=device, requires_grad=True)
+        key = "Linear_%d_%d_%d" % (n, m, d)
+        assert np.max(np.abs(k.K(X).detach().cpu().numpy() - zs[key + "_kx"])) < 1e-12
+        Kx2 = k.K(X, X2)
+        assert np.max(np.abs(Kx2.detach().cpu().numpy() - zs[key + "_kx2"])) < 1e-12
+        assert np.max(np.abs(k.Kdiag(X).detach().cpu().numpy() - zs[key + "_kdiag"])) < 1e-12
+        wn, wsn = rng.normal(41, (n, m)), rng.normal(42, (n, n))
+        ((Kx2 * torch.tensor(wn, device=device)).sum() + (k.K(X) * torch.tensor(wsn, device=device)).sum()).backward()
+        rv = torch.tensor(np.log(v), requires_grad=True)
+        Xo, X2o = torch.tensor(xn, requires_grad=True), torch.tensor(x2n, requires_grad=True)
+        ((orc.linear_K(Xo, X2o, rv.exp()) * torch.tensor(wn)).sum()
+         + (orc.linear_K(Xo, None, rv.exp()) * torch.tensor(wsn)).sum()).backward()
+        for got, ref in [(k.variance.grad, rv.grad), (X.grad, Xo.grad), (X2.grad, X2o.grad)]:
+            assert (got.cpu() - ref).abs().max().item() < 1e-10 * max(1.0, ref.abs().max().item())
 
 
 def test_batched_restarts_match_sequential(device):

@@ -11,7 +11,7 @@ from gptorch_amd import rng
 from tests._util import load_json, load_npz
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-KIND = {"Rbf": 0, "Matern52": 1, "Matern32": 2, "Exp": 3}
+KIND = {"Rbf": 0, "Matern52": 1, "Matern32": 2, "Exp": 3, "Periodic": 5}
 
 
 @pytest.fixture(scope="module")
