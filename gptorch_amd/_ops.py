@@ -331,4 +331,38 @@ class GPRLogLik(torch.autograd.Function):
         return (None, go * g_R if ctx.needs_input_grad[1] else None, go * g_var, go * g_ls, go * g_noise, None, None)
 
 
+class DenseLogLik(torch.autograd.Function):
+    """The same LML for a kernel matrix that arrives as a dense tensor (Sum / Product /
+    Linear / White ... kernels, whose K(X) is composed by autograd from several assemblies):
+    Kyy = K + noise I is copied into the factor buffer, the factorisation and the closed-form
+    backward are the native ones, and dLML/dK = 1/2 (a a^T - dy Kyy^-1) is handed back to
+    autograd as a dense [n, n] gradient for the kernels' own backward sweeps."""
+
+    @staticmethod
+    def forward(ctx, K, R, noise):
+        n = K.shape[0]
+        Kyy = K.detach().clone()
+        Kyy.diagonal().add_(noise.detach()[0])
+        f = cholesky_factor(Kyy, rhs=R)
+        ctx.factor = f
+        return f.lml_terms()[2:3].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _backward
+        f = ctx.factor
+        n, dy = f.n, f.e
+        U = _backward._upper_inverse(f)
+        Kinv = _backward._kinv_lower(f, U)[:n, :n]
+        a_t = gemm_nt(f.A[n:], U, dy, n, round_up(n, 16), tri=TRI_B_UPPER)          # a^T = alpha^T U^T
+        ap = torch.zeros(round_up(n, 16), round_up(dy, 16), dtype=torch.float64, device=f.device)
+        ap[:n, :dy] = a_t.t()
+        G = gemm_nt(ap, ap, n, n, round_up(dy, 16), alpha=0.5)                      # 1/2 a a^T
+        G -= 0.5 * dy * (torch.tril(Kinv) + torch.tril(Kinv, -1).t())
+        go = grad_out.reshape(())
+        return (go * G if ctx.needs_input_grad[0] else None,
+                -go * a_t.t() if ctx.needs_input_grad[1] else None,
+                (go * G.diagonal().sum()).reshape(1) if ctx.needs_input_grad[2] else None)
+
+
 LOG_2PI = math.log(2.0 * math.pi)

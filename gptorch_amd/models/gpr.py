@@ -21,12 +21,10 @@ class GPR(GPModel):
         self._predict_cache = None
 
     def _stationary(self):
+        """the kernel if it is one of the native stationary kinds (fused assembly -> factor
+        path), else None (composite / linear / static kernels: dense-K path)."""
         k = self.kernel
-        if not isinstance(k, kernels.Stationary) or k._kind is None:
-            raise NotImplementedError(
-                "gptorch_amd.GPR runs its fused native path for stationary kernels "
-                "(Rbf, Matern52, Matern32, Exp); got %s" % type(k).__name__)
-        return k
+        return k if isinstance(k, kernels.Stationary) and k._kind is not None else None
 
     def log_likelihood(self, x=None, y=None):
         """gpr.py:47-67; returns a tensor of shape (1,)."""
@@ -36,6 +34,8 @@ class GPR(GPModel):
             raise ValueError("X and Y must have same # data.")
         k = self._stationary()
         resid = y - self.mean_function(x)
+        if k is None:
+            return _ops.DenseLogLik.apply(self.kernel.K(x), resid, self.likelihood.variance.transform())
         return _ops.GPRLogLik.apply(x, resid, k.variance.transform(), k.length_scales.transform(),
                                     self.likelihood.variance.transform(), k._kind, self._holder)
 
@@ -44,6 +44,10 @@ class GPR(GPModel):
         the training / predict paths never materialise it outside the factor buffer."""
         x = x if x is not None else self.X
         k = self._stationary()
+        if k is None:
+            Kyy = self.kernel.K(x).clone()
+            Kyy.diagonal().add_(self.likelihood.variance.transform()[0])
+            return Kyy
         return _ops.kernel_matrix(k._kind, x, None, k.variance.transform(), k.length_scales.transform(),
                                   noise=self.likelihood.variance.transform())
 
@@ -60,10 +64,29 @@ class GPR(GPModel):
                 self._predict_cache = (key, f)
         return self._predict_cache[1], var, ls
 
+    def _predict_dense(self, x_new, diag, x):
+        """gpr.py:88-117 for a kernel without a native kind: the kernel's own K() calls, the
+        native factorisation / right-solves / contractions."""
+        with torch.no_grad():
+            n, ns = x.shape[0], x_new.shape[0]
+            f = _ops.cholesky_factor(self._compute_kyy(x), rhs=self.Y - self.mean_function(x))
+            Bt = _ops.padded_like_factor(f, ns)
+            Bt[:ns, :n] = self.kernel.K(x_new, x)
+            f.solve_right_lt(Bt, ns)                                        # A^T = K(x*, x) L^-T
+            mean = _ops.gemm_nt(Bt, f.A[n:], ns, f.e, _ops.round_up(n, 16)) + self.mean_function(x_new)
+            if diag:
+                v = self.kernel.Kdiag(x_new) - _ops.row_sumsq(Bt, ns, n)
+                return mean, v[:, None].expand_as(mean)
+            cov = self.kernel.K(x_new).clone()
+            _ops.gemm_nt(Bt, Bt, ns, ns, _ops.round_up(n, 16), alpha=-1.0, beta=1.0, C=cov)
+            return mean, cov
+
     def _predict(self, x_new, diag=True, x=None):
         """p(F* | Y) (gpr.py:88-117): mean [n*, dy]; var [n*, dy] (diag) or cov [n*, n*]."""
         x = x if x is not None else self.X
         k = self._stationary()
+        if k is None:
+            return self._predict_dense(x_new, diag, x)
         f, var, ls = self._factor_for_predict(x)
         with torch.no_grad():
             mean, v = _ops.gpr_predict(k._kind, x, x_new, var, ls, f, diag=diag)
@@ -86,6 +109,9 @@ def batched_log_likelihood(models, streams=None):
     with torch.no_grad():
         for m, st in zip(models, streams):
             k = m._stationary()
+            if k is None:                       # dense-K kernels: sequential path
+                pending.append(None)
+                continue
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 resid = m.Y - m.mean_function(m.X)
@@ -97,6 +123,6 @@ def batched_log_likelihood(models, streams=None):
         for st in streams:
             cur.wait_stream(st)
         out = []
-        for m, (f, terms) in zip(models, pending):
-            out.append(terms[2:3] if int(f.info.item()) == 0 else m.log_likelihood())
+        for m, p in zip(models, pending):
+            out.append(p[1][2:3] if p is not None and int(p[0].info.item()) == 0 else m.log_likelihood())
     return out

@@ -126,6 +126,25 @@ def linear_K(X, X2, variance):
     return torch.mm(X * variance, (X if X2 is None else X2).t())
 
 
+def dense_lml(Kyy, resid):
+    """gpr.py:61-67 on a given Kyy = K(x) + sigma_n^2 I (any kernel)."""
+    L = cholesky(Kyy)
+    alpha = trtrs(resid, L)
+    n, dy = resid.shape
+    return -0.5 * alpha.pow(2).sum() - dy * lt_log_determinant(L) - 0.5 * dy * n * math.log(2.0 * math.pi)
+
+
+def dense_predict(Kyy, Ksx, Kss_or_diag, resid, diag=True):
+    """gpr.py:102-115 for given Kyy, K(x, x*) and K(x*) (or its diagonal)."""
+    L = cholesky(Kyy)
+    A = trtrs(Ksx, L)
+    V = trtrs(resid, L)
+    mean = A.t() @ V
+    if diag:
+        return mean, (Kss_or_diag - A.pow(2).sum(0))[:, None].expand_as(mean)
+    return mean, Kss_or_diag - A.t() @ A
+
+
 def linear_Kdiag(X, variance):
     """kernels.py:264-265."""
     return torch.sum(X * X * variance, 1)

@@ -390,6 +390,31 @@ def gen_sparse(out):
     print("sparse: VFE known answer reproduced (8.842242323920674); medium elbo %.8f" % case["elbo"])
 
 
+def gen_composite(out):
+    """GPR with kernels that have no single native kind (Sum / Product / Linear / White,
+    kernels.py:238-306): LML, raw-parameter gradients and predictions from the reference."""
+    cases = []
+    x, y = rng.make_regression(400, 3, 2, seed=0)
+    xs = rng.normal(71, (16, 3))
+    specs = {"rbf_plus_linear": lambda: rk.Rbf(3, variance=1.2, length_scales=1.5) + rk.Linear(3, variance=np.array([0.3, 0.5, 0.7])),
+             "m32_times_rbf": lambda: rk.Matern32(3, variance=0.9, length_scales=2.0) * rk.Rbf(3, variance=1.1, length_scales=np.array([1.0, 2.0, 3.0]), ARD=True),
+             "m52_plus_white": lambda: rk.Matern52(3, variance=1.0, length_scales=1.3) + rk.White(3, variance=0.05)}
+    for name, mk in specs.items():
+        m = RefGPR(x, y, mk(), likelihood=rl.Gaussian(variance=0.05))
+        m.zero_grad()
+        loss = m.loss()
+        loss.backward()
+        grads = {n: p.grad.tolist() for n, p in m.named_parameters() if p.grad is not None}
+        with torch.no_grad():
+            mu, var = m._predict(torch.tensor(xs))
+            _, cov = m._predict(torch.tensor(xs), diag=False)
+        cases.append(dict(name=name, n=400, d=3, dy=2, noise=0.05, seed_xs=71, loss=float(loss.item()), grads=grads,
+                          mean=mu.tolist(), var=var.tolist(), cov=cov.tolist()))
+    with open(os.path.join(out, "composite_cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("composite:", [(c["name"], c["loss"], sorted(c["grads"])) for c in cases])
+
+
 def gen_api(out):
     """API behaviours of the shell."""
     x, y = rng.make_regression(20, 3, 2, seed=5)
@@ -417,7 +442,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
                  lml=lambda: gen_lml(HERE, args.big), adam=lambda: gen_adam(HERE),
-                 func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE))
+                 func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE),
+                 comp=lambda: gen_composite(HERE))
     for k, fn in steps.items():
         if not args.only or k in args.only.split(","):
             fn()

@@ -101,8 +101,8 @@ def test_cpu_tensors_fail_loudly_no_fallback():
         gptorch_amd.functions.cholesky(torch.eye(3, dtype=torch.float64))
     with pytest.raises(ValueError):          # size check precedes any native call (gpr.py:56-57)
         m.loss(x=torch.tensor(x[:5]))
-    with pytest.raises(NotImplementedError):
-        GPR(x, y, kernels.Rbf(2) + kernels.Rbf(2)).loss()
+    with pytest.raises(NativeError):         # composite kernels take the dense-K path: native too
+        GPR(x, y, kernels.Rbf(2) + kernels.Linear(2)).loss()
 
 
 def test_jitter_ladder_logic():
