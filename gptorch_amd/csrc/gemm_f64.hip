@@ -303,7 +303,7 @@ static int launch(hipStream_t s, const GemmArgs& a0) {
   return GPN_OK;
 }
 
-static int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging (debug/A-B)
+static int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
 
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
@@ -317,16 +317,15 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
   a.lower = lower;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
-  // Tile choice = fewest "rounds" of resident workgroups.  128x128 tiles: 2 per CU
-  // (64 KB LDS, 214 VGPRs) = 512 slots, 4 work units each; 64x64 tiles: 5 per CU
-  // (32 KB LDS) = 1280 slots, 1 unit each at ~0.85 of the big tile's efficiency.
+  // Tile choice (measured, tools/gemm_sweep*.py): 64x64 tiles (5 workgroups / CU, 1280 slots)
+  // match or beat 128x128 tiles (2 / CU) on every shape the drivers launch -- better tail
+  // quantisation and more waves to hide DMA latency -- except long-K contractions with many
+  // rounds of tiles (K >= 8192: 65.0 vs 63.1 TFLOP/s at M = 24576 lower).
   auto tiles = [&](int64_t b) {
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
     return lower ? mt * (mt + 1) / 2 : mt * nt;
   };
-  const double t128 = (double)((tiles(128) + 511) / 512) * 8.0;
-  const double t64 = (double)((tiles(64) + 1279) / 1280) * 5.0 / 0.85;
-  const bool small = (N <= 64) || (M <= 64) || t64 < t128;
+  const bool small = !(K >= 8192 && tiles(128) >= 2048 && M > 64 && N > 64);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
@@ -334,6 +333,10 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
     if (g_gemm_variant == 2) return launch<64, 128, 32, 64, true>(s, a);
     return (tri & GPN_TRI_B_LOWER) ? launch<32, 128, 16, 64, true, 4, true>(s, a) : launch<32, 128, 16, 64, true, 4>(s, a);
   }
+  if (g_gemm_variant == 3) return launch<128, 128, 64, 64, true>(s, a);        // A/B: force a tile shape
+  if (g_gemm_variant == 4) return launch<64, 64, 32, 32, true>(s, a);
+  if (g_gemm_variant == 5) return launch<64, 64, 32, 32, true, 8>(s, a);
+  if (g_gemm_variant == 6) return launch<32, 32, 16, 16, true, 8>(s, a);
   if (g_gemm_variant == 0 && tiles(64) <= 64) {
     // a handful of workgroups: per-CU MFMA rate and DMA latency are the limits -> 4x more,
     // 4x smaller workgroups (32x32 tiles) with 8 K-steps of LDS-DMA in flight

@@ -17,7 +17,10 @@
 // "Extra rows" (gpnative.h): rows n..n+e-1 ride along in every panel solve and
 // trailing update of the right spine of the recursion; on exit they hold
 // (L^-1 R)^T -- alpha^T of gpr.py:62 -- for free.
+#include <algorithm>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 #include "gpn_common.h"
 
 namespace gpn {
@@ -392,6 +395,104 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   potrf_rec(c, A21 + h, n - h, e, col0 + h);
 }
 
+// ---- flat right-looking driver with look-ahead -------------------------------------------
+// The recursion above runs every launch of the factorisation back to back on one stream, and
+// most of them are latency-bound (one leaf = one workgroup for ~47 us; panel solves and small
+// updates of ~9 us each).  This driver shortens that serial chain.  Panels of PW columns; inside
+// a panel, per LEAF-wide column block k:
+//     main stream : leaf(k) -> solve ALL rows below against W_k (one in-place launch)
+//                   -> update of the NEXT column block only (what leaf(k+1) waits for)
+//     aux stream  : update of the remaining columns of the panel by block k (needs solve(k)),
+//                   overlapped with leaf(k+1) on the main stream
+// and one large K = PW contraction for everything right of the panel at its end.  The two
+// streams are joined by events (fork/join, so the whole call can also be captured in a
+// hipGraph); no data-dependent host logic.  The upper triangle inside the panel's diagonal
+// square receives finite garbage from the rectangular updates: nothing reads it (the leaf
+// masks j > i on load, every other consumer uses blocks strictly below the diagonal blocks
+// or winv).
+struct Aux {
+  hipStream_t s1 = nullptr;
+  hipEvent_t solve[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t rest[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+static std::mutex g_aux_mutex;
+static std::unordered_map<hipStream_t, Aux> g_aux;
+static int g_potrf_variant = 0;     // 0 = look-ahead panels (default), 1 = plain recursion
+
+static Aux* aux_for(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_aux_mutex);
+  auto it = g_aux.find(s);
+  if (it != g_aux.end()) return &it->second;
+  Aux a;
+  int least = 0, greatest = 0;     // aux work is off the critical path: lowest priority
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+  if (hipStreamCreateWithPriority(&a.s1, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+  for (int i = 0; i < 4; ++i) {
+    if (hipEventCreateWithFlags(&a.solve[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&a.rest[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &g_aux.emplace(s, a).first->second;
+}
+
+static inline int64_t panel_width(int64_t n) { return n > 16384 ? 2048 : 1024; }
+
+static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
+  Aux* ax = aux_for(c.s);
+  if (!ax) { c.rc = GPN_E_HIP; return; }
+  const int64_t lda = c.lda, PW = panel_width(n);
+  auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
+  int step = 0, rest_idx = 0;
+  bool rest_pending = false;
+  for (int64_t p0 = 0; p0 < n && c.rc == GPN_OK; p0 += PW) {
+    const int64_t pw = std::min(PW, n - p0), pend = p0 + pw;
+    for (int64_t k0 = p0; k0 < pend && c.rc == GPN_OK; k0 += LEAF, ++step) {
+      const int64_t kb = std::min<int64_t>(LEAF, n - k0);
+      const int64_t c1 = k0 + kb;                 // first row/column after this block
+      double* Akk = A + k0 * lda + k0;
+      const double* Wk = c.winv + (k0 / LEAF) * (LEAF * LEAF);
+      hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, Akk, lda, (int)kb, (int)k0,
+                         const_cast<double*>(Wk), c.info, 0, nullptr);
+      hip_ok(hipGetLastError());
+      const int64_t m = n + e - c1;                // rows below (incl. the extra rows)
+      if (m <= 0 || c.rc != GPN_OK) continue;
+      double* B = A + c1 * lda + k0;               // [m, kb] <- B W_k^T   (in place)
+      c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
+      if (c.rc != GPN_OK || c1 >= pend) continue;  // last block of the panel: nothing left inside it
+      const int64_t nb1 = std::min<int64_t>(LEAF, pend - c1);
+      const int64_t c2 = c1 + nb1;
+      if (rest_pending) {                          // column block c1 was last written on the aux stream
+        hip_ok(hipStreamWaitEvent(c.s, ax->rest[rest_idx], 0));
+        rest_pending = false;
+      }
+      const bool fork = c2 < pend;
+      if (fork) hip_ok(hipEventRecord(ax->solve[step & 3], c.s));
+      // next column block (rows c1.., columns c1..c2): what the next leaf and solve wait for;
+      // enqueued before the aux work so that it reaches the dispatcher first
+      if (c.rc == GPN_OK)
+        c.rc = gemm_nt(c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
+      if (fork && c.rc == GPN_OK) {                // the rest of the panel on the aux stream
+        hip_ok(hipStreamWaitEvent(ax->s1, ax->solve[step & 3], 0));
+        const int64_t m2 = n + e - c2;
+        c.rc = gemm_nt(ax->s1, m2, pend - c2, kb, -1.0, A + c2 * lda + k0, lda, A + c2 * lda + k0, lda, 1.0,
+                       A + c2 * lda + c2, lda, 0);
+        rest_idx = step & 3;
+        hip_ok(hipEventRecord(ax->rest[rest_idx], ax->s1));
+        rest_pending = true;
+      }
+    }
+    if (c.rc != GPN_OK) break;
+    if (rest_pending) {                            // join before the large update reads the panel
+      hip_ok(hipStreamWaitEvent(c.s, ax->rest[rest_idx], 0));
+      rest_pending = false;
+    }
+    const int64_t m = n + e - pend;
+    if (pend < n) {
+      double* P = A + pend * lda + p0;             // [m, pw] solved panel below the diagonal square
+      c.rc = gemm_nt(c.s, m, m, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+    }
+  }
+}
+
 // U_ii <- W_ii^T for every LEAF x LEAF diagonal block
 __global__ __launch_bounds__(256) void diag_transpose_kernel(const double* winv, double* U, int64_t ldu, int n) {
   // 32x32 sub-tiles through LDS: blockIdx.y enumerates the (LEAF/32)^2 sub-tiles of W
@@ -520,8 +621,14 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
   if (reinterpret_cast<uintptr_t>(A) & 15) return GPN_E_ALIGN;
   if (n == 0) return GPN_OK;
   Ctx c{static_cast<hipStream_t>(stream), lda, winv, info, GPN_OK};
-  potrf_rec(c, A, n, e, 0);
+  if (g_potrf_variant == 1 || n <= 2 * LEAF) potrf_rec(c, A, n, e, 0);
+  else potrf_lookahead(c, A, n, e);
   return c.rc;
+}
+
+extern "C" int gpn_debug_set_potrf_variant(int v) {
+  g_potrf_variant = v;
+  return GPN_OK;
 }
 
 // diagnostic build of the leaf with s_memtime stamps (not part of the public header):
