@@ -434,7 +434,8 @@ static Aux* aux_for(hipStream_t s) {
   return &g_aux.emplace(s, a).first->second;
 }
 
-static inline int64_t panel_width(int64_t n) { return n > 16384 ? 2048 : 1024; }
+static int g_panel_width = 0;        // 0 = by size; debug override
+static inline int64_t panel_width(int64_t n) { return g_panel_width ? g_panel_width : (n >= 8192 ? 2048 : 1024); }
 
 static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   Aux* ax = aux_for(c.s);
@@ -465,11 +466,13 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
         rest_pending = false;
       }
       const bool fork = c2 < pend;
-      if (fork) hip_ok(hipEventRecord(ax->solve[step & 3], c.s));
-      // next column block (rows c1.., columns c1..c2): what the next leaf and solve wait for;
-      // enqueued before the aux work so that it reaches the dispatcher first
+      // next column block (rows c1.., columns c1..c2): what the next leaf and solve wait for.
+      // The aux work is forked AFTER it: launched together, the 1000+ workgroups of the rest
+      // update crowd this small launch out (16 us instead of 7); behind it they overlap with
+      // the next leaf + solve instead.
       if (c.rc == GPN_OK)
         c.rc = gemm_nt(c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
+      if (fork) hip_ok(hipEventRecord(ax->solve[step & 3], c.s));
       if (fork && c.rc == GPN_OK) {                // the rest of the panel on the aux stream
         hip_ok(hipStreamWaitEvent(ax->s1, ax->solve[step & 3], 0));
         const int64_t m2 = n + e - c2;
@@ -627,7 +630,8 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
 }
 
 extern "C" int gpn_debug_set_potrf_variant(int v) {
-  g_potrf_variant = v;
+  g_potrf_variant = v & 1;           // bit 0: plain recursion; bits 8..: panel width / 128 (0 = default)
+  g_panel_width = (v >> 8) * LEAF;
   return GPN_OK;
 }
 

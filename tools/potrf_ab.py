@@ -12,7 +12,7 @@ lib = _native.lib()
 for wl in (sys.argv[1:] or ["c2", "c3"]):
     w = bench.WORKLOADS[wl]
     m, _, _ = bench.build_model(w, 0, torch.device("cuda:0"))
-    for variant in (1, 0, 1, 0):
+    for variant in [int(v, 0) for v in os.environ.get("VARIANTS", "1,0,1,0").split(",")]:
         lib.gpn_debug_set_potrf_variant(variant)
         with torch.no_grad():
             for _ in range(3):
@@ -23,7 +23,7 @@ for wl in (sys.argv[1:] or ["c2", "c3"]):
             for _ in range(reps):
                 out = m.log_likelihood()
             torch.cuda.synchronize()
-        print("%s variant %d: %.3f ms  lml %.10f" % (wl, variant, (time.perf_counter() - t0) / reps * 1e3, out.item()), flush=True)
+        print("%s variant 0x%x: %.3f ms  lml %.10f" % (wl, variant, (time.perf_counter() - t0) / reps * 1e3, out.item()), flush=True)
     lib.gpn_debug_set_potrf_variant(0)
     del m
     torch.cuda.empty_cache()
