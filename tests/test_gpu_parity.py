@@ -106,7 +106,7 @@ def test_kernel_sampled_goldens(device):
 
 
 # ---- functions ---------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 2, 13, 63, 64, 65, 77, 128, 129, 200, 512, 1000, 2048])
+@pytest.mark.parametrize("n", [1, 2, 13, 63, 64, 65, 77, 128, 129, 200, 257, 512, 1000, 1300, 2048, 2500, 3001])
 def test_cholesky_vs_oracle(device, n):
     a = rng.normal(1000 + n, (n, n))
     spd = a @ a.T / n + 0.5 * np.eye(n)
@@ -125,6 +125,32 @@ def test_cholesky_vs_oracle(device, n):
     L2 = L.clone()
     x2 = functions.trtrs(torch.tensor(b, device=device), L2)
     assert (x2.cpu() - x_ref).abs().max().item() < 1e-11
+
+
+@pytest.mark.parametrize("n,e", [(1152, 0), (2500, 3), (8320, 1), (9001, 2)])
+def test_factorisation_drivers_agree(device, n, e):
+    """the look-ahead panel driver (default) and the plain recursion produce the same factor,
+    extra rows and leaf inverses on multi-panel and ragged sizes (panel width 1024 / 2048)."""
+    from gptorch_amd import _native, _ops
+    lib = _native.lib()
+    x = torch.tensor(rng.normal(5, (n, 6)), device=device)
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    R = torch.tensor(rng.normal(6, (n, max(e, 1)))[:, :e], device=device) if e else None
+    out = []
+    for variant in (0, 1):
+        lib.gpn_debug_set_potrf_variant(variant)
+        try:
+            f = _ops.kernel_factor("Matern52", x, one, 2.0 * one, 0.05 * one, R=R)
+        finally:
+            lib.gpn_debug_set_potrf_variant(0)
+        assert int(f.info.item()) == 0
+        out.append((f.lower(), f.extra().clone(), f.winv.clone(), f.lml_terms().clone()))
+    (L0, E0, W0, T0), (L1, E1, W1, T1) = out
+    assert (L0 - L1).abs().max().item() < 1e-11
+    assert (W0 - W1).abs().max().item() < 1e-9 * W1.abs().max().item()
+    if e:
+        assert (E0 - E1).abs().max().item() < 1e-9
+    assert abs(T0[0].item() - T1[0].item()) < 1e-9
 
 
 def test_functions_golden(device):
