@@ -31,6 +31,7 @@ SIGNATURES = {
     "gpn_gemm_nt": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64,
                             c_void_p, c_int64, c_double, c_void_p, c_int64, c_int, c_int]),
     "gpn_trtri_upper": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64]),
+    "gpn_trtri_upper_ws": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
     "gpn_grad_work_bytes": (c_int64, [c_int64, c_int64, c_int, c_int]),
     "gpn_lml_grad": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                              c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),

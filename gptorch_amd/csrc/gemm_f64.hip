@@ -325,7 +325,9 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
     return lower ? mt * (mt + 1) / 2 : mt * nt;
   };
-  const bool small = !(K >= 8192 && tiles(128) >= 2048 && M > 64 && N > 64);
+  // (K-clipped launches -- tri != 0 -- have uneven tiles: the finer 64x64 grain wins there too:
+  //  U U^T at N = 8192: 3.17 vs 3.29 ms.)
+  const bool small = !(K >= 8192 && tiles(128) >= 2048 && M > 64 && N > 64 && tri == 0);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
@@ -337,6 +339,9 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
   if (g_gemm_variant == 4) return launch<64, 64, 32, 32, true>(s, a);
   if (g_gemm_variant == 5) return launch<64, 64, 32, 32, true, 8>(s, a);
   if (g_gemm_variant == 6) return launch<32, 32, 16, 16, true, 8>(s, a);
+  // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
+  // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
+  if (g_gemm_variant == 0 && (M <= 32 || N <= 32)) return launch<32, 32, 16, 16, true, 8>(s, a);
   if (g_gemm_variant == 0 && tiles(64) <= 64) {
     // a handful of workgroups: per-CU MFMA rate and DMA latency are the limits -> 4x more,
     // 4x smaller workgroups (32x32 tiles) with 8 K-steps of LDS-DMA in flight

@@ -21,6 +21,7 @@
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
+#include <vector>
 #include "gpn_common.h"
 
 namespace gpn {
@@ -410,10 +411,14 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
 // square receives finite garbage from the rectangular updates: nothing reads it (the leaf
 // masks j > i on load, every other consumer uses blocks strictly below the diagonal blocks
 // or winv).
+constexpr int NSIDE = 3;              // side streams for level-parallel work (triangular inversion)
 struct Aux {
   hipStream_t s1 = nullptr;
   hipEvent_t solve[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t rest[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr;
+  hipEvent_t join_ev[NSIDE] = {nullptr, nullptr, nullptr};
 };
 static std::mutex g_aux_mutex;
 static std::unordered_map<hipStream_t, Aux> g_aux;
@@ -431,6 +436,11 @@ static Aux* aux_for(hipStream_t s) {
     if (hipEventCreateWithFlags(&a.solve[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.rest[i], hipEventDisableTiming) != hipSuccess) return nullptr;
   }
+  for (int i = 0; i < NSIDE; ++i) {
+    if (hipStreamCreateWithFlags(&a.side[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&a.join_ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  if (hipEventCreateWithFlags(&a.fork_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
   return &g_aux.emplace(s, a).first->second;
 }
 
@@ -673,6 +683,83 @@ extern "C" int gpn_trsm_right_lt(void* stream, const double* L, int64_t n, int64
   Ctx c{static_cast<hipStream_t>(stream), ldl, const_cast<double*>(winv), nullptr, GPN_OK};
   trsm_rec(c, B, m, ldb, L, ldl, n, 0, winv);
   return c.rc;
+}
+
+// Level-parallel variant with a scratch matrix S (same shape as U, zero-initialised):
+//   U12 = -U11 * L21^T * U22  as two NT contractions  T = U11 L21^T  (into S12)  and
+//   U12 = -T * (U22^T)^T  with U22^T written into S22 by an HBM-bound transpose --
+// no right-solve chain, and all nodes of one depth of the recursion tree are independent,
+// so they are dealt round-robin onto the caller's stream and NSIDE side streams (fork/join
+// by events once per depth).
+struct TNode { int64_t off, n, h; int depth; };
+static void trtri_collect(std::vector<TNode>& v, int64_t off, int64_t n, int depth) {
+  if (n <= LEAF) return;
+  const int64_t h = split_point(n);
+  v.push_back({off, n, h, depth});
+  trtri_collect(v, off, h, depth + 1);
+  trtri_collect(v, off + h, n - h, depth + 1);
+}
+
+static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, int64_t ldu, double* S, int64_t lds,
+                        int64_t n) {
+  Aux* ax = aux_for(s);
+  if (!ax) return GPN_E_HIP;
+  std::vector<TNode> nodes;
+  trtri_collect(nodes, 0, n, 0);
+  int maxd = -1;
+  for (const TNode& t : nodes) maxd = std::max(maxd, t.depth);
+  for (int d = maxd; d >= 0; --d) {
+    std::vector<const TNode*> lvl;
+    for (const TNode& t : nodes) if (t.depth == d) lvl.push_back(&t);
+    const int nq = (int)std::min<size_t>(lvl.size(), NSIDE + 1);    // streams used at this depth
+    if (nq > 1) {
+      GPN_HIP_CHECK(hipEventRecord(ax->fork_ev, s));
+      for (int q = 1; q < nq; ++q) GPN_HIP_CHECK(hipStreamWaitEvent(ax->side[q - 1], ax->fork_ev, 0));
+    }
+    for (size_t i = 0; i < lvl.size(); ++i) {
+      const TNode& t = *lvl[i];
+      const int q = (int)(i % nq);
+      hipStream_t sq = q == 0 ? s : ax->side[q - 1];
+      const int64_t h = t.h, m2 = t.n - t.h, o = t.off;
+      const double* U11 = U + o * ldu + o;
+      const double* L21 = L + (o + h) * ldl + o;
+      const double* U22 = U + (o + h) * ldu + o + h;
+      double* S12 = S + o * lds + o + h;
+      double* S22 = S + (o + h) * lds + o + h;
+      dim3 grid((unsigned)((m2 + 31) / 32), (unsigned)((m2 + 31) / 32));
+      hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, sq, U22, m2, m2, ldu, S22, lds);
+      GPN_LAUNCH_CHECK();
+      int rc = gemm_nt(sq, h, m2, h, 1.0, U11, ldu, L21, ldl, 0.0, S12, lds, 0, GPN_TRI_A_UPPER);
+      if (rc != GPN_OK) return rc;
+      rc = gemm_nt(sq, h, m2, round_up(m2, 16), -1.0, S12, lds, S22, lds, 0.0, U + o * ldu + o + h, ldu, 0, GPN_TRI_B_LOWER);
+      if (rc != GPN_OK) return rc;
+    }
+    for (int q = 1; q < nq; ++q) {
+      GPN_HIP_CHECK(hipEventRecord(ax->join_ev[q - 1], ax->side[q - 1]));
+      GPN_HIP_CHECK(hipStreamWaitEvent(s, ax->join_ev[q - 1], 0));
+    }
+  }
+  return GPN_OK;
+}
+
+extern "C" int gpn_trtri_upper_ws(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv,
+                                  double* U, int64_t ldu, double* S, int64_t lds) {
+  if (!L) return -2;
+  if (n < 0) return -3;
+  if (ldl < round_up(n, LEAF) || (ldl % LEAF) != 0) return -4;
+  if (!winv) return -5;
+  if (!U) return -6;
+  if (ldu < round_up(n, LEAF) || (ldu % LEAF) != 0) return -7;
+  if (!S) return -8;
+  if (lds < round_up(n, LEAF) || (lds % LEAF) != 0) return -9;
+  if ((reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(U) & 15) ||
+      (reinterpret_cast<uintptr_t>(S) & 15)) return GPN_E_ALIGN;
+  if (n == 0) return GPN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
+  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb, (LEAF / 32) * (LEAF / 32)), dim3(256), 0, s, winv, U, ldu, (int)n);
+  GPN_LAUNCH_CHECK();
+  return trtri_levels(s, L, ldl, U, ldu, S, lds, n);
 }
 
 extern "C" int gpn_trtri_upper(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv,

@@ -134,6 +134,12 @@ int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
  * PyTorch's CholeskyBackward0 / TriangularSolveBackward0 under gpr.py:47-67. */
 int gpn_trtri_upper(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv,
                     double* U, int64_t ldu);
+/* Same result, throughput-oriented: with a ZERO-INITIALISED scratch matrix S of the same shape
+ * as U the off-diagonal blocks are U12 = -(U11 L21^T) (U22^T)^T -- two NT contractions and an
+ * HBM-bound transpose per node of the recursion tree, no right-solve chain -- and the
+ * independent nodes of one tree depth run on internal side streams (fork/join on `stream`). */
+int gpn_trtri_upper_ws(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv,
+                       double* U, int64_t ldu, double* S, int64_t lds);
 
 /* workspace bytes for the two gradient sweeps below (lml != 0: gpn_lml_grad) */
 int64_t gpn_grad_work_bytes(int64_t n, int64_t m, int nls, int lml);

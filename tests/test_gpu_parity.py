@@ -153,6 +153,23 @@ def test_factorisation_drivers_agree(device, n, e):
     assert abs(T0[0].item() - T1[0].item()) < 1e-9
 
 
+@pytest.mark.parametrize("n", [300, 1000, 2500, 4224])
+def test_triangular_inverse_variants_agree(device, n):
+    """gpn_trtri_upper (right-solve recursion) and gpn_trtri_upper_ws (two contractions per
+    node, level-parallel on side streams) give the same U = L^-T; U^T L = I."""
+    from gptorch_amd import _backward, _ops
+    x = torch.tensor(rng.normal(8, (n, 5)), device=device)
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    f = _ops.kernel_factor("Rbf", x, one, 1.5 * one, 0.1 * one)
+    U0 = _backward._upper_inverse(f, workspace=False)[:n, :n]
+    U1 = _backward._upper_inverse(f, workspace=True)[:n, :n]
+    assert (U0 - U1).abs().max().item() < 1e-10 * U0.abs().max().item()
+    assert torch.equal(torch.tril(U1, -1), torch.zeros_like(U1))
+    L = f.lower()
+    r = (U1.t().cpu() @ L.cpu() - torch.eye(n, dtype=torch.float64)).abs().max().item()
+    assert r < 1e-9
+
+
 def test_functions_golden(device):
     g = load_json("functions_cases.json")
     n, k = g["n"], g["k"]
