@@ -244,15 +244,16 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     const int rho = apart ? tid : tid - 128;
     const bool solve = apart ? (FACTOR && tid >= c0 + 8) : (rho <= c0 + 7);
     if (solve) {
+      // right-looking order: after x[k] is final its contribution goes to ALL later columns at
+      // once, so the dependent chain is 8 FMAs deep (one per column) with 7..1 independent FMAs
+      // in between to fill the fp64 pipeline -- the row-by-row order chains 28 of them
       double x[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) x[c] = xp[tid * XPS + c];
+      for (int c = 0; c < 8; ++c) x[c] = xp[tid * XPS + c] * Ds[c * 8 + c];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        double v = x[c] * Ds[c * 8 + c];
+      for (int k2 = 0; k2 < 7; ++k2) {
 #pragma unroll
-        for (int k2 = 0; k2 < c; ++k2) v = fma(-x[k2], Ds[c * 8 + k2], v);
-        x[c] = v;
+        for (int c = k2 + 1; c < 8; ++c) x[c] = fma(-x[k2], Ds[c * 8 + k2], x[c]);
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) xp[tid * XPS + c] = x[c];
