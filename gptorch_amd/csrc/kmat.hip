@@ -59,8 +59,20 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   __shared__ __attribute__((aligned(16))) double xs[DC][KT];   // row points
   __shared__ __attribute__((aligned(16))) double ys[DC][KT];   // column points
 
-  const int tj = blockIdx.x, ti = blockIdx.y;
-  if (p.lower && tj > ti) return;
+  __shared__ double inv_ell[DC];
+  int tj, ti;
+  if (p.lower) {
+    // only the tiles on/below the diagonal are launched (row-major over the triangle): no
+    // empty workgroups, equal work for every XCD
+    const int q = blockIdx.x;
+    ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > q) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+    tj = q - ti * (ti + 1) / 2;
+  } else {
+    tj = blockIdx.x;
+    ti = blockIdx.y;
+  }
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
   const int i0 = ti * KT, j0 = tj * KT;
@@ -72,7 +84,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
 
   for (int d0 = 0; d0 < p.d; d0 += DC) {
-    // stage: thread -> (point = tid/4, 4 coordinates), scaled by 1/ell
+    // stage: thread -> (point = tid/4, 4 coordinates), scaled by 1/ell (kernels.py:154-158).
+    // One reciprocal per coordinate and workgroup; the points are multiplied by it -- an fp64
+    // division per staged coordinate would be a quarter of the kernel's instructions at D = 8.
+    if (tid < DC) {
+      const int dd = d0 + tid;
+      inv_ell[tid] = dd < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : dd] : 0.0;
+    }
+    __syncthreads();
     {
       const int pt = tid >> 2, c4 = (tid & 3) * 4;
 #pragma unroll
@@ -80,9 +99,9 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
         const int dd = d0 + c4 + c;
         double vx = 0.0, vy = 0.0;
         if (dd < p.d) {
-          const double ell = p.ls[p.nls == 1 ? 0 : dd];   // X / ell as kernels.py:154-158
-          if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd] / ell;
-          if (j0 + pt < p.m) vy = p.X2[(int64_t)(j0 + pt) * p.d + dd] / ell;
+          const double ie = inv_ell[c4 + c];
+          if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd] * ie;
+          if (j0 + pt < p.m) vy = p.X2[(int64_t)(j0 + pt) * p.d + dd] * ie;
         }
         xs[c4 + c][pt] = vx;
         ys[c4 + c][pt] = vy;
@@ -173,7 +192,8 @@ extern "C" int gpn_kernel_matrix(void* stream, int kind, const double* X, int64_
   a.n = (int)n; a.m = (int)m; a.d = d; a.nls = nls;
   a.symmetric = symmetric; a.lower = (uplo == GPN_LOWER);
   a.vec_ok = ((ldk & 1) == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0);
-  dim3 grid((unsigned)((m + KT - 1) / KT), (unsigned)((n + KT - 1) / KT));
+  const unsigned tn = (unsigned)((m + KT - 1) / KT), tm = (unsigned)((n + KT - 1) / KT);
+  dim3 grid = a.lower ? dim3(tm * (tm + 1) / 2) : dim3(tn, tm);
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (kind) {
     case GPN_RBF: hipLaunchKernelGGL(kmat_kernel<GPN_RBF>, grid, dim3(256), 0, s, a); break;
