@@ -94,14 +94,18 @@ __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
   const int tx = tid & 15, ty = tid >> 4;
   const int i0 = ti * GT, j0 = tj * GT;
 
-  // stage both point blocks, divided by the length-scales (kernels.py:154-158)
+  // stage both point blocks, scaled by the reciprocal length-scales (kernels.py:154-158; one
+  // reciprocal per coordinate and workgroup, as in kmat.hip)
+  __shared__ double inv_ell[NCH * GDC];
+  if (tid < NCH * GDC) inv_ell[tid] = tid < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : tid] : 0.0;
+  __syncthreads();
   for (int idx = tid; idx < NCH * GDC * GT; idx += 256) {
     const int dd = idx / GT, pt = idx - dd * GT;   // pt fastest: conflict-free LDS writes
     double vx = 0.0, vy = 0.0;
     if (dd < p.d) {
-      const double ell = p.ls[p.nls == 1 ? 0 : dd];
-      if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd] / ell;
-      if (j0 + pt < p.m) vy = p.X2[(int64_t)(j0 + pt) * p.d + dd] / ell;
+      const double ie = inv_ell[dd];
+      if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd] * ie;   // scaling as kmat.hip
+      if (j0 + pt < p.m) vy = p.X2[(int64_t)(j0 + pt) * p.d + dd] * ie;
     }
     xs[dd][pt] = vx;
     ys[dd][pt] = vy;
@@ -291,11 +295,14 @@ __global__ __launch_bounds__(256) void grad_x2_kernel(GradX2Args p) {
   const int r_end = min(p.n, r_begin + p.slab_rows);
   const double var = p.variance[0];
 
+  __shared__ double inv_ell[DMAX];
+  if (tid < DMAX) inv_ell[tid] = tid < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : tid] : 0.0;
+  __syncthreads();
   double z[DMAX], acc[DMAX];
 #pragma unroll
   for (int c = 0; c < DMAX; ++c) {
     acc[c] = 0.0;
-    z[c] = (c < p.d && col < p.m) ? p.X2[(int64_t)col * p.d + c] / p.ls[p.nls == 1 ? 0 : c] : 0.0;
+    z[c] = (c < p.d && col < p.m) ? p.X2[(int64_t)col * p.d + c] * inv_ell[c] : 0.0;
   }
 
   for (int i0 = r_begin; i0 < r_end; i0 += GT) {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void grad_x2_kernel(GradX2Args p) {
     for (int idx = tid; idx < GT * DMAX; idx += 256) {
       const int pt = idx / DMAX, c = idx - pt * DMAX;
       double v = 0.0;
-      if (c < p.d && i0 + pt < r_end) v = p.X[(int64_t)(i0 + pt) * p.d + c] / p.ls[p.nls == 1 ? 0 : c];
+      if (c < p.d && i0 + pt < r_end) v = p.X[(int64_t)(i0 + pt) * p.d + c] * inv_ell[c];
       xs[pt][c] = v;
     }
     __syncthreads();
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(256) void grad_x2_kernel(GradX2Args p) {
       const int c = ph * (GDC / 4) + q;
       if (cb + c < p.d && col < p.m) {
         const double t = (red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]);
-        p.partial[((int64_t)blockIdx.y * p.m + col) * p.d + cb + c] = t / p.ls[p.nls == 1 ? 0 : cb + c];
+        p.partial[((int64_t)blockIdx.y * p.m + col) * p.d + cb + c] = t * inv_ell[cb + c];
       }
     }
   }
