@@ -100,22 +100,44 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
     mp = _ops.round_up(m, 16)
     Aerr = _zeros(mp, dy, dev)
     nc = min(_ops.round_up(n, _ops.LEAF), _ops.round_up(CHUNK_ROWS, _ops.LEAF))
-    At = _zeros(nc + 16, f_uu.ld, dev)                                     # K(x_c, Z) -> A_c^T
-    A = _zeros(mp, nc, dev)
-    errT = _zeros(_ops.round_up(dy, 16), nc, dev)
-    lib, stream = _ops._native.lib(), _ops._stream(dev)
-    for c0, r in _chunks(n, nc):
-        if r < nc:                                                         # ragged tail: stale entries -> 0
-            At.zero_(), A.zero_(), errT.zero_()
-        _ops.kernel_matrix(kind, x[c0:c0 + r], Z, var, ls, out=At, ldk=f_uu.ld)
-        f_uu.solve_right_lt(At, r)                                         # A_c^T = Kuf_c^T L^-T
-        _ops._native.check(lib.gpn_transpose(stream, _ops._ptr(At), r, m, At.stride(0), _ops._ptr(A), nc),
-                           "gpn_transpose")
-        errT[:dy, :r] = err[c0:c0 + r].t()
-        kp = _ops.round_up(r, 16)
-        first = 0.0 if c0 == 0 else 1.0
-        _ops.gemm_nt(A, A, m, m, kp, alpha=1.0 / s2, beta=first, C=AAT, lower=True)
-        _ops.gemm_nt(A, errT, m, dy, kp, beta=first, C=Aerr)
+    nchunks = (n + nc - 1) // nc
+    # Two chunk pipelines on two streams: while one chunk's SYRK (whose 2080 tiles fill the
+    # 1280 workgroup slots 1.6 times: a poor last round) accumulates, the next chunk's assembly,
+    # right-solve and transpose already run next to it.  The accumulations into AAT / Aerr are
+    # ordered by events.
+    lanes = 2 if nchunks > 1 else 1
+    cur = torch.cuda.current_stream(dev)
+    streams = [cur] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
+    bufs = [(_zeros(nc + 16, f_uu.ld, dev), _zeros(mp, nc, dev), _zeros(_ops.round_up(dy, 16), nc, dev))
+            for _ in range(lanes)]
+    lib = _ops._native.lib()
+    acc_done = None                                                        # event: AAT/Aerr updated through chunk c-1
+    for stq in streams[1:]:
+        stq.wait_stream(cur)
+    for ci, (c0, r) in enumerate(_chunks(n, nc)):
+        stq = streams[ci % lanes]
+        At, A, errT = bufs[ci % lanes]
+        with torch.cuda.stream(stq):
+            stream = _ops._stream(dev)
+            if r < nc:                                                     # ragged tail: stale entries -> 0
+                At.zero_(), A.zero_(), errT.zero_()
+            _ops.kernel_matrix(kind, x[c0:c0 + r], Z, var, ls, out=At, ldk=f_uu.ld)
+            f_uu.solve_right_lt(At, r)                                     # A_c^T = Kuf_c^T L^-T
+            _ops._native.check(lib.gpn_transpose(stream, _ops._ptr(At), r, m, At.stride(0), _ops._ptr(A), nc),
+                               "gpn_transpose")
+            errT[:dy, :r] = err[c0:c0 + r].t()
+            kp = _ops.round_up(r, 16)
+            first = 0.0 if c0 == 0 else 1.0
+            if acc_done is not None:
+                stq.wait_event(acc_done)
+            _ops.gemm_nt(A, A, m, m, kp, alpha=1.0 / s2, beta=first, C=AAT, lower=True)
+            _ops.gemm_nt(A, errT, m, dy, kp, beta=first, C=Aerr)
+            acc_done = torch.cuda.Event()
+            acc_done.record(stq)
+    for stq in streams[1:]:
+        cur.wait_stream(stq)
+    if acc_done is not None:
+        cur.wait_event(acc_done)
     st.Aerr = Aerr[:m]
     st.tr = AAT.diagonal()[:m].sum()
 
