@@ -325,9 +325,9 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
     return lower ? mt * (mt + 1) / 2 : mt * nt;
   };
-  // (K-clipped launches -- tri != 0 -- have uneven tiles: the finer 64x64 grain wins there too:
-  //  U U^T at N = 8192: 3.17 vs 3.29 ms.)
-  const bool small = !(K >= 8192 && tiles(128) >= 2048 && M > 64 && N > 64 && tri == 0);
+  // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer:
+  // U U^T at N = 8192: 3.17 (64) vs 3.29 ms (128); at N = 32768: 199.7 vs 184.0 ms.
+  const bool small = !(K >= 8192 && tiles(128) >= (tri ? 8192 : 2048) && M > 64 && N > 64);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
