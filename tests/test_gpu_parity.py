@@ -617,3 +617,6 @@ def test_batched_restarts_match_sequential(device):
     seq = [m.log_likelihood().item() for m in ms]
     bat = [t.item() for t in batched_log_likelihood(ms)]
     assert seq == bat
+    streams = [torch.cuda.Stream(device=device) for _ in ms]
+    par = [t.item() for t in batched_log_likelihood(ms, streams)]
+    assert seq == par
