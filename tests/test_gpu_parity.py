@@ -606,6 +606,38 @@ def test_gpr_with_composite_kernels(device, idx):
     assert np.max(np.abs(cov - np.asarray(case["cov"]))) < 1e-8
 
 
+def test_evaluation_captures_into_a_hipgraph(device):
+    """the factorisation forks onto internal streams (look-ahead) and joins back, so a whole
+    LML evaluation still captures into ONE hipGraph; replays reproduce the eager value and
+    follow the inputs (new hyper-parameters written into the captured tensors)."""
+    from gptorch_amd import _ops
+    x, y = rng.make_regression(1500, 4, 1, seed=3)
+    m = GPR(x, y, kernels.Matern52(4, length_scales=1.7), likelihood=likelihoods.Gaussian(variance=0.03))
+    m.cuda()
+    k = m.kernel
+    with torch.no_grad():
+        resid = (m.Y - m.mean_function(m.X)).contiguous()
+        var, ls, nz = k.variance.transform().clone(), k.length_scales.transform().clone(), \
+            m.likelihood.variance.transform().clone()
+        f = _ops.kernel_factor_async(k._kind, m.X, var, ls, nz, R=resid)   # warm-up: creates the side streams
+        f.lml_terms()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            _ops.kernel_factor_async(k._kind, m.X, var, ls, nz, R=resid, factor=f)
+            terms = f.lml_terms()
+        eager = m.log_likelihood().item()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        assert int(f.info.item()) == 0 and abs(terms[2].item() - eager) < 1e-9 * abs(eager)
+        ls.mul_(1.25)                                   # same graph, new hyper-parameters
+        g.replay()
+        torch.cuda.synchronize()
+        k.length_scales.data = torch.log(ls.clone())
+        assert abs(terms[2].item() - m.log_likelihood().item()) < 1e-9 * abs(eager)
+
+
 def test_batched_restarts_match_sequential(device):
     from gptorch_amd.models import batched_log_likelihood
     ms = []
