@@ -17,6 +17,11 @@ replicated; every rank ASSEMBLES ITS OWN TILES with the native K-assembly kernel
   4. every rank updates the trailing tiles it owns:  A_IJ -= P_I P_J^T  (gpn_gemm_nt,
      lower-only on diagonal tiles)
 
+Look-ahead: after the exchange of panel k, tile column k+1 is updated FIRST and
+its diagonal tile is factored, broadcast and its panel solved before the rest of the trailing
+update by panel k is issued (`factor`), so the next panel's collectives are in flight while
+every rank is busy with the bulk of step 4.
+
 The residual (y - m)^T is carried as one extra tile ROW (index nt) exactly like the
 single-GPU "extra rows", so alpha^T = (L^-1 (y-m))^T falls out of steps 2-4.  xGMI is a
 full mesh of point-to-point links, so the row/column broadcasts of step 3 run on
@@ -161,59 +166,76 @@ class BlockCyclicGP:
                 self.tiles[(self.nt, J)] = t
 
     # -- factorisation ------------------------------------------------------------
+    def _panel_phase(self, k, info_local):
+        """steps 1-2 for tile column k: diagonal factor + broadcast down its process column,
+        panel solves on my tiles of that column.  Returns the updated local info."""
+        ops, nt, dev = self.ops, self.nt, self.X.device
+        nk, ck = self.rows_of(k), k % self.pc
+        if self.my_c != ck:
+            return info_local
+        diag_owner = self.owner(k, k)
+        if self.rank == diag_owner:
+            Lkk = self.tiles[(k, k)]
+            winv, info = ops.potrf(Lkk, nk)
+            bad = info.to(torch.int64)
+            info_local = torch.where((info_local == 0) & (bad != 0), bad + k * self.T, info_local)
+        else:
+            Lkk = ops.new_tile(nk, nk)
+            winv = torch.empty(self.ops.winv_numel(nk), dtype=torch.float64, device=dev)
+        self._bcast(Lkk, diag_owner, self.col_groups, ck)
+        self._bcast(winv, diag_owner, self.col_groups, ck)
+        for I in list(range(k + 1, nt)) + [nt]:
+            if self.mine(I, k):
+                ops.trsm(Lkk, winv, nk, self.tiles[(I, k)], self.rows_of(I))
+        return info_local
+
+    def _exchange(self, k):
+        """step 3: panel tile (I,k) goes along process row I mod Pr (left operand of tile row I)
+        and along process column I mod Pc (right operand of tile column I)."""
+        ops, nt, nk = self.ops, self.nt, self.rows_of(k)
+        left, right = {}, {}
+        for I in list(range(k + 1, nt)) + [nt]:
+            src = self.owner(I, k)
+            rI = I % self.pr
+            if self.my_r == rI:
+                t = self.tiles[(I, k)] if self.rank == src else ops.new_tile(self.rows_of(I), nk)
+                self._bcast(t, src, self.row_groups, rI)
+                left[I] = t
+        for I in range(k + 1, nt):
+            cI = I % self.pc
+            if self.my_c == cI:
+                # the source is the member of process column cI that already holds P_I: (I mod Pr, cI)
+                src = (I % self.pr) * self.pc + cI
+                t = left[I] if self.rank == src else left.get(I)
+                if t is None:
+                    t = ops.new_tile(self.rows_of(I), nk)
+                self._bcast(t, src, self.col_groups, cI)
+                right[I] = t
+        return left, right
+
+    def _update(self, k, left, right, columns):
+        """step 4 restricted to my tiles in the given tile columns."""
+        nk = self.rows_of(k)
+        for (I, J), t in self.tiles.items():
+            if J > k and I >= J and J in columns:
+                self.ops.update(t, left[I], right[J], self.rows_of(I), self.rows_of(J), nk, lower=(I == J))
+
     def factor(self):
-        """right-looking block-cyclic Cholesky carrying the residual row; returns the
-        global LAPACK-style info (0 = ok)."""
-        ops, nt = self.ops, self.nt
-        dev = self.X.device
-        info_local = torch.zeros(1, dtype=torch.int64, device=dev)
+        """right-looking block-cyclic Cholesky carrying the residual row, with look-ahead: after
+        the exchange of panel k only tile column k+1 is updated before ITS diagonal tile is
+        factored, broadcast and its panel solved (the critical path of step k+1); the rest of
+        the trailing update by panel k follows, so the other process columns never wait for the
+        next panel.  Every tile still receives its updates in the order k = 0, 1, ... .
+        Returns the global LAPACK-style info (0 = ok)."""
+        nt = self.nt
+        info_local = torch.zeros(1, dtype=torch.int64, device=self.X.device)
+        info_local = self._panel_phase(0, info_local)
         for k in range(nt):
-            nk = self.rows_of(k)
-            ck = k % self.pc
-            diag_owner = self.owner(k, k)
-            # 1. diagonal tile
-            in_col = self.my_c == ck
-            if in_col:
-                if self.rank == diag_owner:
-                    Lkk = self.tiles[(k, k)]
-                    winv, info = ops.potrf(Lkk, nk)
-                    bad = info.to(torch.int64)
-                    info_local = torch.where((info_local == 0) & (bad != 0), bad + k * self.T, info_local)
-                else:
-                    Lkk = ops.new_tile(nk, nk)
-                    winv = torch.empty(self.ops.winv_numel(nk), dtype=torch.float64, device=dev)
-                self._bcast(Lkk, diag_owner, self.col_groups, ck)
-                self._bcast(winv, diag_owner, self.col_groups, ck)
-                # 2. panel solves on my tiles of column k
-                for I in list(range(k + 1, nt)) + [nt]:
-                    if self.mine(I, k):
-                        ops.trsm(Lkk, winv, nk, self.tiles[(I, k)], self.rows_of(I))
-            # 3. exchange panel tiles
-            left, right = {}, {}   # P_I as left operand (my tile rows) / right operand (my tile columns)
-            for I in list(range(k + 1, nt)) + [nt]:
-                src = self.owner(I, k)
-                rI = I % self.pr
-                if self.my_r == rI:           # row broadcast: everyone in process row rI needs P_I on the left
-                    t = self.tiles[(I, k)] if self.rank == src else ops.new_tile(self.rows_of(I), nk)
-                    self._bcast(t, src, self.row_groups, rI)
-                    left[I] = t
-            for I in range(k + 1, nt):       # column broadcast: P_I on the right for tile column I
-                cI = I % self.pc
-                if self.my_c == cI:
-                    # the source is the member of process column cI that already holds P_I: (I mod Pr, cI)
-                    src = (I % self.pr) * self.pc + cI
-                    if self.rank == src:
-                        t = left[I]
-                    else:
-                        t = left.get(I)
-                        if t is None:
-                            t = ops.new_tile(self.rows_of(I), nk)
-                    self._bcast(t, src, self.col_groups, cI)
-                    right[I] = t
-            # 4. trailing update of my tiles
-            for (I, J), t in self.tiles.items():
-                if J > k and I >= J:
-                    ops.update(t, left[I], right[J], self.rows_of(I), self.rows_of(J), nk, lower=(I == J))
+            left, right = self._exchange(k)
+            self._update(k, left, right, {k + 1})
+            if k + 1 < nt:
+                info_local = self._panel_phase(k + 1, info_local)
+            self._update(k, left, right, set(range(k + 2, nt)))
         if self.world > 1:
             dist.all_reduce(info_local, op=dist.ReduceOp.MAX, group=self.group)
         self.info = int(info_local.item())
