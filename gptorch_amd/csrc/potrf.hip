@@ -61,7 +61,7 @@ constexpr int LEAF_THREADS = 576;
     last_t = t_;                                                                \
   }
 
-template <bool FACTOR, bool DIAG = false>
+template <bool FACTOR, bool DIAG = false, bool PIPE = false>
 __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int64_t lda, int kb_, int col0_,
                                                                   double* winv_, int32_t* info, int n_total,
                                                                   unsigned long long* diag = nullptr) {
@@ -77,8 +77,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     winv += (int64_t)blockIdx.x * LEAF * LEAF;
   }
   __shared__ double Xp[2][256 * XPS];   // panel rows 0..127: A part, 128..255: identity (-> W^T) part
-  __shared__ double Dg[64];             // L8 (row-major 8x8), for the output rows
-  __shared__ double Ds[64];             // L8 scaled by 1/diag (diagonal slot: 1/diag), for the row solves
+  // small blocks exchanged between the pivot wave and the tile waves, double-buffered by the
+  // parity of the panel they belong to (the pivot wave runs ahead of the tile waves in PIPE mode)
+  __shared__ double Dg2[2][64];         // L8 (row-major 8x8), for the output rows
+  __shared__ double Ds2[2][64];         // L8 scaled by 1/diag (diagonal slot: 1/diag), for the row solves
+  __shared__ double Rn2[2][64];         // PIPE: rows of the panel after next x columns of the next panel (raw)
+  __shared__ double Dn2[2][64];         // PIPE: 8x8 diagonal block of the panel after next (raw)
+  __shared__ int tb_count;              // PIPE: arrivals at the tile waves' software barrier
+  __shared__ double Xs[64];             // PIPE: pivot-wave scratch (its 8 solved rows)
   __shared__ int failflag;
 
   const int tid = threadIdx.x;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   const bool tilewave = wave < 8;
   const int w = wave & 7;
   const int lr = lane >> 4, lc = lane & 15;      // D-layout: rows lr + 4r, column lc
-  if (tid == 0) failflag = 0;
+  if (tid == 0) { failflag = 0; tb_count = 0; }
   if (!tilewave) __builtin_amdgcn_s_setprio(3);   // the pivot chain must not queue behind tile-wave VALU work
 
   // slot J (J = 0..7): A tile (w, J), used when J <= w; slot J+1: identity tile (8+w, J), used
@@ -130,6 +136,35 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     }
   };
 
+  // PIPE: what the pivot wave needs to advance the diagonal block of the panel starting at row
+  // rn0 by itself: Rn = rows rn0..rn0+7 x columns rn0-8..rn0-1, Dn = rows x columns rn0..rn0+7,
+  // both as the tile registers hold them now (one tile wave owns all of them)
+  auto publish_extra = [&](int rn0) {
+    const int wr = rn0 >> 4;
+    if (w != wr) return;                       // wave-uniform
+    const int rh = rn0 & 8;
+    const int J1 = (rn0 - 8) >> 4, h1 = ((rn0 - 8) >> 3) & 1, hd = (rn0 >> 3) & 1;
+    double* Rn = Rn2[(rn0 >> 3) & 1];
+    double* Dn = Dn2[(rn0 >> 3) & 1];
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+      if (J == J1 && (lc >> 3) == h1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row16 = lr + 4 * r;
+          if ((row16 & 8) == rh) Rn[(row16 & 7) * 8 + (lc & 7)] = acc[J][r];
+        }
+      }
+      if (J == wr && (lc >> 3) == hd) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row16 = lr + 4 * r;
+          if ((row16 & 8) == rh) Dn[(row16 & 7) * 8 + (lc & 7)] = acc[J][r];
+        }
+      }
+    }
+  };
+
   // rank-8 update with the solved panel in xp of the tile columns J in [jlo, jhi]
   auto update = [&](const double* xp, int jlo, int jhi, int J0) {
     const bool idlive = w <= J0;                 // identity rows 16w.. have met the pivots yet?
@@ -159,9 +194,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   // l = a*y -> DPP shift -> d' = a' - l*l -> readlane;  the rank-1 update of the other 63
   // elements is one masked FMA whose operands arrive through the LDS crossbar (ds_swizzle row
   // broadcast, ds_bpermute transpose-gather) and never sits on the chain.
-  auto pivot_block = [&](const double* xp, int c0) {
+  auto pivot_block = [&](double a, int c0, double& wt) {
     const int pi = lane >> 3, pc = lane & 7;
-    double a = xp[(c0 + pi) * XPS + pc];
+    (void)wt;
     double invd[8];
     int fail = 0;
     auto bcast = [](double v, int src) -> double {
@@ -230,16 +265,48 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
 #pragma unroll
     for (int j = 1; j < 8; ++j) myinv = (pi == j) ? invd[j] : myinv;
     if (pc <= pi) {
-      Dg[pi * 8 + pc] = a;
-      Ds[pi * 8 + pc] = (pc == pi) ? myinv : a * myinv;
+      Dg2[(c0 >> 3) & 1][pi * 8 + pc] = a;
+      Ds2[(c0 >> 3) & 1][pi * 8 + pc] = (pc == pi) ? myinv : a * myinv;
     }
-    if (lane == 0 && fail) failflag = fail;
+    if (lane == 0 && fail && failflag == 0) failflag = fail;     // keep the FIRST failing column
+  };
+
+  // PIPE (pivot wave): advance the NEXT diagonal block past the 8 pivots just taken, from the raw
+  // blocks the tile waves published:  X = Rn L8^-T,  D' = Dn - X X^T.
+  auto catch_up = [&](int c0) -> double {        // c0: first column of the block just factored
+    const double* Ds = Ds2[(c0 >> 3) & 1];
+    const double* Rn = Rn2[((c0 >> 3) + 1) & 1];
+    const double* Dn = Dn2[((c0 >> 3) + 1) & 1];
+    // lanes 0..7: one row of Rn each, forward substitution against the L8 this wave has just
+    // written to Ds (same right-looking order as solve_rows: 8 dependent FMAs); then all 64
+    // lanes take their element of D' = Dn - X X^T with X read back from LDS
+    const int pi = lane >> 3, pc = lane & 7;
+    if (lane < 8) {
+      double x[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] = Rn[lane * 8 + c] * Ds[c * 8 + c];
+#pragma unroll
+      for (int k2 = 0; k2 < 7; ++k2) {
+#pragma unroll
+        for (int c = k2 + 1; c < 8; ++c) x[c] = fma(-x[k2], Ds[c * 8 + k2], x[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) Xs[lane * 8 + c] = x[c];
+    }
+    const double* xi = Xs + pi * 8;
+    const double* xc = Xs + pc * 8;
+    double d = Dn[lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d = fma(-xi[k], xc[k], d);
+    return d;
   };
 
   // P2 (threads 0..255 = waves 0..3): forward substitution of one panel row against L8;
   // the solved row goes back to LDS (the pivot wave streams it to global one phase later)
   auto solve_rows = [&](double* xp, int c0) {
     if (tid >= 256) return;
+    const double* Ds = Ds2[(c0 >> 3) & 1];
+    const double* Dg = Dg2[(c0 >> 3) & 1];
     const bool apart = tid < 128;
     const int rho = apart ? tid : tid - 128;
     const bool solve = apart ? (FACTOR && tid >= c0 + 8) : (rho <= c0 + 7);
@@ -289,15 +356,98 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   };
 
   // ---- prologue: panel 0 ------------------------------------------------------------------
-  if (tilewave) publish(Xp[0], 0, 0);
+  double a_main = 0.0, wt = 0.0;              // pivot wave: its 8x8 block / carried L8^-T
+  if (tilewave) {
+    publish(Xp[0], 0, 0);
+    if constexpr (PIPE) publish_extra(8);
+  }
   __syncthreads();
-  if (!tilewave) pivot_block(Xp[0], 0);
+  if (!tilewave) {
+    a_main = Xp[0][(lane >> 3) * XPS + (lane & 7)];
+    pivot_block(a_main, 0, wt);
+    if constexpr (PIPE) a_main = catch_up(0);
+  }
   __syncthreads();
   if (!failflag) solve_rows(Xp[0], 0);
   __syncthreads();
 
   // ---- main loop --------------------------------------------------------------------------
   int done = 0;
+  if constexpr (PIPE) {
+    const bool prologue_ok = !failflag;          // read between barriers: the same for every wave
+    if (prologue_ok) {
+    // Two phases per panel.  X: the pivot wave factors the NEXT diagonal block straight from its
+    // registers (it advanced that block itself, see catch_up) while the tile waves apply the
+    // current panel's rank-8 update, publish the next raw panel and store the current one.
+    // Y: row solves of the next panel || the pivot wave advances the block after next.
+    // The two roles run SEPARATE loops with the same barrier sequence: in one loop the loop
+    // invariants of both roles (LDS addresses, lane predicates) are live together and the
+    // 168-VGPR budget of a 9-wave workgroup spills.
+    if (tilewave) {
+      // software barrier of the 8 tile waves (monotonic arrival counter in LDS): the second
+      // hand-over of an iteration (solved panel -> next update) does not involve the pivot wave,
+      // and a hardware barrier there would stall its pivot chain for ~900 cycles per block.
+      // The spin is bounded: on a lost arrival the leaf reports failure instead of hanging.
+      int epoch = 0;
+      auto tile_barrier = [&]() {
+        ++epoch;
+        // LDS only: the LDS unit serves one wave's operations in order, so "my panel writes, then
+        // my arrival" needs no fence; a release/acquire pair would also wait for the panel's
+        // GLOBAL stores (s_waitcnt vmcnt(0), ~1 us) that nobody in this kernel reads back.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&tb_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int spins = 0;
+        while (__hip_atomic_load(&tb_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * epoch) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 22)) { failflag = LEAF + 1; break; }
+        }
+        asm volatile("" ::: "memory");
+      };
+      // (failflag is only examined right after the hardware barrier, where both roles see the
+      //  same value: the pivot wave runs ahead and may raise it at any time)
+      for (int kb8 = 0; kb8 < 16; ++kb8) {
+        const int c0 = kb8 * 8;
+        const int J0 = kb8 >> 1;
+        const int jact = (c0 + 8) >> 4;
+        const int halfn = (kb8 + 1) & 1;
+        const bool has1 = kb8 < 15, has2 = kb8 < 14;
+        double* cur = Xp[kb8 & 1];
+        double* nxt = Xp[(kb8 + 1) & 1];
+        GPN_STAMP(0)
+        if (has1) {
+          update(cur, jact, 7, J0);              // nobody waits for the publish any more: one pass
+          publish(nxt, jact, halfn);
+          if (has2) publish_extra(c0 + 16);
+        }
+        GPN_STAMP(1)
+        if (!has1) { store_panel(cur, c0); break; }
+        GPN_STAMP(2)
+        __syncthreads();                         // all 9 waves: L8(next) and the raw blocks are out
+        GPN_STAMP(3)
+        if (failflag) break;                     // uniform
+        solve_rows(nxt, c0 + 8);                 // waves 0..3
+        store_panel(cur, c0);                    // waves 4..7 (idle in this phase otherwise)
+        GPN_STAMP(4)
+        tile_barrier();
+        GPN_STAMP(5)
+      }
+    } else {
+      for (int kb8 = 0; kb8 < 16; ++kb8) {
+        const int c0 = kb8 * 8;
+        const bool has1 = kb8 < 15, has2 = kb8 < 14;
+        GPN_STAMP(0)
+        if (has1) pivot_block(a_main, c0 + 8, wt);
+        if (!has1) break;
+        GPN_STAMP(2)
+        __syncthreads();
+        GPN_STAMP(3)
+        if (failflag) break;
+        if (has2) a_main = catch_up(c0 + 8);
+        GPN_STAMP(4)
+      }
+    }
+    }
+  } else {
   for (int kb8 = 0; kb8 < 16 && !failflag; ++kb8) {
     const int c0 = kb8 * 8;
     const int J0 = kb8 >> 1;
@@ -320,7 +470,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     GPN_STAMP(2)
     // B
     if (tilewave) update(cur, jact + 1, 7, J0);
-    else pivot_block(nxt, c0 + 8);
+    else { a_main = nxt[(c0 + 8 + (lane >> 3)) * XPS + (lane & 7)]; pivot_block(a_main, c0 + 8, wt); }
     GPN_STAMP(3)
     __syncthreads();
     GPN_STAMP(4)
@@ -332,11 +482,12 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     __syncthreads();
     GPN_STAMP(6)
   }
+  }
   if constexpr (DIAG) {
     GPN_STAMP(7)
     if (lane == 0) for (int k = 0; k < 8; ++k) diag[wave * 8 + k] = acc_t[k];
   }
-  if (!failflag) store_panel(Xp[1], 120);     // last panel (kb8 = 15 lives in buffer 1)
+  if (!PIPE && !failflag) store_panel(Xp[1], 120);     // last panel (kb8 = 15 lives in buffer 1)
   __syncthreads();
   if (failflag) {
     if (tid == 0 && info && *info == 0) *info = col0 + failflag;
@@ -345,6 +496,8 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   }
   (void)done;
 }
+
+static int g_leaf_pipe = 1;          // 1 = two-phase leaf (pivot wave advances its own block); 0 = three-phase
 
 struct Ctx {
   hipStream_t s;
@@ -381,8 +534,12 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
 static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   if (c.rc != GPN_OK || n <= 0) return;
   if (n <= LEAF) {
-    hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, A, c.lda, (int)n, (int)col0,
-                       c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0, nullptr);
+    if (g_leaf_pipe)
+      hipLaunchKernelGGL((potrf_leaf_kernel<true, false, true>), dim3(1), dim3(LEAF_THREADS), 0, c.s, A, c.lda, (int)n,
+                         (int)col0, c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0, nullptr);
+    else
+      hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, A, c.lda, (int)n, (int)col0,
+                         c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0, nullptr);
     if (hipGetLastError() != hipSuccess) { c.rc = GPN_E_HIP; return; }
     if (e > 0) trsm_rec(c, A + n * c.lda, e, c.lda, A, c.lda, n, col0, c.winv);
     return;
@@ -462,8 +619,12 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       const int64_t c1 = k0 + kb;                 // first row/column after this block
       double* Akk = A + k0 * lda + k0;
       const double* Wk = c.winv + (k0 / LEAF) * (LEAF * LEAF);
-      hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, Akk, lda, (int)kb, (int)k0,
-                         const_cast<double*>(Wk), c.info, 0, nullptr);
+      if (g_leaf_pipe)
+        hipLaunchKernelGGL((potrf_leaf_kernel<true, false, true>), dim3(1), dim3(LEAF_THREADS), 0, c.s, Akk, lda, (int)kb,
+                           (int)k0, const_cast<double*>(Wk), c.info, 0, nullptr);
+      else
+        hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, Akk, lda, (int)kb, (int)k0,
+                           const_cast<double*>(Wk), c.info, 0, nullptr);
       hip_ok(hipGetLastError());
       const int64_t m = n + e - c1;                // rows below (incl. the extra rows)
       if (m <= 0 || c.rc != GPN_OK) continue;
@@ -641,7 +802,8 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
 }
 
 extern "C" int gpn_debug_set_potrf_variant(int v) {
-  g_potrf_variant = v & 1;           // bit 0: plain recursion; bits 8..: panel width / 128 (0 = default)
+  g_potrf_variant = v & 1;           // bit 0: plain recursion; bit 2: three-phase leaf; bits 8..: panel width / 128
+  g_leaf_pipe = ((v >> 2) & 1) ? 0 : 1;
   g_panel_width = (v >> 8) * LEAF;
   return GPN_OK;
 }
@@ -651,7 +813,7 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
 // (0 loop top, 1 phase A, 2 barrier, 3 phase B, 4 barrier, 5 phase C, 6 barrier, 7 tail)
 extern "C" int gpn_debug_leaf_timing(void* stream, double* A, int64_t lda, double* winv, int32_t* info,
                                      unsigned long long* diag72) {
-  hipLaunchKernelGGL((potrf_leaf_kernel<true, true>), dim3(1), dim3(LEAF_THREADS), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL((potrf_leaf_kernel<true, true, true>), dim3(1), dim3(LEAF_THREADS), 0, static_cast<hipStream_t>(stream),
                      A, lda, LEAF, 0, winv, info, 0, diag72);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
