@@ -26,6 +26,14 @@ for WL in c2 c3; do
   W=$(ls $O/pmc_write_$WL/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$F" ] && [ -n "$W" ] && python3 $R/tools/pmc_traffic.py $F $W $O/traffic_$WL.json $WL > /dev/null
   rm -rf $O/pmc_fetch_$WL $O/pmc_write_$WL           # raw counter dumps are large
+  # 4. MFMA utilisation of the contraction launches (counters only, own pass)
+  if [ $WL = c3 ]; then
+    timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma_$WL -o m -- \
+        python3 $R/bench.py --workload $WL --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $O/pmc_mfma_$WL.log 2>&1
+    M=$(ls $O/pmc_mfma_$WL/*counter_collection.csv 2>/dev/null | head -1)
+    [ -n "$M" ] && python3 $R/tools/pmc_mfma.py $M $O/mfma_utilisation_$WL.json $WL > /dev/null
+    rm -rf $O/pmc_mfma_$WL
+  fi
   # keep only the stats summary + a compact per-grid trace summary
   T=$(ls $O/stats_$WL/*kernel_trace.csv 2>/dev/null | head -1)
   EV=$((3 + 2 * STEPS))   # warm-up + timed steps + event-profiled steps
