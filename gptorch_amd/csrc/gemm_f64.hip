@@ -20,6 +20,7 @@
 //  * blockIdx -> tile: bijective XCD remap (blocks b, b+8 share an XCD/L2) then
 //    grouped ordering (8 tile-rows per group) so the tiles resident on one XCD
 //    share operand panels in its 4 MiB L2; `lower` drops tiles above the diagonal.
+#include <algorithm>
 #include "gpn_common.h"
 
 namespace gpn {
@@ -37,6 +38,9 @@ struct GemmArgs {
   int lower;
   int tri;          // GPN_TRI_* structure flags: skip the K range where an operand is known zero
   double alpha, beta;
+  // strided batch: problem z uses A + z*sA, B + z*sB, C + z*sC (batch identical shapes in ONE launch)
+  int batch;
+  int64_t sA, sB, sC;
 };
 
 constexpr int BK = 16;
@@ -106,8 +110,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
   int ti, tj;
   const bool spread = (p.tri & (GPN_TRI_A_UPPER | GPN_TRI_A_LOWER | GPN_TRI_B_UPPER)) != 0;
-  if (p.lower) tile_of_block_lower(blockIdx.x, gridDim.x, p.mt, spread, ti, tj);
-  else tile_of_block(blockIdx.x, gridDim.x, p.mt, p.nt, spread, ti, tj);
+  int bid = blockIdx.x, nwg = gridDim.x;
+  if (p.batch > 1) {                               // strided batch: consecutive blocks = one problem
+    nwg = gridDim.x / p.batch;
+    const int z = bid / nwg;
+    bid -= z * nwg;
+    p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC;
+  }
+  if (p.lower) tile_of_block_lower(bid, nwg, p.mt, spread, ti, tj);
+  else tile_of_block(bid, nwg, p.mt, p.nt, spread, ti, tj);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -282,7 +293,7 @@ static int launch(hipStream_t s, const GemmArgs& a0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
-  const int grid = a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt;
+  const int grid = (a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
   constexpr int smem = ((BM + BN) / 16) * 2 * 1024 * NS;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
   static bool attr_set = false;
@@ -294,7 +305,7 @@ static int launch(hipStream_t s, const GemmArgs& a0) {
   const bool prof = profile_on();
   if (prof) {
     // executed flops: tiles actually computed x 2*BM*BN*K
-    const double tiles = a.lower ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt;
+    const double tiles = (a.lower ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt) * std::max(1, a.batch);
     profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
@@ -305,11 +316,30 @@ static int launch(hipStream_t s, const GemmArgs& a0) {
 
 static int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
 
+static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+                        const double* A, int64_t lda, const double* B, int64_t ldb,
+                        double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
+                        int batch, int64_t sA, int64_t sB, int64_t sC);
+
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
             double beta, double* C, int64_t ldc, int lower, int tri, int inplace) {
-  if (M <= 0 || N <= 0) return GPN_OK;
+  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, 1, 0, 0, 0);
+}
+
+int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+                    const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
+                    double beta, double* C, int64_t ldc, int64_t sC, int tri, int batch) {
+  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0, tri, 0, batch, sA, sB, sC);
+}
+
+static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+                        const double* A, int64_t lda, const double* B, int64_t ldb,
+                        double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
+                        int batch, int64_t sA, int64_t sB, int64_t sC) {
+  if (M <= 0 || N <= 0 || batch <= 0) return GPN_OK;
   GemmArgs a;
+  a.batch = batch; a.sA = sA; a.sB = sB; a.sC = sC;
   a.A = A; a.B = B; a.C = C;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
@@ -323,7 +353,7 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
   // rounds of tiles (K >= 8192: 65.0 vs 63.1 TFLOP/s at M = 24576 lower).
   auto tiles = [&](int64_t b) {
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
-    return lower ? mt * (mt + 1) / 2 : mt * nt;
+    return (lower ? mt * (mt + 1) / 2 : mt * nt) * batch;
   };
   // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer:
   // U U^T at N = 8192: 3.17 (64) vs 3.29 ms (128); at N = 32768: 199.7 vs 184.0 ms.

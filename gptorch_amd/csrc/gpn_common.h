@@ -29,6 +29,11 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
             double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0);
 
+// `batch` problems of identical shape at constant strides (elements) in one launch
+int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+                    const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
+                    double beta, double* C, int64_t ldc, int64_t sC, int tri, int batch);
+
 bool profile_on();
 void profile_begin(hipStream_t s, double flops);
 void profile_end(hipStream_t s);

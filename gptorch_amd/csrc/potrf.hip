@@ -746,6 +746,25 @@ __global__ void transpose_kernel(const double* src, int64_t rows, int64_t cols, 
   }
 }
 
+// `gridDim.z` square blocks at constant strides: dst_z[c, r] = src_z[r, c]
+__global__ void transpose_batched_kernel(const double* src, int64_t n, int64_t lds, int64_t ssrc,
+                                         double* dst, int64_t ldd, int64_t sdst) {
+  __shared__ double t[32][33];
+  src += (int64_t)blockIdx.z * ssrc;
+  dst += (int64_t)blockIdx.z * sdst;
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int64_t r = r0 + k, cc = c0 + tx;
+    t[k][tx] = (r < n && cc < n) ? src[r * lds + cc] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int64_t cc = c0 + k, r = r0 + tx;
+    if (cc < n && r < n) dst[cc * ldd + r] = t[tx][k];
+  }
+}
+
 __global__ void copy_matrix_kernel(const double* src, int64_t rows, int64_t cols, int64_t lds,
                                    double* dst, int64_t ldd, int tril) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -874,13 +893,45 @@ static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, 
   for (int d = maxd; d >= 0; --d) {
     std::vector<const TNode*> lvl;
     for (const TNode& t : nodes) if (t.depth == d) lvl.push_back(&t);
-    const int nq = (int)std::min<size_t>(lvl.size(), NSIDE + 1);    // streams used at this depth
+    // Nodes of one depth with the same shape at a constant spacing (all of them when n is a
+    // power-of-two multiple of the leaf) go out as ONE strided-batch launch per operation;
+    // irregular nodes are dealt onto the caller's stream and the side streams.
+    size_t i0 = 0;
+    std::vector<const TNode*> single;
+    while (i0 < lvl.size()) {
+      size_t i1 = i0 + 1;
+      if (i1 < lvl.size() && lvl[i1]->n == lvl[i0]->n && lvl[i1]->h == lvl[i0]->h) {
+        const int64_t step = lvl[i1]->off - lvl[i0]->off;
+        while (i1 < lvl.size() && lvl[i1]->n == lvl[i0]->n && lvl[i1]->h == lvl[i0]->h &&
+               lvl[i1]->off - lvl[i1 - 1]->off == step) ++i1;
+      }
+      const int cnt = (int)(i1 - i0);
+      if (cnt >= 2 && lvl[i0]->n <= 2048) {
+        const TNode& t = *lvl[i0];
+        const int64_t h = t.h, m2 = t.n - t.h, o = t.off, step = lvl[i0 + 1]->off - o;
+        const int64_t sU = step * (ldu + 1), sL = step * (ldl + 1), sS = step * (lds + 1);
+        dim3 grid((unsigned)((m2 + 31) / 32), (unsigned)((m2 + 31) / 32), (unsigned)cnt);
+        hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(256), 0, s, U + (o + h) * ldu + o + h, m2, ldu, sU,
+                           S + (o + h) * lds + o + h, lds, sS);
+        GPN_LAUNCH_CHECK();
+        int rc = gemm_nt_batched(s, h, m2, h, 1.0, U + o * ldu + o, ldu, sU, L + (o + h) * ldl + o, ldl, sL, 0.0,
+                                 S + o * lds + o + h, lds, sS, GPN_TRI_A_UPPER, cnt);
+        if (rc != GPN_OK) return rc;
+        rc = gemm_nt_batched(s, h, m2, round_up(m2, 16), -1.0, S + o * lds + o + h, lds, sS, S + (o + h) * lds + o + h, lds, sS,
+                             0.0, U + o * ldu + o + h, ldu, sU, GPN_TRI_B_LOWER, cnt);
+        if (rc != GPN_OK) return rc;
+      } else {
+        for (size_t i = i0; i < i1; ++i) single.push_back(lvl[i]);
+      }
+      i0 = i1;
+    }
+    const int nq = (int)std::min<size_t>(single.size(), NSIDE + 1);    // streams used at this depth
     if (nq > 1) {
       GPN_HIP_CHECK(hipEventRecord(ax->fork_ev, s));
       for (int q = 1; q < nq; ++q) GPN_HIP_CHECK(hipStreamWaitEvent(ax->side[q - 1], ax->fork_ev, 0));
     }
-    for (size_t i = 0; i < lvl.size(); ++i) {
-      const TNode& t = *lvl[i];
+    for (size_t i = 0; i < single.size(); ++i) {
+      const TNode& t = *single[i];
       const int q = (int)(i % nq);
       hipStream_t sq = q == 0 ? s : ax->side[q - 1];
       const int64_t h = t.h, m2 = t.n - t.h, o = t.off;
