@@ -80,7 +80,7 @@ def kernel_matrix(kind, X, X2, variance, length_scales, noise=None, out=None, ld
 class Factor:
     """A factor buffer (see gpnative.h): n x n lower Cholesky factor in the
     top-left corner of `A` (rows x ld, zero padded), `e` extra rows holding
-    (L^-1 R)^T, and the inverses of the 64x64 diagonal blocks in `winv`."""
+    (L^-1 R)^T, and the inverses of the 128x128 diagonal leaf blocks in `winv`."""
 
     def __init__(self, n, e, device):
         lib = _native.lib()
@@ -137,7 +137,7 @@ class Factor:
         return out
 
     def solve_right_lt(self, B, m):
-        """B[m, :n] <- B * L^-T in place; B must be a [rows>=round_up(m,64)?, ld] buffer
+        """B[m, :n] <- B * L^-T in place; B must be a [rows >= round_up(m,16), ld] buffer
         with ld == self.ld whose padding is zero."""
         st = _native.lib().gpn_trsm_right_lt(_stream(self.device), _ptr(self.A), self.n, self.ld, _ptr(self.winv),
                                              _ptr(B), m, B.stride(0))
@@ -259,7 +259,7 @@ def row_sumsq(A, rows, cols):
 
 
 def padded_like_factor(f, m):
-    """zeroed [round_up(m,64), f.ld] buffer for right-hand sides of solve_right_lt."""
+    """zeroed [round_up(m,128), f.ld] buffer for right-hand sides of solve_right_lt."""
     return torch.zeros(round_up(max(m, 1), LEAF), f.ld, dtype=torch.float64, device=f.device)
 
 

@@ -9,7 +9,7 @@ replicated; every rank ASSEMBLES ITS OWN TILES with the native K-assembly kernel
 (no communication).  Right-looking factorisation, one exchange step per tile column k:
 
   1. owner of (k,k) factors it (gpn_potrf_lower) and broadcasts L_kk (+ the inverses of
-     its 64x64 diagonal blocks) down its process COLUMN  -> column sub-communicator
+     its 128x128 diagonal blocks) down its process COLUMN  -> column sub-communicator
   2. owners of (I,k), I > k, solve  A_Ik <- A_Ik L_kk^-T  (gpn_trsm_right_lt)
   3. panel tile (I,k) is broadcast along process ROW I mod Pr (it multiplies from the
      left in the updates of tile row I) and along process COLUMN I mod Pc (it multiplies
@@ -55,7 +55,7 @@ class NativeTileOps:
         self.device = device
 
     def new_tile(self, rows, cols):
-        """zeroed factor-style buffer holding a rows x cols tile (ld multiple of 64, +apron)."""
+        """zeroed factor-style buffer holding a rows x cols tile (ld multiple of 128, +apron)."""
         return torch.zeros(_ops.round_up(rows, _ops.LEAF) + 16, _ops.round_up(cols, _ops.LEAF), dtype=torch.float64,
                            device=self.device)
 
