@@ -18,9 +18,10 @@ replicated; every rank ASSEMBLES ITS OWN TILES with the native K-assembly kernel
      lower-only on diagonal tiles)
 
 Look-ahead: after the exchange of panel k, tile column k+1 is updated FIRST and
-its diagonal tile is factored, broadcast and its panel solved before the rest of the trailing
-update by panel k is issued (`factor`), so the next panel's collectives are in flight while
-every rank is busy with the bulk of step 4.
+its diagonal tile is factored, broadcast and its panel solved; the row and column broadcasts of
+panel k+1 are then issued asynchronously (`async_op=True`: RCCL runs them on its own stream) in
+front of the two halves of the remaining trailing update by panel k (`factor`), so the next
+panel's collectives are in flight while every rank is busy with the bulk of step 4.
 
 The residual (y - m)^T is carried as one extra tile ROW (index nt) exactly like the
 single-GPU "extra rows", so alpha^T = (L^-1 (y-m))^T falls out of steps 2-4.  xGMI is a
@@ -189,18 +190,36 @@ class BlockCyclicGP:
                 ops.trsm(Lkk, winv, nk, self.tiles[(I, k)], self.rows_of(I))
         return info_local
 
-    def _exchange(self, k):
-        """step 3: panel tile (I,k) goes along process row I mod Pr (left operand of tile row I)
-        and along process column I mod Pc (right operand of tile column I)."""
+    def _bcast_async(self, t, src, groups, key):
+        """-> Work handle or None; the collective runs on the backend's own stream."""
+        if self.world == 1:
+            return None
+        g, ranks = groups[key]
+        if len(ranks) > 1:
+            return dist.broadcast(t, src=src, group=g, async_op=True)
+        return None
+
+    def _start_rows(self, k):
+        """step 3a, asynchronous: panel tile (I,k) along process row I mod Pr (left operand of
+        tile row I).  Returns (left, works)."""
         ops, nt, nk = self.ops, self.nt, self.rows_of(k)
-        left, right = {}, {}
+        left, works = {}, []
         for I in list(range(k + 1, nt)) + [nt]:
             src = self.owner(I, k)
             rI = I % self.pr
             if self.my_r == rI:
                 t = self.tiles[(I, k)] if self.rank == src else ops.new_tile(self.rows_of(I), nk)
-                self._bcast(t, src, self.row_groups, rI)
+                w = self._bcast_async(t, src, self.row_groups, rI)
+                if w is not None:
+                    works.append(w)
                 left[I] = t
+        return left, works
+
+    def _start_cols(self, k, left):
+        """step 3b, asynchronous (after 3a has completed on this rank): P_I down process column
+        I mod Pc (right operand of tile column I).  Returns (right, works)."""
+        ops, nt, nk = self.ops, self.nt, self.rows_of(k)
+        right, works = {}, []
         for I in range(k + 1, nt):
             cI = I % self.pc
             if self.my_c == cI:
@@ -209,9 +228,16 @@ class BlockCyclicGP:
                 t = left[I] if self.rank == src else left.get(I)
                 if t is None:
                     t = ops.new_tile(self.rows_of(I), nk)
-                self._bcast(t, src, self.col_groups, cI)
+                w = self._bcast_async(t, src, self.col_groups, cI)
+                if w is not None:
+                    works.append(w)
                 right[I] = t
-        return left, right
+        return right, works
+
+    @staticmethod
+    def _wait(works):
+        for w in works:
+            w.wait()
 
     def _update(self, k, left, right, columns):
         """step 4 restricted to my tiles in the given tile columns."""
@@ -230,12 +256,24 @@ class BlockCyclicGP:
         nt = self.nt
         info_local = torch.zeros(1, dtype=torch.int64, device=self.X.device)
         info_local = self._panel_phase(0, info_local)
+        left, works = self._start_rows(0)
+        self._wait(works)
+        right, works = self._start_cols(0, left)
         for k in range(nt):
-            left, right = self._exchange(k)
+            self._wait(works)                                   # panel k is everywhere it is needed
             self._update(k, left, right, {k + 1})
+            rest = list(range(k + 2, nt))
+            half = (len(rest) + 1) // 2
             if k + 1 < nt:
                 info_local = self._panel_phase(k + 1, info_local)
-            self._update(k, left, right, set(range(k + 2, nt)))
+                nleft, works = self._start_rows(k + 1)          # in flight under the first half ...
+                self._update(k, left, right, set(rest[:half]))
+                self._wait(works)
+                nright, works = self._start_cols(k + 1, nleft)  # ... and under the second half
+                self._update(k, left, right, set(rest[half:]))
+                left, right = nleft, nright
+            else:
+                works = []
         if self.world > 1:
             dist.all_reduce(info_local, op=dist.ReduceOp.MAX, group=self.group)
         self.info = int(info_local.item())
