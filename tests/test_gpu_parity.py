@@ -366,6 +366,32 @@ def test_block_cyclic_single_rank_native(device):
     assert abs(lml.item() - case["lml"]) < 1e-8
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_block_cyclic_multi_rank_native_shared_gpu(device, world):
+    """the multi-rank orchestration with the product's NativeTileOps: `world` processes share
+    cuda:0 and talk over gloo (tools/dist_bench.py, GPN_SHARED_GPU=1) -- grids 1x2 and 2x2 must
+    reproduce the single-GPU LML of the same problem (C2's matrix) to the last printed digit."""
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GPN_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "dist_bench.py"),
+           "2048", "8", "512"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    vals = [float(v) for v in re.findall(r"lml=(-?[0-9.]+)", out.stdout)]
+    assert len(vals) == 3, out.stdout
+    case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
+    assert abs(case["variance"] - 1.0) < 1e-15 and abs(case["noise"] - 1e-2) < 1e-15     # dist_bench's setting
+    for v in vals:
+        assert abs(v - case["lml"]) < 2e-8, (v, case["lml"])
+
+
 # ---- VFE (sparse_gpr.py:92-195; BASELINE config 5) -------------------------------
 def test_vfe_reference_known_answer(device):
     """The reference's own pins: loss == approx(8.842242323920674) and vfe_y_mean/cov.dat

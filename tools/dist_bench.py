@@ -11,10 +11,16 @@ from gptorch_amd import dist as gdist, rng  # noqa: E402
 n, d, T = (int(a) for a in (sys.argv[1:4] + ["16384", "16", "2048"][len(sys.argv) - 1:]))
 world = int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0"))
+shared = os.environ.get("GPN_SHARED_GPU") == "1"   # every rank on cuda:0 with gloo collectives: exercises the
+if shared:                                         # multi-rank orchestration + native tiles on a 1-GPU box
+    local = 0
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
 if world > 1:
-    dist.init_process_group("nccl", device_id=dev)
+    if shared:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
 x, y = rng.make_regression(n, d, 1, seed=0)
 X, Y = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
 g = gdist.BlockCyclicGP(X, Y, "Rbf", tile=T)
