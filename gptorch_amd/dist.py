@@ -82,9 +82,18 @@ class NativeTileOps:
                                                   _ops._ptr(winv), _ops._ptr(B), m, B.stride(0))
         _ops._native.check(st, "gpn_trsm_right_lt")
 
-    def update(self, C, A, B, m, n, k, lower):
-        """C[:m,:n] -= A[:m,:k] B[:n,:k]^T (lower: only j <= i)."""
-        _ops.gemm_nt(A, B, m, n, _ops.round_up(k, 16), alpha=-1.0, beta=1.0, C=C, lower=lower)
+    def update(self, C, A, B, m, n, k, lower, alpha=-1.0):
+        """C[:m,:n] += alpha A[:m,:k] B[:n,:k]^T (lower: only j <= i)."""
+        _ops.gemm_nt(A, B, m, n, _ops.round_up(k, 16), alpha=alpha, beta=1.0, C=C, lower=lower)
+
+    def set_identity(self, tile, n):
+        tile.diagonal()[:n].fill_(1.0)
+
+    def kernel_grad(self, kind, Xi, Xj, variance, ls, G):
+        """-> tensor [1 + nls]: sum G * dK(Xi, Xj)/d(variance, length_scales) (gpn_kernel_grad)."""
+        from . import _backward
+        gv, gl = _backward.kernel_backward(kind, Xi, Xj, variance, ls, G)
+        return torch.cat([gv, gl])
 
     def log_diag_sum(self, tile, n):
         return tile.diagonal()[:n].log().sum()
@@ -122,9 +131,14 @@ class BlockCyclicGP:
                 self.col_groups[c] = (g, ranks)
         self.tiles = {}
         self.info = 0
+        self.with_inverse = False      # carry I through the factorisation (-> U = L^-T) for the backward
 
     # -- geometry ---------------------------------------------------------------
     def owner(self, I, J):
+        """tile rows 0..nt-1: the matrix; nt: the residual rows; nt+1+i: identity rows of block i
+        (backward only; they live in process row i mod Pr, like matrix row i)."""
+        if I > self.nt:
+            I = I - self.nt - 1
         return (I % self.pr) * self.pc + (J % self.pc)
 
     def mine(self, I, J):
@@ -134,7 +148,22 @@ class BlockCyclicGP:
         """row count of tile row I (tile row nt = the residual rows)."""
         if I == self.nt:
             return self.dy
+        if I > self.nt:
+            I = I - self.nt - 1
         return min(self.T, self.n - I * self.T)
+
+    def _prow(self, I):
+        """process row of tile row I."""
+        return ((I - self.nt - 1) if I > self.nt else I) % self.pr
+
+    def _panel_rows(self, k):
+        """tile rows that have a tile in column k below the diagonal tile (k,k): matrix rows,
+        the residual row and -- when the inverse is carried along -- the identity rows already
+        met by the pivots (block i becomes non-zero at column i)."""
+        rows = list(range(k + 1, self.nt)) + [self.nt]
+        if self.with_inverse:
+            rows += [self.nt + 1 + i for i in range(k + 1)]
+        return rows
 
     def _bcast(self, t, src, groups, key):
         if self.world == 1:
@@ -165,6 +194,15 @@ class BlockCyclicGP:
                 t = ops.new_tile(self.dy, self.rows_of(J))
                 t[:self.dy, :self.rows_of(J)] = resid[J * T:J * T + self.rows_of(J)].t()
                 self.tiles[(self.nt, J)] = t
+        if self.with_inverse:      # identity rows: block i = rows of I that start at column i
+            for i in range(self.nt):
+                R = self.nt + 1 + i
+                for J in range(i, self.nt):
+                    if self.mine(R, J):
+                        t = ops.new_tile(self.rows_of(i), self.rows_of(J))
+                        if J == i:
+                            ops.set_identity(t, self.rows_of(i))
+                        self.tiles[(R, J)] = t
 
     # -- factorisation ------------------------------------------------------------
     def _panel_phase(self, k, info_local):
@@ -185,7 +223,7 @@ class BlockCyclicGP:
             winv = torch.empty(self.ops.winv_numel(nk), dtype=torch.float64, device=dev)
         self._bcast(Lkk, diag_owner, self.col_groups, ck)
         self._bcast(winv, diag_owner, self.col_groups, ck)
-        for I in list(range(k + 1, nt)) + [nt]:
+        for I in self._panel_rows(k):
             if self.mine(I, k):
                 ops.trsm(Lkk, winv, nk, self.tiles[(I, k)], self.rows_of(I))
         return info_local
@@ -204,9 +242,9 @@ class BlockCyclicGP:
         tile row I).  Returns (left, works)."""
         ops, nt, nk = self.ops, self.nt, self.rows_of(k)
         left, works = {}, []
-        for I in list(range(k + 1, nt)) + [nt]:
+        for I in self._panel_rows(k):
             src = self.owner(I, k)
-            rI = I % self.pr
+            rI = self._prow(I)
             if self.my_r == rI:
                 t = self.tiles[(I, k)] if self.rank == src else ops.new_tile(self.rows_of(I), nk)
                 w = self._bcast_async(t, src, self.row_groups, rI)
@@ -243,7 +281,9 @@ class BlockCyclicGP:
         """step 4 restricted to my tiles in the given tile columns."""
         nk = self.rows_of(k)
         for (I, J), t in self.tiles.items():
-            if J > k and I >= J and J in columns:
+            # matrix / residual rows: tiles on or below the diagonal; identity rows: only those
+            # the pivots have met (they are exactly the ones with a panel tile in `left`)
+            if J > k and J in columns and I in left and (I >= J):
                 self.ops.update(t, left[I], right[J], self.rows_of(I), self.rows_of(J), nk, lower=(I == J))
 
     def factor(self):
@@ -291,6 +331,105 @@ class BlockCyclicGP:
         if self.world > 1:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
         return -0.5 * acc[1] - self.dy * acc[0] - 0.5 * self.dy * self.n * math.log(2.0 * math.pi)
+
+    # -- backward (closed form on the same grid) ---------------------------------
+    def _kinv_tiles(self):
+        """Kyy^-1 = U U^T (lower tiles, same owners as the matrix tiles) from U = L^-T, which the
+        factorisation left in the identity rows: (Kyy^-1)_IJ = sum_{K >= I} U_IK U_JK^T.  Per tile
+        column K of U the tiles U_IK (I <= K) travel exactly like a panel of the factorisation:
+        along process row I mod Pr (left operands), then down process column I mod Pc (right)."""
+        ops, nt = self.ops, self.nt
+        kinv = {(I, J): ops.new_tile(self.rows_of(I), self.rows_of(J))
+                for I in range(nt) for J in range(I + 1) if self.mine(I, J)}
+        for K in range(nt):
+            nk = self.rows_of(K)
+            left, right = {}, {}
+            for I in range(K + 1):
+                R = nt + 1 + I
+                src = self.owner(R, K)
+                if self.my_r == I % self.pr:
+                    t = self.tiles[(R, K)] if self.rank == src else ops.new_tile(self.rows_of(I), nk)
+                    self._bcast(t, src, self.row_groups, I % self.pr)
+                    left[I] = t
+            for I in range(K + 1):
+                cI = I % self.pc
+                if self.my_c == cI:
+                    src = (I % self.pr) * self.pc + cI
+                    t = left[I] if self.rank == src else left.get(I)
+                    if t is None:
+                        t = ops.new_tile(self.rows_of(I), nk)
+                    self._bcast(t, src, self.col_groups, cI)
+                    right[I] = t
+            for (I, J), t in kinv.items():
+                if I <= K:
+                    ops.update(t, left[I], right[J], self.rows_of(I), self.rows_of(J), nk, lower=(I == J), alpha=1.0)
+        return kinv
+
+    def backward(self, variance, length_scales):
+        """-> tensor [2 + nls]: dLML/d(variance, length_scales..., noise) w.r.t. the CONSTRAINED
+        values, after a factorisation that carried the identity rows (with_inverse).
+        a = Kyy^-1 (y - m) = U alpha;  G = 1/2 (a a^T - dy Kyy^-1);  every rank contracts the G
+        tiles it owns with dK/dtheta (re-computed from the points) and D + 2 scalars are
+        all-reduced."""
+        assert self.with_inverse, "factor with with_inverse=True first"
+        ops, nt, T, dy, dev = self.ops, self.nt, self.T, self.dy, self.X.device
+        nls = length_scales.numel()
+        # alpha^T [dy, n], replicated
+        alphaT = torch.zeros(dy, self.n, dtype=torch.float64, device=dev)
+        for K in range(nt):
+            if self.mine(nt, K):
+                alphaT[:, K * T:K * T + self.rows_of(K)] = self.tiles[(nt, K)][:dy, :self.rows_of(K)]
+        if self.world > 1:
+            dist.all_reduce(alphaT, op=dist.ReduceOp.SUM, group=self.group)
+        # a^T = alpha^T U^T: block I gets sum_{K >= I} alpha_K^T U_IK^T from the owners of U_IK
+        aT = torch.zeros(dy, self.n, dtype=torch.float64, device=dev)
+        for (R, K), t in self.tiles.items():
+            if R <= nt:
+                continue
+            I = R - nt - 1
+            ri, rk = self.rows_of(I), self.rows_of(K)
+            At = ops.new_tile(dy, rk)
+            At[:dy, :rk] = alphaT[:, K * T:K * T + rk]
+            Ct = ops.new_tile(dy, ri)
+            ops.update(Ct, At, t, dy, ri, rk, lower=False, alpha=1.0)
+            aT[:, I * T:I * T + ri] += Ct[:dy, :ri]
+        if self.world > 1:
+            dist.all_reduce(aT, op=dist.ReduceOp.SUM, group=self.group)
+        kinv = self._kinv_tiles()
+        acc = torch.zeros(2 + nls, dtype=torch.float64, device=dev)
+        kpad = _ops.round_up(dy, 16)
+        for (I, J), Kt in kinv.items():
+            ri, rj = self.rows_of(I), self.rows_of(J)
+            aI = ops.new_tile(ri, kpad)
+            aI[:ri, :dy] = aT[:, I * T:I * T + ri].t()
+            aJ = ops.new_tile(rj, kpad)
+            aJ[:rj, :dy] = aT[:, J * T:J * T + rj].t()
+            Gt = ops.new_tile(ri, rj)
+            ops.update(Gt, aI, aJ, ri, rj, kpad, lower=False, alpha=0.5)          # 1/2 a_I a_J^T
+            Kd = Kt[:ri, :rj]
+            if I == J:
+                Kd = torch.tril(Kd) + torch.tril(Kd, -1).t()
+            G = Gt[:ri, :rj] - 0.5 * dy * Kd
+            if I == J:
+                acc[1 + nls] += G.diagonal().sum()                                 # d/d noise = tr G
+            else:
+                G = 2.0 * G                                                        # symmetric partner (J, I)
+            xi = self.X[I * T:I * T + ri]
+            xj = self.X[J * T:J * T + rj]
+            acc[:1 + nls] += ops.kernel_grad(self.kind, xi, xj, variance, length_scales, G.contiguous())
+        if self.world > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+        return acc
+
+    def log_likelihood_and_grad(self, variance, length_scales, noise, resid, max_tries=10):
+        """(LML, [dLML/dvariance, dLML/dlength_scales..., dLML/dnoise]) with the factorisation
+        carrying U = L^-T along (identity rows); same jitter ladder as log_likelihood."""
+        self.with_inverse = True
+        try:
+            lml = self.log_likelihood(variance, length_scales, noise, resid, max_tries)
+            return lml, self.backward(variance, length_scales)
+        finally:
+            self.with_inverse = False
 
     def log_likelihood(self, variance, length_scales, noise, resid, max_tries=10):
         """assemble + factor with the jitter ladder of functions.py:20-43 (decided on the

@@ -378,18 +378,24 @@ def test_block_cyclic_multi_rank_native_shared_gpu(device, world):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, GPN_SHARED_GPU="1")
+    env = dict(os.environ, GPN_SHARED_GPU="1", GPN_DIST_GRAD="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tools", "dist_bench.py"),
            "2048", "8", "512"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     vals = [float(v) for v in re.findall(r"lml=(-?[0-9.]+)", out.stdout)]
-    assert len(vals) == 3, out.stdout
     case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
     assert abs(case["variance"] - 1.0) < 1e-15 and abs(case["noise"] - 1e-2) < 1e-15     # dist_bench's setting
+    assert len(vals) == 4, out.stdout          # 3 timed evaluations + the one of the gradient call
     for v in vals:
         assert abs(v - case["lml"]) < 2e-8, (v, case["lml"])
+    # the distributed closed-form backward on the same grid vs the oracle's closed form
+    g = [float(t) for t in re.search(r"grad: lml=\S+\s+(.*?)\s+[0-9.]+ ms", out.stdout).group(1).split()]
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    ref = orc.lml_closed_form_grads("Rbf", x, y, 1.0, case["length_scales"], 1e-2)
+    ref_g = np.array([float(ref[1]) / 1.0, float(np.asarray(ref[2]).ravel()[0]) / case["length_scales"], float(ref[3]) / 1e-2])
+    assert np.abs(np.asarray(g) - ref_g).max() < 1e-7 * np.abs(ref_g).max(), (g, ref_g)
 
 
 # ---- VFE (sparse_gpr.py:92-195; BASELINE config 5) -------------------------------

@@ -35,5 +35,13 @@ for it in range(3):
     if g.rank == 0:
         print("N=%d D=%d T=%d world=%d grid=%dx%d: lml=%.8f  %.1f ms  (%.1f TFLOP/s aggregate on N^3/3)" % (
             n, d, T, world, g.pr, g.pc, lml.item(), dt * 1e3, n ** 3 / 3 / dt / 1e12), flush=True)
+if os.environ.get("GPN_DIST_GRAD") == "1":      # distributed closed-form backward on the same grid
+    torch.cuda.synchronize()
+    t0 = time.time()
+    lml, grad = g.log_likelihood_and_grad(one, ls, 0.01 * one, Y)
+    torch.cuda.synchronize()
+    if g.rank == 0:
+        print("grad: lml=%.8f  %s  %.1f ms (factorisation carrying L^-T + K^-1 = U U^T + sweeps)" % (
+            lml.item(), " ".join("%.10e" % v for v in grad.tolist()), (time.time() - t0) * 1e3), flush=True)
 if world > 1:
     dist.destroy_process_group()
