@@ -190,7 +190,10 @@ def main():
         kmat = {"bound": "hbm", "kernel": "kmat_kernel (fused distance + %s + noise, lower tiles)" % w["kind"],
                 "achieved": nbytes / us / 1e3, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / us / 1e3 / 8000.0,
                 "traffic": None, "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
-                "vector_flops_per_entry": 3 * w["d"] + 30}
+                "vector_flops_per_entry": 3 * w["d"] + 30,
+                # "report both GB/s and vector-flop fraction" -- (3D+30) flop per entry
+                "vector_tflops": (3 * w["d"] + 30) * (w["n"] * (w["n"] + 1) / 2.0) / us / 1e6,
+                "vector_frac_of_fp64_peak": (3 * w["d"] + 30) * (w["n"] * (w["n"] + 1) / 2.0) / us / 1e6 / PEAK_FP64_MFMA_TFLOPS}
 
     # extra (not part of `value`): one loss()+backward() step -- what Adam (base.py:260-269) pays
     # per iteration -- and the throughput with 4 independent restarts in flight on 4 HIP streams
