@@ -45,19 +45,19 @@ def _kinv_lower(f, U):
     return Kinv
 
 
-MAX_GRAD_DIM = 64      # grad.hip GMAXD: per-dimension accumulators live in registers
+MAX_POINT_GRAD_DIM = 64      # grad.hip GMAXD: gpn_kernel_grad_x2 keeps one accumulator per dimension in registers
 
 
 def _check_dim(d):
-    if d > MAX_GRAD_DIM:
-        raise NotImplementedError("gptorch_amd: hyper-parameter / point gradients support input dimension <= %d "
-                                  "(got %d); evaluation and prediction have no such limit" % (MAX_GRAD_DIM, d))
+    if d > MAX_POINT_GRAD_DIM:
+        raise NotImplementedError("gptorch_amd: gradients w.r.t. the POINTS (inducing points, Kernel.K inputs) support "
+                                  "input dimension <= %d (got %d); hyper-parameter gradients, evaluation and "
+                                  "prediction have no such limit" % (MAX_POINT_GRAD_DIM, d))
 
 
 def lml_backward(kind, X, variance, length_scales, noise, f):
     """-> (dLML/dvariance [1], dLML/dlength_scales [nls], dLML/dnoise [1], dLML/dR [n, dy])."""
     _req(X, variance, length_scales)
-    _check_dim(X.shape[1])
     n, dy = f.n, f.e
     nls = length_scales.numel()
     lib = _native.lib()
@@ -89,7 +89,6 @@ def kernel_backward(kind, X, X2, variance, length_scales, gK):
     lib = _native.lib()
     Xc = _c(X.detach())
     n, d = Xc.shape
-    _check_dim(d)
     X2c = None if X2 is None else _c(X2.detach())
     m = n if X2c is None else X2c.shape[0]
     nls = length_scales.numel()

@@ -226,6 +226,158 @@ __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
   }
 }
 
+// Any input dimension: the same sweep with the coordinates staged 16 at a time -- once for the
+// squared distances and once more for the per-dimension sums (the resident variant above keeps up
+// to 64 coordinates of both point blocks in LDS and one accumulator per dimension in registers).
+template <int KIND, bool LML>
+__global__ __launch_bounds__(256) void grad_sweep_chunked_kernel(GradArgs p) {
+  __shared__ __attribute__((aligned(16))) double xs[GDC][GT];
+  __shared__ __attribute__((aligned(16))) double ys[GDC][GT];
+  __shared__ double inv_ell[GDC];
+  __shared__ double red[256];
+
+  int ti, tj;
+  if (LML) {
+    const int q = blockIdx.x;
+    ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > q) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+    tj = q - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x / p.tiles_n;
+    tj = blockIdx.x - ti * p.tiles_n;
+  }
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int i0 = ti * GT, j0 = tj * GT;
+
+  auto stage = [&](int c0) {                       // coordinates c0 .. c0+15 of both point blocks
+    __syncthreads();                               // previous chunk fully consumed
+    if (tid < GDC) inv_ell[tid] = c0 + tid < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : c0 + tid] : 0.0;
+    __syncthreads();
+    for (int idx = tid; idx < GDC * GT; idx += 256) {
+      const int dd = idx / GT, pt = idx - dd * GT;
+      double vx = 0.0, vy = 0.0;
+      if (c0 + dd < p.d) {
+        const double ie = inv_ell[dd];
+        if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + c0 + dd] * ie;
+        if (j0 + pt < p.m) vy = p.X2[(int64_t)(j0 + pt) * p.d + c0 + dd] * ie;
+      }
+      xs[dd][pt] = vx;
+      ys[dd][pt] = vy;
+    }
+    __syncthreads();
+  };
+  auto fragments = [&](int dd, double (&xr)[4], double (&yc)[4]) {
+    const d2 xa = *reinterpret_cast<const d2*>(&xs[dd][ty * 4]);
+    const d2 xb = *reinterpret_cast<const d2*>(&xs[dd][ty * 4 + 2]);
+    const d2 ya = *reinterpret_cast<const d2*>(&ys[dd][tx * 2]);
+    const d2 yb = *reinterpret_cast<const d2*>(&ys[dd][32 + tx * 2]);
+    xr[0] = xa.x; xr[1] = xa.y; xr[2] = xb.x; xr[3] = xb.y;
+    yc[0] = ya.x; yc[1] = ya.y; yc[2] = yb.x; yc[3] = yb.y;
+  };
+
+  // pass 1: squared distances
+  double r2[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+  for (int c0 = 0; c0 < p.d; c0 += GDC) {
+    stage(c0);
+    const int lim = min(GDC, p.d - c0);
+    for (int dd = 0; dd < lim; ++dd) {
+      double xr[4], yc[4];
+      fragments(dd, xr, yc);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double df = xr[a] - yc[b];
+          r2[a][b] = fma(df, df, r2[a][b]);
+        }
+    }
+  }
+
+  const double var = p.variance[0];
+  double gb[4][4];
+  double s_var = 0.0, s_tr = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = i0 + ty * 4 + a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = j0 + (b >> 1) * 32 + tx * 2 + (b & 1);
+      double g = 0.0;
+      if (row < p.n && col < p.m) {
+        if constexpr (LML) {
+          if (col <= row) {
+            double aa = 0.0;
+            for (int c = 0; c < p.dy; ++c) aa = fma(p.at[(int64_t)c * p.ldat + row], p.at[(int64_t)c * p.ldat + col], aa);
+            g = 0.5 * (aa - (double)p.dy * p.G[(int64_t)row * p.ldg + col]);
+            if (col == row) s_tr += g;
+            else g *= 2.0;
+          }
+        } else {
+          g = p.G[(int64_t)row * p.ldg + col];
+        }
+      }
+      double K, B;
+      k_and_base<KIND>(r2[a][b], var, K, B);
+      s_var = fma(g, K, s_var);
+      gb[a][b] = g * B;
+    }
+  }
+
+  auto block_sum = [&](double v) -> double {
+    red[tid] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) red[tid] += red[tid + w];
+      __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  double* out = p.partial + (int64_t)blockIdx.x * p.nout;
+  const double tv = block_sum(s_var);
+  if (tid == 0) out[0] = tv / var;
+
+  // pass 2: per-dimension sums, chunk by chunk
+  double s_iso = 0.0;
+  for (int c0 = 0; c0 < p.d; c0 += GDC) {
+    stage(c0);
+    const int lim = min(GDC, p.d - c0);
+    for (int dd = 0; dd < lim; ++dd) {               // uniform
+      double xr[4], yc[4];
+      fragments(dd, xr, yc);
+      double sacc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double df = xr[a] - yc[b];
+          sacc = fma(gb[a][b], df * df, sacc);
+        }
+      if (p.nls == 1) {
+        s_iso += sacc;
+      } else {
+        const double t = block_sum(sacc);
+        if (tid == 0) out[1 + c0 + dd] = t / p.ls[c0 + dd];
+      }
+    }
+  }
+  if (p.nls == 1) {
+    const double t = block_sum(s_iso);
+    if (tid == 0) out[1] = t / p.ls[0];
+  }
+  if (LML) {
+    const double t = block_sum(s_tr);
+    if (tid == 0) out[1 + p.nls] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partial, int64_t nblocks, int nout, double* out) {
   __shared__ double red[256];
   const int k = blockIdx.x, tid = threadIdx.x;
@@ -248,7 +400,7 @@ static int launch_sweep(hipStream_t s, const GradArgs& a, int64_t nblocks) {
     case 2: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 2, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
     case 3: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 3, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
     case 4: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 4, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
-    default: return GPN_E_UNSUPPORTED;
+    default: hipLaunchKernelGGL((grad_sweep_chunked_kernel<KIND, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
   }
   GPN_LAUNCH_CHECK();
   return GPN_OK;
@@ -440,7 +592,7 @@ extern "C" int gpn_lml_grad(void* stream, int kind, const double* X, int64_t n, 
                             double* work, double* out) {
   if (!X) return -3;
   if (n <= 0) return -4;
-  if (d <= 0 || d > GMAXD) return -5;
+  if (d <= 0) return -5;
   if (!variance) return -6;
   if (!length_scales) return -7;
   if (nls != 1 && nls != d) return -8;
@@ -473,7 +625,7 @@ extern "C" int gpn_kernel_grad(void* stream, int kind, const double* X, int64_t 
   const bool symmetric = (X2 == nullptr);
   if (symmetric) m = n;
   if (m <= 0) return -6;
-  if (d <= 0 || d > GMAXD) return -7;
+  if (d <= 0) return -7;
   if (!variance) return -8;
   if (!length_scales) return -9;
   if (nls != 1 && nls != d) return -10;

@@ -638,6 +638,39 @@ def test_gpr_with_composite_kernels(device, idx):
     assert np.max(np.abs(cov - np.asarray(case["cov"]))) < 1e-8
 
 
+@pytest.mark.parametrize("n,d,dy,kind,ard", [(300, 70, 1, "Rbf", False), (400, 100, 2, "Matern52", True)])
+def test_more_than_64_input_dimensions(device, n, d, dy, kind, ard):
+    """D > 64: the hyper-parameter sweeps switch to the variant that stages 16 coordinates at a
+    time (LML mode via loss().backward(), dense-G mode via Kernel.K autograd); points gradients
+    are the documented limit."""
+    x, y = rng.make_regression(n, d, dy, seed=4)
+    ls = (0.7 * np.sqrt(d) * (0.5 + rng.uniform(9, d))) if ard else 0.7 * np.sqrt(d)
+    m = GPR(x, y, KERN[kind](d, variance=1.2, length_scales=ls, ARD=ard), likelihood=likelihoods.Gaussian(variance=0.05))
+    m.cuda()
+    o = orc.GPROracle(x, y, kind=kind, variance=1.2, length_scales=ls, noise=0.05, ARD=ard)
+    lo = o.loss()
+    lo.backward()
+    l = m.loss()
+    l.backward()
+    assert abs(l.item() - lo.item()) < 1e-10 * abs(lo.item())
+    for got, ref in [(m.kernel.variance.grad, o.raw_variance.grad), (m.kernel.length_scales.grad, o.raw_length_scales.grad),
+                     (m.likelihood.variance.grad, o.raw_noise.grad)]:
+        assert (got.cpu() - ref).abs().max().item() < 1e-9 * max(1.0, ref.abs().max().item())
+    k = KERN[kind](d, variance=1.4, length_scales=ls, ARD=ard)
+    k.cuda()
+    wn = rng.normal(23, (n, 50))
+    X2 = torch.tensor(x[:50], device=device)
+    (k.K(torch.tensor(x, device=device), X2) * torch.tensor(wn, device=device)).sum().backward()
+    rv = torch.tensor([np.log(1.4)], dtype=torch.float64, requires_grad=True)
+    rl = torch.tensor(np.log(np.atleast_1d(ls)), dtype=torch.float64, requires_grad=True)
+    (orc.kernel_K(kind, torch.tensor(x), torch.tensor(x[:50]), rv.exp(), rl.exp()) * torch.tensor(wn)).sum().backward()
+    assert (k.variance.grad.cpu() - rv.grad).abs().max().item() < 1e-10
+    assert (k.length_scales.grad.cpu() - rl.grad).abs().max().item() < 1e-10
+    Xg = torch.tensor(x, device=device, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        k.K(Xg).sum().backward()
+
+
 def test_evaluation_captures_into_a_hipgraph(device):
     """the factorisation forks onto internal streams (look-ahead) and joins back, so a whole
     LML evaluation still captures into ONE hipGraph; replays reproduce the eager value and

@@ -4,7 +4,7 @@ import numpy as np, torch
 from gptorch_amd import kernels, likelihoods, rng
 from gptorch_amd.models import GPR
 from oracle import gp_oracle as orc
-for (n, d, dy, kind, ard) in [(600, 3, 200, "Rbf", False), (700, 64, 2, "Matern52", True), (1300, 40, 1, "Rbf", True), (300, 70, 1, "Rbf", False)]:
+for (n, d, dy, kind, ard) in [(600, 3, 200, "Rbf", False), (700, 64, 2, "Matern52", True), (1300, 40, 1, "Rbf", True), (300, 70, 1, "Rbf", False), (400, 100, 2, "Matern52", True)]:
     x, y = rng.make_regression(n, d, dy, seed=4)
     ls = (0.7 * np.sqrt(d) * (0.5 + rng.uniform(9, d))) if ard else 0.7 * np.sqrt(d)
     k = getattr(kernels, kind)(d, variance=1.2, length_scales=ls, ARD=ard)
