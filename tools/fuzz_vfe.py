@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""GPU-box tool: randomized VFE sweep (bound, all gradients incl. inducing points, predictions)
+against the CPU oracle's autograd, with random chunk sizes for the streamed evaluation."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from gptorch_amd import kernels, likelihoods, mean_functions, rng  # noqa: E402
+from gptorch_amd.models import VFE, sparse_gpr  # noqa: E402
+from oracle import gp_oracle as orc  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = {"elbo": 0.0, "grad": 0.0, "mean": 0.0, "var": 0.0}
+bad = 0
+singular = 0
+for it in range(cases):
+    n = int(rs.choice([100, 257, 1000, 1024, 1500, 2500]))
+    m = int(rs.choice([10, 64, 128, 129, 200, 300]))
+    d = int(rs.choice([1, 2, 3, 6]))
+    dy = int(rs.choice([1, 2]))
+    kind = str(rs.choice(["Rbf", "Matern52", "Matern32"]))
+    ard = bool(rs.rand() < 0.5)
+    noise = float(rs.choice([0.05, 0.2]))
+    sparse_gpr.CHUNK_ROWS = int(rs.choice([128, 256, 512, 65536]))
+    x, y = rng.make_regression(n, d, dy, seed=2000 + it)
+    z = rng.normal(3000 + it, (m, d))
+    ls = (0.35 * np.sqrt(d) * (0.6 + rs.rand(d))) if ard else float(0.35 * np.sqrt(d) * (0.7 + rs.rand()))
+    mod = VFE(x, y, getattr(kernels, kind)(d, variance=1.1, length_scales=ls, ARD=ard), inducing_points=z,
+              likelihood=likelihoods.Gaussian(variance=noise), mean_function=mean_functions.Zero(dy))
+    mod.cuda()
+    o = orc.VFEOracle(x, y, z, kind, 1.1, ls, noise)
+    cond = torch.linalg.cond(o.K(o.Z)).item()
+    ref = orc.vfe_grads_autograd(o)
+    elbo_ref = o.log_likelihood().item()
+    mod.zero_grad()
+    loss = mod.loss(); loss.backward()
+    e_l = abs(-loss.item() - elbo_ref) / max(1.0, abs(elbo_ref))
+    got = [mod.kernel.variance.grad.cpu().numpy().ravel() / -1.1, mod.kernel.length_scales.grad.cpu().numpy().ravel() / -np.atleast_1d(ls),
+           mod.likelihood.variance.grad.cpu().numpy().ravel() / -noise, -mod.Z.grad.cpu().numpy()]
+    e_g = max(np.abs(g.reshape(r.shape) - r.numpy()).max() / max(1.0, np.abs(r.numpy()).max()) for g, r in zip(got, ref))
+    xs = rng.normal(4000 + it, (5, d))
+    mu, var = mod.predict_f(xs)
+    with torch.no_grad():
+        omu, ovar = o.predict_f(xs)
+    e_m, e_v = np.abs(mu - omu.numpy()).max(), np.abs(var - ovar.numpy()).max()
+    tol_g = 1e-7 * max(1.0, cond * 1e-6)          # the closed form's error grows like cond(Kuu) * eps
+    if cond > 1e12:                               # numerically singular Kuu (jitter-ladder regime): the
+        singular += 1                             # reference's own value is rounding noise there
+        continue
+    worst["elbo"] = max(worst["elbo"], e_l); worst["grad"] = max(worst["grad"], e_g / max(1.0, cond * 1e-6))
+    worst["mean"] = max(worst["mean"], e_m); worst["var"] = max(worst["var"], e_v)
+    if e_l > 1e-8 or e_g > tol_g or e_m > 1e-6 or e_v > 1e-6:
+        bad += 1
+        print("VIOLATION n=%d m=%d d=%d dy=%d %s ard=%s chunk=%d cond=%.1e: elbo %.2e grad %.2e mean %.2e var %.2e" % (
+            n, m, d, dy, kind, ard, sparse_gpr.CHUNK_ROWS, cond, e_l, e_g, e_m, e_v), flush=True)
+print("cases %d (%d with cond(Kuu) > 1e12 not judged), violations %d, worst: %s" % (cases, singular, bad, {k: "%.2e" % v for k, v in worst.items()}))
+sys.exit(1 if bad else 0)
