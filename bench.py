@@ -187,9 +187,12 @@ def main():
             torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
         nbytes = 8.0 * (w["n"] * (w["n"] + 1) / 2.0 + w["n"] * w["d"])
+        ktraffic = None
+        if os.path.exists(tpath):                  # same committed PMC passes as the contraction kernel's traffic
+            ktraffic = json.load(open(tpath)).get("kmat_bytes_per_launch")
         kmat = {"bound": "hbm", "kernel": "kmat_kernel (fused distance + %s + noise, lower tiles)" % w["kind"],
                 "achieved": nbytes / us / 1e3, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / us / 1e3 / 8000.0,
-                "traffic": None, "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
+                "traffic": ktraffic, "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
                 "vector_flops_per_entry": 3 * w["d"] + 30,
                 # "report both GB/s and vector-flop fraction" -- (3D+30) flop per entry
                 "vector_tflops": (3 * w["d"] + 30) * (w["n"] * (w["n"] + 1) / 2.0) / us / 1e6,
