@@ -270,22 +270,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   // epilogue: reg r of lane l is C[(l>>4) + 4r][l&15] of its 16x16 tile
   const int crow = lane >> 4, ccol = lane & 15;
   const bool diag_tile = p.lower && (ti == tj);
+  // beta != 0: ALL loads of one row of 16x16 tiles are issued before the first use (one HBM
+  // round trip per TN*4 elements); element-by-element load -> fma -> store serialises 16+ round
+  // trips per tile, which is most of the run time of a K = 128 update
+  const bool use_c = p.beta != 0.0;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    double cold[TN][4];
+    bool ok[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wave_n * WN + j * 16 + ccol;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wave_m * WM + i * 16 + crow + 4 * r;
-        if (row < p.M && col < p.N && (!diag_tile || col <= row)) {
-          double* c = p.C + (int64_t)row * p.ldc + col;
-          double v = p.alpha * acc[i][j][r];
-          if (p.beta != 0.0) v += p.beta * *c;
-          *c = v;
-        }
+        ok[j][r] = row < p.M && col < p.N && (!diag_tile || col <= row);
+        cold[j][r] = 0.0;
+        if (use_c && ok[j][r]) cold[j][r] = p.C[(int64_t)row * p.ldc + col];
       }
     }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wave_n * WN + j * 16 + ccol;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wave_m * WM + i * 16 + crow + 4 * r;
+        if (ok[j][r]) p.C[(int64_t)row * p.ldc + col] = fma(p.beta, cold[j][r], p.alpha * acc[i][j][r]);
+      }
+    }
+  }
 }
 
 template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
