@@ -594,11 +594,9 @@ static Aux* aux_for(hipStream_t s) {
     if (hipEventCreateWithFlags(&a.solve[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.rest[i], hipEventDisableTiming) != hipSuccess) return nullptr;
   }
-  for (int i = 0; i < NSIDE; ++i) {
-    if (hipStreamCreateWithFlags(&a.side[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&a.join_ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-  }
-  if (hipEventCreateWithFlags(&a.fork_ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  // (the side streams of the triangular inversion are created on its first call: HIP multiplexes
+  //  streams onto a few hardware queues -- 4 by default -- and streams that share a queue
+  //  serialise, so a forward-only caller should not pay for streams it never uses)
   return &g_aux.emplace(s, a).first->second;
 }
 
@@ -886,6 +884,16 @@ static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, 
                         int64_t n) {
   Aux* ax = aux_for(s);
   if (!ax) return GPN_E_HIP;
+  if (!ax->fork_ev) {
+    std::lock_guard<std::mutex> lock(g_aux_mutex);
+    if (!ax->fork_ev) {
+      for (int i = 0; i < NSIDE; ++i) {
+        GPN_HIP_CHECK(hipStreamCreateWithFlags(&ax->side[i], hipStreamNonBlocking));
+        GPN_HIP_CHECK(hipEventCreateWithFlags(&ax->join_ev[i], hipEventDisableTiming));
+      }
+      GPN_HIP_CHECK(hipEventCreateWithFlags(&ax->fork_ev, hipEventDisableTiming));
+    }
+  }
   std::vector<TNode> nodes;
   trtri_collect(nodes, 0, n, 0);
   int maxd = -1;

@@ -95,6 +95,9 @@ class GPR(GPModel):
         return mean_f, var_f
 
 
+_LANES = {}          # device -> two HIP streams shared by every batched call
+
+
 def batched_log_likelihood(models, streams=None):
     """log_likelihood() of several INDEPENDENT GPR models (multi-start hyper-parameter
     search: one model per restart) without a host round trip per model: every factorisation is
@@ -102,15 +105,28 @@ def batched_log_likelihood(models, streams=None):
     (1,) tensors.  Any model whose factorisation reports info != 0 is re-evaluated through the
     sequential path (jitter ladder of functions.py:20-43).
 
-    streams=None (default): back to back on the current stream -- since the factorisation
-    overlaps its own latency-bound chain with its updates (look-ahead driver), one model already
-    fills the GPU and this is the fastest order.  A list of HIP streams runs one model per
-    stream concurrently instead (measured slower at N = 8192: the models' chains queue behind
-    each other's long-running update workgroups)."""
+    streams=None (default): the models alternate between TWO internal HIP streams.  One
+    factorisation already overlaps its latency-bound chain with its own updates (look-ahead
+    driver), and two of them in flight fill what is left (180 vs 138 evals/s at N = 8192); more
+    concurrent streams than that lose again -- the runtime multiplexes streams onto 4 hardware
+    queues, and each factorisation uses an internal stream of its own.  A list of HIP streams
+    (one per model) overrides the placement; the current stream itself gives back-to-back
+    execution."""
     dev = models[0].X.device
     cur = torch.cuda.current_stream(dev)
     if streams is None:
-        streams = [cur] * len(models)
+        if len(models) < 2:
+            streams = [cur] * len(models)
+        else:
+            if dev not in _LANES:
+                _LANES[dev] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            streams = [_LANES[dev][i % 2] for i in range(len(models))]
+    side = any(st is not cur for st in streams)
+    if side:
+        # host-side fork/join: event waits between a created stream and the legacy default stream
+        # cost ~7 ms per evaluation on this runtime (tools/stream_kind_test2.py), a host sync of an
+        # idle stream costs nothing
+        cur.synchronize()
     pending = []
     with torch.no_grad():
         for m, st in zip(models, streams):
@@ -118,19 +134,18 @@ def batched_log_likelihood(models, streams=None):
             if k is None:                       # dense-K kernels: sequential path
                 pending.append(None)
                 continue
-            if st is not cur:
-                st.wait_stream(cur)
             with torch.cuda.stream(st):
                 resid = m.Y - m.mean_function(m.X)
                 f = _ops.kernel_factor_async(k._kind, m.X, k.variance.transform(), k.length_scales.transform(),
                                              m.likelihood.variance.transform(), R=resid,
                                              factor=m._holder.get("factor"))
                 m._holder["factor"] = f
-                pending.append((f, f.lml_terms()))
-        for st in streams:
-            if st is not cur:
-                cur.wait_stream(st)
+                pending.append((f, f.lml_terms(), st))
         out = []
         for m, p in zip(models, pending):
-            out.append(p[1][2:3] if p is not None and int(p[0].info.item()) == 0 else m.log_likelihood())
+            ok = False
+            if p is not None:
+                with torch.cuda.stream(p[2]):
+                    ok = int(p[0].info.item()) == 0        # synchronises that model's stream
+            out.append(p[1][2:3] if ok else m.log_likelihood())
     return out
