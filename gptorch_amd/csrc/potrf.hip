@@ -2,10 +2,12 @@
 // solves built on it.  Replaces torch.cholesky / torch.triangular_solve under
 // functions.cholesky / functions.trtrs (functions.py:46-47, 71-76).
 //
-// Structure: recursive blocking down to a 128x128 leaf.
+// Two host drivers over the same kernels: the flat panel driver with look-ahead on an auxiliary
+// stream (potrf_lookahead, the default for the factorisation) and recursive blocking down to a
+// 128x128 leaf (used for small n, the right-solves and as the A/B reference):
 //   potrf(A):  A11 = potrf(A11);  A21 <- A21 * L11^-T;  A22 -= A21 A21^T;  potrf(A22)
 //   trsm(B,L): B1 <- B1 * L11^-T; B2 -= B1 * L21^T;     B2 <- B2 * L22^-T
-// Every flop outside the 64x64 leaves is an "NT" fp64-MFMA contraction
+// Every flop outside the 128x128 leaves is an "NT" fp64-MFMA contraction
 // (gemm_f64.hip) whose K extent is as large as the recursion allows, so the
 // N^2 matrix is streamed O(log N) times instead of N/nb times and the trailing
 // updates stay MFMA-bound rather than HBM-bound.  The leaf kernel factors its
@@ -569,14 +571,10 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
 // square receives finite garbage from the rectangular updates: nothing reads it (the leaf
 // masks j > i on load, every other consumer uses blocks strictly below the diagonal blocks
 // or winv).
-constexpr int NSIDE = 3;              // side streams for level-parallel work (triangular inversion)
 struct Aux {
   hipStream_t s1 = nullptr;
   hipEvent_t solve[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t rest[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
-  hipEvent_t fork_ev = nullptr;
-  hipEvent_t join_ev[NSIDE] = {nullptr, nullptr, nullptr};
 };
 static std::mutex g_aux_mutex;
 static std::unordered_map<hipStream_t, Aux> g_aux;
@@ -594,9 +592,8 @@ static Aux* aux_for(hipStream_t s) {
     if (hipEventCreateWithFlags(&a.solve[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.rest[i], hipEventDisableTiming) != hipSuccess) return nullptr;
   }
-  // (the side streams of the triangular inversion are created on its first call: HIP multiplexes
-  //  streams onto a few hardware queues -- 4 by default -- and streams that share a queue
-  //  serialise, so a forward-only caller should not pay for streams it never uses)
+  // (one aux stream only: HIP multiplexes streams onto a few hardware queues -- 4 by default --
+  //  and streams that share a queue serialise)
   return &g_aux.emplace(s, a).first->second;
 }
 
@@ -868,9 +865,9 @@ extern "C" int gpn_trsm_right_lt(void* stream, const double* L, int64_t n, int64
 // Level-parallel variant with a scratch matrix S (same shape as U, zero-initialised):
 //   U12 = -U11 * L21^T * U22  as two NT contractions  T = U11 L21^T  (into S12)  and
 //   U12 = -T * (U22^T)^T  with U22^T written into S22 by an HBM-bound transpose --
-// no right-solve chain, and all nodes of one depth of the recursion tree are independent,
-// so they are dealt round-robin onto the caller's stream and NSIDE side streams (fork/join
-// by events once per depth).
+// no right-solve chain, and all nodes of one depth of the recursion tree are independent:
+// equal-shaped ones go out as one strided-batch launch per operation.  (Dealing them onto side
+// streams as well was measured and dropped: 199 vs 196 ms at N = 32768, 3.96 vs 3.89 at 8192.)
 struct TNode { int64_t off, n, h; int depth; };
 static void trtri_collect(std::vector<TNode>& v, int64_t off, int64_t n, int depth) {
   if (n <= LEAF) return;
@@ -882,18 +879,6 @@ static void trtri_collect(std::vector<TNode>& v, int64_t off, int64_t n, int dep
 
 static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, int64_t ldu, double* S, int64_t lds,
                         int64_t n) {
-  Aux* ax = aux_for(s);
-  if (!ax) return GPN_E_HIP;
-  if (!ax->fork_ev) {
-    std::lock_guard<std::mutex> lock(g_aux_mutex);
-    if (!ax->fork_ev) {
-      for (int i = 0; i < NSIDE; ++i) {
-        GPN_HIP_CHECK(hipStreamCreateWithFlags(&ax->side[i], hipStreamNonBlocking));
-        GPN_HIP_CHECK(hipEventCreateWithFlags(&ax->join_ev[i], hipEventDisableTiming));
-      }
-      GPN_HIP_CHECK(hipEventCreateWithFlags(&ax->fork_ev, hipEventDisableTiming));
-    }
-  }
   std::vector<TNode> nodes;
   trtri_collect(nodes, 0, n, 0);
   int maxd = -1;
@@ -903,7 +888,7 @@ static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, 
     for (const TNode& t : nodes) if (t.depth == d) lvl.push_back(&t);
     // Nodes of one depth with the same shape at a constant spacing (all of them when n is a
     // power-of-two multiple of the leaf) go out as ONE strided-batch launch per operation;
-    // irregular nodes are dealt onto the caller's stream and the side streams.
+    // irregular and large nodes follow one by one.
     size_t i0 = 0;
     std::vector<const TNode*> single;
     while (i0 < lvl.size()) {
@@ -933,15 +918,8 @@ static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, 
       }
       i0 = i1;
     }
-    const int nq = (int)std::min<size_t>(single.size(), NSIDE + 1);    // streams used at this depth
-    if (nq > 1) {
-      GPN_HIP_CHECK(hipEventRecord(ax->fork_ev, s));
-      for (int q = 1; q < nq; ++q) GPN_HIP_CHECK(hipStreamWaitEvent(ax->side[q - 1], ax->fork_ev, 0));
-    }
-    for (size_t i = 0; i < single.size(); ++i) {
-      const TNode& t = *single[i];
-      const int q = (int)(i % nq);
-      hipStream_t sq = q == 0 ? s : ax->side[q - 1];
+    for (const TNode* tp : single) {
+      const TNode& t = *tp;
       const int64_t h = t.h, m2 = t.n - t.h, o = t.off;
       const double* U11 = U + o * ldu + o;
       const double* L21 = L + (o + h) * ldl + o;
@@ -949,16 +927,12 @@ static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, 
       double* S12 = S + o * lds + o + h;
       double* S22 = S + (o + h) * lds + o + h;
       dim3 grid((unsigned)((m2 + 31) / 32), (unsigned)((m2 + 31) / 32));
-      hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, sq, U22, m2, m2, ldu, S22, lds);
+      hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, U22, m2, m2, ldu, S22, lds);
       GPN_LAUNCH_CHECK();
-      int rc = gemm_nt(sq, h, m2, h, 1.0, U11, ldu, L21, ldl, 0.0, S12, lds, 0, GPN_TRI_A_UPPER);
+      int rc = gemm_nt(s, h, m2, h, 1.0, U11, ldu, L21, ldl, 0.0, S12, lds, 0, GPN_TRI_A_UPPER);
       if (rc != GPN_OK) return rc;
-      rc = gemm_nt(sq, h, m2, round_up(m2, 16), -1.0, S12, lds, S22, lds, 0.0, U + o * ldu + o + h, ldu, 0, GPN_TRI_B_LOWER);
+      rc = gemm_nt(s, h, m2, round_up(m2, 16), -1.0, S12, lds, S22, lds, 0.0, U + o * ldu + o + h, ldu, 0, GPN_TRI_B_LOWER);
       if (rc != GPN_OK) return rc;
-    }
-    for (int q = 1; q < nq; ++q) {
-      GPN_HIP_CHECK(hipEventRecord(ax->join_ev[q - 1], ax->side[q - 1]));
-      GPN_HIP_CHECK(hipStreamWaitEvent(s, ax->join_ev[q - 1], 0));
     }
   }
   return GPN_OK;

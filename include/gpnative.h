@@ -137,7 +137,7 @@ int gpn_trtri_upper(void* stream, const double* L, int64_t n, int64_t ldl, const
 /* Same result, throughput-oriented: with a ZERO-INITIALISED scratch matrix S of the same shape
  * as U the off-diagonal blocks are U12 = -(U11 L21^T) (U22^T)^T -- two NT contractions and an
  * HBM-bound transpose per node of the recursion tree, no right-solve chain -- and the
- * independent nodes of one tree depth run on internal side streams (fork/join on `stream`). */
+ * equal-shaped nodes of one tree depth go out as one strided-batch launch per operation. */
 int gpn_trtri_upper_ws(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv,
                        double* U, int64_t ldu, double* S, int64_t lds);
 
