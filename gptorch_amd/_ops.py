@@ -285,14 +285,35 @@ def trtrs_lower(b, f):
 # ----------------------------------------------------------------------------
 # GPR predictive equations (gpr.py:88-117) in transposed storage
 # ----------------------------------------------------------------------------
-def gpr_predict(kind, X, x_new, variance, length_scales, f, diag=True):
+def lower_inverse(f):
+    """W = L^-1 (lower, row-major, zero padded [rows, ld]) of a factor, cached on it: with W every
+    right-solve X L^T = B is ONE K-clipped contraction X = B W^T instead of a chain of ~2 n/128
+    small launches -- worth its n^3/3 flops for a model that serves many predictions."""
+    W = getattr(f, "_winv_full", None)
+    if W is None:
+        from . import _backward
+        U = _backward._upper_inverse(f)
+        W = torch.zeros_like(U)
+        if f.n:
+            st = _native.lib().gpn_transpose(_stream(f.device), _ptr(U), f.n, f.n, f.ld, _ptr(W), f.ld)
+            _native.check(st, "gpn_transpose")
+        f._winv_full = W
+    return W
+
+
+def gpr_predict(kind, X, x_new, variance, length_scales, f, diag=True, use_inverse=False):
     """Returns (A^T V  [n*, dy],  var) with A = L^-1 K(X, x*), V = L^-1 (Y - m) held
     in f.extra(); var = rowsumsq-reduced diag [n*] or full K(x*) - A^T A [n*, n*]."""
     ns = x_new.shape[0]
     n, dy = f.n, f.e
     Bt = padded_like_factor(f, ns)
-    kernel_matrix(kind, x_new, X, variance, length_scales, out=Bt, ldk=f.ld)   # K(x*, X) = k_ys^T
-    f.solve_right_lt(Bt, ns)                                                   # A^T = K(x*,X) L^-T
+    if use_inverse:
+        Ks = padded_like_factor(f, ns)
+        kernel_matrix(kind, x_new, X, variance, length_scales, out=Ks, ldk=f.ld)
+        gemm_nt(Ks, lower_inverse(f), ns, n, round_up(n, 16), C=Bt, tri=TRI_B_LOWER)   # A^T = K(x*,X) W^T
+    else:
+        kernel_matrix(kind, x_new, X, variance, length_scales, out=Bt, ldk=f.ld)   # K(x*, X) = k_ys^T
+        f.solve_right_lt(Bt, ns)                                                   # A^T = K(x*,X) L^-T
     kpad = round_up(n, 16)
     mean = gemm_nt(Bt, f.A[n:], ns, dy, kpad)                                  # A^T V
     if diag:

@@ -14,11 +14,15 @@ from .. import kernels
 from .base import GPModel
 
 
+INVERSE_AFTER_CALLS = 3      # predictions with one cached factor before L^-1 is formed (see _predict)
+
+
 class GPR(GPModel):
     def __init__(self, x, y, kernel, mean_function=None, likelihood=None, name="gpr"):
         super().__init__(x, y, kernel, likelihood, mean_function, name)
         self._holder = {}        # reusable factor buffer for the training loop
         self._predict_cache = None
+        self._predict_calls = 0
 
     def _stationary(self):
         """the kernel if it is one of the native stationary kinds (fused assembly -> factor
@@ -62,6 +66,8 @@ class GPR(GPModel):
             if self._predict_cache is None or self._predict_cache[0] != key:
                 f = _ops.kernel_factor(k._kind, x, var, ls, noise, R=self.Y - mean_x)
                 self._predict_cache = (key, f)
+                self._predict_calls = 0
+            self._predict_calls += 1
         return self._predict_cache[1], var, ls
 
     def _predict_dense(self, x_new, diag, x):
@@ -89,7 +95,10 @@ class GPR(GPModel):
             return self._predict_dense(x_new, diag, x)
         f, var, ls = self._factor_for_predict(x)
         with torch.no_grad():
-            mean, v = _ops.gpr_predict(k._kind, x, x_new, var, ls, f, diag=diag)
+            # from the third prediction with the same factor on, the right-solve chain is replaced
+            # by one contraction with the explicit inverse (built once, n^3/3 flops)
+            mean, v = _ops.gpr_predict(k._kind, x, x_new, var, ls, f, diag=diag,
+                                       use_inverse=self._predict_calls >= INVERSE_AFTER_CALLS)
             mean_f = mean + self.mean_function(x_new)
             var_f = v[:, None].expand_as(mean_f) if diag else v
         return mean_f, var_f

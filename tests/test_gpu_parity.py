@@ -671,6 +671,26 @@ def test_more_than_64_input_dimensions(device, n, d, dy, kind, ard):
         k.K(Xg).sum().backward()
 
 
+def test_repeated_predictions_switch_to_the_explicit_inverse(device):
+    """from the third prediction with one cached factor the right-solve chain is replaced by a
+    contraction with L^-1 (built once): same numbers, for diag and full covariance, ragged n."""
+    case = [c for c in LML if c["name"] == "rbf_1000_8_ls1"][0]
+    m, x, y = _model(case, device)
+    xs = rng.normal(91, (37, case["d"]))
+    mu1, v1 = m.predict_f(xs)
+    _, c1 = m.predict_f(xs, diag=False)
+    assert getattr(m._predict_cache[1], "_winv_full", None) is None
+    mu3, v3 = m.predict_f(xs)
+    _, c3 = m.predict_f(xs, diag=False)
+    assert m._predict_cache[1]._winv_full is not None
+    o = orc.GPROracle(x, y, kind=case["kind"], variance=case["variance"], length_scales=case["length_scales"], noise=case["noise"])
+    with torch.no_grad():
+        omu, ocov = o.predict_f(xs, diag=False)
+    for a, b in [(mu1, mu3), (v1, v3), (c1, c3)]:
+        assert np.abs(a - b).max() < 1e-10
+    assert np.abs(mu3 - omu.numpy()).max() < 1e-8 and np.abs(c3 - ocov.numpy()).max() < 1e-8
+
+
 def test_evaluation_captures_into_a_hipgraph(device):
     """the factorisation forks onto internal streams (look-ahead) and joins back, so a whole
     LML evaluation still captures into ONE hipGraph; replays reproduce the eager value and

@@ -27,6 +27,11 @@ def cold():
     return m.predict_y(xs)
 
 
-print("%s N*=%d: predict_y diag, factor cached   %.3f ms" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+import gptorch_amd.models.gpr as gpr_mod
+gpr_mod.INVERSE_AFTER_CALLS = 10 ** 9
+print("%s N*=%d: predict_y diag, factor cached   %.3f ms (right-solve chain)" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+gpr_mod.INVERSE_AFTER_CALLS = 0
+print("%s N*=%d: predict_y diag, factor cached   %.3f ms (explicit inverse, after its one-off construction)" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+gpr_mod.INVERSE_AFTER_CALLS = 10 ** 9
 print("%s N*=%d: predict_y full cov, cached      %.3f ms" % (w["name"][:2], ns, t(lambda: m.predict_y(xs, diag=False))))
 print("%s N*=%d: predict_y diag, incl. re-factor %.3f ms (the reference re-factorises every call)" % (w["name"][:2], ns, t(cold)))
