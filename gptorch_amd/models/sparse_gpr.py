@@ -48,6 +48,27 @@ from ..util import as_tensor
 from .base import GPModel
 
 CHUNK_ROWS = 65536   # rows of x per streamed chunk (scratch: 2 x CHUNK_ROWS x ld(M) x 8 B)
+# N-sharding over the GPUs of a node: when set to a torch.distributed process group
+# (or True for the default group) every rank holds a ROW SHARD of (x, y) and the same Z and
+# hyper-parameters; the M-sized sums A A^T, A err and the scalars N, |y|^2 are all-reduced in the
+# forward and the gradients in the backward, so every rank sees the bound and the gradients of the
+# WHOLE data set (optimisers on all ranks stay in step).
+SHARD_GROUP = None
+
+
+def _all_reduce(t):
+    import torch.distributed as dist
+    if SHARD_GROUP is None:
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=None if SHARD_GROUP is True else SHARD_GROUP)
+    return t
+
+
+def _shard_rank():
+    import torch.distributed as dist
+    if SHARD_GROUP is None:
+        return 0
+    return dist.get_rank(None if SHARD_GROUP is True else SHARD_GROUP)
 
 
 class _InducingPointsGP(GPModel):
@@ -84,7 +105,7 @@ def _chunks(n, nc):
 
 class _State:
     """what one evaluation of the bound leaves behind (all M-sized)."""
-    __slots__ = ("f_uu", "fB", "AAT", "Aerr", "s2", "tr", "terms", "n")
+    __slots__ = ("f_uu", "fB", "AAT", "Aerr", "s2", "tr", "terms", "n", "n_all", "yy_all")
 
 
 def _vfe_forward(kind, x, err, Z, var, ls, s2):
@@ -138,6 +159,14 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
         cur.wait_stream(stq)
     if acc_done is not None:
         cur.wait_event(acc_done)
+    # row shards: one all-reduce of the M-sized sums and of (N, |err|^2)
+    scal = torch.tensor([float(n), 0.0], dtype=torch.float64, device=dev)
+    scal[1] = err.pow(2).sum()
+    if SHARD_GROUP is not None:
+        _all_reduce(AAT)
+        _all_reduce(Aerr)
+        _all_reduce(scal)
+    st.n_all, st.yy_all = int(round(scal[0].item())), scal[1]
     st.Aerr = Aerr[:m]
     st.tr = AAT.diagonal()[:m].sum()
 
@@ -189,10 +218,12 @@ def _vfe_backward(kind, x, err, Z, var, ls, st):
     Guu = _sandwich(U, W, m)                                               # dF/dKuu
     gt = _ops.gemm_nt(bt, U, p, m, mp, tri=_ops.TRI_B_UPPER)              # gamma^T = beta^T L^-1
 
-    # K(Z, Z) part
+    # K(Z, Z) part (identical on every rank of a sharded run: counted on the first one only)
     g_var, g_ls = _backward.kernel_backward(kind, Z, None, var, ls, Guu[:m, :m])
     g_var, g_ls = g_var.clone(), g_ls.clone()
     g_Z = _backward.kernel_backward_x2(kind, Z, Z, var, ls, Guu[:m, :m], scale=2.0)
+    if _shard_rank() != 0:
+        g_var.zero_(), g_ls.zero_(), g_Z.zero_()
 
     # K(x, Z) part, streamed:  G_c = 1/s [K(x_c, Z) | err_c] [P | gamma]^T
     ldk = mp + pp
@@ -212,12 +243,15 @@ def _vfe_backward(kind, x, err, Z, var, ls, st):
         g_ls += gl
         _backward.kernel_backward_x2(kind, xc, Z, var, ls, G[:r, :m], out=g_Z)
 
-    g_var = g_var - 0.5 * p * n / s                                        # tr Kff = N * variance
+    if SHARD_GROUP is not None:                                            # sum the row shards' contributions
+        _all_reduce(g_var), _all_reduce(g_ls), _all_reduce(g_Z)
+    n_all = st.n_all
+    g_var = g_var - 0.5 * p * n_all / s                                    # tr Kff = N * variance
     c2 = st.terms[1] / (s * s)
     b = beta[:m, :p]
     quad = (b * st.Aerr).sum() / s - (b * b).sum()                         # beta^T (B - I) beta
     g_noise = (0.5 * p / s) * (m - Binv.diagonal().sum()) - c2 / s + 0.5 * quad / s - 0.5 * p * st.tr / s \
-        - 0.5 * p * n / s + 0.5 * (err.pow(2).sum() + p * n * var[0]) / (s * s)
+        - 0.5 * p * n_all / s + 0.5 * (st.yy_all + p * n_all * var[0]) / (s * s)
     return g_var, g_ls, g_noise.reshape(1), g_Z
 
 
@@ -228,11 +262,11 @@ class _VFEBound(torch.autograd.Function):
     def forward(ctx, variance, length_scales, noise, Z, kind, x, err, holder):
         s2 = float(noise.item())
         st = _vfe_forward(kind, x, err, Z.detach(), variance.detach(), length_scales.detach(), s2)
-        n, p = err.shape
+        n, p = st.n_all, err.shape[1]                                   # N of the whole data set
         elbo = -0.5 * p * n * math.log(2.0 * math.pi)
         elbo = elbo - p * st.terms[0]
         elbo = elbo - 0.5 * p * n * math.log(s2)
-        elbo = elbo - 0.5 * (err.pow(2).sum() + p * n * variance.detach()[0]) / s2   # Kdiag = variance
+        elbo = elbo - 0.5 * (st.yy_all + p * n * variance.detach()[0]) / s2   # Kdiag = variance
         elbo = elbo + 0.5 * st.terms[1] / (s2 * s2)                     # c = LB^-1 (A err) / s2
         elbo = elbo + 0.5 * p * st.tr
         ctx.kind, ctx.x, ctx.err, ctx.st = kind, x, err, st

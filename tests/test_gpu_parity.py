@@ -507,6 +507,36 @@ def test_vfe_adam_trajectory(device):
     assert abs(m.Z.detach().sum().item() - case["adam_final_Z_sum"]) < 1e-7
 
 
+def test_vfe_row_shards_over_ranks(device):
+    """sparse_gpr.SHARD_GROUP: two processes (sharing cuda:0, gloo) hold half of the rows each and
+    must both report the bound and all gradients of the whole data set (tools/vfe_shard_check.py)."""
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "vfe_shard_check.py")
+    ref = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stderr[-2000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), script],
+                         env=dict(os.environ, GPN_SHARED_GPU="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+
+    def parse(text):
+        rows = []
+        for mm in re.finditer(r"rank \d+: loss=(\S+) grads=(.*?) zsum=(\S+) zabs=(\S+)", text):
+            rows.append(np.array([float(mm.group(1))] + [float(v) for v in mm.group(2).split()] + [float(mm.group(3)), float(mm.group(4))]))
+        return rows
+    r0 = parse(ref.stdout)[0]
+    rows = parse(out.stdout)
+    assert len(rows) == 2
+    for r in rows:
+        assert np.abs(r - r0).max() < 1e-8 * np.abs(r0).max(), (r, r0)
+
+
 # ---- edge cases -------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,dy", [(1, 1, 1), (2, 3, 1), (127, 2, 3), (128, 2, 1), (129, 4, 2), (255, 1, 1),
                                      (256, 3, 4), (257, 2, 1), (383, 5, 1), (640, 2, 130)])
