@@ -385,7 +385,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
   // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
   if (g_gemm_variant == 0 && (M <= 32 || N <= 32)) return launch<32, 32, 16, 16, true, 8>(s, a);
-  if (g_gemm_variant == 0 && tiles(64) <= 64) {
+  if (g_gemm_variant == 0 && (tiles(64) <= 64 || (N <= 128 && tiles(64) <= 128))) {   // (M = 4096, N = 128, K = 128: 8.1 vs 10.9 us)
     // a handful of workgroups: per-CU MFMA rate and DMA latency are the limits -> 4x more,
     // 4x smaller workgroups (32x32 tiles) with 8 K-steps of LDS-DMA in flight
     return launch<32, 32, 16, 16, true, 8>(s, a);
