@@ -91,6 +91,8 @@ class Factor:
         self.winv = torch.empty(max(1, int(lib.gpn_winv_bytes(n)) // 8), dtype=torch.float64, device=device)
         self.info = torch.zeros(1, dtype=torch.int32, device=device)
         self.jitter_rung = -1
+        self.generation = 0          # bumped by every factorisation into this buffer
+        self._winv_full = None       # explicit L^-1 (lower_inverse), valid for one generation
 
     @property
     def device(self):
@@ -124,6 +126,8 @@ class Factor:
         """In-place factorisation; returns the LAPACK-style info (host int; syncs) or,
         with check=False, enqueues only and returns None (read self.info later)."""
         self.info.zero_()
+        self.generation += 1
+        self._winv_full = None
         st = _native.lib().gpn_potrf_lower(_stream(self.device), _ptr(self.A), self.n, self.e, self.ld,
                                            _ptr(self.winv), _ptr(self.info))
         _native.check(st, "gpn_potrf_lower")
@@ -289,7 +293,7 @@ def lower_inverse(f):
     """W = L^-1 (lower, row-major, zero padded [rows, ld]) of a factor, cached on it: with W every
     right-solve X L^T = B is ONE K-clipped contraction X = B W^T instead of a chain of ~2 n/128
     small launches -- worth its n^3/3 flops for a model that serves many predictions."""
-    W = getattr(f, "_winv_full", None)
+    W = f._winv_full
     if W is None:
         from . import _backward
         U = _backward._upper_inverse(f)
@@ -340,14 +344,21 @@ class GPRLogLik(torch.autograd.Function):
         terms = f.lml_terms()
         ctx.kind = kind
         ctx.factor = f
-        ctx.save_for_backward(X, variance, length_scales, noise)
+        ctx.generation = f.generation
+        ctx.save_for_backward(X, R, variance, length_scales, noise)
         return terms[2:3].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         from . import _backward
-        X, variance, length_scales, noise = ctx.saved_tensors
-        g_var, g_ls, g_noise, g_R = _backward.lml_backward(ctx.kind, X, variance, length_scales, noise, ctx.factor)
+        X, R, variance, length_scales, noise = ctx.saved_tensors
+        f = ctx.factor
+        if f.generation != ctx.generation:
+            # the model's reusable buffer was refactorised by a later forward (two losses alive at
+            # once): this node's factor is gone, rebuild it privately rather than differentiate
+            # the wrong one
+            f = kernel_factor(ctx.kind, X, variance, length_scales, noise, R=R)
+        g_var, g_ls, g_noise, g_R = _backward.lml_backward(ctx.kind, X, variance, length_scales, noise, f)
         go = grad_out.reshape(())
         return (None, go * g_R if ctx.needs_input_grad[1] else None, go * g_var, go * g_ls, go * g_noise, None, None)
 

@@ -823,3 +823,28 @@ def test_c4_full_size_factor_properties(device):
             worst_k = max(worst_k, abs(got - want))
     assert worst_k < 1e-11, worst_k       # measured 2e-14..1e-13: backward error of the factorisation
     assert worst_s < 1e-10, worst_s
+
+
+def test_backward_after_a_later_forward_reused_the_buffer(device):
+    """Two losses alive at once: the model's reusable factor buffer is refactorised by the second
+    forward (different hyper-parameters) before the first loss is differentiated.  The first
+    backward must still differentiate ITS factor (it rebuilds it), not the newer one."""
+    x, y = rng.make_regression(700, 4, 2, seed=21)
+    o = orc.GPROracle(x, y, kind="Matern52", variance=1.4, length_scales=1.7, noise=0.03)
+    lo = o.loss()
+    lo.backward()
+    m = GPR(x, y, kernels.Matern52(4, variance=1.4, length_scales=1.7), likelihood=likelihoods.Gaussian(variance=0.03))
+    m.cuda()
+    first = m.loss()
+    with torch.no_grad():
+        saved = m.kernel.length_scales.data.clone()
+        m.kernel.length_scales.data.add_(0.5)
+    second = m.loss()                       # same buffer, new factor
+    with torch.no_grad():
+        m.kernel.length_scales.data.copy_(saved)
+    assert abs(second.item() - first.item()) > 1.0
+    first.backward()
+    assert abs(first.item() - lo.item()) < 1e-8
+    for got, want in [(m.kernel.variance.grad, o.raw_variance.grad), (m.kernel.length_scales.grad, o.raw_length_scales.grad),
+                      (m.likelihood.variance.grad, o.raw_noise.grad)]:
+        assert (got.cpu() - want).abs().max().item() < 1e-8 * max(1.0, want.abs().max().item())
