@@ -30,7 +30,14 @@ mod.cuda()
 loss = mod.loss()
 loss.backward()
 g = [mod.kernel.variance.grad, mod.kernel.length_scales.grad, mod.likelihood.variance.grad, mod.Z.grad]
-print("rank %d: loss=%.10f grads=%s zsum=%.10e zabs=%.10e" % (rank, loss.item(), " ".join("%.10e" % v for t in g[:3] for v in t.flatten().tolist()),
-                                                        g[3].sum().item(), g[3].abs().sum().item()), flush=True)
+line = "rank %d: loss=%.10f grads=%s zsum=%.10e zabs=%.10e" % (
+    rank, loss.item(), " ".join("%.10e" % v for t in g[:3] for v in t.flatten().tolist()), g[3].sum().item(), g[3].abs().sum().item())
+if world > 1:                    # one writer: two ranks printing at once interleave inside a line
+    lines = [None] * world
+    dist.all_gather_object(lines, line)
+    if rank == 0:
+        print("\n".join(lines), flush=True)
+else:
+    print(line, flush=True)
 if world > 1:
     dist.destroy_process_group()
