@@ -56,22 +56,21 @@ def _check_dim(d):
 
 
 def lml_backward(kind, X, variance, length_scales, noise, f):
-    """-> (dLML/dvariance [1], dLML/dlength_scales [nls], dLML/dnoise [1], dLML/dR [n, dy])."""
+    """-> (dLML/dvariance [1], dLML/dlength_scales [nls], dLML/dnoise [1], dLML/dR [n, dy]):
+    ONE library call (gpn_lml_backward: U = L^-T, Kyy^-1 = U U^T, a = U alpha, gradient sweep)."""
     _req(X, variance, length_scales)
     n, dy = f.n, f.e
     nls = length_scales.numel()
     lib = _native.lib()
-    U = _upper_inverse(f)
-    Kinv = _kinv_lower(f, U)
-    a_t = _ops.gemm_nt(f.A[n:], U, dy, n, round_up(n, 16), tri=_ops.TRI_B_UPPER)       # a^T = alpha^T U^T
-    work = torch.empty(max(1, int(lib.gpn_grad_work_bytes(n, n, nls, 1)) // 8), dtype=torch.float64, device=f.device)
+    work = torch.empty(max(1, int(lib.gpn_lml_backward_work_bytes(n, dy, nls)) // 8), dtype=torch.float64, device=f.device)
     out = torch.empty(2 + nls, dtype=torch.float64, device=f.device)
+    g_R = torch.empty(n, dy, dtype=torch.float64, device=f.device)
     Xc = _c(X.detach())
-    st = lib.gpn_lml_grad(_stream(f.device), _ops.KINDS[kind], _ptr(Xc), n, Xc.shape[1],
-                          _ptr(_c(variance.detach())), _ptr(_c(length_scales.detach())), nls,
-                          _ptr(Kinv), Kinv.stride(0), _ptr(a_t), a_t.stride(0), dy, _ptr(work), _ptr(out))
-    _native.check(st, "gpn_lml_grad")
-    return out[0:1], out[1:1 + nls], out[1 + nls:2 + nls], -a_t.t().contiguous()
+    st = lib.gpn_lml_backward(_stream(f.device), _ops.KINDS[kind], _ptr(Xc), n, Xc.shape[1],
+                              _ptr(_c(variance.detach())), _ptr(_c(length_scales.detach())), nls,
+                              _ptr(f.A), f.ld, _ptr(f.winv), dy, _ptr(work), _ptr(out), _ptr(g_R))
+    _native.check(st, "gpn_lml_backward")
+    return out[0:1], out[1:1 + nls], out[1 + nls:2 + nls], g_R
 
 
 def _rowmajor(t):

@@ -40,6 +40,14 @@ SIGNATURES = {
     "gpn_grad_x2_work_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "gpn_kernel_grad_x2": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                    c_int, c_void_p, c_int64, c_double, c_int, c_void_p, c_void_p]),
+    "gpn_lml_forward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "gpn_lml_backward_work_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "gpn_lml_backward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gpn_predict_work_bytes": (c_int64, [c_int64, c_int64, c_int]),
+    "gpn_predict": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                            c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gpn_transpose": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64]),
     "gpn_copy_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "gpn_row_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),

@@ -231,6 +231,35 @@ def kernel_factor(kind, X, variance, length_scales, noise, R=None, factor=None):
     return f
 
 
+def lml_forward(kind, X, R, variance, length_scales, noise, factor=None):
+    """GPR.log_likelihood (gpr.py:47-67) as ONE library call (gpn_lml_forward: assembly ->
+    factorisation with the residual riding along -> reductions) plus the jitter ladder of
+    functions.py:20-43 on its info word.  -> (Factor, terms [3]: sum log L_ii, |alpha|^2, LML)."""
+    _req(X, R, variance, length_scales, noise)
+    n, e = R.shape
+    if X.shape[0] != n:
+        raise ValueError("X and Y must have same # data.")
+    f = factor if (factor is not None and factor.n == n and factor.e == e and factor.device == X.device) \
+        else Factor(n, e, X.device)
+    Xc, Rc = _c(X.detach()), _c(R.detach())
+    var, ls, nz0 = _c(variance.detach()), _c(length_scales.detach()), _c(noise.detach())
+    out = torch.empty(3, dtype=torch.float64, device=X.device)
+    lib = _native.lib()
+
+    def attempt(jitter):
+        nz = nz0 if jitter is None else nz0 + jitter
+        f.generation += 1
+        f._winv_full = None
+        st = lib.gpn_lml_forward(_stream(X.device), KINDS[kind], _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e,
+                                 _ptr(var), _ptr(ls), ls.numel(), _ptr(nz), _ptr(f.A), f.ld, _ptr(f.winv),
+                                 _ptr(f.info), _ptr(out))
+        _native.check(st, "gpn_lml_forward")
+        return int(f.info.item())
+
+    f.jitter_rung = _ladder(attempt)
+    return f, out
+
+
 TRI_A_UPPER, TRI_A_LOWER, TRI_B_UPPER, TRI_B_LOWER = 1, 2, 4, 8
 
 
@@ -310,6 +339,19 @@ def gpr_predict(kind, X, x_new, variance, length_scales, f, diag=True, use_inver
     in f.extra(); var = rowsumsq-reduced diag [n*] or full K(x*) - A^T A [n*, n*]."""
     ns = x_new.shape[0]
     n, dy = f.n, f.e
+    if not use_inverse and dy > 0:
+        # one library call: K(x*, X) -> right-solve chain -> mean / variance (gpn_predict)
+        _req(X, x_new, variance, length_scales)
+        lib = _native.lib()
+        Xc, Xs = _c(X.detach()), _c(x_new.detach())
+        var, ls = _c(variance.detach()), _c(length_scales.detach())
+        work = torch.empty(max(1, int(lib.gpn_predict_work_bytes(n, ns, dy)) // 8), dtype=torch.float64, device=f.device)
+        mean = torch.empty(ns, dy, dtype=torch.float64, device=f.device)
+        out = torch.empty((ns,) if diag else (ns, ns), dtype=torch.float64, device=f.device)
+        st = lib.gpn_predict(_stream(f.device), KINDS[kind], _ptr(Xc), n, Xc.shape[1], _ptr(Xs), ns, _ptr(var), _ptr(ls),
+                             ls.numel(), _ptr(f.A), f.ld, _ptr(f.winv), dy, 0 if diag else 1, _ptr(work), _ptr(mean), _ptr(out))
+        _native.check(st, "gpn_predict")
+        return mean, out
     Bt = padded_like_factor(f, ns)
     if use_inverse:
         Ks = padded_like_factor(f, ns)
@@ -339,9 +381,8 @@ class GPRLogLik(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, R, variance, length_scales, noise, kind, holder):
-        f = kernel_factor(kind, X, variance, length_scales, noise, R=R, factor=holder.get("factor"))
+        f, terms = lml_forward(kind, X, R, variance, length_scales, noise, factor=holder.get("factor"))
         holder["factor"] = f
-        terms = f.lml_terms()
         ctx.kind = kind
         ctx.factor = f
         ctx.generation = f.generation

@@ -171,6 +171,47 @@ int gpn_kernel_grad_x2(void* stream, int kind, const double* X, int64_t n, const
                        const double* G, int64_t ldg, double scale, int accumulate,
                        double* work, double* out);
 
+/* ---- whole-path entry points: one call per reference method -------------------
+ * Fixed sequences of the entry points above on ONE stream (no host synchronisation, no
+ * allocation) for callers that do not want to issue them one by one.
+ *
+ * gpn_lml_forward = GPR.log_likelihood (gpr.py:47-67): K(X)+noise*I assembled into the lower
+ * triangle of the factor buffer A (gpn_factor_rows(n,dy) x lda, lda = gpn_factor_ld(n,dy),
+ * zero-initialised ONCE by the caller; reusable across calls), (Y - M)^T packed into the extra
+ * rows, factorisation with fused forward substitution, reductions.  out3 as gpn_lml_reduce
+ * (out3[2] = LML).  *info is cleared and set here: info > 0 => replay with noise + 10^(-10+i)
+ * (functions.py:20-43).  A/winv afterwards hold L, alpha^T and the leaf inverses for the two
+ * calls below. */
+int gpn_lml_forward(void* stream, int kind, const double* X, int64_t n, int d,
+                    const double* Y, const double* M, int dy,
+                    const double* variance, const double* length_scales, int nls,
+                    const double* noise, double* A, int64_t lda, double* winv,
+                    int32_t* info, double* out3);
+
+/* gpn_lml_backward = the autograd backward of gpr.py:47-67 in closed form (what PyTorch's
+ * CholeskyBackward0 + TriangularSolveBackward0 + elementwise chain compute for the reference):
+ * U = L^-T, Kyy^-1 = U U^T, a = U alpha, one sweep.  grads[0] = dLML/d variance,
+ * grads[1..nls] = dLML/d length_scales, grads[1+nls] = dLML/d noise (CONSTRAINED values);
+ * grad_resid (may be NULL) [n, dy] = dLML/d(y - m) = -a.  A/winv from gpn_lml_forward with
+ * info == 0; work: gpn_lml_backward_work_bytes(n, dy, nls) bytes (two factor-sized matrices). */
+int64_t gpn_lml_backward_work_bytes(int64_t n, int dy, int nls);
+int gpn_lml_backward(void* stream, int kind, const double* X, int64_t n, int d,
+                     const double* variance, const double* length_scales, int nls,
+                     const double* A, int64_t lda, const double* winv, int dy,
+                     double* work, double* grads, double* grad_resid);
+
+/* gpn_predict = GPR._predict (gpr.py:88-117) for a zero mean function, given the factor of
+ * gpn_lml_forward: mean [ns, dy] = A^T V with A = L^-1 K(X, x*), V = alpha;
+ * var = [ns] K_diag - colsumsq(A) (full_cov == 0; the reference expands it to [ns, dy])
+ * or [ns, ns] K(x*) - A^T A.  A non-zero mean function is added to `mean` by the caller
+ * (gpr.py:108).  work: gpn_predict_work_bytes(n, ns, dy) bytes. */
+int64_t gpn_predict_work_bytes(int64_t n, int64_t ns, int dy);
+int gpn_predict(void* stream, int kind, const double* X, int64_t n, int d,
+                const double* Xs, int64_t ns,
+                const double* variance, const double* length_scales, int nls,
+                const double* A, int64_t lda, const double* winv, int dy, int full_cov,
+                double* work, double* mean, double* var);
+
 /* ---- small utilities -------------------------------------------------------- */
 /* dst[r, c] = src[c, r] for src[rows, cols] */
 int gpn_transpose(void* stream, const double* src, int64_t rows, int64_t cols, int64_t lds,

@@ -848,3 +848,64 @@ def test_backward_after_a_later_forward_reused_the_buffer(device):
     for got, want in [(m.kernel.variance.grad, o.raw_variance.grad), (m.kernel.length_scales.grad, o.raw_length_scales.grad),
                       (m.likelihood.variance.grad, o.raw_noise.grad)]:
         assert (got.cpu() - want).abs().max().item() < 1e-8 * max(1.0, want.abs().max().item())
+
+
+def test_whole_path_entry_points_called_directly(device):
+    """gpn_lml_forward / gpn_lml_backward / gpn_predict through ctypes exactly as a non-Python
+    consumer of include/gpnative.h would call them (caller-owned buffers, one call per reference
+    method), against the oracle: gpr.py:47-67, its autograd backward, gpr.py:88-117."""
+    import ctypes
+    from gptorch_amd import _native
+    lib = _native.lib()
+    n, d, dy, ns = 777, 5, 2, 19
+    x, y = rng.make_regression(n, d, dy, seed=31)
+    ell = np.linspace(1.2, 2.4, d)
+    o = orc.GPROracle(x, y, kind="Matern52", variance=1.3, length_scales=ell, noise=0.04, ARD=True)
+    lo = o.log_likelihood()
+    lo.backward()
+    xs = rng.normal(32, (ns, d))
+    with torch.no_grad():
+        omu, ovar = o.predict_f(xs)
+        _, ocov = o.predict_f(xs, diag=False)
+        a = np.linalg.solve(o.compute_kyy().numpy(), y)
+
+    dev = device
+    T = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    X, Y, Xs = T(x), T(y), T(xs)
+    var, ls, noise = T([1.3]), T(ell), T([0.04])
+    ld, rows = lib.gpn_factor_ld(n, dy), lib.gpn_factor_rows(n, dy)
+    A = torch.zeros(rows, ld, dtype=torch.float64, device=dev)
+    winv = torch.empty(lib.gpn_winv_bytes(n) // 8, dtype=torch.float64, device=dev)
+    info = torch.ones(1, dtype=torch.int32, device=dev)        # cleared by the call
+    out3 = torch.empty(3, dtype=torch.float64, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(2):                                          # the factor buffer is reusable as is
+        assert lib.gpn_lml_forward(stream, 1, P(X), n, d, P(Y), None, dy, P(var), P(ls), d, P(noise),
+                                   P(A), ld, P(winv), P(info), P(out3)) == 0
+    assert int(info.item()) == 0
+    assert abs(out3[2].item() - lo.item()) < 1e-8
+
+    work = torch.empty(lib.gpn_lml_backward_work_bytes(n, dy, d) // 8, dtype=torch.float64, device=dev)
+    grads = torch.empty(2 + d, dtype=torch.float64, device=dev)
+    g_res = torch.empty(n, dy, dtype=torch.float64, device=dev)
+    assert lib.gpn_lml_backward(stream, 1, P(X), n, d, P(var), P(ls), d, P(A), ld, P(winv), dy,
+                                P(work), P(grads), P(g_res)) == 0
+    g = grads.cpu().numpy()
+    # the oracle differentiates w.r.t. the raw (log) parameters: d/d log(theta) = theta * d/d theta
+    want = np.concatenate([o.raw_variance.grad.numpy() / 1.3, o.raw_length_scales.grad.numpy() / ell,
+                           o.raw_noise.grad.numpy() / 0.04])
+    assert np.abs(g - want).max() < 1e-8 * max(1.0, np.abs(want).max()), (g, want)
+    assert np.abs(g_res.cpu().numpy() + a).max() < 1e-8
+
+    pw = torch.empty(lib.gpn_predict_work_bytes(n, ns, dy) // 8, dtype=torch.float64, device=dev)
+    mean = torch.empty(ns, dy, dtype=torch.float64, device=dev)
+    v = torch.empty(ns, dtype=torch.float64, device=dev)
+    assert lib.gpn_predict(stream, 1, P(X), n, d, P(Xs), ns, P(var), P(ls), d, P(A), ld, P(winv), dy, 0,
+                           P(pw), P(mean), P(v)) == 0
+    assert np.abs(mean.cpu().numpy() - omu.numpy()).max() < 1e-8
+    assert np.abs(v.cpu().numpy() - ovar.numpy()[:, 0]).max() < 1e-8
+    cov = torch.empty(ns, ns, dtype=torch.float64, device=dev)
+    assert lib.gpn_predict(stream, 1, P(X), n, d, P(Xs), ns, P(var), P(ls), d, P(A), ld, P(winv), dy, 1,
+                           P(pw), P(mean), P(cov)) == 0
+    assert np.abs(cov.cpu().numpy() - ocov.numpy()).max() < 1e-8
