@@ -79,3 +79,20 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_native.NativeError, match="no CPU fallback"):
         _native.lib()
+
+
+def _build_c_consumer(out_path):
+    import subprocess
+    lib_dir = os.path.dirname(_native.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", os.path.join(ROOT, "examples", "lml_consumer.c"), "-I" + os.path.join(ROOT, "include"),
+           "-I/opt/rocm/include", "-L" + lib_dir, "-lgpnative", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", str(out_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return str(out_path)
+
+
+def test_header_is_plain_c_and_a_c_consumer_links(tmp_path):
+    """include/gpnative.h compiles as C99 and examples/lml_consumer.c (gcc, no hipcc, no Python)
+    links against libgpnative.so: the boundary really is a C ABI.  (It is RUN in the gpu suite.)"""
+    _build_c_consumer(tmp_path / "lml_consumer")

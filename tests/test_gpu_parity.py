@@ -909,3 +909,29 @@ def test_whole_path_entry_points_called_directly(device):
     assert lib.gpn_predict(stream, 1, P(X), n, d, P(Xs), ns, P(var), P(ls), d, P(A), ld, P(winv), dy, 1,
                            P(pw), P(mean), P(cov)) == 0
     assert np.abs(cov.cpu().numpy() - ocov.numpy()).max() < 1e-8
+
+
+def test_c_consumer_matches_the_shell(device, tmp_path):
+    """examples/lml_consumer.c -- plain C99 over the three whole-path entry points, built with gcc --
+    prints the same LML, gradients and prediction as the Python shell on the same generated inputs
+    (its libm-based Box-Muller may differ from numpy's in the last bit of an input, hence 1e-9)."""
+    import re
+    import subprocess
+    from tests.test_abi import _build_c_consumer
+    exe = _build_c_consumer(tmp_path / "lml_consumer")
+    n, d = 1500, 4
+    r = subprocess.run([exe, str(n), str(d)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mm = re.search(r"lml=(\S+) grads=(\S+) (\S+) (\S+) mean0=(\S+) var0=(\S+)", r.stdout)
+    got = np.array([float(v) for v in mm.groups()])
+    x, y = rng.make_regression(n, d, 1, seed=0)
+    ls = float(np.sqrt(d))
+    m = GPR(x, y, kernels.Rbf(d, variance=1.0, length_scales=ls), likelihood=likelihoods.Gaussian(variance=1e-2))
+    m.cuda()
+    loss = m.loss()
+    loss.backward()
+    # the C call returns gradients w.r.t. the constrained values; the shell's are w.r.t. log(value)
+    want_g = [-m.kernel.variance.grad.item() / 1.0, -m.kernel.length_scales.grad.item() / ls, -m.likelihood.variance.grad.item() / 1e-2]
+    mu, var = m.predict_f(rng.normal(2, (4, d)))
+    want = np.array([-loss.item()] + want_g + [mu[0, 0], var[0, 0]])
+    assert np.abs(got - want).max() < 1e-9 * np.abs(want).max(), (got, want)
