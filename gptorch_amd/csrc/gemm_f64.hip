@@ -301,19 +301,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
+static int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
+
 template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
 static int launch(hipStream_t s, const GemmArgs& a0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
   const int grid = (a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
-  constexpr int smem = ((BM + BN) / 16) * 2 * 1024 * NS;
+  const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int attr_set = -1;
+  if (attr_set != smem) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
+    attr_set = smem;
   }
   const bool prof = profile_on();
   if (prof) {
@@ -399,7 +401,8 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
 }  // namespace gpn
 
 extern "C" int gpn_debug_set_gemm_variant(int v) {
-  gpn::g_gemm_variant = v;
+  gpn::g_gemm_variant = v & 0xff;
+  gpn::g_smem_pad = v >> 8;           // bits 8..: KiB of LDS padding per workgroup
   return GPN_OK;
 }
 
