@@ -695,21 +695,42 @@ static void trtri_rec(Ctx& c, const double* L, int64_t ldl, double* U, int64_t l
 }
 
 // ---- reductions / utilities -------------------------------------------------
-__global__ __launch_bounds__(256) void lml_reduce_kernel(const double* A, int64_t n, int64_t e, int64_t lda,
-                                                         double* out3) {
-  // single workgroup: sums are O(N) work
-  __shared__ double red[2][256];
+__global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* A, int64_t n, int64_t e, int64_t lda,
+                                                          double* out3) {
+  // single workgroup: sums are O(N) work.  The diagonal is one cache line per element, so the
+  // loads go out in batches of 8 per thread before the first log() needs one (issued one by
+  // one behind a log() each they cost a full memory round trip per element: 30 us at N = 8192)
+  constexpr int NT = 1024;
+  __shared__ double red[2][NT];
   const int tid = threadIdx.x;
   double ld = 0.0, sq = 0.0;
-  for (int64_t i = tid; i < n; i += 256) ld += log(A[i * lda + i]);
+  for (int64_t base = tid; base < n; base += (int64_t)NT * 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t i = base + (int64_t)k * NT;
+      v[k] = i < n ? A[i * lda + i] : 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ld += log(v[k]);
+  }
   for (int64_t c = 0; c < e; ++c) {
     const double* row = A + (n + c) * lda;
-    for (int64_t i = tid; i < n; i += 256) sq = fma(row[i], row[i], sq);
+    for (int64_t base = tid; base < n; base += (int64_t)NT * 8) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t i = base + (int64_t)k * NT;
+        v[k] = i < n ? row[i] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sq = fma(v[k], v[k], sq);
+    }
   }
   red[0][tid] = ld;
   red[1][tid] = sq;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = NT / 2; s > 0; s >>= 1) {
     if (tid < s) {
       red[0][tid] += red[0][tid + s];
       red[1][tid] += red[1][tid + s];
@@ -983,7 +1004,7 @@ extern "C" int gpn_lml_reduce(void* stream, const double* A, int64_t n, int64_t 
   if (e < 0) return -4;
   if (lda < n) return -5;
   if (!out3) return -6;
-  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), A, n, e, lda, out3);
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), A, n, e, lda, out3);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
