@@ -5,7 +5,7 @@ noise.  Prints the worst relative errors; exits 1 on a violation."""
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 from gptorch_amd import kernels, likelihoods, rng  # noqa: E402
 from gptorch_amd.models import GPR  # noqa: E402

@@ -4,7 +4,7 @@ against the CPU oracle's autograd, with random chunk sizes for the streamed eval
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 from gptorch_amd import kernels, likelihoods, mean_functions, rng  # noqa: E402
 from gptorch_amd.models import VFE, sparse_gpr  # noqa: E402

@@ -4,7 +4,7 @@ ops (torch.mm / exp / linalg.cholesky / solve_triangular = rocBLAS + rocSOLVER +
 kernels) -- i.e. gptorch after model.cuda() -- next to the native path.  Context only."""
 import os, sys, time, math
 import torch
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from oracle import gp_oracle as orc  # noqa: E402  (checker/tool use only)
