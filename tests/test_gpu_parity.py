@@ -935,3 +935,29 @@ def test_c_consumer_matches_the_shell(device, tmp_path):
     mu, var = m.predict_f(rng.normal(2, (4, d)))
     want = np.array([-loss.item()] + want_g + [mu[0, 0], var[0, 0]])
     assert np.abs(got - want).max() < 1e-9 * np.abs(want).max(), (got, want)
+
+
+def test_repeated_evaluations_are_bitwise_identical(device):
+    """Idempotence / race check: the leaf kernel hands blocks between its pivot wave and its tile
+    waves through LDS (one hardware + one software barrier per panel) and the factorisation forks
+    onto a second stream -- a lost ordering would flip a last bit sooner or later.  The same
+    evaluation (and every 5th time its backward) must reproduce the first result exactly
+    (tools/soak.py is the long version: 1500 + 4000 evaluations, 0 differences)."""
+    for n, d, dy, kind, reps in [(2500, 6, 1, "Rbf", 120), (700, 3, 2, "Matern52", 400)]:
+        x, y = rng.make_regression(n, d, dy, seed=77)
+        m = GPR(x, y, KERN[kind](d, variance=1.1, length_scales=1.6), likelihood=likelihoods.Gaussian(variance=0.02))
+        m.cuda()
+        ref = {}
+        for i in range(reps):
+            if i % 5 == 0:
+                m.zero_grad()
+                loss = m.loss()
+                loss.backward()
+                cur = torch.cat([loss.detach().reshape(1)] + [p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+                key = "grad"
+            else:
+                with torch.no_grad():
+                    cur = m.log_likelihood().reshape(1)
+                key = "fwd"
+            cur = cur.cpu().numpy().tobytes()
+            assert ref.setdefault(key, cur) == cur, (n, i, key)

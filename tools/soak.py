@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""GPU-box tool: determinism / race soak.  The same evaluation repeated many times must give the
+bitwise-identical LML and gradients every time (the leaf kernel hands blocks between its pivot
+wave and its tile waves through LDS with one hardware and one software barrier per panel, and
+the factorisation forks onto a second stream: a race would show up as a flipped last bit).
+usage: soak.py [evaluations at N=8192 = 1500] [evaluations at N=1000 = 4000]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from gptorch_amd import kernels, likelihoods, rng  # noqa: E402
+from gptorch_amd.models import GPR, batched_log_likelihood  # noqa: E402
+
+dev = torch.device("cuda:0")
+n_big = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+n_small = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+
+
+def soak(model, reps, label, grads_every=0):
+    ref = None
+    t0 = time.perf_counter()
+    bad = 0
+    for i in range(reps):
+        if grads_every and i % grads_every == 0:
+            model.zero_grad()
+            loss = model.loss()
+            loss.backward()
+            cur = torch.cat([-loss.detach().reshape(1)] + [p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+            key = "g"
+        else:
+            with torch.no_grad():
+                cur = model.log_likelihood().reshape(1)
+            key = "f"
+        cur = cur.cpu().numpy().tobytes()
+        if ref is None:
+            ref = {}
+        if key not in ref:
+            ref[key] = cur
+        elif ref[key] != cur:
+            bad += 1
+    print("%s: %d evaluations, %d differ from the first, %.1f s" % (label, reps, bad, time.perf_counter() - t0), flush=True)
+    return bad
+
+
+bad = 0
+m2, _, _ = bench.build_model(bench.WORKLOADS["c2"], 0, dev)
+bad += soak(m2, n_big, "N=8192 D=8 Rbf", grads_every=10)
+x, y = rng.make_regression(1000, 5, 2, seed=4)
+m1 = GPR(x, y, kernels.Matern52(5, variance=1.1, length_scales=1.5), likelihood=likelihoods.Gaussian(variance=0.02))
+m1.cuda()
+bad += soak(m1, n_small, "N=1000 D=5 dy=2 Matern52 (ragged)", grads_every=7)
+# two evaluations in flight on two streams
+models = [bench.build_model(bench.WORKLOADS["c2"], 50 + r, dev)[0] for r in range(4)]
+ref = None
+t0 = time.perf_counter()
+nb = 0
+for i in range(max(1, n_big // 8)):
+    out = torch.cat(batched_log_likelihood(models)).cpu().numpy().tobytes()
+    if ref is None:
+        ref = out
+    elif out != ref:
+        nb += 1
+print("4 restarts on two lanes: %d rounds, %d differ, %.1f s" % (max(1, n_big // 8), nb, time.perf_counter() - t0), flush=True)
+bad += nb
+print("SOAK", "OK" if bad == 0 else "MISMATCHES %d" % bad)
+sys.exit(0 if bad == 0 else 1)
