@@ -34,6 +34,10 @@ int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha
                     const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
                     double beta, double* C, int64_t ldc, int64_t sC, int tri, int batch);
 
+// extra rows <- (Y - M)^T, corner right of them <- 0, *info <- 0 (kmat.hip; used by gpn_lml_forward)
+int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
+                  int32_t* info);
+
 bool profile_on();
 void profile_begin(hipStream_t s, double flops);
 void profile_end(hipStream_t s);

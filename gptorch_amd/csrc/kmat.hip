@@ -154,14 +154,30 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   }
 }
 
-__global__ void pack_rhs_kernel(const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde) {
+// corner != 0: also clear columns n..lde-1 of the extra rows (the corner of the factor buffer that
+// accumulates -alpha alpha^T during the factorisation) and the info word -- one launch instead of
+// this one plus two fills in gpn_lml_forward
+__global__ void pack_rhs_kernel(const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
+                                int corner, int32_t* info) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (corner) {
+    if (i == 0 && info) *info = 0;
+    if (i >= n && i < lde)
+      for (int c = 0; c < dy; ++c) E[(int64_t)c * lde + i] = 0.0;
+  }
   if (i >= n) return;
   for (int c = 0; c < dy; ++c) {
     double v = Y[i * dy + c];
     if (M) v -= M[i * dy + c];
     E[(int64_t)c * lde + i] = v;
   }
+}
+
+int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
+                  int32_t* info) {
+  hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((lde + 255) / 256)), dim3(256), 0, s, Y, M, n, dy, E, lde, 1, info);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
 }
 
 }  // namespace gpn
@@ -216,7 +232,7 @@ extern "C" int gpn_pack_rhs(void* stream, const double* Y, const double* M, int6
   if (lde < n) return -7;
   if (n == 0) return GPN_OK;
   hipLaunchKernelGGL(gpn::pack_rhs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), Y, M, n, dy, E, lde);
+                     static_cast<hipStream_t>(stream), Y, M, n, dy, E, lde, 0, (int32_t*)nullptr);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

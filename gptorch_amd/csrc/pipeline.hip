@@ -58,13 +58,14 @@ extern "C" int gpn_lml_forward(void* stream, int kind, const double* X, int64_t 
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = gpn_kernel_matrix(stream, kind, X, n, nullptr, n, d, variance, length_scales, nls, noise, GPN_LOWER, A, lda);
   if (rc != GPN_OK) return rc;
+  // (Y - M)^T into the extra rows; the corner right of them (it accumulates -alpha alpha^T during
+  // the factorisation) and the info word are cleared by the same launch
   if (n > 0) {
-    // the corner right of the extra rows accumulates -alpha alpha^T during the factorisation
-    if (lda > n) GPN_HIP_CHECK(hipMemset2DAsync(A + n * lda + n, lda * sizeof(double), 0, (lda - n) * sizeof(double), dy, s));
-    rc = gpn_pack_rhs(stream, Y, M, n, dy, A + n * lda, lda);
+    rc = pack_rhs_full(s, Y, M, n, dy, A + n * lda, lda, info);
     if (rc != GPN_OK) return rc;
+  } else {
+    GPN_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t), s));
   }
-  GPN_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t), s));
   rc = gpn_potrf_lower(stream, A, n, dy, lda, winv, info);
   if (rc != GPN_OK) return rc;
   return gpn_lml_reduce(stream, A, n, dy, lda, out3);
