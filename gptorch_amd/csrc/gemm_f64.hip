@@ -9,9 +9,10 @@
 //  * v_mfma_f64_16x16x4_f64: lane l supplies A[row l&15][k l>>4] and
 //    B[k l>>4][col l&15]; result reg r of lane l is C[(l>>4)+4r][l&15].
 //  * operand tiles are staged global->LDS by LDS-DMA (global_load_lds_dwordx4):
-//    one wave-instruction fills one 1 KiB "fragment block" = 16 rows x 8 k's in
-//    exactly the order the wave later reads it back with ONE ds_read_b128 per
-//    lane (lane-linear => bank-conflict free).  A lane's 16 bytes are the pair
+//    one wave-instruction fills one 1 KiB "fragment block" = 16 rows x 8 k's; the
+//    wave later reads it back with ONE ds_read_b128 per lane (a swizzled slot per
+//    lane, bank-conflict free; the DMA side has a lane quad fetch 64 contiguous
+//    bytes of one row).  A lane's 16 bytes are the pair
 //    (k=2g, k=2g+1) of its row, g = l>>4, so one b128 read feeds two MFMAs
 //    (first MFMA sums k = {0,2,4,6}, second k = {1,3,5,7}: the k order inside a
 //    K-step is a permutation shared by A and B, so the product is unchanged).
@@ -42,8 +43,6 @@ struct GemmArgs {
   int batch;
   int64_t sA, sB, sC;
 };
-
-constexpr int BK = 16;
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   // bijective XCD remap: consecutive logical ids land on the same XCD (blocks b, b+8 share one)
@@ -98,11 +97,14 @@ __device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bo
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
+// KG = 8-column k groups per K-step (K-step = 8 KG columns): 2 everywhere except the A/B variant
+// with half-sized stages and a deeper ring at the same LDS footprint
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, int KG = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
-  constexpr int A_BLOCKS = (BM / 16) * 2, B_BLOCKS = (BN / 16) * 2;
+  constexpr int BK = 8 * KG;
+  constexpr int A_BLOCKS = (BM / 16) * KG, B_BLOCKS = (BN / 16) * KG;
   constexpr int NBLK = A_BLOCKS + B_BLOCKS;      // 1 KiB fragment blocks per K-step
   constexpr int PER_WAVE = (NBLK + 3) / 4;
   constexpr int STAGE = NBLK * 1024;             // bytes
@@ -128,8 +130,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int mlim = (p.M + 15) & ~15, nlim = (p.N + 15) & ~15;
 
   // per-lane source offsets inside a fragment block
-  const int frow = lane & 15;
-  const int fk = 2 * (lane >> 4);
+  // quad layout: lanes 4r..4r+3 fetch the four 16-byte segments of row r -- one 64-byte piece per
+  // lane quad instead of four different rows (cache lines) per quad, which is what the address
+  // path of the LDS-DMA coalesces on (r1x: +5 % on the K = 1024 SYRKs, C3 211 -> 203 ms).  The
+  // segment order inside a quad is XOR-swizzled with r>>2 so that the operand read (row l&15,
+  // segment l>>4) still touches 16 distinct bank groups per 16 lanes.
+  const int frow = lane >> 2;
+  const int fk = 2 * ((lane & 3) ^ ((lane >> 4) & 3));
+  const int rslot = 4 * (lane & 15) + ((lane >> 4) ^ ((lane >> 2) & 3));   // LDS slot holding (row l&15, segment l>>4)
 
   d4 acc[TM][TN];
 #pragma unroll
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     const int idx = wave + 4 * i;
     const bool isA = idx < A_BLOCKS;
     const int b = isA ? idx : idx - A_BLOCKS;
-    const int rg = b >> 1, kg8 = b & 1;
+    const int rg = b / KG, kg8 = b % KG;
     const int row = (isA ? m0 : n0) + rg * 16;
     src_ok[i] = (idx < NBLK) && row < (isA ? mlim : nlim);
     // row groups past the operand's end re-read its first row group instead (always
@@ -190,16 +198,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   // BLOW: B is lower-triangular (panel solve against an inverted leaf block, B[j][k] = 0 for
   // k > j): a 16-column tile needs no K beyond its last column -- skipped per (tile, 8-k group)
   auto compute = [&](int s, int k0) {
-    const char* base = smem + s * STAGE + lane * 16;
+    const char* base = smem + s * STAGE + rslot * 16;
 #pragma unroll
-    for (int kg8 = 0; kg8 < 2; ++kg8) {
+    for (int kg8 = 0; kg8 < KG; ++kg8) {
       d2 a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const d2*>(base + (((wave_m * TM + i) * 2 + kg8) * 1024));
+        a[i] = *reinterpret_cast<const d2*>(base + (((wave_m * TM + i) * KG + kg8) * 1024));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const d2*>(base + ((A_BLOCKS + (wave_n * TN + j) * 2 + kg8) * 1024));
+        b[j] = *reinterpret_cast<const d2*>(base + ((A_BLOCKS + (wave_n * TN + j) * KG + kg8) * 1024));
       if constexpr (BLOW) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -303,14 +311,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
 static int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, int KG = 2>
 static int launch(hipStream_t s, const GemmArgs& a0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
   const int grid = (a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
-  const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
+  const int smem = ((BM + BN) / 16) * KG * 1024 * NS + g_smem_pad * 1024;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW, KG>;
   static int attr_set = -1;
   if (attr_set != smem) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -384,6 +392,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   if (g_gemm_variant == 4) return launch<64, 64, 32, 32, true>(s, a);
   if (g_gemm_variant == 5) return launch<64, 64, 32, 32, true, 8>(s, a);
   if (g_gemm_variant == 6) return launch<32, 32, 16, 16, true, 8>(s, a);
+  if (g_gemm_variant == 7) return launch<64, 64, 32, 32, true, 4, false, 1>(s, a);   // half stages, 4-deep ring, same LDS
   // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
   // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
   if (g_gemm_variant == 0 && (M <= 32 || N <= 32)) return launch<32, 32, 16, 16, true, 8>(s, a);
