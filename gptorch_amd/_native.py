@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpnative.so")
+LIB_PATH = os.environ.get("GPN_LIB", os.path.join(_HERE, "lib", "libgpnative.so"))   # GPN_LIB: A/B builds (tools/)
 
 c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 

@@ -9,13 +9,13 @@
 //  * v_mfma_f64_16x16x4_f64: lane l supplies A[row l&15][k l>>4] and
 //    B[k l>>4][col l&15]; result reg r of lane l is C[(l>>4)+4r][l&15].
 //  * operand tiles are staged global->LDS by LDS-DMA (global_load_lds_dwordx4):
-//    one wave-instruction fills one 1 KiB "fragment block" = 16 rows x 8 k's; the
-//    wave later reads it back with ONE ds_read_b128 per lane (a swizzled slot per
-//    lane, bank-conflict free; the DMA side has a lane quad fetch 64 contiguous
-//    bytes of one row).  A lane's 16 bytes are the pair
-//    (k=2g, k=2g+1) of its row, g = l>>4, so one b128 read feeds two MFMAs
-//    (first MFMA sums k = {0,2,4,6}, second k = {1,3,5,7}: the k order inside a
-//    K-step is a permutation shared by A and B, so the product is unchanged).
+//    one wave-instruction fills one 1 KiB "fragment block" = 8 rows x 16 k's, eight
+//    adjacent lanes per 128-byte line; the wave later reads a 16-row operand tile
+//    back with ONE ds_read_b128 per lane and 8-k group (XOR-swizzled slots, bank-
+//    conflict free).  A lane's 16 bytes are the pair (k=2g, k=2g+1) of its row,
+//    g = l>>4, so one b128 read feeds two MFMAs (first MFMA sums k = {0,2,4,6},
+//    second k = {1,3,5,7}: the k order inside a K-step is a permutation shared by
+//    A and B, so the product is unchanged).
 //  * 128x128 block tile, 4 waves each 64x64 (16 accumulator tiles = 128 VGPRs),
 //    BK = 16, two LDS stages (64 KB) => 2 workgroups per CU, one barrier / K-step.
 //  * blockIdx -> tile: bijective XCD remap (blocks b, b+8 share an XCD/L2) then
@@ -97,15 +97,12 @@ __device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bo
   }
 }
 
-// KG = 8-column k groups per K-step (K-step = 8 KG columns): 2 everywhere except the A/B variant
-// with half-sized stages and a deeper ring at the same LDS footprint
-// LINE: full-line staging layout (below); measured better for the 128x128 tile only
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, int KG = 2, bool LINE = false>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
-  constexpr int BK = 8 * KG;
-  constexpr int A_BLOCKS = (BM / 16) * KG, B_BLOCKS = (BN / 16) * KG;
+  constexpr int BK = 16;
+  constexpr int A_BLOCKS = (BM / 16) * 2, B_BLOCKS = (BN / 16) * 2;
   constexpr int NBLK = A_BLOCKS + B_BLOCKS;      // 1 KiB fragment blocks per K-step
   constexpr int PER_WAVE = (NBLK + 3) / 4;
   constexpr int STAGE = NBLK * 1024;             // bytes
@@ -130,23 +127,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int m0 = ti * BM, n0 = tj * BN;
   const int mlim = (p.M + 15) & ~15, nlim = (p.N + 15) & ~15;
 
-  // per-lane source offsets inside a fragment block
-  // quad layout: lanes 4r..4r+3 fetch the four 16-byte segments of row r -- one 64-byte piece per
-  // lane quad instead of four different rows (cache lines) per quad, which is what the address
-  // path of the LDS-DMA coalesces on (r1x: +5 % on the K = 1024 SYRKs, C3 211 -> 203 ms).  The
-  // segment order inside a quad is XOR-swizzled with r>>2 so that the operand read (row l&15,
-  // segment l>>4) still touches 16 distinct bank groups per 16 lanes.
-  const int frow = lane >> 2;
-  const int fk = 2 * ((lane & 3) ^ ((lane >> 4) & 3));
-  const int rslot = 4 * (lane & 15) + ((lane >> 4) ^ ((lane >> 2) & 3));   // LDS slot holding (row l&15, segment l>>4)
-  // LINE layout (KG == 2): a fragment block is 8 rows x 16 k -- lanes 8r..8r+7 fetch the eight
-  // 16-byte segments of ONE 128-byte line, block h of a 16-row group holds its rows 8h..8h+7, and
-  // the segment index is XORed with (row>>1)&7 so the operand read stays conflict free.  Each
-  // operand line is requested once per K-step instead of once per 8-k half.  66.7 vs 64.8 TFLOP/s
-  // for the 128x128 tile at 8192^3, but 65.0 vs 66.0 for the 64x64 tile, which keeps the quads.
-  static_assert(!LINE || KG == 2, "the full-line layout covers a 16-column K-step");
+  // Fragment blocks.  One LDS-DMA wave-instruction moves 1 KiB = 8 rows x 16 k: lanes 8r..8r+7
+  // fetch the eight 16-byte segments of ONE 128-byte line of row r (block h of a 16-row group
+  // holds its rows 8h..8h+7), so every operand line is requested once per K-step by 8 adjacent
+  // lanes -- that is what the DMA's address path coalesces on.  (Until r1x a block was 16 rows x
+  // 8 k with lane l on row l&15: 16 different lines per instruction, each line fetched twice.
+  // Same-box A/B: 8192^3 65.9 -> 68.7 TFLOP/s with 128x128 tiles, C3 212 -> 203 ms, C4 1569 ->
+  // 1493 ms.)  The DMA writes LDS lane-linearly, so the segment index is XORed with (row>>1)&7 to
+  // keep the operand read (lane l: row l&15, k pair l>>4) on 16 distinct 16-byte bank groups.
   const int R16 = lane & 15;
-  const int roff0 = (R16 >> 3) * 1024 + ((R16 & 7) * 8 + ((lane >> 4) ^ ((R16 >> 1) & 7))) * 16;   // kg8 = 0; kg8 = 1: ^ 64
+  const int roff0 = (R16 >> 3) * 1024 + ((R16 & 7) * 8 + ((lane >> 4) ^ ((R16 >> 1) & 7))) * 16;   // k group 0; group 1: ^ 64
 
   d4 acc[TM][TN];
 #pragma unroll
@@ -165,20 +155,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     const int idx = wave + 4 * i;
     const bool isA = idx < A_BLOCKS;
     const int b = isA ? idx : idx - A_BLOCKS;
-    const int rg = b / KG, kg8 = b % KG;
+    const int rg = b >> 1, half = b & 1;
     const int row = (isA ? m0 : n0) + rg * 16;
     src_ok[i] = (idx < NBLK) && row < (isA ? mlim : nlim);
     // row groups past the operand's end re-read its first row group instead (always
     // readable; the garbage only reaches output rows/cols that are never stored), so
     // every wave issues exactly PER_WAVE DMAs per K-step and the counted waits stay exact
     const int srow = src_ok[i] ? row : 0;
-    if constexpr (LINE) {
-      const int r16 = kg8 * 8 + (lane >> 3);        // here the block's second index is the row half
-      const int seg = (lane & 7) ^ ((r16 >> 1) & 7);
-      src_base[i] = (isA ? p.A + (int64_t)(srow + r16) * p.lda : p.B + (int64_t)(srow + r16) * p.ldb) + seg * 2;
-    } else {
-      src_base[i] = (isA ? p.A + (int64_t)(srow + frow) * p.lda : p.B + (int64_t)(srow + frow) * p.ldb) + kg8 * 8 + fk;
-    }
+    const int r16 = half * 8 + (lane >> 3);
+    const int seg = (lane & 7) ^ ((r16 >> 1) & 7);
+    src_base[i] = (isA ? p.A + (int64_t)(srow + r16) * p.lda : p.B + (int64_t)(srow + r16) * p.ldb) + seg * 2;
   }
 
   // issue the loads of K-step `t` into LDS stage `s` (DMA) or registers (!DMA)
@@ -213,20 +199,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   // BLOW: B is lower-triangular (panel solve against an inverted leaf block, B[j][k] = 0 for
   // k > j): a 16-column tile needs no K beyond its last column -- skipped per (tile, 8-k group)
   auto compute = [&](int s, int k0) {
-    const char* base = smem + s * STAGE + (LINE ? 0 : rslot * 16);
+    const char* base = smem + s * STAGE;
 #pragma unroll
-    for (int kg8 = 0; kg8 < KG; ++kg8) {
+    for (int kg8 = 0; kg8 < 2; ++kg8) {
       d2 a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const d2*>(
-            LINE ? base + (wave_m * TM + i) * 2048 + (kg8 ? (roff0 ^ 64) : roff0)
-                 : base + (((wave_m * TM + i) * KG + kg8) * 1024));
+        a[i] = *reinterpret_cast<const d2*>(base + (wave_m * TM + i) * 2048 + (kg8 ? (roff0 ^ 64) : roff0));
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const d2*>(
-            LINE ? base + (A_BLOCKS + (wave_n * TN + j) * 2) * 1024 + (kg8 ? (roff0 ^ 64) : roff0)
-                 : base + ((A_BLOCKS + (wave_n * TN + j) * KG + kg8) * 1024));
+        b[j] = *reinterpret_cast<const d2*>(base + (A_BLOCKS + (wave_n * TN + j) * 2) * 1024 + (kg8 ? (roff0 ^ 64) : roff0));
       if constexpr (BLOW) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -330,14 +312,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
 static int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, int KG = 2, bool LINE = false>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
 static int launch(hipStream_t s, const GemmArgs& a0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
   const int grid = (a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
-  const int smem = ((BM + BN) / 16) * KG * 1024 * NS + g_smem_pad * 1024;
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW, KG, LINE>;
+  const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
   static int attr_set = -1;
   if (attr_set != smem) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -389,17 +371,18 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   a.lower = lower;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
-  // Tile choice (measured, tools/gemm_sweep*.py): 64x64 tiles (5 workgroups / CU, 1280 slots)
-  // match or beat 128x128 tiles (2 / CU) on every shape the drivers launch -- better tail
-  // quantisation and more waves to hide DMA latency -- except long-K contractions with many
-  // rounds of tiles (K >= 8192: 65.0 vs 63.1 TFLOP/s at M = 24576 lower).
+  // Tile choice (same-box sweep, tools/ab_layout.py): 128x128 tiles (2 workgroups / CU, half the
+  // L2->LDS traffic per flop) win once there are >= 8 rounds of them (M = 61440 lower, K = 1024:
+  // 66.0 vs 62.5 TFLOP/s; 8192^2 x 4096: 68.2 vs 66.4); below that the 64x64 tiles' (5 / CU, 1280
+  // slots) better tail quantisation wins (M = 7168 lower, K = 1024: 56.8 vs 62.0).
   auto tiles = [&](int64_t b) {
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
     return (lower ? mt * (mt + 1) / 2 : mt * nt) * batch;
   };
   // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer:
   // U U^T at N = 8192: 3.17 (64) vs 3.29 ms (128); at N = 32768: 199.7 vs 184.0 ms.
-  const bool small = !(K >= 8192 && tiles(128) >= (tri ? 8192 : 2048) && M > 64 && N > 64);
+  const bool small = tri ? !(K >= 8192 && tiles(128) >= 8192 && M > 64 && N > 64)
+                         : !(K >= 512 && tiles(128) >= 4096 && M > 64 && N > 64);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
@@ -407,11 +390,10 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
     if (g_gemm_variant == 2) return launch<64, 128, 32, 64, true>(s, a);
     return (tri & GPN_TRI_B_LOWER) ? launch<32, 128, 16, 64, true, 4, true>(s, a) : launch<32, 128, 16, 64, true, 4>(s, a);
   }
-  if (g_gemm_variant == 3) return launch<128, 128, 64, 64, true, 2, false, 2, true>(s, a);        // A/B: force a tile shape
+  if (g_gemm_variant == 3) return launch<128, 128, 64, 64, true>(s, a);        // A/B: force a tile shape
   if (g_gemm_variant == 4) return launch<64, 64, 32, 32, true>(s, a);
   if (g_gemm_variant == 5) return launch<64, 64, 32, 32, true, 8>(s, a);
   if (g_gemm_variant == 6) return launch<32, 32, 16, 16, true, 8>(s, a);
-  if (g_gemm_variant == 7) return launch<64, 64, 32, 32, true, 4, false, 1>(s, a);   // half stages, 4-deep ring, same LDS
   // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
   // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
   if (g_gemm_variant == 0 && (M <= 32 || N <= 32)) return launch<32, 32, 16, 16, true, 8>(s, a);
@@ -421,9 +403,9 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
     return launch<32, 32, 16, 16, true, 8>(s, a);
   }
   if (g_gemm_variant == 0) {
-    return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true, 2, false, 2, true>(s, a);
+    return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true>(s, a);
   }
-  return small ? launch<64, 64, 32, 32, false>(s, a) : launch<128, 128, 64, 64, false, 2, false, 2, true>(s, a);
+  return small ? launch<64, 64, 32, 32, false>(s, a) : launch<128, 128, 64, 64, false>(s, a);
 }
 
 }  // namespace gpn
