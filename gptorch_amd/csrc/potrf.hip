@@ -598,7 +598,7 @@ static Aux* aux_for(hipStream_t s) {
 }
 
 static int g_panel_width = 0;        // 0 = by size; debug override
-static inline int64_t panel_width(int64_t n) { (void)n; return g_panel_width ? g_panel_width : 1024; }   // re-measured with the 39 us leaf: 512 / 1024 / 1536 / 2048 -> 7.47 / 7.33 / 7.27 / 7.38 ms (C2), 1024 / 2048 / 3072 -> 211 / 213 / 218 ms (C3)
+static inline int64_t panel_width(int64_t n) { (void)n; return g_panel_width ? g_panel_width : 1536; }   // same-box sweeps (r1y, full-line contraction kernel), 1024 / 1536 / 2048: C2 7.10 / 7.00 / 7.01 ms, C3 201.5 / 200.0 / 201.1 ms, C4 1492 / 1473 / 1472 ms
 
 static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   Aux* ax = aux_for(c.s);
