@@ -61,3 +61,29 @@ def test_gemm_random_fp64(device):
     C = _ops.gemm_nt(A, B, M, N, K)
     ref = A[:M] @ B[:N].t()
     assert (C - ref).abs().max().item() < 1e-11
+
+
+@pytest.mark.parametrize("variant", [3, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K,lower", [(333, 257, 80, False), (1000, 700, 144, False), (129, 127, 16, False),
+                                         (777, 777, 96, True), (1100, 1100, 64, True), (130, 130, 32, True)])
+def test_every_tile_shape_on_ragged_sizes(device, variant, M, N, K, lower):
+    """The launcher picks a tile shape by problem size (128x128 from 8 rounds of tiles up, 64x64,
+    64x64 / 32x32 with the deep LDS-DMA ring); here each one is FORCED onto small ragged problems
+    (sizes that are no multiple of any tile edge) with exact integer data: bit-identical results."""
+    _native.lib().gpn_debug_set_gemm_variant(variant)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(variant * 1000 + M + N + K)
+        A = torch.randint(-8, 9, (M, K), generator=g).double().to(device)
+        B = A if lower else torch.randint(-8, 9, (N, K), generator=g).double().to(device)
+        C0 = torch.randint(-8, 9, (M, N), generator=g).double().to(device)
+        Ap, Bp = _pad_rows(A), _pad_rows(B)
+        C = C0.clone()
+        _ops.gemm_nt(Ap, Bp, M, N, K, alpha=-1.0, beta=1.0, C=C, lower=lower)
+        ref = C0 - A @ B.t()
+        if lower:
+            assert torch.equal(torch.tril(C), torch.tril(ref))
+            assert torch.equal(torch.triu(C, 1), torch.triu(C0, 1))
+        else:
+            assert torch.equal(C, ref)
+    finally:
+        _native.lib().gpn_debug_set_gemm_variant(0)
