@@ -87,3 +87,32 @@ def test_every_tile_shape_on_ragged_sizes(device, variant, M, N, K, lower):
             assert torch.equal(C, ref)
     finally:
         _native.lib().gpn_debug_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("variant", [0, 3, 4, 6])
+@pytest.mark.parametrize("n", [200, 777, 1300])
+def test_k_clipped_triangular_operands(device, variant, n):
+    """GPN_TRI_* flags (the K range of a tile is clipped where an operand is structurally zero) on
+    every tile shape: U U^T for an upper-triangular U (the backward's Kyy^-1 product) and B W^T for
+    a lower-triangular W, exact integers."""
+    _native.lib().gpn_debug_set_gemm_variant(variant)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(variant * 100 + n)
+        kp = (n + 15) // 16 * 16
+        U = torch.zeros(kp + 16, kp, dtype=torch.float64)
+        U[:n, :n] = torch.triu(torch.randint(-4, 5, (n, n), generator=g).double())
+        U = U.to(device)
+        C = torch.zeros(n, n, dtype=torch.float64, device=device)
+        _ops.gemm_nt(U, U, n, n, kp, C=C, lower=True, tri=_ops.TRI_A_UPPER | _ops.TRI_B_UPPER)
+        ref = U[:n, :n] @ U[:n, :n].t()
+        assert torch.equal(torch.tril(C), torch.tril(ref))
+        W = torch.zeros(kp + 16, kp, dtype=torch.float64)
+        W[:n, :n] = torch.tril(torch.randint(-4, 5, (n, n), generator=g).double())
+        W = W.to(device)
+        Bm = torch.zeros(112, kp, dtype=torch.float64)
+        Bm[:100, :n] = torch.randint(-4, 5, (100, n), generator=g).double()
+        Bm = Bm.to(device)
+        X = _ops.gemm_nt(Bm, W, 100, n, kp, tri=_ops.TRI_B_LOWER)
+        assert torch.equal(X, Bm[:100, :n] @ W[:n, :n].t())
+    finally:
+        _native.lib().gpn_debug_set_gemm_variant(0)
