@@ -54,6 +54,8 @@ CHUNK_ROWS = 65536   # rows of x per streamed chunk (scratch: 2 x CHUNK_ROWS x l
 # forward and the gradients in the backward, so every rank sees the bound and the gradients of the
 # WHOLE data set (optimisers on all ranks stay in step).
 SHARD_GROUP = None
+LANES = 2                # chunk pipelines in flight (1: strictly one chunk after the other)
+SYRK_K_SLICE = 8192      # columns of a chunk per accumulation launch (0: the whole chunk at once)
 
 
 def _all_reduce(t):
@@ -126,7 +128,7 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
     # 1280 workgroup slots 1.6 times: a poor last round) accumulates, the next chunk's assembly,
     # right-solve and transpose already run next to it.  The accumulations into AAT / Aerr are
     # ordered by events.
-    lanes = 2 if nchunks > 1 else 1
+    lanes = min(LANES, 2) if nchunks > 1 else 1
     cur = torch.cuda.current_stream(dev)
     streams = [cur] + [torch.cuda.Stream(device=dev) for _ in range(lanes - 1)]
     bufs = [(_zeros(nc + 16, f_uu.ld, dev), _zeros(mp, nc, dev), _zeros(_ops.round_up(dy, 16), nc, dev))
@@ -151,7 +153,13 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
             first = 0.0 if c0 == 0 else 1.0
             if acc_done is not None:
                 stq.wait_event(acc_done)
-            _ops.gemm_nt(A, A, m, m, kp, alpha=1.0 / s2, beta=first, C=AAT, lower=True)
+            # the accumulation in K slices: one launch over the whole chunk keeps every workgroup
+            # slot for ~10 ms, and the other lane's short kernels (128-column solves, K = 128 / 256
+            # updates) starve behind it -- there is no pre-emption
+            ks = SYRK_K_SLICE or kp
+            for k0 in range(0, kp, ks):
+                kk = min(ks, kp - k0)
+                _ops.gemm_nt(A[:, k0:], A[:, k0:], m, m, kk, alpha=1.0 / s2, beta=(first if k0 == 0 else 1.0), C=AAT, lower=True)
             _ops.gemm_nt(A, errT, m, dy, kp, beta=first, C=Aerr)
             acc_done = torch.cuda.Event()
             acc_done.record(stq)

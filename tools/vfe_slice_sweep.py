@@ -1,0 +1,20 @@
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from gptorch_amd import kernels, likelihoods, mean_functions, rng
+from gptorch_amd.models import VFE, sparse_gpr
+n, m, d = 1000000, 4096, 8
+x, y = rng.make_regression(n, d, 1, seed=0)
+z = rng.normal(99, (m, d))
+model = VFE(x, y, kernels.Rbf(d, variance=1.0, length_scales=float(np.sqrt(d))), inducing_points=z,
+            likelihood=likelihoods.Gaussian(variance=1e-2), mean_function=mean_functions.Zero(1))
+model.cuda()
+with torch.no_grad():
+    model.log_likelihood(); torch.cuda.synchronize()
+    for rnd in range(2):
+        for ks in (0, 16384, 8192, 4096, 2048):
+            sparse_gpr.SYRK_K_SLICE = ks
+            model.log_likelihood(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(2): v = model.log_likelihood()
+            torch.cuda.synchronize()
+            print("K slice %6d: %.3f s  elbo %.6f" % (ks, (time.perf_counter() - t0) / 2, v.item()), flush=True)
