@@ -961,3 +961,30 @@ def test_repeated_evaluations_are_bitwise_identical(device):
                 key = "fwd"
             cur = cur.cpu().numpy().tobytes()
             assert ref.setdefault(key, cur) == cur, (n, i, key)
+
+
+def test_bench_multi_rank_control_flow(device):
+    """bench.py under torch.distributed.run with 2 ranks (both on cuda:0, gloo collectives via
+    --test-shared-gpu): the N > 1 path of the bench contract -- barrier-bracketed timing, MAX over
+    ranks, rank 0 prints ONE JSON line with the whole-job value -- which the driver otherwise only
+    exercises on a multi-GPU node."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "c1", "--test-shared-gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "LML evals/s" and d["dtype"] == "f64" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 4 / 1e3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
+    assert "replicas x2" in d["config"]["parallelism"]
