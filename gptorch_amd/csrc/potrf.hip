@@ -564,7 +564,8 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
 //     main stream : leaf(k) -> solve ALL rows below against W_k (one in-place launch)
 //                   -> update of the NEXT column block only (what leaf(k+1) waits for)
 //     aux stream  : update of the remaining columns of the panel by block k (needs solve(k)),
-//                   overlapped with leaf(k+1) on the main stream
+//                   overlapped with leaf(k+1) on the main stream; for N >= 24576 the left-looking
+//                   form instead (the column block after the next one by all solved panel columns)
 // and one large K = PW contraction for everything right of the panel at its end.  The two
 // streams are joined by events (fork/join, so the whole call can also be captured in a
 // hipGraph); no data-dependent host logic.  The upper triangle inside the panel's diagonal
@@ -598,12 +599,18 @@ static Aux* aux_for(hipStream_t s) {
 }
 
 static int g_panel_width = 0;        // 0 = by size; debug override
-static inline int64_t panel_width(int64_t n) { (void)n; return g_panel_width ? g_panel_width : 1536; }   // same-box sweeps (r1y, full-line contraction kernel), 1024 / 1536 / 2048: C2 7.10 / 7.00 / 7.01 ms, C3 201.5 / 200.0 / 201.1 ms, C4 1492 / 1473 / 1472 ms
+static int g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
+// Same-box sweeps (r1z, tools/potrf_ab.py): panel width 1024 / 1536 / 2048 -> C2 7.10 / 7.00 / 7.01 ms,
+// N = 16384 31.9 (1536) vs 32.2 (2048), C3 201.5 / 200.0 / 201.1, C4 1492 / 1473 / 1472; with the
+// left-looking aux update (below) the large sizes prefer 2048: C3 198.1, C4 1454 ms.
+static inline bool large_problem(int64_t n) { return n >= 24576; }
+static inline int64_t panel_width(int64_t n) { return g_panel_width ? g_panel_width : (large_problem(n) ? 2048 : 1536); }
 
 static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   Aux* ax = aux_for(c.s);
   if (!ax) { c.rc = GPN_E_HIP; return; }
   const int64_t lda = c.lda, PW = panel_width(n);
+  const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
   bool rest_pending = false;
@@ -643,8 +650,20 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       if (fork && c.rc == GPN_OK) {                // the rest of the panel on the aux stream
         hip_ok(hipStreamWaitEvent(ax->s1, ax->solve[step & 3], 0));
         const int64_t m2 = n + e - c2;
-        c.rc = gemm_nt(ax->s1, m2, pend - c2, kb, -1.0, A + c2 * lda + k0, lda, A + c2 * lda + k0, lda, 1.0,
-                       A + c2 * lda + c2, lda, 0);
+        if (!left_looking) {
+          // right-looking: all remaining columns of the panel by block k (K = LEAF)
+          c.rc = gemm_nt(ax->s1, m2, pend - c2, kb, -1.0, A + c2 * lda + k0, lda, A + c2 * lda + k0, lda, 1.0,
+                         A + c2 * lda + c2, lda, 0);
+        } else {
+          // left-looking: only the column block AFTER the next one, by every solved column of the
+          // panel so far (K = c1 - p0) -- each block of the panel is read and written once here
+          // instead of once per earlier block.  Pays from N ~ 32768 up, where the K = 128 rank
+          // updates of 250+ tile rows outlast the leaf (C3 200.6 -> 198.9 ms, C4 1473 -> 1463 ms);
+          // costs 2 % at C2, where the long-K launches of one tile column are latency-bound
+          const int64_t nb2 = std::min<int64_t>(LEAF, pend - c2);
+          c.rc = gemm_nt(ax->s1, m2, nb2, c1 - p0, -1.0, A + c2 * lda + p0, lda, A + c2 * lda + p0, lda, 1.0,
+                         A + c2 * lda + c2, lda, 0);
+        }
         rest_idx = step & 3;
         hip_ok(hipEventRecord(ax->rest[rest_idx], ax->s1));
         rest_pending = true;
@@ -840,6 +859,7 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_potrf_variant = v & 1;           // bit 0: plain recursion; bit 2: three-phase leaf; bits 8..: panel width / 128
   g_leaf_pipe = ((v >> 2) & 1) ? 0 : 1;
   g_panel_width = (v >> 8) * LEAF;
+  g_aux_left_looking = ((v >> 3) & 1) ? 1 : (((v >> 5) & 1) ? 0 : -1);   // bit 3: force left-looking aux update, bit 5: force right-looking
   return GPN_OK;
 }
 

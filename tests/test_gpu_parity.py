@@ -129,15 +129,16 @@ def test_cholesky_vs_oracle(device, n):
 
 @pytest.mark.parametrize("n,e", [(1152, 0), (2500, 3), (8320, 1), (9001, 2)])
 def test_factorisation_drivers_agree(device, n, e):
-    """the look-ahead panel driver (default) and the plain recursion produce the same factor,
-    extra rows and leaf inverses on multi-panel and ragged sizes (panel width 1024 / 2048)."""
+    """the look-ahead panel driver (default), its left-looking form (default from N = 24576) and the
+    plain recursion produce the same factor, extra rows and leaf inverses on multi-panel and
+    ragged sizes."""
     from gptorch_amd import _native, _ops
     lib = _native.lib()
     x = torch.tensor(rng.normal(5, (n, 6)), device=device)
     one = torch.ones(1, dtype=torch.float64, device=device)
     R = torch.tensor(rng.normal(6, (n, max(e, 1)))[:, :e], device=device) if e else None
     out = []
-    for variant in (0, 1):
+    for variant in (1, 0, 8, 0x408):     # recursion | look-ahead (default) | left-looking aux update | + 512-wide panels
         lib.gpn_debug_set_potrf_variant(variant)
         try:
             f = _ops.kernel_factor("Matern52", x, one, 2.0 * one, 0.05 * one, R=R)
@@ -145,12 +146,13 @@ def test_factorisation_drivers_agree(device, n, e):
             lib.gpn_debug_set_potrf_variant(0)
         assert int(f.info.item()) == 0
         out.append((f.lower(), f.extra().clone(), f.winv.clone(), f.lml_terms().clone()))
-    (L0, E0, W0, T0), (L1, E1, W1, T1) = out
-    assert (L0 - L1).abs().max().item() < 1e-11
-    assert (W0 - W1).abs().max().item() < 1e-9 * W1.abs().max().item()
-    if e:
-        assert (E0 - E1).abs().max().item() < 1e-9
-    assert abs(T0[0].item() - T1[0].item()) < 1e-9
+    L1, E1, W1, T1 = out[0]
+    for L0, E0, W0, T0 in out[1:]:
+        assert (L0 - L1).abs().max().item() < 1e-11
+        assert (W0 - W1).abs().max().item() < 1e-9 * W1.abs().max().item()
+        if e:
+            assert (E0 - E1).abs().max().item() < 1e-9
+        assert abs(T0[0].item() - T1[0].item()) < 1e-9
 
 
 @pytest.mark.parametrize("n", [300, 1000, 2500, 4224])

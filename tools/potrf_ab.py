@@ -10,7 +10,11 @@ from gptorch_amd import _native  # noqa: E402
 
 lib = _native.lib()
 for wl in (sys.argv[1:] or ["c2", "c3"]):
-    w = bench.WORKLOADS[wl]
+    if wl.startswith("n="):          # ad-hoc size: Rbf, D = 8
+        nn = int(wl[2:])
+        w = dict(name=wl, kind="Rbf", n=nn, d=8, dy=1, variance=1.0, length_scales=8.0 ** 0.5, noise=1e-2)
+    else:
+        w = bench.WORKLOADS[wl]
     m, _, _ = bench.build_model(w, 0, torch.device("cuda:0"))
     for variant in [int(v, 0) for v in os.environ.get("VARIANTS", "1,0,1,0").split(",")]:
         lib.gpn_debug_set_potrf_variant(variant)
