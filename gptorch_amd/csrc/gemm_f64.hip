@@ -379,9 +379,10 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
     return (lower ? mt * (mt + 1) / 2 : mt * nt) * batch;
   };
-  // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer:
-  // U U^T at N = 8192: 3.17 (64) vs 3.29 ms (128); at N = 32768: 199.7 vs 184.0 ms.
-  const bool small = tri ? !(K >= 8192 && tiles(128) >= 8192 && M > 64 && N > 64)
+  // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer.  U U^T (lower):
+  // N = 8192 3.02 (64) vs 3.12 ms (128), N = 12288 10.3 vs 9.8, N = 16384 25.3 vs 22.7; the
+  // triangular inversion's rectangular products stay on 64x64 tiles up to N = 16384 (28.0 vs 29.2 ms).
+  const bool small = tri ? !(K >= 8192 && tiles(128) >= (lower ? 4096 : 8192) && M > 64 && N > 64)
                          : !(K >= 512 && tiles(128) >= 4096 && M > 64 && N > 64);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover

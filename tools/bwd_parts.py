@@ -7,7 +7,11 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from gptorch_amd import _backward, _native, _ops  # noqa: E402
 lib = _native.lib()
-w = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
+wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+if wl.startswith("n="):           # ad-hoc size: Rbf, D = 8
+    w = dict(name=wl, kind="Rbf", n=int(wl[2:]), d=8, dy=1, variance=1.0, length_scales=8.0 ** 0.5, noise=1e-2)
+else:
+    w = bench.WORKLOADS[wl]
 m, _, _ = bench.build_model(w, 0, torch.device("cuda:0"))
 with torch.no_grad():
     m.log_likelihood()
@@ -26,7 +30,7 @@ def t(fn, reps=5):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for v in (0, 3, 4):
+for v in (0, 3, 4, 0, 3, 4):
     lib.gpn_debug_set_gemm_variant(v)
     a = t(lambda: _backward._kinv_lower(f, U))
     lib.gpn_debug_set_gemm_variant(0)
@@ -36,4 +40,9 @@ for v in (0, 4, 5, 6):
     a = t(lambda: _ops.gemm_nt(f.A[n:], U, dy, n, _ops.round_up(n, 16), tri=_ops.TRI_B_UPPER))
     lib.gpn_debug_set_gemm_variant(0)
     print("a^T = alpha^T U^T (skinny), variant %d: %8.1f us" % (v, a))
-print("U = L^-T: ws %8.1f us, recursion %8.1f us" % (t(lambda: _backward._upper_inverse(f, True), 3), t(lambda: _backward._upper_inverse(f, False), 3)))
+for v in (0, 3, 4, 0, 3, 4):
+    lib.gpn_debug_set_gemm_variant(v)
+    a = t(lambda: _backward._upper_inverse(f, True), 3)
+    lib.gpn_debug_set_gemm_variant(0)
+    print("U = L^-T (level-wise, incl. zeroing two buffers), variant %d: %8.1f us" % (v, a))
+print("U = L^-T: chain-based recursion %8.1f us" % t(lambda: _backward._upper_inverse(f, False), 3))
