@@ -1,3 +1,5 @@
+"""GPU-box tool: LML evals/s with R = 1..8 independent C2 models in flight -- default two internal
+lanes, back to back on one stream, one free stream per model (batched_log_likelihood)."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench

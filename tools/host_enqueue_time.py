@@ -1,3 +1,4 @@
+"""GPU-box tool: host time to ENQUEUE one C2 evaluation (no synchronisation) vs its GPU time."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench

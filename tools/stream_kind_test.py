@@ -1,3 +1,4 @@
+"""GPU-box experiment: cost of event waits between created streams, per stream kind / priority."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench

@@ -1,3 +1,5 @@
+"""GPU-box experiment: event waits against the legacy default (null) stream vs created streams
+(the ~7 ms per evaluation finding quoted in DESIGN.md 3.2)."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench

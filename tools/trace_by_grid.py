@@ -1,3 +1,5 @@
+"""Aggregate a rocprofv3 kernel_trace.csv of tools/vfe_fwd_once.py by (kernel, workgroup count) for the
+SECOND evaluation in the trace.  usage: trace_by_grid.py <rocprof output dir>"""
 import csv,glob,collections,sys
 f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f))); rows.sort(key=lambda r:int(r["Start_Timestamp"]))

@@ -1,3 +1,5 @@
+"""GPU-box tool: VFE config-5 forward time against the K-slice of the A A^T accumulation launches
+(sparse_gpr.SYRK_K_SLICE), same process = same box."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
