@@ -1,4 +1,7 @@
-"""Global defaults (gptorch/settings.py:7): positive parameters are stored as logs."""
-from torch.distributions.transforms import ExpTransform
+"""Library-wide defaults.  Positive hyper-parameters (variances, length-scales) are optimised
+through their logarithm, as in the reference (gptorch/settings.py:7)."""
+import torch.distributions.transforms as _transforms
 
-DefaultPositiveTransform = ExpTransform
+
+class DefaultPositiveTransform(_transforms.ExpTransform):
+    """value = exp(raw): the constraint every positive Param is created with."""
