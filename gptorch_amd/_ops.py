@@ -274,6 +274,16 @@ def gemm_nt(A, B, M, N, K, alpha=1.0, beta=0.0, C=None, lower=False, tri=0):
     return C
 
 
+def gemm_nt_batched(A, B, M, N, K, batch, sA, sB, C, alpha=1.0, beta=0.0, lower=False, tri=0):
+    """`batch` contractions of one shape in one launch: C[z] = alpha*A_z*B_z^T + beta*C[z], A_z = A + z*sA
+    elements (row stride from the tensor), C [batch, rows, ld] contiguous."""
+    _req(A, B, C)
+    st = _native.lib().gpn_gemm_nt_batched(_stream(A.device), M, N, K, alpha, _ptr(A), A.stride(0), sA, _ptr(B), B.stride(0), sB,
+                                           beta, _ptr(C), C.stride(1), C.stride(0), 1 if lower else 0, tri, batch)
+    _native.check(st, "gpn_gemm_nt_batched")
+    return C
+
+
 def transpose(src):
     _req(src)
     src = _c(src.detach())

@@ -417,6 +417,24 @@ extern "C" int gpn_debug_set_gemm_variant(int v) {
   return GPN_OK;
 }
 
+extern "C" int gpn_gemm_nt_batched(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
+                                   const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
+                                   double beta, double* C, int64_t ldc, int64_t sC, int lower, int tri, int batch) {
+  if (M < 0) return -2;
+  if (N < 0) return -3;
+  if (K < 0 || (K % 16) != 0) return -4;
+  if (batch < 1) return -18;
+  if (M == 0 || N == 0) return GPN_OK;
+  if (!A) return -6;
+  if (!B) return -9;
+  if (!C) return -13;
+  if (lower && M != N) return -16;
+  if ((lda % 2) || (ldb % 2) || (sA % 2) || (sB % 2)) return GPN_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GPN_E_ALIGN;
+  return gpn::gemm_nt_impl(static_cast<hipStream_t>(stream), M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                           lower ? 1 : 0, tri, 0, batch, sA, sB, sC);
+}
+
 extern "C" int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
                            const double* A, int64_t lda, const double* B, int64_t ldb,
                            double beta, double* C, int64_t ldc, int lower, int tri) {

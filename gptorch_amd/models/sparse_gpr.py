@@ -55,6 +55,7 @@ CHUNK_ROWS = 65536   # rows of x per streamed chunk (scratch: 2 x CHUNK_ROWS x l
 # WHOLE data set (optimisers on all ranks stay in step).
 SHARD_GROUP = None
 LANES = 2                # chunk pipelines in flight (1: strictly one chunk after the other)
+SPLIT_K = 8              # partial accumulators of the A A^T accumulation (1: none)
 SYRK_K_SLICE = 8192      # columns of a chunk per accumulation launch (0: the whole chunk at once)
 
 
@@ -134,6 +135,10 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
     bufs = [(_zeros(nc + 16, f_uu.ld, dev), _zeros(mp, nc, dev), _zeros(_ops.round_up(dy, 16), nc, dev))
             for _ in range(lanes)]
     lib = _ops._native.lib()
+    # split-K partial accumulators (see below): only when M^2/2 has too few 128x128 tiles to fill the GPU
+    mt128 = (m + 127) // 128
+    split = SPLIT_K if (mt128 * (mt128 + 1) // 2 < 4096 and nc >= 4096 * SPLIT_K) else 1
+    parts = torch.zeros(split, AAT.shape[0], AAT.shape[1], dtype=torch.float64, device=dev) if split > 1 else None
     acc_done = None                                                        # event: AAT/Aerr updated through chunk c-1
     for stq in streams[1:]:
         stq.wait_stream(cur)
@@ -153,13 +158,21 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
             first = 0.0 if c0 == 0 else 1.0
             if acc_done is not None:
                 stq.wait_event(acc_done)
-            # the accumulation in K slices: one launch over the whole chunk keeps every workgroup
-            # slot for ~10 ms, and the other lane's short kernels (128-column solves, K = 128 / 256
-            # updates) starve behind it -- there is no pre-emption
-            ks = SYRK_K_SLICE or kp
-            for k0 in range(0, kp, ks):
-                kk = min(ks, kp - k0)
-                _ops.gemm_nt(A[:, k0:], A[:, k0:], m, m, kk, alpha=1.0 / s2, beta=(first if k0 == 0 else 1.0), C=AAT, lower=True)
+            if split > 1 and kp % (16 * split) == 0:
+                # split-K: M^2/2 alone is too few tiles for the GPU (M = 4096: 2080 64x64 tiles = 1.6
+                # rounds of the 1280 slots, 528 128x128 tiles = 1.03 rounds of 512), so the chunk's K
+                # range is dealt over `split` partial accumulators in ONE launch (8 x 528 tiles =
+                # 8.25 rounds); the partials are summed once, after the last chunk
+                _ops.gemm_nt_batched(A, A, m, m, kp // split, split, kp // split, kp // split, parts,
+                                     alpha=1.0 / s2, beta=first, lower=True)
+            else:
+                # K slices in sequence: one launch over the whole chunk keeps every workgroup slot
+                # for ~10 ms and the other lane's short kernels starve behind it (no pre-emption)
+                ks = SYRK_K_SLICE or kp
+                tgt = parts[0] if split > 1 else AAT
+                for k0 in range(0, kp, ks):
+                    kk = min(ks, kp - k0)
+                    _ops.gemm_nt(A[:, k0:], A[:, k0:], m, m, kk, alpha=1.0 / s2, beta=(first if k0 == 0 else 1.0), C=tgt, lower=True)
             _ops.gemm_nt(A, errT, m, dy, kp, beta=first, C=Aerr)
             acc_done = torch.cuda.Event()
             acc_done.record(stq)
@@ -167,6 +180,9 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
         cur.wait_stream(stq)
     if acc_done is not None:
         cur.wait_event(acc_done)
+    if split > 1:
+        torch.sum(parts, dim=0, out=AAT)
+        del parts
     # row shards: one all-reduce of the M-sized sums and of (N, |err|^2)
     scal = torch.tensor([float(n), 0.0], dtype=torch.float64, device=dev)
     scal[1] = err.pow(2).sum()

@@ -126,6 +126,14 @@ int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
                 const double* A, int64_t lda, const double* B, int64_t ldb,
                 double beta, double* C, int64_t ldc, int lower, int tri);
 
+/* `batch` problems of identical shape in ONE launch: problem z uses A + z*sA, B + z*sB, C + z*sC
+ * (strides in elements; sA, sB even).  With sA = sB = K and one set of rows this is a split-K
+ * contraction into `batch` partial results -- how the sparse model's M x M accumulation
+ * (sparse_gpr.py:131 `AAT`) fills the GPU when M^2 alone has too few tiles. */
+int gpn_gemm_nt_batched(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
+                        const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
+                        double beta, double* C, int64_t ldc, int64_t sC, int lower, int tri, int batch);
+
 /* ---- backward of the LML (closed form) ---------------------
  * U <- L^-T (upper triangular, row-major) into a ZERO-INITIALISED buffer of
  * gpn_factor_rows(n,0) x ldu (ldu = gpn_factor_ld(n,0)); L/winv from gpn_potrf_lower.

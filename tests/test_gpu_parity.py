@@ -990,3 +990,36 @@ def test_bench_multi_rank_control_flow(device):
     assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 4 / 1e3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
     assert "replicas x2" in d["config"]["parallelism"]
+
+
+def test_vfe_split_k_accumulation(device, monkeypatch):
+    """The A A^T accumulation of the sparse bound switches to split-K partial accumulators
+    (gpn_gemm_nt_batched) when a chunk is long and M^2 has few tiles: N = 40000 = one 32768-row chunk
+    through the batched launch + a ragged 7232-row tail through the sequential one.  Against the
+    CPU oracle and against the same evaluation without the split."""
+    from gptorch_amd.models import VFE, sparse_gpr
+    n, d, m = 40000, 3, 200
+    x, y = rng.make_regression(n, d, 1, seed=12)
+    z = rng.normal(13, (m, d))
+    def model():
+        mod = VFE(x, y, kernels.Matern32(d, variance=1.1, length_scales=1.4), inducing_points=z,
+                  likelihood=likelihoods.Gaussian(variance=0.05), mean_function=mean_functions.Zero(1))
+        mod.cuda()
+        return mod
+    monkeypatch.setattr(sparse_gpr, "CHUNK_ROWS", 32768)
+    monkeypatch.setattr(sparse_gpr, "SPLIT_K", 8)
+    mod = model()
+    loss = mod.loss()
+    loss.backward()
+    g_split = [p.grad.clone() for p in (mod.kernel.variance, mod.kernel.length_scales, mod.likelihood.variance)]
+    monkeypatch.setattr(sparse_gpr, "SPLIT_K", 1)
+    mod2 = model()
+    loss2 = mod2.loss()
+    assert abs(loss.item() - loss2.item()) < 1e-10 * abs(loss2.item())
+    o = orc.VFEOracle(x, y, z, kind="Matern32", variance=1.1, length_scales=1.4, noise=0.05)
+    with torch.no_grad():
+        ref = -o.log_likelihood().item()
+    assert abs(loss.item() - ref) < 1e-9 * abs(ref), (loss.item(), ref)
+    loss2.backward()
+    for a, b in zip(g_split, (mod2.kernel.variance.grad, mod2.kernel.length_scales.grad, mod2.likelihood.variance.grad)):
+        assert (a - b).abs().max().item() < 1e-9 * max(1.0, b.abs().max().item())

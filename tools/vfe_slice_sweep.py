@@ -1,5 +1,5 @@
-"""GPU-box tool: VFE config-5 forward time against the K-slice of the A A^T accumulation launches
-(sparse_gpr.SYRK_K_SLICE), same process = same box."""
+"""GPU-box tool: VFE config-5 forward time against the split-K / K-slice settings of the A A^T
+accumulation (sparse_gpr.SPLIT_K, SYRK_K_SLICE), same process = same box."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -14,9 +14,9 @@ model.cuda()
 with torch.no_grad():
     model.log_likelihood(); torch.cuda.synchronize()
     for rnd in range(2):
-        for ks in (0, 16384, 8192, 4096, 2048):
-            sparse_gpr.SYRK_K_SLICE = ks
+        for split, ks in ((1, 0), (1, 8192), (8, 8192), (4, 8192), (16, 8192)):
+            sparse_gpr.SPLIT_K, sparse_gpr.SYRK_K_SLICE = split, ks
             model.log_likelihood(); torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(2): v = model.log_likelihood()
             torch.cuda.synchronize()
-            print("K slice %6d: %.3f s  elbo %.6f" % (ks, (time.perf_counter() - t0) / 2, v.item()), flush=True)
+            print("split-K %2d, K slice %6d: %.3f s  elbo %.6f" % (split, ks, (time.perf_counter() - t0) / 2, v.item()), flush=True)
