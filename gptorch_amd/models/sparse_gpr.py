@@ -139,6 +139,7 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
     mt128 = (m + 127) // 128
     split = SPLIT_K if (mt128 * (mt128 + 1) // 2 < 4096 and nc >= 4096 * SPLIT_K) else 1
     parts = torch.zeros(split, AAT.shape[0], AAT.shape[1], dtype=torch.float64, device=dev) if split > 1 else None
+    aerr_parts = torch.zeros(split, mp, dy, dtype=torch.float64, device=dev) if split > 1 else None
     acc_done = None                                                        # event: AAT/Aerr updated through chunk c-1
     for stq in streams[1:]:
         stq.wait_stream(cur)
@@ -165,6 +166,9 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
                 # 8.25 rounds); the partials are summed once, after the last chunk
                 _ops.gemm_nt_batched(A, A, m, m, kp // split, split, kp // split, kp // split, parts,
                                      alpha=1.0 / s2, beta=first, lower=True)
+                # A err likewise: a 4096 x 65536 matrix-vector product is 128 workgroups of 4096
+                # K-steps each as one skinny contraction (0.98 ms), 8x more of 8x shorter ones here
+                _ops.gemm_nt_batched(A, errT, m, dy, kp // split, split, kp // split, kp // split, aerr_parts, beta=first)
             else:
                 # K slices in sequence: one launch over the whole chunk keeps every workgroup slot
                 # for ~10 ms and the other lane's short kernels starve behind it (no pre-emption)
@@ -173,7 +177,7 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
                 for k0 in range(0, kp, ks):
                     kk = min(ks, kp - k0)
                     _ops.gemm_nt(A[:, k0:], A[:, k0:], m, m, kk, alpha=1.0 / s2, beta=(first if k0 == 0 else 1.0), C=tgt, lower=True)
-            _ops.gemm_nt(A, errT, m, dy, kp, beta=first, C=Aerr)
+                _ops.gemm_nt(A, errT, m, dy, kp, beta=first, C=(aerr_parts[0] if split > 1 else Aerr))
             acc_done = torch.cuda.Event()
             acc_done.record(stq)
     for stq in streams[1:]:
@@ -182,6 +186,7 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
         cur.wait_event(acc_done)
     if split > 1:
         torch.sum(parts, dim=0, out=AAT)
+        torch.sum(aerr_parts, dim=0, out=Aerr)
         del parts
     # row shards: one all-reduce of the M-sized sums and of (N, |err|^2)
     scal = torch.tensor([float(n), 0.0], dtype=torch.float64, device=dev)
