@@ -25,6 +25,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64]),
     "gpn_pack_rhs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64]),
     "gpn_potrf_lower": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "gpn_potrf_panel_width": (c_int64, [c_int64]),
+    "gpn_release_stream": (c_int, [c_void_p]),
     "gpn_trtri_diag": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gpn_trsm_right_lt": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "gpn_lml_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
@@ -62,6 +64,7 @@ DEBUG_SIGNATURES = {
     "gpn_debug_leaf_timing": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_profile_enable": (c_int, [c_int]),
     "gpn_profile_collect": (c_int, [ctypes.POINTER(c_double)]),
+    "gpn_profile_collect_classes": (c_int, [ctypes.POINTER(c_double), c_int]),
 }
 
 _lib = None

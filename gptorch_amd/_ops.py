@@ -155,10 +155,18 @@ JITTER_TRIES = 10  # functions.py:21 max_tries
 def _ladder(attempt):
     """functions.py:20-43: plain try, then +10^(-10+i) I for i = 0..9, then
     RuntimeError("Max tries exceeded.").  `attempt(jitter)` -> info."""
-    if attempt(None) == 0:
+    def run(jitter):
+        info = attempt(jitter)
+        if info < 0:
+            # GPN_INFO_INTERNAL: a hand-over inside the leaf kernel failed -- says nothing about the
+            # matrix, so adding jitter would only hide it
+            raise NativeError("factorisation reported the internal status %d (not a property of the matrix)" % info)
+        return info
+
+    if run(None) == 0:
         return -1
     for i in range(JITTER_TRIES):
-        if attempt(10.0 ** (-JITTER_TRIES + i)) == 0:
+        if run(10.0 ** (-JITTER_TRIES + i)) == 0:
             return i
     raise RuntimeError("Max tries exceeded.")
 

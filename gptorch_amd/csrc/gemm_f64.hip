@@ -22,6 +22,7 @@
 //    grouped ordering (8 tile-rows per group) so the tiles resident on one XCD
 //    share operand panels in its 4 MiB L2; `lower` drops tiles above the diagonal.
 #include <algorithm>
+#include <atomic>
 #include "gpn_common.h"
 
 namespace gpn {
@@ -313,27 +314,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 static int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
 
 template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
-static int launch(hipStream_t s, const GemmArgs& a0) {
+static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
   const int grid = (a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
   const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
-  static int attr_set = -1;
-  if (attr_set != smem) {
+  static std::atomic<int> attr_set{-1};      // per template instance; racing threads set the same value
+  if (attr_set.load(std::memory_order_acquire) != smem) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = smem;
+    attr_set.store(smem, std::memory_order_release);
   }
   const bool prof = profile_on();
+  int rec = -1;
   if (prof) {
     // executed flops: tiles actually computed x 2*BM*BN*K
     const double tiles = (a.lower ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt) * std::max(1, a.batch);
-    profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K);
+    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : (a.lower ? PROF_GEMM_SYRK : PROF_GEMM));
+    rec = profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K, cls);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
-  if (prof) profile_end(s);
+  if (prof) profile_end(s, rec);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
@@ -388,8 +391,8 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
     if (N > 128 || K > 128 || lower) return GPN_E_UNSUPPORTED;
-    if (g_gemm_variant == 2) return launch<64, 128, 32, 64, true>(s, a);
-    return (tri & GPN_TRI_B_LOWER) ? launch<32, 128, 16, 64, true, 4, true>(s, a) : launch<32, 128, 16, 64, true, 4>(s, a);
+    if (g_gemm_variant == 2) return launch<64, 128, 32, 64, true>(s, a, 1);
+    return (tri & GPN_TRI_B_LOWER) ? launch<32, 128, 16, 64, true, 4, true>(s, a, 1) : launch<32, 128, 16, 64, true, 4>(s, a, 1);
   }
   if (g_gemm_variant == 3) return launch<128, 128, 64, 64, true>(s, a);        // A/B: force a tile shape
   if (g_gemm_variant == 4) return launch<64, 64, 32, 32, true>(s, a);

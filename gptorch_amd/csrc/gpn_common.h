@@ -38,8 +38,17 @@ int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha
 int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
                   int32_t* info);
 
+// launch classes of the optional HIP-event profiler (profile.hip; bench.py's roofline legs)
+enum { PROF_GEMM = 0,         // rectangular contraction (in-panel updates, predict, VFE ...)
+       PROF_GEMM_SYRK = 1,    // lower-tile contraction: the SYRK trailing updates of the factorisation
+       PROF_GEMM_SOLVE = 2,   // in-place panel solve against an inverted leaf block
+       PROF_GEMM_TRI = 3,     // K-clipped contraction (triangular inversion, Kyy^-1 = U U^T)
+       PROF_KMAT = 4,         // K assembly (work = algorithmic bytes)
+       PROF_GRAD = 5,         // gradient sweep (work = algorithmic bytes)
+       PROF_LEAF = 6,         // 128x128 diagonal leaf
+       PROF_NCLASSES = 7 };
 bool profile_on();
-void profile_begin(hipStream_t s, double flops);
-void profile_end(hipStream_t s);
+int profile_begin(hipStream_t s, double work, int cls);
+void profile_end(hipStream_t s, int idx);
 
 }  // namespace gpn

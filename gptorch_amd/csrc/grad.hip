@@ -395,6 +395,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partial,
 template <int KIND, bool LML>
 static int launch_sweep(hipStream_t s, const GradArgs& a, int64_t nblocks) {
   const int nch = (a.d + GDC - 1) / GDC;
+  int rec = -1;
+  if (profile_on())   // algorithmic bytes: the gradient matrix is read once (lower triangle for the LML sweep)
+    rec = profile_begin(s, 8.0 * (LML ? 0.5 * a.n * (a.n + 1.0) : (double)a.n * a.m) + 8.0 * (a.n + (LML ? 0 : a.m)) * a.d, PROF_GRAD);
   switch (nch) {
     case 1: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 1, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 2, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
@@ -402,6 +405,7 @@ static int launch_sweep(hipStream_t s, const GradArgs& a, int64_t nblocks) {
     case 4: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 4, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL((grad_sweep_chunked_kernel<KIND, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
   }
+  if (rec >= 0) profile_end(s, rec);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

@@ -211,6 +211,10 @@ extern "C" int gpn_kernel_matrix(void* stream, int kind, const double* X, int64_
   const unsigned tn = (unsigned)((m + KT - 1) / KT), tm = (unsigned)((n + KT - 1) / KT);
   dim3 grid = a.lower ? dim3(tm * (tm + 1) / 2) : dim3(tn, tm);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  int rec = -1;
+  if (profile_on())   // algorithmic bytes: the entries written once + the points read once
+    rec = profile_begin(s, a.lower ? 8.0 * (0.5 * n * (n + 1.0) + (double)n * d) : 8.0 * ((double)n * m + (double)(n + (symmetric ? 0 : m)) * d),
+                        PROF_KMAT);
   switch (kind) {
     case GPN_RBF: hipLaunchKernelGGL(kmat_kernel<GPN_RBF>, grid, dim3(256), 0, s, a); break;
     case GPN_MATERN52: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN52>, grid, dim3(256), 0, s, a); break;
@@ -219,6 +223,7 @@ extern "C" int gpn_kernel_matrix(void* stream, int kind, const double* X, int64_
     case GPN_PERIODIC: hipLaunchKernelGGL(kmat_kernel<GPN_PERIODIC>, grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(kmat_kernel<GPN_SQDIST>, grid, dim3(256), 0, s, a); break;
   }
+  if (rec >= 0) profile_end(s, rec);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

@@ -492,7 +492,14 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   if (!PIPE && !failflag) store_panel(Xp[1], 120);     // last panel (kb8 = 15 lives in buffer 1)
   __syncthreads();
   if (failflag) {
-    if (tid == 0 && info && *info == 0) *info = col0 + failflag;
+    // failflag == LEAF + 1: the software barrier of the tile waves lost an arrival (bounded spin
+    // ran out) -- an internal failure, NOT a statement about the matrix: reported as the negative
+    // status GPN_INFO_INTERNAL, which overrides any pivot index and which the shell raises on
+    // instead of climbing the jitter ladder.
+    if (tid == 0 && info) {
+      if (failflag > LEAF) *info = GPN_INFO_INTERNAL;
+      else if (*info == 0) *info = col0 + failflag;
+    }
     // leave the rest of A untouched; publish a finite (zero) winv so later kernels stay finite
     for (int idx = tid; idx < LEAF * LEAF; idx += LEAF_THREADS) winv[idx] = 0.0;
   }
@@ -621,12 +628,14 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       const int64_t c1 = k0 + kb;                 // first row/column after this block
       double* Akk = A + k0 * lda + k0;
       const double* Wk = c.winv + (k0 / LEAF) * (LEAF * LEAF);
+      const int rec = profile_on() ? profile_begin(c.s, 2.0 * LEAF * LEAF * LEAF / 3.0, PROF_LEAF) : -1;
       if (g_leaf_pipe)
         hipLaunchKernelGGL((potrf_leaf_kernel<true, false, true>), dim3(1), dim3(LEAF_THREADS), 0, c.s, Akk, lda, (int)kb,
                            (int)k0, const_cast<double*>(Wk), c.info, 0, nullptr);
       else
         hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, Akk, lda, (int)kb, (int)k0,
                            const_cast<double*>(Wk), c.info, 0, nullptr);
+      if (rec >= 0) profile_end(c.s, rec);
       hip_ok(hipGetLastError());
       const int64_t m = n + e - c1;                // rows below (incl. the extra rows)
       if (m <= 0 || c.rc != GPN_OK) continue;
@@ -853,6 +862,32 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
   if (g_potrf_variant == 1 || n <= 2 * LEAF) potrf_rec(c, A, n, e, 0);
   else potrf_lookahead(c, A, n, e);
   return c.rc;
+}
+
+// panel width of the look-ahead driver for an n x n factorisation (what bench.py needs to count the
+// algorithmic flops of the SYRK trailing updates: one lower-tile K = width contraction per panel)
+extern "C" int64_t gpn_potrf_panel_width(int64_t n) { return (g_potrf_variant == 1 || n <= 2 * LEAF) ? 0 : panel_width(n); }
+
+// The library keeps one low-priority helper stream + a few events per caller stream that has run a
+// factorisation (created on first use).  A caller that destroys a stream releases them here, so a
+// recycled hipStream_t handle never meets stale helpers.  stream == NULL releases all of them.
+extern "C" int gpn_release_stream(void* stream) {
+  std::lock_guard<std::mutex> lock(g_aux_mutex);
+  auto drop = [](Aux& a) {
+    if (a.s1) { (void)hipStreamSynchronize(a.s1); (void)hipStreamDestroy(a.s1); }
+    for (int i = 0; i < 4; ++i) {
+      if (a.solve[i]) (void)hipEventDestroy(a.solve[i]);
+      if (a.rest[i]) (void)hipEventDestroy(a.rest[i]);
+    }
+  };
+  if (!stream) {
+    for (auto& kv : g_aux) drop(kv.second);
+    g_aux.clear();
+    return GPN_OK;
+  }
+  auto it = g_aux.find(static_cast<hipStream_t>(stream));
+  if (it != g_aux.end()) { drop(it->second); g_aux.erase(it); }
+  return GPN_OK;
 }
 
 extern "C" int gpn_debug_set_potrf_variant(int v) {

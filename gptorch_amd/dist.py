@@ -1,37 +1,60 @@
 """
-2-D block-cyclic exact-GP log marginal likelihood over the GPUs of one node
-(BASELINE.json config 4: N = 65536 across 8 x MI355X).
+2-D block-cyclic exact-GP log marginal likelihood (and its closed-form backward) over the GPUs
+of one node (BASELINE.json config 4: N = 65536 across 8 x MI355X).  The
+reference has no multi-GPU path at all (`gptorch/models/base.py:33` "Assume single GPU"); this
+is the distributed form of `GPR.log_likelihood` (gpr.py:47-67) and of its autograd backward.
 
-One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The
-N x N Gram matrix is cut into T x T tiles; tile (I, J), I >= J, lives on rank
-(I mod Pr) * Pc + (J mod Pc) of a Pr x Pc process grid.  X [N, D] is tiny and
-replicated; every rank ASSEMBLES ITS OWN TILES with the native K-assembly kernel
-(no communication).  Right-looking factorisation, one exchange step per tile column k:
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The N x N Gram
+matrix is cut into T x T tiles; tile (I, J), I >= J, lives on rank (I mod Pr) * Pc + (J mod Pc)
+of a Pr x Pc process grid (Pr divides Pc: 1x1, 1x2, 2x2, 2x4).
 
-  1. owner of (k,k) factors it (gpn_potrf_lower) and broadcasts L_kk (+ the inverses of
-     its 128x128 diagonal blocks) down its process COLUMN  -> column sub-communicator
-  2. owners of (I,k), I > k, solve  A_Ik <- A_Ik L_kk^-T  (gpn_trsm_right_lt)
-  3. panel tile (I,k) is broadcast along process ROW I mod Pr (it multiplies from the
-     left in the updates of tile row I) and along process COLUMN I mod Pc (it multiplies
-     from the right in tile column I)            -> row / column sub-communicators
-  4. every rank updates the trailing tiles it owns:  A_IJ -= P_I P_J^T  (gpn_gemm_nt,
-     lower-only on diagonal tiles)
+Layout in HBM (one allocation per rank, made once and reused by every evaluation):
 
-Look-ahead: after the exchange of panel k, tile column k+1 is updated FIRST and
-its diagonal tile is factored, broadcast and its panel solved; the row and column broadcasts of
-panel k+1 are then issued asynchronously (`async_op=True`: RCCL runs them on its own stream) in
-front of the two halves of the remaining trailing update by panel k (`factor`), so the next
-panel's collectives are in flight while every rank is busy with the bulk of step 4.
+    Aloc [rows, ld]   row-major fp64, ld = (#my tile columns) * T
+      rows  0 .. nrow_t*T          my tile rows I = r, r+Pr, ... stacked in ascending order
+                                   (a ragged last tile still takes T rows, zero padded)
+      rows  res_off .. +dy         the residual (y - m)^T  -- only in process row nt mod Pr;
+                                   becomes alpha^T = (L^-1 (y-m))^T            ("extra rows")
+      rows  id_off .. +nrow_t*T    (backward only) identity blocks i = r, r+Pr, ...: block i is
+                                   I at tile column i and becomes U_i,: = (L^-T)_i,: from there on
+      columns                      my tile columns J = c, c+Pc, ... side by side
 
-The residual (y - m)^T is carried as one extra tile ROW (index nt) exactly like the
-single-GPU "extra rows", so alpha^T = (L^-1 (y-m))^T falls out of steps 2-4.  xGMI is a
-full mesh of point-to-point links, so the row/column broadcasts of step 3 run on
-disjoint links concurrently; only the two scalars (sum log L_ii, ||alpha||^2) are
-all-reduced.
+With this order the rows that take part in panel k -- matrix tile rows I > k, the residual and
+the identity blocks i <= k -- are ONE contiguous row range of Aloc on every rank, so each step
+of the factorisation is a handful of large launches and packed collectives instead of one
+launch and one message per tile:
 
-The dense arithmetic is behind a small `TileOps` interface: `NativeTileOps` (the product)
-calls libgpnative through `_ops`; the CPU test-suite injects a torch-CPU implementation
-to exercise this orchestration under gloo with world_size 2 and 4 (tests/test_dist_gloo.py).
+  1. the owner of (k,k) factors it (gpn_potrf_lower) and sends  [L_kk | leaf inverses]  as ONE
+     packed buffer down its process COLUMN (nothing to send when Pr = 1);
+  2. every rank of that process column solves ALL its panel rows in one call
+     (gpn_trsm_right_lt on the stacked rows);
+  3. the solved rows are packed and sent along each process ROW (one broadcast per process row:
+     every rank then holds the panel rows of its own tile rows = the left operands);
+  4. the tiles P_J that multiply from the right in my tile columns J all live in process row
+     c mod Pr (because Pr | Pc), so ONE packed broadcast down each process column delivers them;
+  5. trailing update: per local tile column one contraction over the stacked rows below it
+     (gpn_gemm_nt, K = T) plus a lower-only one for a diagonal tile.
+
+Look-ahead: after the exchange of panel k only tile column k+1 is updated before
+ITS diagonal tile is factored and its panel solved; the row broadcast of panel k+1 is then in
+flight (async_op: RCCL runs it on its own stream) under the first half of the remaining
+trailing update by panel k and the column broadcast under the second half.  Receive buffers
+are allocated once (two sets, alternating by panel parity); nothing is allocated and the host
+never waits inside `factor()` -- the only read-back is one small all-reduced vector at the end
+(log-det partials, |alpha|^2 and the per-tile `info` words).
+
+xGMI is a full mesh of point-to-point links, so the row and column broadcasts run on disjoint
+links concurrently.  The backward runs on the same grid: U = L^-T falls out of the same panel
+solves / updates (the stacked [A ; I] trick of the leaf kernel at tile scale), Kyy^-1 = U U^T is
+accumulated with the tile columns of U travelling exactly like factorisation panels, and D + 2
+gradient scalars are all-reduced.
+
+The dense arithmetic is behind a small `TileOps` interface: `NativeTileOps` (the product) calls
+libgpnative through `_ops`; the CPU test-suite injects a torch-CPU implementation to exercise
+this orchestration under gloo with world_size 2 and 4 (tests/test_dist_gloo.py).
+
+`phantom=(rank, world)`: timing aid for a 1-GPU box -- do the work of ONE rank of a larger grid
+with the collectives skipped (results are meaningless, the launches and their sizes are real).
 """
 import math
 
@@ -39,6 +62,8 @@ import torch
 import torch.distributed as dist
 
 from . import _ops
+
+LEAF = _ops.LEAF
 
 
 def choose_grid(world):
@@ -50,31 +75,26 @@ def choose_grid(world):
 
 
 class NativeTileOps:
-    """Tile arithmetic on libgpnative (fp64 tensors on this rank's GPU)."""
+    """Tile arithmetic on libgpnative (fp64 tensors / strided 2-D views on this rank's GPU)."""
 
     def __init__(self, device):
         self.device = device
 
-    def new_tile(self, rows, cols):
-        """zeroed factor-style buffer holding a rows x cols tile (ld multiple of 128, +apron)."""
-        return torch.zeros(_ops.round_up(rows, _ops.LEAF) + 16, _ops.round_up(cols, _ops.LEAF), dtype=torch.float64,
-                           device=self.device)
+    def zeros(self, rows, cols):
+        return torch.zeros(rows, cols, dtype=torch.float64, device=self.device)
 
-    def kernel_tile(self, kind, Xi, Xj, variance, ls, noise, out):
-        """out[:ri, :rj] <- K(Xi, Xj) (+ noise*I when Xj is None)."""
-        _ops.kernel_matrix(kind, Xi, Xj, variance, ls, noise=noise, out=out, ldk=out.stride(0))
-
-    def potrf(self, tile, n):
-        """in-place lower Cholesky of tile[:n,:n]; returns (winv, info_tensor)."""
-        winv = torch.empty(int(_ops._native.lib().gpn_winv_bytes(n)) // 8, dtype=torch.float64, device=tile.device)
-        info = torch.zeros(1, dtype=torch.int32, device=tile.device)
-        st = _ops._native.lib().gpn_potrf_lower(_ops._stream(tile.device), _ops._ptr(tile), n, 0, tile.stride(0),
-                                                _ops._ptr(winv), _ops._ptr(info))
-        _ops._native.check(st, "gpn_potrf_lower")
-        return winv, info
+    def kernel_block(self, kind, Xi, Xj, variance, ls, out):
+        """out[:ri, :rj] <- K(Xi, Xj) (rectangular; out is a view with a leading dimension)."""
+        _ops.kernel_matrix(kind, Xi, Xj, variance, ls, out=out, ldk=out.stride(0))
 
     def winv_numel(self, n):
         return int(_ops._native.lib().gpn_winv_bytes(n)) // 8
+
+    def potrf(self, A, n, e, winv, info):
+        """in-place lower Cholesky of A[:n,:n] carrying the e rows below it; info: int32 view."""
+        st = _ops._native.lib().gpn_potrf_lower(_ops._stream(A.device), _ops._ptr(A), n, e, A.stride(0),
+                                                _ops._ptr(winv), _ops._ptr(info))
+        _ops._native.check(st, "gpn_potrf_lower")
 
     def trsm(self, L, winv, n, B, m):
         """B[:m,:n] <- B L^-T."""
@@ -82,12 +102,15 @@ class NativeTileOps:
                                                   _ops._ptr(winv), _ops._ptr(B), m, B.stride(0))
         _ops._native.check(st, "gpn_trsm_right_lt")
 
-    def update(self, C, A, B, m, n, k, lower, alpha=-1.0):
-        """C[:m,:n] += alpha A[:m,:k] B[:n,:k]^T (lower: only j <= i)."""
-        _ops.gemm_nt(A, B, m, n, _ops.round_up(k, 16), alpha=alpha, beta=1.0, C=C, lower=lower)
+    def update(self, C, A, B, m, n, k, lower, alpha=-1.0, beta=1.0):
+        """C[:m,:n] = alpha A[:m,:k] B[:n,:k]^T + beta C (lower: only j <= i)."""
+        _ops.gemm_nt(A, B, m, n, _ops.round_up(k, 16), alpha=alpha, beta=beta, C=C, lower=lower)
 
-    def set_identity(self, tile, n):
-        tile.diagonal()[:n].fill_(1.0)
+    def copy(self, dst, src, rows, cols):
+        """dst[:rows,:cols] <- src[:rows,:cols] (both strided row-major views)."""
+        st = _ops._native.lib().gpn_copy_matrix(_ops._stream(dst.device), _ops._ptr(src), rows, cols, src.stride(0),
+                                                _ops._ptr(dst), dst.stride(0), 0)
+        _ops._native.check(st, "gpn_copy_matrix")
 
     def kernel_grad(self, kind, Xi, Xj, variance, ls, G):
         """-> tensor [1 + nls]: sum G * dK(Xi, Xj)/d(variance, length_scales) (gpn_kernel_grad)."""
@@ -95,43 +118,79 @@ class NativeTileOps:
         gv, gl = _backward.kernel_backward(kind, Xi, Xj, variance, ls, G)
         return torch.cat([gv, gl])
 
-    def log_diag_sum(self, tile, n):
-        return tile.diagonal()[:n].log().sum()
+    def log_diag_sum(self, A, n):
+        out = torch.empty(3, dtype=torch.float64, device=A.device)
+        st = _ops._native.lib().gpn_lml_reduce(_ops._stream(A.device), _ops._ptr(A), n, 0, A.stride(0), _ops._ptr(out))
+        _ops._native.check(st, "gpn_lml_reduce")
+        return out[0]
 
-    def sumsq(self, tile, m, n):
-        return tile[:m, :n].pow(2).sum()
+    def sumsq(self, A, m, n):
+        return _ops.row_sumsq(A, m, n).sum()
 
 
 class BlockCyclicGP:
     """Distributed LML for a stationary kernel.  All ranks call every method collectively."""
 
-    def __init__(self, X, Y, kind, tile=2048, grid=None, ops=None, group=None):
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+    def __init__(self, X, Y, kind, tile=2048, grid=None, ops=None, group=None, phantom=None, force_comm=False):
+        """force_comm: issue the row / column collectives even where a sub-communicator has a single
+        member (world 1, or Pr = 1) -- a test hook that drives the RCCL calls on a 1-GPU box."""
+        live = dist.is_available() and dist.is_initialized() and phantom is None
+        self.rank = dist.get_rank(group) if live else 0
+        self.world = dist.get_world_size(group) if live else 1
+        self.comm = live and (self.world > 1 or force_comm)
+        if phantom is not None:
+            self.rank, self.world = phantom
         self.pr, self.pc = grid if grid is not None else choose_grid(self.world)
-        assert self.pr * self.pc == self.world
+        if self.pr * self.pc != self.world or self.pc % self.pr:
+            raise ValueError("process grid %dx%d does not fit %d ranks (Pr must divide Pc)" % (self.pr, self.pc, self.world))
         self.my_r, self.my_c = divmod(self.rank, self.pc)
         self.X, self.Y, self.kind = X, Y, kind
         self.n, self.dy = Y.shape
         self.T = int(tile)
-        assert self.T % _ops.LEAF == 0
+        if self.T % LEAF:
+            raise ValueError("tile must be a multiple of %d" % LEAF)
         self.nt = (self.n + self.T - 1) // self.T
         self.ops = ops if ops is not None else NativeTileOps(X.device)
         self.group = group
         # sub-communicators: one per process row and per process column (created collectively)
-        self.row_groups, self.col_groups = {}, {}
-        if self.world > 1:
+        self.row_group = self.col_group = None
+        self.xrow = self.comm and (self.pc > 1 or force_comm)      # panels travel along process rows
+        self.xcol = self.comm and (self.pr > 1 or force_comm)      # ... and down process columns
+        if self.comm:
             for r in range(self.pr):
                 ranks = [r * self.pc + c for c in range(self.pc)]
-                g = dist.new_group(ranks)
-                self.row_groups[r] = (g, ranks)
+                g = dist.new_group(ranks) if self.xrow else None
+                if r == self.my_r:
+                    self.row_group = g
             for c in range(self.pc):
                 ranks = [r * self.pc + c for r in range(self.pr)]
-                g = dist.new_group(ranks)
-                self.col_groups[c] = (g, ranks)
-        self.tiles = {}
+                g = dist.new_group(ranks) if self.xcol else None
+                if c == self.my_c:
+                    self.col_group = g
+        # -- local geometry -------------------------------------------------------
+        T, nt, r, c = self.T, self.nt, self.my_r, self.my_c
+        self.nrow_t = len(range(r, nt, self.pr))
+        self.ncol_t = len(range(c, nt, self.pc))
+        self.has_res = (nt % self.pr) == r
+        self.res_off = self.nrow_t * T
+        self.id_off = self.res_off + (_ops.round_up(self.dy, LEAF) if self.has_res else 0)
+        self.ld = max(self.ncol_t, 1) * T
+        dev = X.device
+        # X rows in my local row / column order (the ragged tile is the last one in both orders,
+        # so the real rows are a prefix)
+        ridx = torch.cat([torch.arange(I * T, I * T + self.rows_of(I)) for I in range(r, nt, self.pr)] or
+                         [torch.zeros(0, dtype=torch.long)]).to(dev)
+        cidx = torch.cat([torch.arange(J * T, J * T + self.rows_of(J)) for J in range(c, nt, self.pc)] or
+                         [torch.zeros(0, dtype=torch.long)]).to(dev)
+        self.ridx, self.cidx = ridx, cidx
+        self.Xrow = X.index_select(0, ridx).contiguous()
+        self.Xcol = X.index_select(0, cidx).contiguous()
+        self.A = None                  # allocated on first use (size depends on with_inverse)
+        self.kinv = None
+        self._alloc_inverse = False
         self.info = 0
         self.with_inverse = False      # carry I through the factorisation (-> U = L^-T) for the backward
+        self._dirty = False            # a failed factorisation may have left non-finite padding
 
     # -- geometry ---------------------------------------------------------------
     def owner(self, I, J):
@@ -152,218 +211,289 @@ class BlockCyclicGP:
             I = I - self.nt - 1
         return min(self.T, self.n - I * self.T)
 
-    def _prow(self, I):
-        """process row of tile row I."""
-        return ((I - self.nt - 1) if I > self.nt else I) % self.pr
+    def _rows_le(self, k, r=None):
+        """how many of process row r's tile rows have index <= k."""
+        r = self.my_r if r is None else r
+        return 0 if k < r else min((k - r) // self.pr + 1, len(range(r, self.nt, self.pr)))
 
-    def _panel_rows(self, k):
-        """tile rows that have a tile in column k below the diagonal tile (k,k): matrix rows,
-        the residual row and -- when the inverse is carried along -- the identity rows already
-        met by the pivots (block i becomes non-zero at column i)."""
-        rows = list(range(k + 1, self.nt)) + [self.nt]
+    def _cols_le(self, k):
+        c = self.my_c
+        return 0 if k < c else min((k - c) // self.pc + 1, self.ncol_t)
+
+    def _active(self, k):
+        """[lo, hi): my local rows that take part in panel k (matrix tile rows > k, the residual,
+        identity blocks <= k) -- contiguous by construction of the layout."""
+        lo = self._rows_le(k) * self.T
         if self.with_inverse:
-            rows += [self.nt + 1 + i for i in range(k + 1)]
-        return rows
-
-    def _bcast(self, t, src, groups, key):
-        if self.world == 1:
-            return
-        g, ranks = groups[key]
-        if len(ranks) > 1:
-            dist.broadcast(t, src=src, group=g)
-
-    # -- assembly ---------------------------------------------------------------
-    def assemble(self, variance, length_scales, noise, resid):
-        """each rank builds the tiles it owns; resid = y - m(x) [n, dy] (replicated)."""
-        ops, T = self.ops, self.T
-        self.tiles = {}
-        for I in range(self.nt):
-            xi = self.X[I * T:I * T + self.rows_of(I)]
-            for J in range(I + 1):
-                if not self.mine(I, J):
-                    continue
-                t = ops.new_tile(self.rows_of(I), self.rows_of(J))
-                if I == J:
-                    ops.kernel_tile(self.kind, xi, None, variance, length_scales, noise, t)
-                else:
-                    ops.kernel_tile(self.kind, xi, self.X[J * T:J * T + self.rows_of(J)], variance, length_scales,
-                                    None, t)
-                self.tiles[(I, J)] = t
-        for J in range(self.nt):   # residual tile row
-            if self.mine(self.nt, J):
-                t = ops.new_tile(self.dy, self.rows_of(J))
-                t[:self.dy, :self.rows_of(J)] = resid[J * T:J * T + self.rows_of(J)].t()
-                self.tiles[(self.nt, J)] = t
-        if self.with_inverse:      # identity rows: block i = rows of I that start at column i
-            for i in range(self.nt):
-                R = self.nt + 1 + i
-                for J in range(i, self.nt):
-                    if self.mine(R, J):
-                        t = ops.new_tile(self.rows_of(i), self.rows_of(J))
-                        if J == i:
-                            ops.set_identity(t, self.rows_of(i))
-                        self.tiles[(R, J)] = t
-
-    # -- factorisation ------------------------------------------------------------
-    def _panel_phase(self, k, info_local):
-        """steps 1-2 for tile column k: diagonal factor + broadcast down its process column,
-        panel solves on my tiles of that column.  Returns the updated local info."""
-        ops, nt, dev = self.ops, self.nt, self.X.device
-        nk, ck = self.rows_of(k), k % self.pc
-        if self.my_c != ck:
-            return info_local
-        diag_owner = self.owner(k, k)
-        if self.rank == diag_owner:
-            Lkk = self.tiles[(k, k)]
-            winv, info = ops.potrf(Lkk, nk)
-            bad = info.to(torch.int64)
-            info_local = torch.where((info_local == 0) & (bad != 0), bad + k * self.T, info_local)
+            hi = self.id_off + self._rows_le(k) * self.T
         else:
-            Lkk = ops.new_tile(nk, nk)
-            winv = torch.empty(self.ops.winv_numel(nk), dtype=torch.float64, device=dev)
-        self._bcast(Lkk, diag_owner, self.col_groups, ck)
-        self._bcast(winv, diag_owner, self.col_groups, ck)
-        for I in self._panel_rows(k):
-            if self.mine(I, k):
-                ops.trsm(Lkk, winv, nk, self.tiles[(I, k)], self.rows_of(I))
-        return info_local
+            hi = self.res_off + (self.dy if self.has_res else 0)
+        return lo, max(hi, lo)
 
-    def _bcast_async(self, t, src, groups, key):
-        """-> Work handle or None; the collective runs on the backend's own stream."""
-        if self.world == 1:
+    def local_shape(self):
+        return tuple(self.A.shape) if self.A is not None else None
+
+    # -- buffers ------------------------------------------------------------------
+    def _ensure_buffers(self):
+        T, ops = self.T, self.ops
+        if self.A is not None and (self._alloc_inverse or not self.with_inverse):
+            return
+        self._alloc_inverse = self.with_inverse
+        rows = self.id_off + (self.nrow_t * T if self.with_inverse else 0) + LEAF
+        self.A = ops.zeros(rows, self.ld)
+        # panel operands: left = the panel rows of my tile rows, right = the panel tiles of my tile
+        # columns; two sets, alternating by panel parity (one is read by the trailing update while
+        # the next panel is being received into the other)
+        lrows = (rows + T - 1) // T * T
+        self.left = [ops.zeros(lrows + 16, T) for _ in range(2)]
+        self.right = [ops.zeros(max(self.ncol_t, 1) * T + 16, T) for _ in range(2)]
+        self.wn = ops.winv_numel(T)
+        self.diag = ops.zeros(T * T + self.wn, 1).view(-1)        # [L_kk | leaf inverses], packed
+        self.winv = ops.zeros(self.wn, 1).view(-1)
+        self.stats = ops.zeros(self.nt + 2, 1).view(-1)           # log-det partial, |alpha|^2, info per tile
+        self.info_t = torch.zeros(self.nt, dtype=torch.int32, device=self.X.device)
+        self._dirty = False
+
+    # -- collectives ----------------------------------------------------------------
+    def _bcast(self, t, src, group, async_op=False):
+        """broadcast a contiguous tensor inside a row / column sub-communicator; -> Work or None."""
+        if not self.comm or group is None:
             return None
-        g, ranks = groups[key]
-        if len(ranks) > 1:
-            return dist.broadcast(t, src=src, group=g, async_op=True)
-        return None
-
-    def _start_rows(self, k):
-        """step 3a, asynchronous: panel tile (I,k) along process row I mod Pr (left operand of
-        tile row I).  Returns (left, works)."""
-        ops, nt, nk = self.ops, self.nt, self.rows_of(k)
-        left, works = {}, []
-        for I in self._panel_rows(k):
-            src = self.owner(I, k)
-            rI = self._prow(I)
-            if self.my_r == rI:
-                t = self.tiles[(I, k)] if self.rank == src else ops.new_tile(self.rows_of(I), nk)
-                w = self._bcast_async(t, src, self.row_groups, rI)
-                if w is not None:
-                    works.append(w)
-                left[I] = t
-        return left, works
-
-    def _start_cols(self, k, left):
-        """step 3b, asynchronous (after 3a has completed on this rank): P_I down process column
-        I mod Pc (right operand of tile column I).  Returns (right, works)."""
-        ops, nt, nk = self.ops, self.nt, self.rows_of(k)
-        right, works = {}, []
-        for I in range(k + 1, nt):
-            cI = I % self.pc
-            if self.my_c == cI:
-                # the source is the member of process column cI that already holds P_I: (I mod Pr, cI)
-                src = (I % self.pr) * self.pc + cI
-                t = left[I] if self.rank == src else left.get(I)
-                if t is None:
-                    t = ops.new_tile(self.rows_of(I), nk)
-                w = self._bcast_async(t, src, self.col_groups, cI)
-                if w is not None:
-                    works.append(w)
-                right[I] = t
-        return right, works
+        return dist.broadcast(t, src=src, group=group, async_op=async_op)
 
     @staticmethod
     def _wait(works):
         for w in works:
-            w.wait()
+            if w is not None:
+                w.wait()
 
-    def _update(self, k, left, right, columns):
-        """step 4 restricted to my tiles in the given tile columns."""
+    # -- assembly ---------------------------------------------------------------
+    def assemble(self, variance, length_scales, noise, resid):
+        """each rank builds the tiles it owns -- one rectangular K(X_rows, X_J) per local tile
+        column over all my tile rows at or below the diagonal; resid = y - m(x) [n, dy]."""
+        ops, T, nt = self.ops, self.T, self.nt
+        self._ensure_buffers()
+        if self._dirty:
+            self.A.zero_()
+            for b in self.left + self.right:
+                b.zero_()
+            self._dirty = False
+        A = self.A
+        nreal = self.Xrow.shape[0]
+        for lj, J in enumerate(range(self.my_c, nt, self.pc)):
+            nJ = self.rows_of(J)
+            li0 = self._rows_le(J - 1)                 # first of my tile rows with I >= J
+            r0 = li0 * T
+            if r0 >= nreal:
+                continue
+            xj = self.Xcol[lj * T:lj * T + nJ]
+            ops.kernel_block(self.kind, self.Xrow[r0:nreal], xj, variance, length_scales, A[r0:nreal, lj * T:lj * T + nJ])
+            if li0 * self.pr + self.my_r == J:         # the diagonal tile is mine: + noise I (gpr.py:83-86)
+                A[r0:r0 + nJ, lj * T:lj * T + nJ].diagonal().add_(noise.reshape(()))
+        if self.has_res and self.ncol_t:
+            A[self.res_off:self.res_off + self.dy, :self.cidx.numel()] = resid.index_select(0, self.cidx).t()
+        if self.with_inverse:
+            A[self.id_off:self.id_off + self.nrow_t * T].zero_()
+            for li, i in enumerate(range(self.my_r, nt, self.pr)):
+                if i % self.pc == self.my_c:
+                    lj = (i - self.my_c) // self.pc
+                    ni = self.rows_of(i)
+                    A[self.id_off + li * T:self.id_off + li * T + ni, lj * T:lj * T + ni].diagonal().fill_(1.0)
+
+    # -- factorisation ------------------------------------------------------------
+    def _panel_phase(self, k):
+        """steps 1-2 for tile column k: diagonal factor (+ packed broadcast down its process
+        column), panel solve of all my rows of that column in one call."""
+        ops, T = self.ops, self.T
+        nk, ck = self.rows_of(k), k % self.pc
+        if self.my_c != ck:
+            return
+        lk = (k - self.my_c) // self.pc
+        lo, hi = self._active(k)
+        m = hi - lo
+        colk = self.A[:, lk * T:lk * T + nk]
+        diag_mine = (k % self.pr) == self.my_r
+        exchange = self.xcol
+        Lp, Wp = self.diag[:T * T].view(T, T), self.diag[T * T:]
+        L = Lp
+        if diag_mine:
+            d0 = (self._rows_le(k) - 1) * T
+            L = colk[d0:]
+            self.ops.potrf(L, nk, 0, Wp, self.info_t[k:k + 1])
+            if exchange:
+                ops.copy(Lp, L, nk, nk)
+                L = Lp
+        if exchange:
+            self._bcast(self.diag, (k % self.pr) * self.pc + ck, self.col_group)
+        if m:
+            ops.trsm(L, Wp, nk, colk[lo:], m)
+
+    def _start_rows(self, k, matrix=None):
+        """step 3, asynchronous: the solved panel rows of process row r, packed, from their owner
+        (r, k mod Pc) to the whole process row.  -> (left buffer, [work])."""
+        ops, T = self.ops, self.T
+        nk, ck = self.rows_of(k), k % self.pc
+        lo, hi = self._active(k) if matrix is None else matrix
+        m = hi - lo
+        buf = self.left[k & 1]
+        if m == 0:
+            return buf, []
+        if nk < T:
+            buf[:, nk:].zero_()                                   # K padding of the ragged last panel
+        if self.my_c == ck:
+            lk = (k - self.my_c) // self.pc
+            ops.copy(buf, self.A[lo:hi, lk * T:lk * T + nk], m, nk)
+        w = self._bcast(buf.view(-1)[:m * T], self.my_r * self.pc + ck, self.row_group, async_op=True)
+        return buf, [w]
+
+    def _start_cols(self, k, left, first_tile=None, count=None):
+        """step 4, asynchronous (after step 3 has completed on this rank): the panel tiles P_J of
+        my tile columns J > k.  They all sit in process row c mod Pr (Pr | Pc), in that rank's
+        left buffer, every Pc/Pr-th tile: gathered into one packed buffer and broadcast down the
+        process column.  -> (right operand [count*T, T], [work])."""
+        T = self.T
+        rs = self.my_c % self.pr                                  # process row that holds my P_J
+        if first_tile is None:
+            lj0 = self._cols_le(k)                                # my first tile column > k
+            count = self.ncol_t - lj0
+            J0 = lj0 * self.pc + self.my_c
+            first_tile = (J0 - rs) // self.pr - self._rows_le(k, rs)   # its slot in rs's left buffer
+        if count <= 0:
+            return self.right[k & 1], []
+        step = self.pc // self.pr
+        i_am_src = self.my_r == rs
+        if i_am_src and step == 1:
+            buf = left[first_tile * T:]                           # already contiguous: no gather
+        else:
+            buf = self.right[k & 1]
+            if i_am_src:
+                nslot = (left.shape[0] - 16) // T
+                src = left[:nslot * T].view(nslot, T, T)[first_tile::step][:count]
+                buf[:count * T].view(count, T, T).copy_(src)
+        w = self._bcast(buf.view(-1)[:count * T * T], rs * self.pc + self.my_c, self.col_group, async_op=True) \
+            if self.xcol else None
+        return buf, [w]
+
+    def _update(self, k, left, right, lj_from, lj_to):
+        """step 5 restricted to my local tile columns [lj_from, lj_to): per column one contraction
+        over the stacked rows below the diagonal tile, plus a lower-only one for a diagonal tile."""
+        ops, T = self.ops, self.T
         nk = self.rows_of(k)
-        for (I, J), t in self.tiles.items():
-            # matrix / residual rows: tiles on or below the diagonal; identity rows: only those
-            # the pivots have met (they are exactly the ones with a panel tile in `left`)
-            if J > k and J in columns and I in left and (I >= J):
-                self.ops.update(t, left[I], right[J], self.rows_of(I), self.rows_of(J), nk, lower=(I == J))
+        lo, hi = self._active(k)
+        base = self._cols_le(k)
+        A = self.A
+        for lj in range(max(lj_from, base), min(lj_to, self.ncol_t)):
+            J = lj * self.pc + self.my_c
+            nJ = self.rows_of(J)
+            li0 = self._rows_le(J - 1)
+            r0 = max(li0 * T, lo)
+            if r0 >= hi:
+                continue
+            B = right[(lj - base) * T:]
+            if li0 < self.nrow_t and li0 * self.pr + self.my_r == J:
+                ops.update(A[r0:, lj * T:], left[r0 - lo:], B, nJ, nJ, nk, lower=True)
+                r0 += T
+            if hi > r0:
+                ops.update(A[r0:, lj * T:], left[r0 - lo:], B, hi - r0, nJ, nk, lower=False)
 
     def factor(self):
-        """right-looking block-cyclic Cholesky carrying the residual row, with look-ahead: after
-        the exchange of panel k only tile column k+1 is updated before ITS diagonal tile is
-        factored, broadcast and its panel solved (the critical path of step k+1); the rest of
-        the trailing update by panel k follows, so the other process columns never wait for the
-        next panel.  Every tile still receives its updates in the order k = 0, 1, ... .
+        """right-looking block-cyclic Cholesky carrying the residual row, with look-ahead (module
+        docstring).  Every tile still receives its updates in the order k = 0, 1, ... .
         Returns the global LAPACK-style info (0 = ok)."""
         nt = self.nt
-        info_local = torch.zeros(1, dtype=torch.int64, device=self.X.device)
-        info_local = self._panel_phase(0, info_local)
-        left, works = self._start_rows(0)
-        self._wait(works)
-        right, works = self._start_cols(0, left)
-        for k in range(nt):
-            self._wait(works)                                   # panel k is everywhere it is needed
-            self._update(k, left, right, {k + 1})
-            rest = list(range(k + 2, nt))
-            half = (len(rest) + 1) // 2
-            if k + 1 < nt:
-                info_local = self._panel_phase(k + 1, info_local)
-                nleft, works = self._start_rows(k + 1)          # in flight under the first half ...
-                self._update(k, left, right, set(rest[:half]))
+        self.info_t.zero_()
+        self._panel_phase(0)
+        left = right = None
+        works = []
+        if nt > 1:
+            left, works = self._start_rows(0)
+            self._wait(works)
+            right, works = self._start_cols(0, left)
+        for k in range(nt - 1):
+            self._wait(works)                                     # panel k is everywhere it is needed
+            works = []
+            nxt = self._cols_le(k + 1) - 1 if (k + 1) % self.pc == self.my_c else -1
+            if nxt >= 0:
+                self._update(k, left, right, nxt, nxt + 1)        # tile column k+1 first ...
+            self._panel_phase(k + 1)                              # ... so only ITS panel is on the critical path
+            if k + 2 < nt:
+                nleft, works = self._start_rows(k + 1)            # in flight under the first half ...
+                a = self._cols_le(k + 1)
+                half = a + (self.ncol_t - a + 1) // 2
+                self._update(k, left, right, a, half)
                 self._wait(works)
-                nright, works = self._start_cols(k + 1, nleft)  # ... and under the second half
-                self._update(k, left, right, set(rest[half:]))
+                nright, works = self._start_cols(k + 1, nleft)    # ... and under the second half
+                self._update(k, left, right, half, self.ncol_t)
                 left, right = nleft, nright
-            else:
-                works = []
-        if self.world > 1:
-            dist.all_reduce(info_local, op=dist.ReduceOp.MAX, group=self.group)
-        self.info = int(info_local.item())
+        return self._finish()
+
+    def _finish(self):
+        """one small all-reduce: log-det partials, |alpha|^2 and every tile's info word."""
+        ops, T, nt = self.ops, self.T, self.nt
+        st = self.stats
+        st.zero_()
+        for lj, J in enumerate(range(self.my_c, nt, self.pc)):
+            if J % self.pr == self.my_r:
+                li = (J - self.my_r) // self.pr
+                st[0] += ops.log_diag_sum(self.A[li * T:, lj * T:], self.rows_of(J))
+        if self.has_res and self.ncol_t:
+            st[1] += ops.sumsq(self.A[self.res_off:], self.dy, self.cidx.numel())
+        st[2:] += self.info_t.to(torch.float64)
+        if self.comm:
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+        host = st.cpu()
+        self._logdet, self._sumsq = float(host[0]), float(host[1])
+        if bool((host[2:] < 0).any()):
+            raise _ops.NativeError("a tile factorisation reported an internal status (not a property of the matrix)")
+        bad = torch.nonzero(host[2:] != 0)
+        self.info = 0 if bad.numel() == 0 else int(bad[0, 0]) * T + int(host[2 + int(bad[0, 0])])
+        if self.info:
+            self._dirty = True
         return self.info
 
     def lml(self):
-        """LML of gpr.py:63-67 from the distributed factor (all-reduce of two scalars)."""
-        ops = self.ops
-        acc = torch.zeros(2, dtype=torch.float64, device=self.X.device)
-        for k in range(self.nt):
-            if self.mine(k, k):
-                acc[0] += ops.log_diag_sum(self.tiles[(k, k)], self.rows_of(k))
-            if self.mine(self.nt, k):
-                acc[1] += ops.sumsq(self.tiles[(self.nt, k)], self.dy, self.rows_of(k))
-        if self.world > 1:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
-        return -0.5 * acc[1] - self.dy * acc[0] - 0.5 * self.dy * self.n * math.log(2.0 * math.pi)
+        """LML of gpr.py:63-67 from the distributed factor (the two sums were all-reduced by factor())."""
+        v = -0.5 * self._sumsq - self.dy * self._logdet - 0.5 * self.dy * self.n * math.log(2.0 * math.pi)
+        return torch.tensor(v, dtype=torch.float64, device=self.X.device)
 
     # -- backward (closed form on the same grid; SURVEY 8(e)) ---------------------------------
-    def _kinv_tiles(self):
-        """Kyy^-1 = U U^T (lower tiles, same owners as the matrix tiles) from U = L^-T, which the
-        factorisation left in the identity rows: (Kyy^-1)_IJ = sum_{K >= I} U_IK U_JK^T.  Per tile
-        column K of U the tiles U_IK (I <= K) travel exactly like a panel of the factorisation:
-        along process row I mod Pr (left operands), then down process column I mod Pc (right)."""
-        ops, nt = self.ops, self.nt
-        kinv = {(I, J): ops.new_tile(self.rows_of(I), self.rows_of(J))
-                for I in range(nt) for J in range(I + 1) if self.mine(I, J)}
+    def _kinv_local(self):
+        """Kyy^-1 = U U^T into self.kinv (same layout as the matrix tiles; diagonal tiles full)
+        from U = L^-T, which the factorisation left in the identity rows:
+        (Kyy^-1)_IJ = sum_{K >= I} U_IK U_JK^T.  Per tile column K of U the blocks U_IK (I <= K)
+        travel exactly like a panel of the factorisation: packed along each process row (left
+        operands), then the tiles of my tile columns down the process column (right operands)."""
+        ops, T, nt = self.ops, self.T, self.nt
+        if self.kinv is None:
+            self.kinv = ops.zeros(self.nrow_t * T + LEAF, self.ld)
+        else:
+            self.kinv.zero_()
+        C = self.kinv
+        rs = self.my_c % self.pr
+
+        def start(K):
+            nid = self._rows_le(K)                                 # my identity blocks i <= K
+            left, works = self._start_rows(K, matrix=(self.id_off, self.id_off + nid * T))
+            return left, works
+
+        left, works = start(0)
         for K in range(nt):
-            nk = self.rows_of(K)
-            left, right = {}, {}
-            for I in range(K + 1):
-                R = nt + 1 + I
-                src = self.owner(R, K)
-                if self.my_r == I % self.pr:
-                    t = self.tiles[(R, K)] if self.rank == src else ops.new_tile(self.rows_of(I), nk)
-                    self._bcast(t, src, self.row_groups, I % self.pr)
-                    left[I] = t
-            for I in range(K + 1):
-                cI = I % self.pc
-                if self.my_c == cI:
-                    src = (I % self.pr) * self.pc + cI
-                    t = left[I] if self.rank == src else left.get(I)
-                    if t is None:
-                        t = ops.new_tile(self.rows_of(I), nk)
-                    self._bcast(t, src, self.col_groups, cI)
-                    right[I] = t
-            for (I, J), t in kinv.items():
-                if I <= K:
-                    ops.update(t, left[I], right[J], self.rows_of(I), self.rows_of(J), nk, lower=(I == J), alpha=1.0)
-        return kinv
+            nK = self.rows_of(K)
+            self._wait(works)
+            ncol = self._cols_le(K)                                # my tile columns J <= K, first at slot ...
+            first = (self.my_c - rs) // self.pr                    # ... of tile J = c in process row rs's buffer
+            right, works = self._start_cols(K, left, first_tile=first, count=ncol)
+            self._wait(works)
+            nleft, works = start(K + 1) if K + 1 < nt else (None, [])
+            hi = self._rows_le(K) * T                              # rows I <= K of the result
+            for lj in range(ncol):
+                J = lj * self.pc + self.my_c
+                nJ = self.rows_of(J)
+                r0 = self._rows_le(J - 1) * T
+                if r0 < hi:
+                    ops.update(C[r0:, lj * T:], left[r0:], right[lj * T:], hi - r0, nJ, nK, lower=False, alpha=1.0)
+            left = nleft
+        return C
 
     def backward(self, variance, length_scales):
         """-> tensor [2 + nls]: dLML/d(variance, length_scales..., noise) w.r.t. the CONSTRAINED
@@ -374,50 +504,52 @@ class BlockCyclicGP:
         assert self.with_inverse, "factor with with_inverse=True first"
         ops, nt, T, dy, dev = self.ops, self.nt, self.T, self.dy, self.X.device
         nls = length_scales.numel()
+        A = self.A
+        ncr = self.cidx.numel()
         # alpha^T [dy, n], replicated
         alphaT = torch.zeros(dy, self.n, dtype=torch.float64, device=dev)
-        for K in range(nt):
-            if self.mine(nt, K):
-                alphaT[:, K * T:K * T + self.rows_of(K)] = self.tiles[(nt, K)][:dy, :self.rows_of(K)]
-        if self.world > 1:
+        if self.has_res and ncr:
+            alphaT[:, self.cidx] = A[self.res_off:self.res_off + dy, :ncr]
+        if self.comm:
             dist.all_reduce(alphaT, op=dist.ReduceOp.SUM, group=self.group)
-        # a^T = alpha^T U^T: block I gets sum_{K >= I} alpha_K^T U_IK^T from the owners of U_IK
+        # a^T = alpha^T U^T: my identity rows x my tile columns give a partial sum
         aT = torch.zeros(dy, self.n, dtype=torch.float64, device=dev)
-        for (R, K), t in self.tiles.items():
-            if R <= nt:
-                continue
-            I = R - nt - 1
-            ri, rk = self.rows_of(I), self.rows_of(K)
-            At = ops.new_tile(dy, rk)
-            At[:dy, :rk] = alphaT[:, K * T:K * T + rk]
-            Ct = ops.new_tile(dy, ri)
-            ops.update(Ct, At, t, dy, ri, rk, lower=False, alpha=1.0)
-            aT[:, I * T:I * T + ri] += Ct[:dy, :ri]
-        if self.world > 1:
+        nrr = self.ridx.numel()
+        if nrr and ncr:
+            al = ops.zeros(_ops.round_up(dy, 16), self.ld)
+            al[:dy, :ncr] = alphaT.index_select(1, self.cidx)
+            part = ops.zeros(_ops.round_up(dy, 16), _ops.round_up(nrr, 16))
+            ops.update(part, al, A[self.id_off:], dy, nrr, self.ld, lower=False, alpha=1.0, beta=0.0)
+            aT[:, self.ridx] = part[:dy, :nrr]
+        if self.comm:
             dist.all_reduce(aT, op=dist.ReduceOp.SUM, group=self.group)
-        kinv = self._kinv_tiles()
+        C = self._kinv_local()
         acc = torch.zeros(2 + nls, dtype=torch.float64, device=dev)
         kpad = _ops.round_up(dy, 16)
-        for (I, J), Kt in kinv.items():
-            ri, rj = self.rows_of(I), self.rows_of(J)
-            aI = ops.new_tile(ri, kpad)
-            aI[:ri, :dy] = aT[:, I * T:I * T + ri].t()
-            aJ = ops.new_tile(rj, kpad)
-            aJ[:rj, :dy] = aT[:, J * T:J * T + rj].t()
-            Gt = ops.new_tile(ri, rj)
-            ops.update(Gt, aI, aJ, ri, rj, kpad, lower=False, alpha=0.5)          # 1/2 a_I a_J^T
-            Kd = Kt[:ri, :rj]
-            if I == J:
-                Kd = torch.tril(Kd) + torch.tril(Kd, -1).t()
-            G = Gt[:ri, :rj] - 0.5 * dy * Kd
-            if I == J:
+        arow = ops.zeros(_ops.round_up(max(nrr, 1), 16) + 16, kpad)      # a for my tile rows / columns, K-padded
+        acol = ops.zeros(_ops.round_up(max(ncr, 1), 16) + 16, kpad)
+        if nrr:
+            arow[:nrr, :dy] = aT.index_select(1, self.ridx).t()
+        if ncr:
+            acol[:ncr, :dy] = aT.index_select(1, self.cidx).t()
+        for lj, J in enumerate(range(self.my_c, nt, self.pc)):
+            nJ = self.rows_of(J)
+            li0 = self._rows_le(J - 1)
+            r0 = li0 * T
+            if r0 >= nrr:
+                continue
+            xj = self.Xcol[lj * T:lj * T + nJ]
+            # G = 1/2 a_I a_J^T - dy/2 Kinv_IJ, in place over the stacked rows of this tile column
+            ops.update(C[r0:, lj * T:], arow[r0:], acol[lj * T:], nrr - r0, nJ, kpad, lower=False, alpha=0.5, beta=-0.5 * dy)
+            if li0 * self.pr + self.my_r == J:
+                G = C[r0:r0 + nJ, lj * T:lj * T + nJ]
                 acc[1 + nls] += G.diagonal().sum()                                 # d/d noise = tr G
-            else:
-                G = 2.0 * G                                                        # symmetric partner (J, I)
-            xi = self.X[I * T:I * T + ri]
-            xj = self.X[J * T:J * T + rj]
-            acc[:1 + nls] += ops.kernel_grad(self.kind, xi, xj, variance, length_scales, G.contiguous())
-        if self.world > 1:
+                acc[:1 + nls] += ops.kernel_grad(self.kind, self.Xrow[r0:r0 + nJ], xj, variance, length_scales, G)
+                r0 += T
+            if r0 < nrr:                                                           # symmetric partners (J, I): x 2
+                G = C[r0:nrr, lj * T:lj * T + nJ]
+                acc[:1 + nls] += 2.0 * ops.kernel_grad(self.kind, self.Xrow[r0:nrr], xj, variance, length_scales, G)
+        if self.comm:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
         return acc
 
@@ -435,10 +567,12 @@ class BlockCyclicGP:
         """assemble + factor with the jitter ladder of functions.py:20-43 (decided on the
         all-reduced info, so every rank takes the same branch)."""
         self.assemble(variance, length_scales, noise, resid)
+        self.jitter_rung = -1
         if self.factor() == 0:
             return self.lml()
         for i in range(max_tries):
             self.assemble(variance, length_scales, noise + 10.0 ** (-max_tries + i), resid)
+            self.jitter_rung = i
             if self.factor() == 0:
                 return self.lml()
         raise RuntimeError("Max tries exceeded.")

@@ -13,10 +13,12 @@
  *    nothing synchronises the host (graph-capturable) unless stated;
  *  - return value: 0 = ok, <0 = -(index of the bad argument) or a GPN_E* code;
  *    never throws, never allocates device memory: workspaces are sized by the
- *    *_workspace_bytes queries and owned by the caller;
+ *    *_work_bytes / gpn_winv_bytes queries and owned by the caller;
  *  - LAPACK-style `info` lives on the device (int32): 0 = ok, j>0 = the leading
  *    minor of order j is not positive definite (first failing pivot, 1-based).
  *    The Python shell maps info>0 to the jitter ladder of functions.py:20-43.
+ *    info == GPN_INFO_INTERNAL (< 0) is NOT about the matrix: a kernel-internal
+ *    hand-over failed; the shell raises instead of adding jitter.
  *
  * "Factor buffers": dense factorisation kernels work on a caller-owned,
  * ZERO-INITIALISED buffer `A` of `gpn_factor_rows(n,e)` rows and leading
@@ -50,6 +52,8 @@ enum {
   GPN_E_ALIGN = -101,    /* pointer / leading dimension violates an alignment rule */
   GPN_E_UNSUPPORTED = -102
 };
+/* device-side `info` value for an internal failure of the leaf kernel (see conventions) */
+#define GPN_INFO_INTERNAL (-1000)
 
 int gpn_version(void);
 /* name of the gfx target compiled into the library, e.g. "gfx950" */
@@ -93,6 +97,13 @@ int gpn_pack_rhs(void* stream, const double* Y, const double* M, int64_t n, int 
  * (see header comment).  *info must be 0 on entry. */
 int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
                     double* winv, int32_t* info);
+
+/* Panel width the driver uses for an n x n factorisation (0 = the recursive driver): each panel ends
+ * with one lower-tile K = width contraction -- the SYRK trailing update priced by bench.py. */
+int64_t gpn_potrf_panel_width(int64_t n);
+/* Release the helper stream/events the library keeps for `stream` (created by the first
+ * factorisation enqueued on it); call before destroying the stream.  NULL = release all. */
+int gpn_release_stream(void* stream);
 
 /* winv <- inverses of the 128x128 diagonal blocks of a GIVEN lower-triangular L
  * (n x n, row-major, ldl): what functions.trtrs (functions.py:71-76) needs when

@@ -16,39 +16,37 @@ from oracle import gp_oracle as orc
 
 
 class CpuTileOps:
-    """torch-CPU stand-in for NativeTileOps (same contract)."""
+    """torch-CPU stand-in for NativeTileOps (same contract: strided 2-D views in, in-place results)."""
 
-    def new_tile(self, rows, cols):
-        return torch.zeros((rows + 127) // 128 * 128 + 16, (cols + 127) // 128 * 128, dtype=torch.float64)
+    def zeros(self, rows, cols):
+        return torch.zeros(rows, cols, dtype=torch.float64)
 
-    def kernel_tile(self, kind, Xi, Xj, variance, ls, noise, out):
+    def kernel_block(self, kind, Xi, Xj, variance, ls, out):
         K = orc.kernel_K(kind, Xi, Xj, variance, ls)
-        if Xj is None and noise is not None:
-            K = K + noise * torch.eye(K.shape[0], dtype=torch.float64)
         out[:K.shape[0], :K.shape[1]] = K
-
-    def potrf(self, tile, n):
-        info = torch.zeros(1, dtype=torch.int32)
-        L, inf = torch.linalg.cholesky_ex(tile[:n, :n])
-        info[0] = int(inf)
-        if int(inf) == 0:
-            tile[:n, :n] = L
-        return torch.zeros(1, dtype=torch.float64), info
 
     def winv_numel(self, n):
         return 1
 
+    def potrf(self, A, n, e, winv, info):
+        assert e == 0
+        L, inf = torch.linalg.cholesky_ex(A[:n, :n])
+        info[0] = int(inf)
+        if int(inf) == 0:
+            A[:n, :n] = L
+
     def trsm(self, L, winv, n, B, m):
         B[:m, :n] = torch.linalg.solve_triangular(L[:n, :n], B[:m, :n].t(), upper=False).t()
 
-    def update(self, C, A, B, m, n, k, lower, alpha=-1.0):
-        upd = A[:m, :k] @ B[:n, :k].t()
+    def update(self, C, A, B, m, n, k, lower, alpha=-1.0, beta=1.0):
+        upd = alpha * (A[:m, :k] @ B[:n, :k].t())
         if lower:
-            upd = torch.tril(upd)
-        C[:m, :n] += alpha * upd
+            C[:m, :n] = torch.where(torch.ones(m, n).tril().bool(), upd + beta * C[:m, :n], C[:m, :n])
+        else:
+            C[:m, :n] = upd + beta * C[:m, :n]
 
-    def set_identity(self, tile, n):
-        tile.diagonal()[:n].fill_(1.0)
+    def copy(self, dst, src, rows, cols):
+        dst[:rows, :cols] = src[:rows, :cols]
 
     def kernel_grad(self, kind, Xi, Xj, variance, ls, G):
         v = variance.clone().requires_grad_(True)
@@ -56,11 +54,11 @@ class CpuTileOps:
         (orc.kernel_K(kind, Xi, Xj, v, l) * G).sum().backward()
         return torch.cat([v.grad, l.grad])
 
-    def log_diag_sum(self, tile, n):
-        return tile.diagonal()[:n].log().sum()
+    def log_diag_sum(self, A, n):
+        return A.diagonal()[:n].log().sum()
 
-    def sumsq(self, tile, m, n):
-        return tile[:m, :n].pow(2).sum()
+    def sumsq(self, A, m, n):
+        return A[:m, :n].pow(2).sum()
 
 
 def _free_port():
@@ -83,8 +81,8 @@ def _worker(rank, world, port, n, d, dy, tile, kind, noise, out_path):
         var, ls = torch.tensor([1.3], dtype=torch.float64), torch.tensor([1.7], dtype=torch.float64)
         lml = g.log_likelihood(var, ls, torch.tensor([noise], dtype=torch.float64), Y)
         # every rank must hold only its block-cyclic share
-        for (I, J) in g.tiles:
-            assert g.owner(I, J) == rank
+        assert g.local_shape()[1] == max(1, len(range(g.my_c, g.nt, g.pc))) * tile
+        assert g.local_shape()[0] < (len(range(g.my_r, g.nt, g.pr)) + 2) * tile + 1
         if rank == 0:
             np.save(out_path, np.array([float(lml), float(g.info)]))
     finally:
@@ -92,7 +90,9 @@ def _worker(rank, world, port, n, d, dy, tile, kind, noise, out_path):
 
 
 @pytest.mark.parametrize("world,n,tile,dy,kind", [(2, 300, 128, 1, "Rbf"), (4, 700, 128, 2, "Matern52"),
-                                                    (2, 129, 128, 1, "Rbf"), (4, 128, 128, 1, "Rbf")])
+                                                    (2, 129, 128, 1, "Rbf"), (4, 128, 128, 1, "Rbf"),
+                                                    (8, 1500, 128, 2, "Rbf"), (8, 1100, 256, 1, "Matern52"),
+                                                    (4, 1281, 128, 1, "Rbf")])
 def test_block_cyclic_lml_matches_oracle(tmp_path, world, n, tile, dy, kind):
     out = str(tmp_path / "lml.npy")
     mp.spawn(_worker, args=(world, _free_port(), n, 3, dy, tile, kind, 0.05, out), nprocs=world, join=True)
@@ -136,7 +136,8 @@ def _grad_worker(rank, world, port, n, d, dy, tile, kind, noise, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,tile,dy,kind", [(2, 300, 128, 1, "Rbf"), (4, 700, 128, 2, "Matern52"), (1, 260, 128, 3, "Rbf")])
+@pytest.mark.parametrize("world,n,tile,dy,kind", [(2, 300, 128, 1, "Rbf"), (4, 700, 128, 2, "Matern52"), (1, 260, 128, 3, "Rbf"),
+                                                    (8, 1100, 128, 2, "Rbf"), (2, 1000, 128, 1, "Matern52")])
 def test_block_cyclic_gradients_match_oracle(tmp_path, world, n, tile, dy, kind):
     """distributed closed-form backward (U = L^-T carried as identity rows, Kyy^-1 = U U^T on the
     grid, D + 2 scalars all-reduced) vs the oracle's closed form (gradients w.r.t. log-parameters
@@ -151,3 +152,51 @@ def test_block_cyclic_gradients_match_oracle(tmp_path, world, n, tile, dy, kind)
     ref_g = np.concatenate([[float(ref[1]) / 1.3], np.asarray(ref[2], dtype=np.float64).ravel() / ls, [float(ref[3]) / 0.05]])
     assert abs(got[0] - ref_lml) < 1e-9 * max(1.0, abs(ref_lml))
     assert np.abs(got[1:] - ref_g).max() < 1e-8 * max(1.0, np.abs(ref_g).max()), (got[1:], ref_g)
+
+
+def _reuse_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, d = 520, 2
+        x, y = rng.make_regression(n // 2, d, 1, seed=5)
+        x, y = np.repeat(x, 2, axis=0), np.repeat(y, 2, axis=0)        # duplicate points: K is singular
+        X, Y = torch.tensor(x), torch.tensor(y)
+        g = gdist.BlockCyclicGP(X, Y, "Rbf", tile=128, ops=CpuTileOps())
+        one = torch.ones(1, dtype=torch.float64)
+        vals = []
+        vals.append(float(g.log_likelihood(one, one, 0.1 * one, Y)))           # plain
+        shape0 = g.local_shape()
+        vals.append(float(g.log_likelihood(one, one, -1e-3 * one, Y)))          # needs the ladder
+        vals.append(float(g.info))
+        rung = g.jitter_rung
+        vals.append(float(g.log_likelihood(one, one, 0.1 * one, Y)))           # buffers clean again
+        assert g.local_shape() == shape0                                       # nothing re-allocated
+        lml, grad = g.log_likelihood_and_grad(one, one, 0.1 * one, Y)          # grows the identity rows
+        vals.append(float(lml))
+        vals.append(float(g.log_likelihood(one, one, 0.1 * one, Y)))
+        if rank == 0:
+            np.save(out_path, np.array(vals + [rung]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_block_cyclic_buffers_are_reused_and_ladder_replays(tmp_path):
+    """repeated evaluations on one BlockCyclicGP reuse its buffers; a failed factorisation
+    (duplicate points, noise < 0) climbs the jitter ladder of functions.py:20-43 collectively and
+    leaves no poisoned padding behind."""
+    out = str(tmp_path / "v.npy")
+    mp.spawn(_reuse_worker, args=(4, _free_port(), out), nprocs=4, join=True)
+    v = np.load(out)
+    x, y = rng.make_regression(260, 2, 1, seed=5)
+    x, y = np.repeat(x, 2, axis=0), np.repeat(y, 2, axis=0)
+    with torch.no_grad():
+        ref = orc.GPROracle(x, y, kind="Rbf", noise=0.1).log_likelihood().item()
+    assert abs(v[0] - ref) < 1e-9 * abs(ref) and v[3] == v[0] and v[5] == v[0]
+    assert abs(v[4] - ref) < 1e-9 * abs(ref)
+    assert v[2] == 0 and np.isfinite(v[1])
+    with torch.no_grad():
+        ref_j = orc.GPROracle(x, y, kind="Rbf", noise=-1e-3 + 1e-2).log_likelihood().item()
+    assert v[6] == 8 and abs(v[1] - ref_j) < 1e-8 * abs(ref_j)      # -1e-3 + 10^(-10+8) is the first positive shift

@@ -25,8 +25,9 @@ TOL_LML = 1e-8
 # path itself gives -90285.1725861576 (8 threads), ...1630 (1 thread), ...1659 (direct-difference
 # distances): a 5-8e-9 spread; rocSOLVER's factor of the same K gives ...1601.  Ours: ...1672 with
 # 64x64 leaves, ...1361 with 128x128 leaves, at a normwise backward error ||LL^T-K||/||K|| = 1.9e-15
-# (rocSOLVER: 2.4e-15; tools/accuracy.py).  Held to 5e-8.
-TOL_LML_ILL = {"rbf_4096_8_n1e-4": 1e-10 * 979625.9, "C2_rbf_8192_8": 5e-8}
+# (rocSOLVER: 2.4e-15; tools/accuracy.py).  The shipped driver lands 6e-10 from the golden, so C2 is
+# held to north_star's 1e-8 like every other case -- a driver variant that drifts past it has to be fixed.
+TOL_LML_ILL = {"rbf_4096_8_n1e-4": 1e-10 * 979625.9}
 
 
 def _model(case, device, x=None, y=None):
@@ -398,6 +399,53 @@ def test_block_cyclic_multi_rank_native_shared_gpu(device, world):
     ref = orc.lml_closed_form_grads("Rbf", x, y, 1.0, case["length_scales"], 1e-2)
     ref_g = np.array([float(ref[1]) / 1.0, float(np.asarray(ref[2]).ravel()[0]) / case["length_scales"], float(ref[3]) / 1e-2])
     assert np.abs(np.asarray(g) - ref_g).max() < 1e-7 * np.abs(ref_g).max(), (g, ref_g)
+
+
+def _torchrun(nproc, script_args, env_extra, timeout=900):
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + [os.path.join(root, script_args[0])] + script_args[1:]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+def test_block_cyclic_over_rccl_world1(device):
+    """the RCCL path itself on the 1-GPU box: `init_process_group("nccl")`, row / column
+    sub-communicators and every packed broadcast of the factorisation AND of the distributed
+    backward issued through RCCL (single-member groups, GPN_FORCE_COMM=1) -- the calls, buffer
+    shapes and stream hand-overs are the ones an 8-GPU run makes."""
+    import re
+    out = _torchrun(1, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_FORCE_COMM": "1", "GPN_DIST_GRAD": "1"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "backend=nccl" in out.stdout, out.stdout
+    vals = [float(v) for v in re.findall(r"lml=(-?[0-9.]+)", out.stdout)]
+    case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
+    assert len(vals) == 4, out.stdout
+    for v in vals:
+        assert abs(v - case["lml"]) < 1e-8, (v, case["lml"])
+
+
+def test_bench_multi_rank_line_shared_gpu(device):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), on
+    the 1-GPU box: both ranks on cuda:0 over gloo (--test-shared-gpu), C2's matrix block-cyclic over
+    the two ranks.  The JSON line must describe ONE sharded model (strong scaling), reproduce the
+    reference's C2 LML and agree with the single-GPU evaluation of the same run."""
+    import json
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--workload", "c2", "--tile", "1024", "--steps", "2", "--warmup", "1",
+                        "--test-shared-gpu"], {})
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["world_size_reported_by_backend"] == 2
+    assert "block-cyclic 1x2" in line["config"]["parallelism"]
+    case = [c for c in LML if c["name"] == "C2_rbf_8192_8"][0]
+    assert abs(line["lml"] - case["lml"]) < 1e-8, (line["lml"], case["lml"])
+    assert line["lml_abs_diff_vs_single_gpu"] < 1e-8
+    assert line["replicas_c2"]["value"] > 0 and line["single_gpu_same_run"]["value"] > 0
 
 
 # ---- VFE (sparse_gpr.py:92-195; BASELINE config 5) -------------------------------
@@ -774,13 +822,13 @@ def test_batched_restarts_match_sequential(device):
 def test_c3_full_size_lml_golden(device):
     """BASELINE config 3 at FULL size (N = 32768, D = 16, Matern52; 8.6 GB factor) against the
     LML the reference itself computed in the build container (make_golden.py, 104 s on 8 host
-    threads).  |LML| = 1.5e5: 5e-8 absolute is 3e-13 relative (see TOL_LML_ILL for why not 1e-8)."""
+    threads).  |LML| = 1.5e5: north_star's 1e-8 absolute is 7e-14 relative; the shipped driver lands 3e-9 away."""
     case = load_json("lml_c3.json")
     m, x, y = _model(case, device)
     assert rng.checksum(x) == case["x_checksum"] and rng.checksum(y) == case["y_checksum"]
     with torch.no_grad():
         lml = m.log_likelihood().item()
-    assert abs(lml - case["lml"]) < 5e-8, (lml, case["lml"])
+    assert abs(lml - case["lml"]) < 1e-8, (lml, case["lml"])
 
 
 def test_c4_full_size_factor_properties(device):

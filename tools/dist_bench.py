@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
-"""2-D block-cyclic LML (gptorch_amd/dist.py) timing.  Single GPU:  python tools/dist_bench.py 16384 16 2048
-8 GPUs:  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/dist_bench.py 65536 32 2048"""
+"""2-D block-cyclic LML (gptorch_amd/dist.py) timing.
+Single GPU:   python tools/dist_bench.py 16384 16 2048
+8 GPUs:       python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/dist_bench.py 65536 32 2048
+Env: GPN_SHARED_GPU=1   every rank on cuda:0 with gloo collectives (multi-rank orchestration on a 1-GPU box)
+     GPN_DIST_GRAD=1    also the distributed closed-form backward
+     GPN_FORCE_COMM=1   issue the row/column collectives even in single-member groups (drives the RCCL calls at world 1)
+     GPN_PHANTOM=r/w    do the work of rank r of a w-rank grid with the collectives skipped (timing only)
+     GPN_NATIVE=1       also time the single-GPU native factorisation of the same matrix"""
 import os, sys, time
 import torch
 import torch.distributed as dist
@@ -11,30 +17,40 @@ from gptorch_amd import dist as gdist, rng  # noqa: E402
 n, d, T = (int(a) for a in (sys.argv[1:4] + ["16384", "16", "2048"][len(sys.argv) - 1:]))
 world = int(os.environ.get("WORLD_SIZE", "1"))
 local = int(os.environ.get("LOCAL_RANK", "0"))
-shared = os.environ.get("GPN_SHARED_GPU") == "1"   # every rank on cuda:0 with gloo collectives: exercises the
-if shared:                                         # multi-rank orchestration + native tiles on a 1-GPU box
+shared = os.environ.get("GPN_SHARED_GPU") == "1"
+if shared:
     local = 0
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
-if world > 1:
+if "RANK" in os.environ:                      # under torch.distributed.run, also with one process
     if shared:
         dist.init_process_group("gloo")
     else:
         dist.init_process_group("nccl", device_id=dev)
 x, y = rng.make_regression(n, d, 1, seed=0)
 X, Y = torch.tensor(x, device=dev), torch.tensor(y, device=dev)
-g = gdist.BlockCyclicGP(X, Y, "Rbf", tile=T)
+phantom = None
+if os.environ.get("GPN_PHANTOM"):
+    r, w = os.environ["GPN_PHANTOM"].split("/")
+    phantom = (int(r), int(w))
+g = gdist.BlockCyclicGP(X, Y, "Rbf", tile=T, phantom=phantom, force_comm=os.environ.get("GPN_FORCE_COMM") == "1")
 one = torch.ones(1, dtype=torch.float64, device=dev)
 ls = one * float(d) ** 0.5
 for it in range(3):
     torch.cuda.synchronize()
     t0 = time.time()
-    lml = g.log_likelihood(one, ls, 0.01 * one, Y)
+    if phantom:
+        g.assemble(one, ls, 0.01 * one, Y)
+        g.factor()
+        lml = torch.zeros(())
+    else:
+        lml = g.log_likelihood(one, ls, 0.01 * one, Y)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    if g.rank == 0:
-        print("N=%d D=%d T=%d world=%d grid=%dx%d: lml=%.8f  %.1f ms  (%.1f TFLOP/s aggregate on N^3/3)" % (
-            n, d, T, world, g.pr, g.pc, lml.item(), dt * 1e3, n ** 3 / 3 / dt / 1e12), flush=True)
+    if g.rank == 0 or phantom:
+        print("N=%d D=%d T=%d world=%d grid=%dx%d backend=%s%s: lml=%.8f  %.1f ms  (%.1f TFLOP/s aggregate on N^3/3)" % (
+            n, d, T, g.world, g.pr, g.pc, dist.get_backend() if dist.is_initialized() else "none",
+            " PHANTOM rank %d" % g.rank if phantom else "", lml.item(), dt * 1e3, n ** 3 / 3 / dt / 1e12), flush=True)
 if os.environ.get("GPN_DIST_GRAD") == "1":      # distributed closed-form backward on the same grid
     torch.cuda.synchronize()
     t0 = time.time()
@@ -43,5 +59,14 @@ if os.environ.get("GPN_DIST_GRAD") == "1":      # distributed closed-form backwa
     if g.rank == 0:
         print("grad: lml=%.8f  %s  %.1f ms (factorisation carrying L^-T + K^-1 = U U^T + sweeps)" % (
             lml.item(), " ".join("%.10e" % v for v in grad.tolist()), (time.time() - t0) * 1e3), flush=True)
-if world > 1:
+if os.environ.get("GPN_NATIVE") == "1" and g.rank == 0:
+    from gptorch_amd import _ops
+    f = None
+    for it in range(3):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        f, terms = _ops.lml_forward("Rbf", X, Y, one, ls, 0.01 * one, factor=f)
+        torch.cuda.synchronize()
+        print("native single-GPU: lml=%.8f  %.1f ms" % (terms[2].item(), (time.time() - t0) * 1e3), flush=True)
+if dist.is_initialized():
     dist.destroy_process_group()
