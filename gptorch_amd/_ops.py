@@ -282,6 +282,32 @@ def gemm_nt(A, B, M, N, K, alpha=1.0, beta=0.0, C=None, lower=False, tri=0):
     return C
 
 
+def matmul_nt(A, B, alpha=1.0):
+    """alpha * A @ B^T for arbitrary 2-D fp64 device tensors through the native contraction (pads K to
+    a multiple of 16 and re-packs operands that are not 16-byte aligned row-major); for the
+    autograd nodes of the off-hot-path `functions` / `util` surface."""
+    _req(A, B)
+    M, K = A.shape
+    N = B.shape[0]
+    if B.shape[1] != K:
+        raise RuntimeError("matmul_nt: inner dimensions differ")
+    out = torch.zeros(M, N, dtype=torch.float64, device=A.device)
+    if M == 0 or N == 0 or K == 0:
+        return out
+    Kp = round_up(K, 16)
+
+    def prep(T, rows):
+        T = T.detach()
+        ok = T.stride(1) == 1 and T.stride(0) % 2 == 0 and T.stride(0) >= Kp and T.data_ptr() % 16 == 0 \
+            and K == Kp and T.shape[0] % 16 == 0
+        if ok:
+            return T
+        P = torch.zeros(round_up(rows, 16), Kp, dtype=torch.float64, device=T.device)
+        P[:rows, :K] = T
+        return P
+    return gemm_nt(prep(A, M), prep(B, N), M, N, Kp, alpha=alpha, C=out)
+
+
 def gemm_nt_batched(A, B, M, N, K, batch, sA, sB, C, alpha=1.0, beta=0.0, lower=False, tri=0):
     """`batch` contractions of one shape in one launch: C[z] = alpha*A_z*B_z^T + beta*C[z], A_z = A + z*sA
     elements (row stride from the tensor), C [batch, rows, ld] contiguous."""

@@ -47,6 +47,12 @@ __device__ __forceinline__ void k_and_base(double r2, double var, double& K, dou
   if constexpr (KIND == GPN_RBF) {
     K = var * exp(-0.5 * r2);
     B = K;
+  } else if constexpr (KIND == GPN_SQDIST) {
+    // util.squared_distance itself (util.py:73-88): K = r^2, no variance.  B = -2 dK/d(r^2) = -2
+    // everywhere, also at r = 0 (direct differences: nothing is clamped, so the second derivative
+    // the reference guards with its detach() trick, test_util.py:78-106, is the plain 2)
+    K = 0.0;
+    B = -2.0;
   } else {
     const bool dead = r2 < 1e-40;                 // kernels.py:172 clamp: no gradient below it
     const double r = sqrt(fmax(r2, 1e-40));
@@ -418,6 +424,7 @@ static int dispatch_kind(hipStream_t s, int kind, const GradArgs& a, int64_t nbl
     case GPN_MATERN32: return launch_sweep<GPN_MATERN32, LML>(s, a, nblocks);
     case GPN_EXP: return launch_sweep<GPN_EXP, LML>(s, a, nblocks);
     case GPN_PERIODIC: return launch_sweep<GPN_PERIODIC, LML>(s, a, nblocks);
+    case GPN_SQDIST: return launch_sweep<GPN_SQDIST, LML>(s, a, nblocks);
     default: return -2;
   }
 }
@@ -573,6 +580,7 @@ extern "C" int gpn_kernel_grad_x2(void* stream, int kind, const double* X, int64
     case GPN_MATERN32: rc = launch_x2<GPN_MATERN32>(s, a, grid); break;
     case GPN_EXP: rc = launch_x2<GPN_EXP>(s, a, grid); break;
     case GPN_PERIODIC: rc = launch_x2<GPN_PERIODIC>(s, a, grid); break;
+    case GPN_SQDIST: rc = launch_x2<GPN_SQDIST>(s, a, grid); break;
     default: return -2;
   }
   if (rc != GPN_OK) return rc;

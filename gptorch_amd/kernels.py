@@ -66,6 +66,69 @@ class _StationaryK(torch.autograd.Function):
         return g_var, g_ls, g_x, g_x2, None
 
 
+class _SqDistPointGrad(torch.autograd.Function):
+    """d sum(gK * r^2(X, Z)) / d(X or Z) as its own node, so that the SECOND derivative of
+    util.squared_distance w.r.t. the points exists (test/test_util.py:78-106 pins it at r = 0):
+    with w = 1/ell^2, R_i = sum_j gK_ij, C_j = sum_i gK_ij
+        g_X = 2 w (R x - gK Z),      g_Z = 2 w (C z - gK^T X)
+    forward = native sweep (gpn_kernel_grad_x2, kind SQDIST); backward = the closed-form derivative
+    of the expressions above (native contractions + elementwise)."""
+
+    @staticmethod
+    def forward(ctx, gK, X, Z, ls, wrt_z):
+        from . import _backward
+        one = torch.ones(1, dtype=torch_dtype, device=X.device)
+        if wrt_z:
+            g = _backward.kernel_backward_x2("SqDist", X, Z, one, ls, gK)
+        else:
+            g = _backward.kernel_backward_x2("SqDist", Z, X, one, ls, _ops.transpose(gK))
+        ctx.wrt_z = wrt_z
+        ctx.save_for_backward(gK, X, Z, ls)
+        return g
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, H):
+        gK, X, Z, ls = ctx.saved_tensors
+        w = (1.0 / (ls * ls)).expand(X.shape[1])
+        Hw = H * w
+        G = gK.t() if ctx.wrt_z else gK              # rows = the points differentiated in `forward`
+        P, Q = (Z, X) if ctx.wrt_z else (X, Z)       # g = 2 w (rowsum(G) P - G Q)
+        g_gK = g_P = g_Q = None
+        if ctx.needs_input_grad[0]:
+            t = 2.0 * ((Hw * P).sum(1, keepdim=True) - _ops.matmul_nt(Hw.contiguous(), Q))
+            g_gK = t.t() if ctx.wrt_z else t
+        g_P = 2.0 * G.sum(1, keepdim=True) * Hw
+        g_Q = -2.0 * _ops.matmul_nt(_ops.transpose(G), _ops.transpose(Hw))
+        g_X, g_Z = (g_Q, g_P) if ctx.wrt_z else (g_P, g_Q)
+        return g_gK, g_X, g_Z, None, None
+
+
+class _SqDist(torch.autograd.Function):
+    """util.squared_distance / Stationary.squared_dist (util.py:73-88, kernels.py:149-159): r^2 by
+    direct differences in the native assembly kernel (never negative, so the reference's
+    clamp-and-detach is the identity), differentiable w.r.t. the points (twice) and the
+    length-scales."""
+
+    @staticmethod
+    def forward(ctx, X, Z, ls):
+        one = torch.ones(1, dtype=torch_dtype, device=X.device)
+        ctx.save_for_backward(X, Z, ls)
+        return _ops.kernel_matrix("SqDist", X, Z, one, ls)
+
+    @staticmethod
+    def backward(ctx, gK):
+        from . import _backward
+        X, Z, ls = ctx.saved_tensors
+        g_x = _SqDistPointGrad.apply(gK, X, Z, ls, False) if ctx.needs_input_grad[0] else None
+        g_z = _SqDistPointGrad.apply(gK, X, Z, ls, True) if ctx.needs_input_grad[1] else None
+        g_ls = None
+        if ctx.needs_input_grad[2]:
+            one = torch.ones(1, dtype=torch_dtype, device=X.device)
+            g_ls = _backward.kernel_backward("SqDist", X.detach(), Z.detach(), one, ls.detach(), gK.detach())[1]
+        return g_x, g_z, g_ls
+
+
 class Stationary(Kernel):
     """Kernels of r = ||(x - x') / ell||; ARD = one length-scale per input
     dimension (kernels.py:108-179)."""
@@ -103,9 +166,9 @@ class Stationary(Kernel):
         return self.variance.transform().expand(X.size(0))
 
     def squared_dist(self, X, X2):
-        """scaled squared distance (kernels.py:149-159); forward only."""
-        one = torch.ones(1, dtype=torch_dtype, device=X.device)
-        return _ops.kernel_matrix("SqDist", X, X2, one, self.length_scales.transform())
+        """scaled squared distance (kernels.py:149-159), differentiable w.r.t. the length-scales
+        and the points."""
+        return _SqDist.apply(X, X if X2 is None else X2, self.length_scales.transform())
 
     def dist(self, X, X2):
         """kernels.py:161-172."""

@@ -128,6 +128,93 @@ def test_cholesky_vs_oracle(device, n):
     assert (x2.cpu() - x_ref).abs().max().item() < 1e-11
 
 
+def test_squared_distance_reference_values_and_derivatives(device):
+    """util.squared_distance as a public op (native kind SQDIST behind an autograd node): the
+    reference's own pins, test/test_util.py:38-106 -- values, first derivatives (exactly -4 and 0)
+    and the SECOND derivative at r = 0 (exactly 2: nothing may clamp the gradient flow away)."""
+    from gptorch_amd import util
+    t = lambda v: torch.tensor(v, dtype=torch.float64, device=device)
+    x1 = t([[0.0], [1.0], [2.0]]) + 1.0 / 65.0
+    x2 = t([[0.0], [2.0], [4.0]]) + 1.0 / 65.0
+    r2 = util.squared_distance(x1, x2)
+    assert r2.shape == (3, 3)
+    expected = [[0.0, 4.0, 16.0], [1.0, 1.0, 9.0], [4.0, 0.0, 4.0]]
+    assert r2.cpu().numpy().ravel() == pytest.approx(np.ravel(expected))
+    assert np.allclose(r2.cpu().numpy(), load_json("api_cases.json")["squared_distance_test_util"], atol=1e-14)
+    x1g = x1.clone().requires_grad_(True)
+    util.squared_distance(x1g, x2)[0, 1].backward()
+    assert x1g.grad[0].item() == -4.0
+    x1g = x1.clone().requires_grad_(True)
+    util.squared_distance(x1g, x2)[0, 0].backward()
+    assert x1g.grad[0].item() == 0.0
+    rows = [xi.clone().requires_grad_(True) for xi in x1]
+    r00 = util.squared_distance(torch.stack(rows), x2)[0, 0]
+    (d1,) = torch.autograd.grad(r00, rows[0], create_graph=True)
+    assert d1[0].item() == 0.0
+    (d2,) = torch.autograd.grad(d1[0], rows[0])
+    assert d2[0].item() == 2.0
+    # one-argument form = squared_distance(x, x) (util.py:80-81); random multi-dimensional values and
+    # both first derivatives against the oracle's autograd
+    a, b = rng.normal(5, (37, 5)), rng.normal(6, (21, 5))
+    A, B = t(a).requires_grad_(True), t(b).requires_grad_(True)
+    Ao, Bo = torch.tensor(a, requires_grad=True), torch.tensor(b, requires_grad=True)
+    wgt = rng.normal(7, (37, 21))
+    (util.squared_distance(A, B) * t(wgt)).sum().backward()
+    (orc.squared_distance(Ao, Bo) * torch.tensor(wgt)).sum().backward()
+    assert (A.grad.cpu() - Ao.grad).abs().max().item() < 1e-11 and (B.grad.cpu() - Bo.grad).abs().max().item() < 1e-11
+    assert (util.squared_distance(A).detach().cpu() - orc.squared_distance(Ao.detach())).abs().max().item() < 1e-12
+    # Stationary.squared_dist / dist (kernels.py:149-172): scaled by the ARD length-scales, differentiable
+    k = kernels.Matern52(5, length_scales=np.array([0.7, 1.1, 1.9, 0.5, 1.3]), ARD=True)
+    k.cuda()
+    A.grad = None
+    (k.dist(A, B) * t(wgt)).sum().backward()
+    lo = torch.tensor([0.7, 1.1, 1.9, 0.5, 1.3], dtype=torch.float64, requires_grad=True)
+    Ao.grad = None
+    r2o = orc.squared_distance(Ao / lo, Bo.detach() / lo)
+    (torch.sqrt(torch.clamp(r2o, min=1e-40)) * torch.tensor(wgt)).sum().backward()
+    assert (A.grad.cpu() - Ao.grad).abs().max().item() < 1e-10
+    g_log_ls = k.length_scales.grad.cpu()          # Param gradients are w.r.t. log(length_scales)
+    assert (g_log_ls - lo.grad * lo.detach()).abs().max().item() < 1e-9 * max(1.0, lo.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("n", [5, 150, 300])
+def test_functions_are_differentiable(device, n):
+    """functions.cholesky / trtrs (lower and upper) / lt_log_determinant / cholesky_inverse (lower and
+    upper) are autograd nodes like the torch ops the reference wraps (functions.py:46-76): gradients
+    against torch-CPU autograd through the same op chain."""
+    a = rng.normal(300 + n, (n, n))
+    spd = a @ a.T / n + 0.5 * np.eye(n)
+    b = rng.normal(400 + n, (n, 3))
+    w1, w2, w3 = rng.normal(500 + n, (n, 3)), rng.normal(600 + n, (n, n)), rng.normal(700 + n, (n, 3))
+    t = lambda v: torch.tensor(v, dtype=torch.float64, device=device)
+
+    def chain(chol, solve, logdet, cinv, A, Bm, dev):
+        tt = (lambda v: torch.tensor(v, dtype=torch.float64, device=dev))
+        L = chol(A)
+        x = solve(Bm, L, True)                     # L^-1 b
+        u = solve(Bm, L.t(), False)                # L^-T b  (upper-triangular argument)
+        return ((x * tt(w1)).sum() + 0.3 * logdet(L) + (cinv(L, False) * tt(w2)).sum()
+                + (u * tt(w3)).sum() + 0.1 * (cinv(L.t(), True) * tt(w2).t()).sum())
+
+    A, Bm = t(spd).requires_grad_(True), t(b).requires_grad_(True)
+    val = chain(functions.cholesky, functions.trtrs, functions.lt_log_determinant, functions.cholesky_inverse, A, Bm, device)
+    val.backward()
+    Ao, Bo = torch.tensor(spd, requires_grad=True), torch.tensor(b, requires_grad=True)
+    ref = chain(torch.linalg.cholesky, lambda bb, aa, lower: torch.linalg.solve_triangular(aa, bb, upper=not lower),
+                lambda L: L.diagonal().log().sum(), lambda L, upper: torch.cholesky_inverse(L, upper=upper), Ao, Bo, "cpu")
+    ref.backward()
+    assert abs(val.item() - ref.item()) < 1e-9 * max(1.0, abs(ref.item()))
+    sym = lambda g: 0.5 * (g + g.t())              # only the symmetric part of dA is defined
+    assert (sym(A.grad.cpu()) - sym(Ao.grad)).abs().max().item() < 1e-9 * max(1.0, Ao.grad.abs().max().item())
+    assert (Bm.grad.cpu() - Bo.grad).abs().max().item() < 1e-9 * max(1.0, Bo.grad.abs().max().item())
+    # an in-place edit of L invalidates the factor remembered on it (no stale solves)
+    L = functions.cholesky(t(spd))
+    L.mul_(2.0)
+    x = functions.trtrs(t(b), L)
+    assert (x.cpu() - torch.linalg.solve_triangular(2.0 * torch.linalg.cholesky(torch.tensor(spd)), torch.tensor(b), upper=False)
+            ).abs().max().item() < 1e-10
+
+
 @pytest.mark.parametrize("n,e", [(1152, 0), (2500, 3), (8320, 1), (9001, 2)])
 def test_factorisation_drivers_agree(device, n, e):
     """the look-ahead panel driver (default), its left-looking form (default from N = 24576) and the
@@ -1016,28 +1103,21 @@ def test_repeated_evaluations_are_bitwise_identical(device):
 def test_bench_multi_rank_control_flow(device):
     """bench.py under torch.distributed.run with 2 ranks (both on cuda:0, gloo collectives via
     --test-shared-gpu): the N > 1 path of the bench contract -- barrier-bracketed timing, MAX over
-    ranks, rank 0 prints ONE JSON line with the whole-job value -- which the driver otherwise only
-    exercises on a multi-GPU node."""
+    ranks, rank 0 prints ONE JSON line with the whole-job value of the ONE block-cyclic model --
+    which the driver otherwise only exercises on a multi-GPU node.  (C1's matrix in 128-wide tiles.)"""
     import json
-    import os
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "c1", "--test-shared-gpu"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", "c1", "--tile", "128",
+                        "--test-shared-gpu", "--no-extras"], {}, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["unit"] == "LML evals/s" and d["dtype"] == "f64" and d["vs_baseline"] is None and d["higher_is_better"] is True
-    assert abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 4 / 1e3)) < 1e-6 * d["value"]
-    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
-    assert "replicas x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 2 * 78.6
+    case = [c for c in LML if c["name"] == "C1_rbf_512_2"][0]
+    assert abs(d["lml"] - case["lml"]) < 1e-8 and d["info"] == 0
 
 
 def test_vfe_split_k_accumulation(device, monkeypatch):

@@ -105,6 +105,30 @@ def test_cpu_tensors_fail_loudly_no_fallback():
         GPR(x, y, kernels.Rbf(2) + kernels.Linear(2)).loss()
 
 
+def test_jit_op_is_the_same_ladder():
+    """functions.jit_op (functions.py:20-43) for a caller-supplied op: plain try, then
+    x + 10^(-10+i) I, then RuntimeError("Max tries exceeded.") -- on top of _ops._ladder."""
+    from gptorch_amd import functions
+    seen = []
+
+    def op(m):
+        seen.append(m[0, 0].item())
+        if m[0, 0].item() < 1.0 + 5e-7:
+            raise RuntimeError("not yet")
+        return m * 2.0
+
+    out = functions.jit_op(op, torch.eye(2, dtype=torch.float64))
+    assert seen == [1.0] + [1.0 + 10.0 ** (-10 + i) for i in range(5)]
+    assert out[0, 0].item() == 2.0 * (1.0 + 1e-6) and out[0, 1].item() == 0.0
+
+    def never(m):
+        raise RuntimeError("no")
+    with pytest.raises(RuntimeError, match="Max tries exceeded."):
+        functions.jit_op(never, torch.eye(2, dtype=torch.float64))
+    with pytest.raises(NativeError):          # the differentiable surface has no CPU path either
+        gptorch_amd.util.squared_distance(torch.zeros(3, 2, dtype=torch.float64))
+
+
 def test_jitter_ladder_logic():
     """functions.py:20-43 replayed by _ops._ladder on the LAPACK-style info."""
     from gptorch_amd import _ops
