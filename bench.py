@@ -381,6 +381,14 @@ def run_single(args, device):
     if gl is not None:
         line["lml_reference_golden"] = gl
         line["lml_abs_err_vs_reference_golden"] = abs(lml - gl)
+    if args.workload == "c3":
+        try:     # extended-precision value of the same expression (tests/golden/make_c3_extended.py)
+            ext = json.load(open(os.path.join(ROOT, "tests", "golden", "lml_c3_extended.json")))
+            line["lml_extended_precision"] = ext["lml_extended"]
+            line["lml_abs_err_vs_extended_precision"] = abs(lml - ext["lml_extended"])
+            line["reference_abs_err_vs_extended_precision"] = ext["reference_abs_err_vs_extended"]
+        except Exception:
+            pass
     line.update(roofs)
     line.update(extra)
     if not args.no_cpu_baseline:
