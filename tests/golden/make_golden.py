@@ -415,6 +415,58 @@ def gen_composite(out):
     print("composite:", [(c["name"], c["loss"], sorted(c["grads"])) for c in cases])
 
 
+def gen_c2_grad(out):
+    """BASELINE config 2 (N = 8192, D = 8, Rbf): d loss / d raw parameters from autograd through the
+    reference (gpr.py:47-67 + PyTorch's CholeskyBackward0 ...), ~15 s -- the full-size gradient pin."""
+    case = C2_CASE
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    t0 = time.time()
+    m = ref_model(case, x, y)
+    loss = m.loss()
+    loss.backward()
+    entry = dict(case)
+    entry["x_checksum"], entry["y_checksum"] = rng.checksum(x), rng.checksum(y)
+    entry["lml"] = float(-loss.item())
+    entry["grad_loss"] = {"kernel.variance": m.kernel.variance.grad.numpy().tolist(),
+                          "kernel.length_scales": m.kernel.length_scales.grad.numpy().tolist(),
+                          "likelihood.variance": m.likelihood.variance.grad.numpy().tolist()}
+    entry["ref_seconds"] = time.time() - t0
+    o = oracle_model(case, x, y)
+    ol, og = o.loss_and_grads()
+    for a, b in zip(og, [m.kernel.variance.grad, m.kernel.length_scales.grad, m.likelihood.variance.grad]):
+        assert rel(a.numpy(), b.numpy()) < 1e-10, (a, b)
+    with open(os.path.join(out, "lml_c2_grad.json"), "w") as f:
+        json.dump(entry, f, indent=1)
+    print("c2 grad:", entry["lml"], entry["grad_loss"], "%.1f s" % entry["ref_seconds"])
+
+
+def gen_lbfgs(out):
+    """What examples/regression_1d.py:34-53 actually runs: GPR over Linear + Rbf + Constant on n = 100
+    points, model.optimize(method="L-BFGS-B") (base.py:298-320 -> scipy.optimize.minimize over
+    model._loss_and_grad, model.py:84-133).  Golden = every loss value the reference printed
+    (one per function evaluation), the final flat parameter vector and predictions."""
+    rs = np.random.RandomState(42)
+    n = 100
+    x = np.linspace(0, 1, n).reshape((-1, 1))
+    y = np.sin(2.0 * np.pi * x) + np.cos(3.5 * np.pi * x) - 3.0 * x + 5.0 + 0.1 * rs.randn(n, 1)
+    kern = rk.Linear(1) + rk.Rbf(1) + rk.Constant(1)
+    m = RefGPR(x, y, kern)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        m.optimize(method="L-BFGS-B", max_iter=25)
+    losses = [float(l.split("loss:")[1]) for l in buf.getvalue().splitlines() if l.startswith("loss:")]
+    names = [nm for nm, p in m.named_parameters() if p.requires_grad]
+    xt = np.linspace(-0.2, 1.2, 11).reshape((-1, 1))
+    with torch.no_grad():
+        mu, var = m.predict_y(xt)
+    res = dict(n=n, seed=42, max_iter=25, x=x.ravel().tolist(), y=y.ravel().tolist(), losses=losses,
+               param_names=names, final_params=m._get_param_array().tolist(), final_loss=float(m.loss().item()),
+               x_test=xt.ravel().tolist(), mean_y=np.asarray(mu).ravel().tolist(), var_y=np.asarray(var).ravel().tolist())
+    with open(os.path.join(out, "lbfgs_case.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("lbfgs:", len(losses), "evaluations", losses[:3], "...", losses[-1], names)
+
+
 def gen_api(out):
     """API behaviours of the shell."""
     x, y = rng.make_regression(20, 3, 2, seed=5)
@@ -443,7 +495,7 @@ if __name__ == "__main__":
     steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
                  lml=lambda: gen_lml(HERE, args.big), adam=lambda: gen_adam(HERE),
                  func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE),
-                 comp=lambda: gen_composite(HERE))
+                 comp=lambda: gen_composite(HERE), c2grad=lambda: gen_c2_grad(HERE), lbfgs=lambda: gen_lbfgs(HERE))
     for k, fn in steps.items():
         if not args.only or k in args.only.split(","):
             fn()

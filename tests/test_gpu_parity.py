@@ -357,6 +357,99 @@ def test_loss_gradients_golden(device, case):
         assert err < (1e-5 if ill else 1e-8), (name, g, ref)
 
 
+def test_c2_gradient_golden(device):
+    """BASELINE config 2 at FULL size (N = 8192, D = 8, Rbf): d loss / d raw parameters against
+    autograd through the reference (tests/golden/lml_c2_grad.json, make_golden.py --only c2grad)."""
+    case = load_json("lml_c2_grad.json")
+    m, x, y = _model(case, device)
+    assert rng.checksum(x) == case["x_checksum"] and rng.checksum(y) == case["y_checksum"]
+    loss = m.loss()
+    assert abs(-loss.item() - case["lml"]) < 1e-8
+    loss.backward()
+    for name, g in [("kernel.variance", m.kernel.variance.grad), ("kernel.length_scales", m.kernel.length_scales.grad),
+                    ("likelihood.variance", m.likelihood.variance.grad)]:
+        ref = np.asarray(case["grad_loss"][name])
+        err = np.max(np.abs(g.cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref)))
+        assert err < 1e-8, (name, g, ref)
+
+
+def test_c3_full_size_backward_properties(device):
+    """BASELINE config 3's backward at FULL size (N = 32768, D = 16, Matern52: the 2048-wide panels,
+    the left-looking in-panel update, 128x128 K-clipped tiles in the triangular inversion and in
+    U U^T).  No reference finishes autograd at this size in the build container, so size-independent
+    properties of the closed form:
+      (1) the three analytic gradients against central finite differences of the (golden-checked)
+          LML in the raw (log) parameters;
+      (2) a = Kyy^-1 y (what dLML/d(y - m) = -a returns) satisfies (Kyy a)_i = y_i on sampled rows;
+      (3) sampled rows of Kyy * Kyy^-1 (the matrix the gradient sweep reads) reproduce the identity."""
+    from gptorch_amd import _backward, _ops
+    case = load_json("lml_c3.json")
+    m, x, y = _model(case, device)
+    loss = m.loss()
+    loss.backward()
+    params = [("kernel.variance", m.kernel.variance), ("kernel.length_scales", m.kernel.length_scales),
+              ("likelihood.variance", m.likelihood.variance)]
+    grads = {nm: p.grad.item() for nm, p in params}
+    h = 1e-4
+    for nm, p in params:
+        vals = []
+        for sgn in (+1.0, -1.0):
+            with torch.no_grad():
+                p.data += sgn * h
+                vals.append(m.loss().item())
+                p.data -= sgn * h
+        fd = (vals[0] - vals[1]) / (2.0 * h)
+        # rounding noise of the LML (1e-8) / h plus the h^2 truncation term: the difference quotient
+        # resolves about 1e-6 relative
+        assert abs(fd - grads[nm]) < 2e-6 * max(1.0, abs(grads[nm])), (nm, fd, grads[nm])
+    # (2), (3): the factor of a forward at the base point
+    with torch.no_grad():
+        m.loss()
+    f = m._holder["factor"]
+    n = f.n
+    k = m.kernel
+    var, ls, nz = k.variance.transform().detach(), k.length_scales.transform().detach(), m.likelihood.variance.transform().detach()
+    g_var, g_ls, g_nz, g_R = _backward.lml_backward(k._kind, m.X, var, ls, nz, f)
+    a = -g_R[:, 0]
+    U = _backward._upper_inverse(f)
+    Kinv = _backward._kinv_lower(f, U)
+    rows = torch.tensor([0, 1, 127, 128, 2047, 2048, 4097, 16383, 16384, 20000, 31111, n - 1], device=device)
+    Krows = _ops.kernel_matrix(k._kind, m.X[rows], m.X, var, ls)                    # [12, n]
+    Krows[torch.arange(len(rows), device=device), rows] += nz[0]
+    assert (Krows @ a - m.Y[rows, 0]).abs().max().item() < 1e-8
+    for j in (0, 129, 5000, 16384, n - 1):
+        col = torch.cat([Kinv[j, :j + 1], Kinv[j + 1:n, j]])                          # column j of the symmetric inverse
+        e = Krows @ col
+        e[rows == j] -= 1.0
+        assert e.abs().max().item() < 1e-8, (j, e)
+
+
+def test_lbfgs_trajectory_golden(device):
+    """What examples/regression_1d.py:34-53 runs: GPR over Linear + Rbf + Constant, n = 100,
+    model.optimize(method="L-BFGS-B") (base.py:298-320, model.py:84-133) -- every loss value scipy asked
+    for, the final parameters and predictions, against the reference's run (make_golden.py --only lbfgs).
+    Everything under the optimiser runs on the HIP path (dense-K node: native factorisation,
+    closed-form backward, native kernel sweeps)."""
+    import contextlib, io
+    g = load_json("lbfgs_case.json")
+    x, y = np.asarray(g["x"]).reshape(-1, 1), np.asarray(g["y"]).reshape(-1, 1)
+    m = GPR(x, y, kernels.Linear(1) + kernels.Rbf(1) + kernels.Constant(1))
+    m.cuda()
+    assert [nm for nm, p in m.named_parameters() if p.requires_grad] == g["param_names"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        m.optimize(method="L-BFGS-B", max_iter=g["max_iter"])
+    losses = [float(l.split("loss:")[1]) for l in buf.getvalue().splitlines() if l.startswith("loss:")]
+    ref = np.asarray(g["losses"])
+    assert len(losses) == len(ref), (len(losses), len(ref))
+    rel = np.abs(np.asarray(losses) - ref) / np.maximum(1.0, np.abs(ref))
+    assert rel[:10].max() < 1e-9 and rel.max() < 1e-6, rel
+    assert np.max(np.abs(m._get_param_array() - np.asarray(g["final_params"]))) < 1e-5
+    assert abs(m.loss().item() - g["final_loss"]) < 1e-6
+    mu, var = m.predict_y(np.asarray(g["x_test"]).reshape(-1, 1))
+    assert np.max(np.abs(mu.ravel() - np.asarray(g["mean_y"]))) < 1e-6 and np.max(np.abs(var.ravel() - np.asarray(g["var_y"]))) < 1e-6
+
+
 def test_gradient_wrt_mean_function(device):
     """dLML/d(y - m) = -a flows into a trainable mean (gpr.py:62 `y - mean_function(x)`)."""
     x, y = rng.make_regression(90, 2, 2, seed=8)
@@ -1126,6 +1219,54 @@ def test_bench_multi_rank_control_flow(device):
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma" and d["roofline"]["peak"] == 2 * 78.6
     case = [c for c in LML if c["name"] == "C1_rbf_512_2"][0]
     assert abs(d["lml"] - case["lml"]) < 1e-8 and d["info"] == 0
+
+
+def test_c5_full_size_properties(device, monkeypatch):
+    """BASELINE config 5 at FULL size (sparse VFE, N = 10^6, M = 4096, D = 8; 16 streamed chunks, two
+    chunk pipelines, split-K = 8 accumulation).  No CPU path finishes this, so size-independent
+    properties: (1) the bound is invariant (to rounding) under the streaming configuration -- chunk
+    rows, number of pipelines, split-K on/off -- which changes every launch shape and summation order
+    of the N-sized part; (2) sampled entries of L L^T reproduce K(Z) (+ the ladder's jitter);
+    (3) sampled entries of LB LB^T reproduce B = A A^T + I."""
+    from gptorch_amd import _ops
+    from gptorch_amd.models import VFE, sparse_gpr
+    n, mm, d = 1000000, 4096, 8
+    x, y = rng.make_regression(n, d, 1, seed=0)
+    z = rng.normal(99, (mm, d))
+    m = VFE(x, y, kernels.Rbf(d, variance=1.0, length_scales=float(np.sqrt(d))), inducing_points=z,
+            likelihood=likelihoods.Gaussian(variance=1e-2), mean_function=mean_functions.Zero(1))
+    m.cuda()
+    with torch.no_grad():
+        elbo0, st = m._bound(m.X)
+        elbo0 = elbo0.item()
+    assert np.isfinite(elbo0)
+    # (2) L L^T = K(Z) + jitter I
+    f = st.f_uu
+    L = f.A[:mm, :mm]
+    idx = torch.tensor([0, 1, 127, 128, 1000, 2047, 2048, 3000, 4095], device=device)
+    k = m.kernel
+    var, ls = k.variance.transform().detach(), k.length_scales.transform().detach()
+    Kz = _ops.kernel_matrix("Rbf", m.Z.detach()[idx], m.Z.detach()[idx], var, ls)
+    if f.jitter_rung >= 0:
+        Kz += 10.0 ** (-10 + f.jitter_rung) * torch.eye(len(idx), dtype=torch.float64, device=device)
+    Lr = torch.tril(L)[idx]
+    assert (Lr @ Lr.t() - Kz).abs().max().item() < 1e-12
+    # (3) LB LB^T = A A^T + I
+    LB = torch.tril(st.fB.A[:mm, :mm])[idx]
+    AAT = torch.tril(st.AAT[:mm, :mm])
+    B = (AAT + torch.tril(AAT, -1).t())[idx][:, idx] + torch.eye(len(idx), dtype=torch.float64, device=device)
+    scale = B.abs().max().item()
+    assert (LB @ LB.t() - B).abs().max().item() < 1e-12 * scale
+    del st, f, L, LB, AAT
+    torch.cuda.empty_cache()
+    # (1) other streaming configurations
+    for chunk, lanes, split in [(32768, 2, 8), (65536, 1, 1), (131072, 2, 8)]:
+        monkeypatch.setattr(sparse_gpr, "CHUNK_ROWS", chunk)
+        monkeypatch.setattr(sparse_gpr, "LANES", lanes)
+        monkeypatch.setattr(sparse_gpr, "SPLIT_K", split)
+        with torch.no_grad():
+            e = m.log_likelihood().item()
+        assert abs(e - elbo0) < 1e-9 * abs(elbo0), (chunk, lanes, split, e, elbo0)
 
 
 def test_vfe_split_k_accumulation(device, monkeypatch):
