@@ -56,6 +56,43 @@ SIGNATURES = {
     "gpn_copy_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "gpn_row_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
 }
+# callback table of the distributed driver (include/gpnative.h gpn_dist_comm)
+BCAST_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)
+
+
+class DistComm(ctypes.Structure):
+    _fields_ = [("ctx", c_void_p), ("bcast", BCAST_FN), ("allreduce", ALLREDUCE_FN), ("flags", c_int)]
+
+
+SIGNATURES.update({
+    "gpn_dist_work_bytes": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int64]),
+    "gpn_dist_lml_forward": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
+                                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+})
+# libgpnative_rccl.so: the RCCL adapter of that table (declared in the same header)
+RCCL_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpnative_rccl.so")
+RCCL_SIGNATURES = {
+    "gpn_rccl_comm_create": (ctypes.POINTER(DistComm), [c_void_p, c_void_p, c_void_p]),
+    "gpn_rccl_comm_destroy": (None, [ctypes.POINTER(DistComm)]),
+}
+_rccl_lib = None
+
+
+def rccl_lib():
+    """the RCCL adapter library (loads librccl); raises if it was not built."""
+    global _rccl_lib
+    if _rccl_lib is None:
+        if not os.path.exists(RCCL_LIB_PATH):
+            raise NativeError("libgpnative_rccl.so not found at %s -- run gptorch_amd/csrc/build.sh" % RCCL_LIB_PATH)
+        handle = ctypes.CDLL(RCCL_LIB_PATH)
+        for name, (res, args) in RCCL_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _rccl_lib = handle
+    return _rccl_lib
+
+
 # not part of the public header: debugging switches
 DEBUG_SIGNATURES = {
     "gpn_debug_set_gemm_variant": (c_int, [c_int]),

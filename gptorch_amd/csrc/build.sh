@@ -19,3 +19,9 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgpnative.so" "$OBJ"/*.o
 echo "built $OUT/libgpnative.so"
+# the RCCL adapter of the gpn_dist_comm callback table (a separate library: libgpnative itself links no
+# communication runtime)
+if [ ! -f "$OUT/libgpnative_rccl.so" ] || [ "$HERE/rccl_adapter.cpp" -nt "$OUT/libgpnative_rccl.so" ] || [ "$HERE/../../include/gpnative.h" -nt "$OUT/libgpnative_rccl.so" ]; then
+  $HIPCC -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$HERE/rccl_adapter.cpp" -o "$OUT/libgpnative_rccl.so" -L/opt/rocm/lib -lrccl -lamdhip64
+  echo "built $OUT/libgpnative_rccl.so"
+fi

@@ -1,0 +1,427 @@
+// gpn_dist_*: the 2-D block-cyclic log marginal likelihood behind the C ABI (SURVEY.md 8(b):
+// "multi-GPU handle gpn_dist_* taking an RCCL communicator + process grid"; 8(e)).
+//
+// The reference has no multi-GPU path (gptorch/models/base.py:33 "Assume single GPU"); this is the
+// distributed form of GPR.log_likelihood (gpr.py:47-67) for callers that are not Python.  It is the
+// same algorithm, layout and launch sequence as gptorch_amd/dist.py (read that module's header for
+// the layout): tile (I,J) of T x T on rank (I mod Pr) * Pc + (J mod Pc), Pr | Pc; one stacked
+// row-major local matrix per rank whose rows taking part in panel k are contiguous; per panel
+//   1. owner factors the diagonal tile, [L_kk | leaf inverses] packed down the process COLUMN;
+//   2. every rank of that process column solves all its panel rows in one call;
+//   3. the solved rows, packed, along each process ROW;
+//   4. the tiles of my tile columns, packed, down each process column;
+//   5. per local tile column one contraction over the stacked rows below it,
+// with look-ahead: tile column k+1 is updated, factored and solved first and its two exchanges
+// run on their own HIP streams underneath the two halves of the remaining update by panel k.
+//
+// Communication goes through a small callback table (gpn_dist_comm) so that the library itself
+// does not link a communication runtime: libgpnative_rccl.so (csrc/rccl_adapter.cpp) provides the
+// table over three ncclComm_t (process row, process column, world); the test-suite provides one over
+// torch.distributed/gloo to run several ranks on a 1-GPU box.  No allocation, no host
+// synchronisation: the caller owns one workspace of gpn_dist_work_bytes() bytes and reads the four
+// result words back itself.
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
+#include "gpn_common.h"
+
+namespace gpn {
+
+struct DistGeom {
+  int rank, pr, pc, my_r, my_c;
+  int64_t n, T, nt;
+  int dy;
+  int64_t nrow_t, ncol_t, res_off, rows, ld;
+  bool has_res;
+  int64_t rows_of(int64_t I) const { return I == nt ? dy : std::min<int64_t>(T, n - I * T); }
+  int64_t rows_le(int64_t k, int r) const {          // how many of process row r's tile rows have index <= k
+    const int64_t cnt = (nt - r + pr - 1) / pr;
+    return k < r ? 0 : std::min<int64_t>((k - r) / pr + 1, std::max<int64_t>(cnt, 0));
+  }
+  int64_t cols_le(int64_t k) const { return k < my_c ? 0 : std::min<int64_t>((k - my_c) / pc + 1, ncol_t); }
+  int64_t nreal_rows() const {                       // real (unpadded) rows of my matrix segment: a prefix
+    if (nrow_t == 0) return 0;
+    const int64_t last = my_r + (nrow_t - 1) * pr;
+    return (nrow_t - 1) * T + rows_of(last);
+  }
+  int64_t nreal_cols() const {
+    if (ncol_t == 0) return 0;
+    const int64_t last = my_c + (ncol_t - 1) * pc;
+    return (ncol_t - 1) * T + rows_of(last);
+  }
+};
+
+static int make_geom(DistGeom& g, int rank, int pr, int pc, int64_t n, int dy, int64_t tile) {
+  if (pr < 1 || pc < 1 || pc % pr) return -4;
+  if (rank < 0 || rank >= pr * pc) return -3;
+  if (tile < LEAF || tile % LEAF) return -15;
+  g.rank = rank; g.pr = pr; g.pc = pc; g.my_r = rank / pc; g.my_c = rank % pc;
+  g.n = n; g.T = tile; g.dy = dy;
+  g.nt = (n + tile - 1) / tile;
+  g.nrow_t = g.nt > g.my_r ? (g.nt - g.my_r + pr - 1) / pr : 0;
+  g.ncol_t = g.nt > g.my_c ? (g.nt - g.my_c + pc - 1) / pc : 0;
+  g.has_res = (g.nt % pr) == g.my_r;
+  g.res_off = g.nrow_t * tile;
+  g.rows = g.res_off + (g.has_res ? round_up(dy, LEAF) : 0) + LEAF;
+  g.ld = std::max<int64_t>(g.ncol_t, 1) * tile;
+  return GPN_OK;
+}
+
+// workspace layout (doubles)
+struct DistLayout {
+  int64_t A, left[2], right[2], diag, winv, xrow, xcol, stats, info, sums, total;
+};
+static DistLayout make_layout(const DistGeom& g, int d) {
+  DistLayout L;
+  const int64_t T = g.T;
+  const int64_t lrows = (g.rows + T - 1) / T * T + 16;
+  const int64_t wn = gpn_winv_bytes(T) / 8;
+  int64_t o = 0;
+  auto take = [&](int64_t cnt) { const int64_t at = o; o += round_up(cnt, 32); return at; };   // 256-byte granules
+  L.A = take(g.rows * g.ld);
+  for (int i = 0; i < 2; ++i) L.left[i] = take(lrows * T);
+  for (int i = 0; i < 2; ++i) L.right[i] = take((std::max<int64_t>(g.ncol_t, 1) * T + 16) * T);
+  L.diag = take(T * T + wn);
+  L.winv = take(wn);
+  L.xrow = take(std::max<int64_t>(g.nrow_t, 1) * T * d);
+  L.xcol = take(std::max<int64_t>(g.ncol_t, 1) * T * d);
+  L.stats = take(3 * (g.ncol_t + 1) + g.dy + 8);      // lml_reduce triples per diagonal tile, residual row sums
+  L.info = take(g.nt + 8);                            // int32 per tile column (stored in double-sized slots)
+  L.sums = take(g.nt + 8);                            // all-reduced vector: log-det, |alpha|^2, info per tile
+  L.total = o;
+  return L;
+}
+
+// helper streams / events per caller stream (row and column exchanges run beside the compute stream)
+struct DistAux {
+  hipStream_t row_s = nullptr, col_s = nullptr;
+  hipEvent_t ready = nullptr;                          // compute stream -> exchange streams
+  hipEvent_t row_done[2] = {nullptr, nullptr}, col_done[2] = {nullptr, nullptr};
+};
+static std::mutex g_dist_mutex;
+static std::unordered_map<hipStream_t, DistAux> g_dist_aux;
+static DistAux* dist_aux_for(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_dist_mutex);
+  auto it = g_dist_aux.find(s);
+  if (it != g_dist_aux.end()) return &it->second;
+  DistAux a;
+  if (hipStreamCreateWithFlags(&a.row_s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipStreamCreateWithFlags(&a.col_s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.ready, hipEventDisableTiming) != hipSuccess) return nullptr;
+  for (int i = 0; i < 2; ++i) {
+    if (hipEventCreateWithFlags(&a.row_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&a.col_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &g_dist_aux.emplace(s, a).first->second;
+}
+void dist_release(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_dist_mutex);
+  auto drop = [](DistAux& a) {
+    if (a.row_s) { (void)hipStreamSynchronize(a.row_s); (void)hipStreamDestroy(a.row_s); }
+    if (a.col_s) { (void)hipStreamSynchronize(a.col_s); (void)hipStreamDestroy(a.col_s); }
+    if (a.ready) (void)hipEventDestroy(a.ready);
+    for (int i = 0; i < 2; ++i) {
+      if (a.row_done[i]) (void)hipEventDestroy(a.row_done[i]);
+      if (a.col_done[i]) (void)hipEventDestroy(a.col_done[i]);
+    }
+  };
+  if (!s) { for (auto& kv : g_dist_aux) drop(kv.second); g_dist_aux.clear(); return; }
+  auto it = g_dist_aux.find(s);
+  if (it != g_dist_aux.end()) { drop(it->second); g_dist_aux.erase(it); }
+}
+
+// sums[0] = sum over my diagonal tiles of sum log L_ii, sums[1] = |alpha|^2 of my residual columns,
+// sums[2 + k] = info word of tile column k (as a double; only its owner is non-zero)
+__global__ void dist_local_sums_kernel(const double* stats, int ndiag, const double* rowsq, int dy, const int32_t* info, int nt,
+                                       double* sums) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    double s = 0.0;
+    for (int i = 0; i < ndiag; ++i) s += stats[3 * i];
+    sums[0] = s;
+    double q = 0.0;
+    for (int c = 0; c < dy; ++c) q += rowsq[c];
+    sums[1] = q;
+  }
+  for (int k = t; k < nt; k += blockDim.x) sums[2 + k] = (double)info[k];
+}
+
+// out[0] = sum log L_ii, out[1] = |alpha|^2, out[2] = LML (gpr.py:63-67), out[3] = LAPACK-style info of the
+// whole matrix (first failing pivot, 1-based; GPN_INFO_INTERNAL if any tile reported it; 0 = ok)
+__global__ void dist_finish_kernel(const double* sums, int nt, int64_t T, int64_t n, int dy, double* out4) {
+  if (threadIdx.x != 0) return;
+  double info = 0.0;
+  for (int k = 0; k < nt; ++k) {
+    if (sums[2 + k] < 0.0) { info = (double)GPN_INFO_INTERNAL; break; }
+    if (sums[2 + k] > 0.0 && info == 0.0) info = (double)k * (double)T + sums[2 + k];
+  }
+  out4[0] = sums[0];
+  out4[1] = sums[1];
+  out4[2] = -0.5 * sums[1] - (double)dy * sums[0] - 0.5 * (double)dy * (double)n * 1.8378770664093454836;   // log(2 pi)
+  out4[3] = info;
+}
+
+struct DistRun {
+  hipStream_t s;
+  DistAux* ax;
+  const gpn_dist_comm* comm;
+  DistGeom g;
+  DistLayout L;
+  double* W;
+  int rc = GPN_OK;
+  bool force() const { return comm && (comm->flags & GPN_DIST_FORCE_COLLECTIVES); }
+  bool xrow() const { return comm && (g.pc > 1 || force()); }
+  bool xcol() const { return comm && (g.pr > 1 || force()); }
+  void ok(int r) { if (r != GPN_OK && rc == GPN_OK) rc = r; }
+  void hip(hipError_t e, const char* where) { if (e != hipSuccess && rc == GPN_OK) { set_hip_error(e, where); rc = GPN_E_HIP; } }
+
+  void active(int64_t k, int64_t& lo, int64_t& hi) const {
+    lo = g.rows_le(k, g.my_r) * g.T;
+    hi = std::max(lo, g.res_off + (g.has_res ? g.dy : 0));
+  }
+
+  // steps 1-2
+  void panel_phase(int64_t k) {
+    const int64_t T = g.T, nk = g.rows_of(k), ck = k % g.pc;
+    if (g.my_c != ck || rc != GPN_OK) return;
+    const int64_t lk = (k - g.my_c) / g.pc;
+    int64_t lo, hi;
+    active(k, lo, hi);
+    const int64_t m = hi - lo;
+    double* colk = W + L.A + lk * T;
+    const bool mine = (k % g.pr) == g.my_r;
+    double* Lp = W + L.diag;
+    double* Wp = Lp + T * T;
+    const double* Lsrc = Lp;
+    int64_t ldl = T;
+    int32_t* info = reinterpret_cast<int32_t*>(W + L.info) + k;
+    if (mine) {
+      double* Lt = colk + (g.rows_le(k, g.my_r) - 1) * T * g.ld;
+      ok(gpn_potrf_lower(s, Lt, nk, 0, g.ld, Wp, info));
+      if (xcol()) ok(gpn_copy_matrix(s, Lt, nk, nk, g.ld, Lp, T, 0));
+      else { Lsrc = Lt; ldl = g.ld; }
+    }
+    if (xcol() && rc == GPN_OK) {
+      // the exchange is short and everything after it depends on it: it stays on the compute stream
+      ok(comm->bcast(comm->ctx, 1, Lp, T * T + gpn_winv_bytes(T) / 8, (int)(k % g.pr), s));
+    }
+    if (m > 0 && rc == GPN_OK) ok(gpn_trsm_right_lt(s, Lsrc, nk, ldl, Wp, colk + lo * g.ld, m, g.ld));
+  }
+
+  // step 3 (asynchronous on the row stream): -> left operand buffer
+  double* start_rows(int64_t k, bool& pending) {
+    const int64_t T = g.T, nk = g.rows_of(k), ck = k % g.pc;
+    int64_t lo, hi;
+    active(k, lo, hi);
+    const int64_t m = hi - lo;
+    double* buf = W + L.left[k & 1];
+    pending = false;
+    if (m == 0 || rc != GPN_OK) return buf;
+    if (nk < T) hip(hipMemsetAsync(buf, 0, (size_t)m * T * sizeof(double), s), "start_rows memset");
+    if (g.my_c == ck) ok(gpn_copy_matrix(s, W + L.A + lo * g.ld + ((k - g.my_c) / g.pc) * T, m, nk, g.ld, buf, T, 0));
+    if (xrow() && rc == GPN_OK) {
+      hip(hipEventRecord(ax->ready, s), "start_rows");
+      hip(hipStreamWaitEvent(ax->row_s, ax->ready, 0), "start_rows");
+      ok(comm->bcast(comm->ctx, 0, buf, m * T, (int)ck, ax->row_s));
+      hip(hipEventRecord(ax->row_done[k & 1], ax->row_s), "start_rows");
+      pending = true;
+    }
+    return buf;
+  }
+  void wait_rows(int64_t k, bool& pending) {
+    if (pending) hip(hipStreamWaitEvent(s, ax->row_done[k & 1], 0), "wait_rows");
+    pending = false;
+  }
+
+  // step 4 (asynchronous on the column stream, after step 3 has completed): -> right operand
+  double* start_cols(int64_t k, double* left, bool& pending) {
+    const int64_t T = g.T;
+    pending = false;
+    const int rs = g.my_c % g.pr;
+    const int64_t lj0 = g.cols_le(k), count = g.ncol_t - lj0;
+    if (count <= 0 || rc != GPN_OK) return W + L.right[k & 1];
+    const int64_t J0 = lj0 * g.pc + g.my_c;
+    const int64_t first = (J0 - rs) / g.pr - g.rows_le(k, rs);
+    const int64_t step = g.pc / g.pr;
+    const bool src = g.my_r == rs;
+    double* buf;
+    if (src && step == 1) buf = left + first * T * T;                     // already contiguous
+    else {
+      buf = W + L.right[k & 1];
+      if (src)   // every step-th tile of my left buffer -> consecutive tiles: ONE strided 2-D copy (tile = T*T doubles)
+        hip(hipMemcpy2DAsync(buf, (size_t)T * T * sizeof(double), left + first * T * T, (size_t)step * T * T * sizeof(double),
+                             (size_t)T * T * sizeof(double), (size_t)count, hipMemcpyDeviceToDevice, s), "start_cols gather");
+    }
+    if (xcol() && rc == GPN_OK) {
+      hip(hipEventRecord(ax->ready, s), "start_cols");
+      hip(hipStreamWaitEvent(ax->col_s, ax->ready, 0), "start_cols");
+      ok(comm->bcast(comm->ctx, 1, buf, count * T * T, rs, ax->col_s));
+      hip(hipEventRecord(ax->col_done[k & 1], ax->col_s), "start_cols");
+      pending = true;
+    }
+    return buf;
+  }
+  void wait_cols(int64_t k, bool& pending) {
+    if (pending) hip(hipStreamWaitEvent(s, ax->col_done[k & 1], 0), "wait_cols");
+    pending = false;
+  }
+
+  // step 5 on my local tile columns [from, to)
+  void update(int64_t k, const double* left, const double* right, int64_t from, int64_t to) {
+    const int64_t T = g.T, nk = round_up(g.rows_of(k), 16);
+    int64_t lo, hi;
+    active(k, lo, hi);
+    const int64_t base = g.cols_le(k);
+    double* A = W + L.A;
+    for (int64_t lj = std::max(from, base); lj < std::min(to, g.ncol_t) && rc == GPN_OK; ++lj) {
+      const int64_t J = lj * g.pc + g.my_c, nJ = g.rows_of(J);
+      const int64_t li0 = g.rows_le(J - 1, g.my_r);
+      int64_t r0 = std::max(li0 * T, lo);
+      if (r0 >= hi) continue;
+      const double* B = right + (lj - base) * T * T;
+      if (li0 < g.nrow_t && li0 * g.pr + g.my_r == J) {
+        ok(gemm_nt(s, nJ, nJ, nk, -1.0, left + (r0 - lo) * T, T, B, T, 1.0, A + r0 * g.ld + lj * T, g.ld, 1));
+        r0 += T;
+      }
+      if (hi > r0) ok(gemm_nt(s, hi - r0, nJ, nk, -1.0, left + (r0 - lo) * T, T, B, T, 1.0, A + r0 * g.ld + lj * T, g.ld, 0));
+    }
+  }
+};
+
+}  // namespace gpn
+
+using namespace gpn;
+
+extern "C" int64_t gpn_dist_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile) {
+  DistGeom g;
+  if (make_geom(g, rank, pr, pc, n, dy, tile) != GPN_OK || d <= 0 || dy <= 0) return -1;
+  return make_layout(g, d).total * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                                    const double* X, int64_t n, int d, const double* Y, int dy,
+                                    const double* variance, const double* length_scales, int nls, const double* noise,
+                                    int64_t tile, double* work, int64_t work_bytes, double* out4) {
+  DistRun R;
+  int rc = make_geom(R.g, rank, pr, pc, n, dy, tile);
+  if (rc != GPN_OK) return rc;
+  if (pr * pc > 1 && (!comm || !comm->bcast || !comm->allreduce)) return -2;
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -6;
+  if (!X) return -7;
+  if (n <= 0) return -8;
+  if (d <= 0) return -9;
+  if (!Y) return -10;
+  if (dy <= 0) return -11;
+  if (!variance || !length_scales || !noise) return -12;
+  if (nls != 1 && nls != d) return -14;
+  if (!work) return -16;
+  if (!out4) return -18;
+  R.L = make_layout(R.g, d);
+  if (work_bytes < R.L.total * (int64_t)sizeof(double)) return -17;
+  if (reinterpret_cast<uintptr_t>(work) & 255) return GPN_E_ALIGN;
+  R.s = static_cast<hipStream_t>(stream);
+  R.comm = (pr * pc > 1 || (comm && (comm->flags & GPN_DIST_FORCE_COLLECTIVES))) ? comm : nullptr;
+  R.W = work;
+  R.ax = dist_aux_for(R.s);
+  if (!R.ax) return GPN_E_HIP;
+  const DistGeom& g = R.g;
+  const DistLayout& L = R.L;
+  const int64_t T = g.T, nt = g.nt;
+  hipStream_t s = R.s;
+
+  // ---- assembly: X rows in my tile-row / tile-column order, then one rectangular K per local tile column
+  GPN_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)R.L.total * sizeof(double), s));
+  const int64_t nrr = g.nreal_rows(), ncr = g.nreal_cols();
+  double* Xrow = work + L.xrow;
+  double* Xcol = work + L.xcol;
+  for (int64_t li = 0; li < g.nrow_t; ++li) {          // tile rows are T-row blocks of X at stride Pr*T
+    const int64_t I = g.my_r + li * g.pr;
+    GPN_HIP_CHECK(hipMemcpyAsync(Xrow + li * T * d, X + I * T * d, (size_t)g.rows_of(I) * d * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  for (int64_t lj = 0; lj < g.ncol_t; ++lj) {
+    const int64_t J = g.my_c + lj * g.pc;
+    GPN_HIP_CHECK(hipMemcpyAsync(Xcol + lj * T * d, X + J * T * d, (size_t)g.rows_of(J) * d * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  double* A = work + L.A;
+  for (int64_t lj = 0; lj < g.ncol_t; ++lj) {
+    const int64_t J = g.my_c + lj * g.pc, nJ = g.rows_of(J);
+    if (g.has_res) {                                     // residual rows: (y)^T of this tile column
+      rc = gpn_pack_rhs(stream, Y + J * T * dy, nullptr, nJ, dy, A + g.res_off * g.ld + lj * T, g.ld);
+      if (rc != GPN_OK) return rc;
+    }
+    const int64_t li0 = g.rows_le(J - 1, g.my_r);
+    int64_t r0 = li0 * T;
+    if (r0 >= nrr) continue;                             // no matrix tile of mine at or below the diagonal here
+    const double* xj = Xcol + lj * T * d;
+    if (li0 * g.pr + g.my_r == J) {                     // the diagonal tile is mine: K(X_J) + noise I (gpr.py:83-86)
+      rc = gpn_kernel_matrix(stream, kind, xj, nJ, nullptr, nJ, d, variance, length_scales, nls, noise, GPN_FULL,
+                             A + r0 * g.ld + lj * T, g.ld);
+      if (rc != GPN_OK) return rc;
+      r0 += T;
+    }
+    if (r0 < nrr) {
+      rc = gpn_kernel_matrix(stream, kind, Xrow + r0 * d, nrr - r0, xj, nJ, d, variance, length_scales, nls, nullptr, GPN_FULL,
+                             A + r0 * g.ld + lj * T, g.ld);
+      if (rc != GPN_OK) return rc;
+    }
+  }
+
+  // ---- factorisation with look-ahead
+  R.panel_phase(0);
+  double *left = nullptr, *right = nullptr;
+  bool rows_pending = false, cols_pending = false;
+  if (nt > 1) {
+    left = R.start_rows(0, rows_pending);
+    R.wait_rows(0, rows_pending);
+    right = R.start_cols(0, left, cols_pending);
+  }
+  for (int64_t k = 0; k + 1 < nt && R.rc == GPN_OK; ++k) {
+    R.wait_cols(k, cols_pending);                        // panel k is everywhere it is needed
+    if ((k + 1) % g.pc == g.my_c) {
+      const int64_t nxt = g.cols_le(k + 1) - 1;
+      R.update(k, left, right, nxt, nxt + 1);            // tile column k+1 first ...
+    }
+    R.panel_phase(k + 1);                                // ... so only ITS panel is on the critical path
+    if (k + 2 < nt) {
+      bool rp = false, cp = false;
+      double* nleft = R.start_rows(k + 1, rp);           // in flight under the first half ...
+      const int64_t a = g.cols_le(k + 1);
+      const int64_t half = a + (g.ncol_t - a + 1) / 2;
+      R.update(k, left, right, a, half);
+      R.wait_rows(k + 1, rp);
+      double* nright = R.start_cols(k + 1, nleft, cp);   // ... and under the second half
+      R.update(k, left, right, half, g.ncol_t);
+      left = nleft; right = nright;
+      cols_pending = cp;
+    }
+  }
+  if (R.rc != GPN_OK) return R.rc;
+
+  // ---- log-det partials, |alpha|^2, info words: one small all-reduce
+  double* stats = work + L.stats;
+  int ndiag = 0;
+  for (int64_t lj = 0; lj < g.ncol_t; ++lj) {
+    const int64_t J = g.my_c + lj * g.pc;
+    if (J % g.pr != g.my_r) continue;
+    const int64_t li = (J - g.my_r) / g.pr;
+    rc = gpn_lml_reduce(stream, A + li * T * g.ld + lj * T, g.rows_of(J), 0, g.ld, stats + 3 * ndiag);
+    if (rc != GPN_OK) return rc;
+    ++ndiag;
+  }
+  double* rowsq = stats + 3 * (g.ncol_t + 1);
+  if (g.has_res && ncr > 0) {
+    rc = gpn_row_sumsq(stream, A + g.res_off * g.ld, dy, ncr, g.ld, rowsq);
+    if (rc != GPN_OK) return rc;
+  }
+  double* sums = work + L.sums;
+  hipLaunchKernelGGL(dist_local_sums_kernel, dim3(1), dim3(256), 0, s, stats, ndiag, rowsq, (g.has_res && ncr > 0) ? dy : 0,
+                     reinterpret_cast<const int32_t*>(work + L.info), (int)nt, sums);
+  GPN_LAUNCH_CHECK();
+  if (R.comm) {
+    rc = R.comm->allreduce(R.comm->ctx, sums, nt + 2, s);
+    if (rc != GPN_OK) return rc;
+  }
+  hipLaunchKernelGGL(dist_finish_kernel, dim3(1), dim3(64), 0, s, sums, (int)nt, T, n, dy, out4);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}

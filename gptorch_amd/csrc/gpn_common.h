@@ -47,6 +47,9 @@ enum { PROF_GEMM = 0,         // rectangular contraction (in-panel updates, pred
        PROF_GRAD = 5,         // gradient sweep (work = algorithmic bytes)
        PROF_LEAF = 6,         // 128x128 diagonal leaf
        PROF_NCLASSES = 7 };
+// release the exchange streams/events gpn_dist_lml_forward keeps for a caller stream (dist.hip)
+void dist_release(hipStream_t s);
+
 bool profile_on();
 int profile_begin(hipStream_t s, double work, int cls);
 void profile_end(hipStream_t s, int idx);

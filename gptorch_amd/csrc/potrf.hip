@@ -872,6 +872,7 @@ extern "C" int64_t gpn_potrf_panel_width(int64_t n) { return (g_potrf_variant ==
 // factorisation (created on first use).  A caller that destroys a stream releases them here, so a
 // recycled hipStream_t handle never meets stale helpers.  stream == NULL releases all of them.
 extern "C" int gpn_release_stream(void* stream) {
+  dist_release(static_cast<hipStream_t>(stream));
   std::lock_guard<std::mutex> lock(g_aux_mutex);
   auto drop = [](Aux& a) {
     if (a.s1) { (void)hipStreamSynchronize(a.s1); (void)hipStreamDestroy(a.s1); }

@@ -576,3 +576,117 @@ class BlockCyclicGP:
             if self.factor() == 0:
                 return self.lml()
         raise RuntimeError("Max tries exceeded.")
+
+
+class NativeDistLML:
+    """The same distributed evaluation through the C ABI (`gpn_dist_lml_forward`, csrc/dist.hip): the whole
+    panel loop runs in the library, Python only supplies the communicator.  `comm` is either
+    "rccl" (three RCCL communicators created here from the torch.distributed store -> the adapter
+    library libgpnative_rccl.so; what a non-Python consumer does with its own ncclComm_t) or
+    "torch" (callbacks over torch.distributed collectives -- any backend; how the test-suite runs
+    several ranks on one GPU over gloo)."""
+
+    def __init__(self, X, Y, kind, tile=2048, grid=None, comm="torch", force_comm=False):
+        import ctypes
+        from . import _native
+        self._ct, self._native = ctypes, _native
+        live = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if live else 0
+        self.world = dist.get_world_size() if live else 1
+        self.pr, self.pc = grid if grid is not None else choose_grid(self.world)
+        if self.pr * self.pc != self.world or self.pc % self.pr:
+            raise ValueError("process grid %dx%d does not fit %d ranks (Pr must divide Pc)" % (self.pr, self.pc, self.world))
+        self.X, self.Y, self.kind, self.T = X.contiguous(), Y.contiguous(), kind, int(tile)
+        self.n, self.dy = Y.shape
+        self.d = X.shape[1]
+        lib = _native.lib()
+        nbytes = int(lib.gpn_dist_work_bytes(self.rank, self.pr, self.pc, self.n, self.d, self.dy, self.T))
+        if nbytes < 0:
+            raise ValueError("bad grid / tile for gpn_dist_lml_forward")
+        self.work = torch.empty(nbytes // 8, dtype=torch.float64, device=X.device)
+        self.out = torch.zeros(4, dtype=torch.float64, device=X.device)
+        self.info = 0
+        self.table = None
+        self._keep = []
+        need = live and (self.world > 1 or force_comm)
+        if need and comm == "torch":
+            self.table = self._torch_table(force_comm)
+        elif need and comm == "rccl":
+            raise NotImplementedError("pass your own ncclComm_t triple to gpn_rccl_comm_create (INTEGRATION.md); "
+                                      "torch.distributed does not expose its RCCL communicators")
+
+    def _torch_table(self, force):
+        ct, nat = self._ct, self._native
+        my_r, my_c = divmod(self.rank, self.pc)
+        row_group = col_group = None
+        for r in range(self.pr):
+            g = dist.new_group([r * self.pc + c for c in range(self.pc)]) if (self.pc > 1 or force) else None
+            if r == my_r:
+                row_group = g
+        for c in range(self.pc):
+            g = dist.new_group([r * self.pc + c for r in range(self.pr)]) if (self.pr > 1 or force) else None
+            if c == my_c:
+                col_group = g
+        base, work = self.work.data_ptr(), self.work
+
+        def view(ptr, count):
+            off = (ptr - base) // 8
+            assert 0 <= off and off + count <= work.numel()
+            return work[off:off + count]
+
+        def bcast(ctx, which, buf, count, root, stream):
+            try:
+                torch.cuda.synchronize()          # the table's contract is stream order; this transport is host-side
+                if which == 0:
+                    dist.broadcast(view(buf, count), src=my_r * self.pc + root, group=row_group)
+                else:
+                    dist.broadcast(view(buf, count), src=root * self.pc + my_c, group=col_group)
+                torch.cuda.synchronize()
+                return 0
+            except Exception:                     # never let an exception cross the C frame
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        def allreduce(ctx, buf, count, stream):
+            try:
+                torch.cuda.synchronize()
+                dist.all_reduce(view(buf, count))
+                torch.cuda.synchronize()
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        b, a = nat.BCAST_FN(bcast), nat.ALLREDUCE_FN(allreduce)
+        self._keep = [b, a]                       # the C side holds raw pointers to these
+        return nat.DistComm(None, b, a, 1 if force else 0)
+
+    def _evaluate(self, variance, length_scales, noise):
+        ct = self._ct
+        lib = self._native.lib()
+        var, ls, nz = (_ops._c(t.detach()) for t in (variance, length_scales, noise))
+        st = lib.gpn_dist_lml_forward(_ops._stream(self.X.device), ct.byref(self.table) if self.table is not None else None,
+                                      self.rank, self.pr, self.pc, _ops.KINDS[self.kind], _ops._ptr(self.X), self.n, self.d,
+                                      _ops._ptr(self.Y), self.dy, _ops._ptr(var), _ops._ptr(ls), ls.numel(), _ops._ptr(nz),
+                                      self.T, _ops._ptr(self.work), self.work.numel() * 8, _ops._ptr(self.out))
+        self._native.check(st, "gpn_dist_lml_forward")
+        host = self.out.cpu()
+        self.info = int(host[3])
+        if self.info < 0:
+            raise _ops.NativeError("a tile factorisation reported an internal status (not a property of the matrix)")
+        return host
+
+    def log_likelihood(self, variance, length_scales, noise, max_tries=10):
+        """LML with the jitter ladder of functions.py:20-43 on the all-reduced info word."""
+        host = self._evaluate(variance, length_scales, noise)
+        self.jitter_rung = -1
+        for i in range(max_tries):
+            if self.info == 0:
+                break
+            self.jitter_rung = i
+            host = self._evaluate(variance, length_scales, noise + 10.0 ** (-max_tries + i))
+        if self.info != 0:
+            raise RuntimeError("Max tries exceeded.")
+        return host[2].to(self.X.device)

@@ -101,8 +101,9 @@ int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
 /* Panel width the driver uses for an n x n factorisation (0 = the recursive driver): each panel ends
  * with one lower-tile K = width contraction -- the SYRK trailing update priced by bench.py. */
 int64_t gpn_potrf_panel_width(int64_t n);
-/* Release the helper stream/events the library keeps for `stream` (created by the first
- * factorisation enqueued on it); call before destroying the stream.  NULL = release all. */
+/* Release the helper streams/events the library keeps for `stream` (created by the first
+ * factorisation / distributed evaluation enqueued on it); call before destroying the stream.
+ * NULL = release all. */
 int gpn_release_stream(void* stream);
 
 /* winv <- inverses of the 128x128 diagonal blocks of a GIVEN lower-triangular L
@@ -230,6 +231,48 @@ int gpn_predict(void* stream, int kind, const double* X, int64_t n, int d,
                 const double* variance, const double* length_scales, int nls,
                 const double* A, int64_t lda, const double* winv, int dy, int full_cov,
                 double* work, double* mean, double* var);
+
+/* ---- several GPUs: 2-D block-cyclic log marginal likelihood --------------------
+ * The reference is single-GPU (gptorch/models/base.py:33 "Assume single GPU"); this is
+ * GPR.log_likelihood (gpr.py:47-67) for a Gram matrix that is partitioned over a Pr x Pc process
+ * grid (Pr divides Pc: 1x1, 1x2, 2x2, 2x4), one process per GPU, tile (I,J) of `tile` x `tile`
+ * on rank (I mod Pr) * Pc + (J mod Pc).  Same algorithm, layout and launch sequence as
+ * gptorch_amd/dist.py (csrc/dist.hip).  Every rank calls it collectively with the same arguments
+ * (X [n,d] and Y [n,dy] replicated on every GPU; each rank assembles its own tiles).
+ *
+ * Communication goes through a callback table so that libgpnative does not link a communication
+ * runtime.  libgpnative_rccl.so (gpn_rccl_comm_create below) fills it from three RCCL
+ * communicators; any other transport can be supplied the same way.  Both callbacks ENQUEUE on
+ * the given HIP stream and return 0 on success:
+ *   bcast(ctx, which, buf, count, root, stream): in-place broadcast of `count` doubles inside this
+ *       rank's process ROW (which = 0; root = the source's process-column index 0..Pc-1) or process
+ *       COLUMN (which = 1; root = the source's process-row index 0..Pr-1) sub-communicator;
+ *   allreduce(ctx, buf, count, stream): in-place sum over all Pr*Pc ranks. */
+enum { GPN_DIST_FORCE_COLLECTIVES = 1 /* issue them in single-member communicators too (tests) */ };
+typedef struct gpn_dist_comm {
+  void* ctx;
+  int (*bcast)(void* ctx, int which, double* buf, int64_t count, int root, void* stream);
+  int (*allreduce)(void* ctx, double* buf, int64_t count, void* stream);
+  int flags;
+} gpn_dist_comm;
+/* bytes of the caller-owned device workspace of rank `rank` (256-byte aligned; contents arbitrary on
+ * entry: the call clears what it needs).  <0: bad grid / tile. */
+int64_t gpn_dist_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile);
+/* out4 (device): [0] = sum log L_ii, [1] = |alpha|^2, [2] = LML (gpr.py:63-67), [3] = LAPACK-style
+ * info of the WHOLE matrix as a double (0 = ok, j > 0 = first failing pivot: replay with
+ * noise + 10^(-10+i) as functions.py:20-43 does; GPN_INFO_INTERNAL = internal failure), identical on
+ * every rank.  comm may be NULL for a 1 x 1 grid.  No host synchronisation. */
+int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                         const double* X, int64_t n, int d, const double* Y, int dy,
+                         const double* variance, const double* length_scales, int nls, const double* noise,
+                         int64_t tile, double* work, int64_t work_bytes, double* out4);
+/* libgpnative_rccl.so only: a callback table over RCCL communicators (ncclComm_t passed as void*):
+ * `row` spans this rank's process row with rank-in-communicator = process-column index, `col` its
+ * process column with rank-in-communicator = process-row index, `world` all ranks.  row / col may be
+ * NULL where that communicator has a single member.  Destroy with gpn_rccl_comm_destroy (the
+ * communicators themselves stay the caller's). */
+gpn_dist_comm* gpn_rccl_comm_create(void* row, void* col, void* world);
+void gpn_rccl_comm_destroy(gpn_dist_comm* comm);
 
 /* ---- small utilities -------------------------------------------------------- */
 /* dst[r, c] = src[c, r] for src[rows, cols] */

@@ -30,10 +30,14 @@ def test_every_declared_symbol_is_exported_and_bound():
     lib = ctypes.CDLL(_native.LIB_PATH)
     names = _declared()
     assert len(names) >= 18
+    rccl = ctypes.CDLL(_native.RCCL_LIB_PATH)       # the RCCL adapter of the gpn_dist_comm table: its own library
     for n in names:
+        if n in _native.RCCL_SIGNATURES:
+            assert hasattr(rccl, n), "libgpnative_rccl.so does not export %s" % n
+            continue
         assert hasattr(lib, n), "libgpnative.so does not export %s" % n
         assert n in _native.SIGNATURES, "gptorch_amd._native has no ctypes signature for %s" % n
-    for n in _native.SIGNATURES:
+    for n in list(_native.SIGNATURES) + list(_native.RCCL_SIGNATURES):
         assert n in names, "%s is bound but not declared in include/gpnative.h" % n
 
 
@@ -67,6 +71,13 @@ def test_argument_validation_without_launch():
     assert lib.gpn_predict(null, 0, null, 4, 2, null, 3, null, null, 1, null, 128, null, 1, 0, null, null, null) == -6
     assert lib.gpn_lml_backward_work_bytes(1000, 2, 3) >= 2 * lib.gpn_factor_rows(1000, 0) * lib.gpn_factor_ld(1000, 0) * 8
     assert lib.gpn_predict_work_bytes(1000, 5, 2) == 128 * lib.gpn_factor_ld(1000, 2) * 8
+    # distributed driver: grid / tile validation and workspace sizing are pure host code
+    assert lib.gpn_dist_work_bytes(0, 2, 3, 1000, 2, 1, 128) == -1             # Pr must divide Pc
+    assert lib.gpn_dist_work_bytes(0, 2, 4, 1000, 2, 1, 100) == -1             # tile % 128
+    assert lib.gpn_dist_work_bytes(8, 2, 4, 1000, 2, 1, 128) == -1             # rank outside the grid
+    w1, w8 = lib.gpn_dist_work_bytes(0, 1, 1, 65536, 32, 1, 2048), lib.gpn_dist_work_bytes(3, 2, 4, 65536, 32, 1, 2048)
+    assert w1 > 65536 * 65536 * 8 and w8 < w1 / 5 and w8 % 256 == 0
+    assert lib.gpn_dist_lml_forward(null, null, 0, 2, 4, 0, null, 100, 2, null, 1, null, null, 1, null, 128, null, 0, null) == -2   # no comm table
     # zero-size problems are no-ops that succeed
     one = ctypes.c_double(0.0)
     p = ctypes.cast(ctypes.pointer(one), ctypes.c_void_p)

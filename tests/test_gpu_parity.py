@@ -628,6 +628,67 @@ def test_bench_multi_rank_line_shared_gpu(device):
     assert line["replicas_c2"]["value"] > 0 and line["single_gpu_same_run"]["value"] > 0
 
 
+def test_c_driver_single_rank_and_rccl_adapter(device):
+    """gpn_dist_lml_forward (csrc/dist.hip), the block-cyclic evaluation behind the C ABI: (1) a 1x1 grid
+    without a communicator on ragged multi-tile problems against the goldens; (2) the same call with
+    the RCCL callback table of libgpnative_rccl.so over a real (single-rank) ncclComm_t created here
+    through librccl's C API, collectives forced -- every ncclBroadcast / ncclAllReduce an 8-GPU run
+    issues, on this box's GPU."""
+    import ctypes
+    from gptorch_amd import _native, dist as gdist
+    t = lambda v: torch.tensor([v], dtype=torch.float64, device=device)
+    for name, tile in [("rbf_1000_8_ls1", 256), ("rbf_2048_8", 512), ("C2_rbf_8192_8", 2048)]:
+        case = [c for c in LML if c["name"] == name][0]
+        x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+        X, Y = torch.tensor(x, device=device), torch.tensor(y, device=device)
+        g = gdist.NativeDistLML(X, Y, "Rbf", tile=tile)
+        lml = g.log_likelihood(t(case["variance"]), t(case["length_scales"]), t(case["noise"]))
+        assert g.info == 0 and abs(lml.item() - case["lml"]) < 1e-8, (name, lml.item(), case["lml"])
+    # (2) RCCL: ncclGetUniqueId / ncclCommInitRank(world = 1) through ctypes
+    rccl = ctypes.CDLL("librccl.so")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        lib = _native.rccl_lib()
+        table = lib.gpn_rccl_comm_create(comm, comm, comm)
+        assert table
+        table.contents.flags = 1                     # GPN_DIST_FORCE_COLLECTIVES
+        case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
+        x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+        X, Y = torch.tensor(x, device=device), torch.tensor(y, device=device)
+        g = gdist.NativeDistLML(X, Y, "Rbf", tile=512)
+        g.table = table.contents
+        lml = g.log_likelihood(t(case["variance"]), t(case["length_scales"]), t(case["noise"]))
+        assert g.info == 0 and abs(lml.item() - case["lml"]) < 1e-8, (lml.item(), case["lml"])
+        torch.cuda.synchronize()
+        lib.gpn_rccl_comm_destroy(table)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c_driver_multi_rank_shared_gpu(device, world):
+    """the C-ABI driver on grids 1x2, 2x2 and 2x4 (the 8-GPU grid: every second tile of the row exchange
+    gathered for the column exchange): `world` processes share cuda:0, the communicator callbacks
+    run torch.distributed/gloo collectives (tools/dist_bench.py GPN_CDRIVER=1) -- the panel loop,
+    packing, look-ahead and exchange order are the library's own."""
+    import re
+    out = _torchrun(world, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_SHARED_GPU": "1", "GPN_CDRIVER": "1"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    vals = [float(v) for v in re.findall(r"cdriver: lml=(-?[0-9.]+)", out.stdout)]
+    case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
+    assert len(vals) == 2, out.stdout
+    for v in vals:
+        assert abs(v - case["lml"]) < 1e-8, (v, case["lml"])
+
+
 # ---- VFE (sparse_gpr.py:92-195; BASELINE config 5) -------------------------------
 def test_vfe_reference_known_answer(device):
     """The reference's own pins: loss == approx(8.842242323920674) and vfe_y_mean/cov.dat

@@ -6,7 +6,8 @@ Env: GPN_SHARED_GPU=1   every rank on cuda:0 with gloo collectives (multi-rank o
      GPN_DIST_GRAD=1    also the distributed closed-form backward
      GPN_FORCE_COMM=1   issue the row/column collectives even in single-member groups (drives the RCCL calls at world 1)
      GPN_PHANTOM=r/w    do the work of rank r of a w-rank grid with the collectives skipped (timing only)
-     GPN_NATIVE=1       also time the single-GPU native factorisation of the same matrix"""
+     GPN_NATIVE=1       also time the single-GPU native factorisation of the same matrix
+     GPN_CDRIVER=1      also the C-ABI driver (gpn_dist_lml_forward) over torch.distributed callbacks"""
 import os, sys, time
 import torch
 import torch.distributed as dist
@@ -68,5 +69,14 @@ if os.environ.get("GPN_NATIVE") == "1" and g.rank == 0:
         f, terms = _ops.lml_forward("Rbf", X, Y, one, ls, 0.01 * one, factor=f)
         torch.cuda.synchronize()
         print("native single-GPU: lml=%.8f  %.1f ms" % (terms[2].item(), (time.time() - t0) * 1e3), flush=True)
+if os.environ.get("GPN_CDRIVER") == "1":
+    c = gdist.NativeDistLML(X, Y, "Rbf", tile=T, comm="torch", force_comm=os.environ.get("GPN_FORCE_COMM") == "1")
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        lml = c.log_likelihood(one, ls, 0.01 * one)
+        torch.cuda.synchronize()
+        if c.rank == 0:
+            print("cdriver: lml=%.8f  %.1f ms  grid=%dx%d" % (lml.item(), (time.time() - t0) * 1e3, c.pr, c.pc), flush=True)
 if dist.is_initialized():
     dist.destroy_process_group()
