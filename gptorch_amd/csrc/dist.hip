@@ -96,6 +96,7 @@ static DistLayout make_layout(const DistGeom& g, int d) {
 struct DistAux {
   hipStream_t row_s = nullptr, col_s = nullptr;
   hipEvent_t ready = nullptr;                          // compute stream -> exchange streams
+  hipEvent_t diag_done = nullptr;
   hipEvent_t row_done[2] = {nullptr, nullptr}, col_done[2] = {nullptr, nullptr};
 };
 static std::mutex g_dist_mutex;
@@ -108,6 +109,7 @@ static DistAux* dist_aux_for(hipStream_t s) {
   if (hipStreamCreateWithFlags(&a.row_s, hipStreamNonBlocking) != hipSuccess) return nullptr;
   if (hipStreamCreateWithFlags(&a.col_s, hipStreamNonBlocking) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.ready, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.diag_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (int i = 0; i < 2; ++i) {
     if (hipEventCreateWithFlags(&a.row_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.col_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -120,6 +122,7 @@ void dist_release(hipStream_t s) {
     if (a.row_s) { (void)hipStreamSynchronize(a.row_s); (void)hipStreamDestroy(a.row_s); }
     if (a.col_s) { (void)hipStreamSynchronize(a.col_s); (void)hipStreamDestroy(a.col_s); }
     if (a.ready) (void)hipEventDestroy(a.ready);
+    if (a.diag_done) (void)hipEventDestroy(a.diag_done);
     for (int i = 0; i < 2; ++i) {
       if (a.row_done[i]) (void)hipEventDestroy(a.row_done[i]);
       if (a.col_done[i]) (void)hipEventDestroy(a.col_done[i]);
@@ -202,8 +205,13 @@ struct DistRun {
       else { Lsrc = Lt; ldl = g.ld; }
     }
     if (xcol() && rc == GPN_OK) {
-      // the exchange is short and everything after it depends on it: it stays on the compute stream
-      ok(comm->bcast(comm->ctx, 1, Lp, T * T + gpn_winv_bytes(T) / 8, (int)(k % g.pr), s));
+      // short, and everything after it depends on it -- but it goes through the column stream like the
+      // panel exchange of step 4, so that one communicator is only ever driven from one stream
+      hip(hipEventRecord(ax->ready, s), "panel_phase");
+      hip(hipStreamWaitEvent(ax->col_s, ax->ready, 0), "panel_phase");
+      ok(comm->bcast(comm->ctx, 1, Lp, T * T + gpn_winv_bytes(T) / 8, (int)(k % g.pr), ax->col_s));
+      hip(hipEventRecord(ax->diag_done, ax->col_s), "panel_phase");
+      hip(hipStreamWaitEvent(s, ax->diag_done, 0), "panel_phase");
     }
     if (m > 0 && rc == GPN_OK) ok(gpn_trsm_right_lt(s, Lsrc, nk, ldl, Wp, colk + lo * g.ld, m, g.ld));
   }

@@ -612,8 +612,42 @@ class NativeDistLML:
         if need and comm == "torch":
             self.table = self._torch_table(force_comm)
         elif need and comm == "rccl":
-            raise NotImplementedError("pass your own ncclComm_t triple to gpn_rccl_comm_create (INTEGRATION.md); "
-                                      "torch.distributed does not expose its RCCL communicators")
+            self.table = self._rccl_table(force_comm)
+
+    def _rccl_table(self, force):
+        """RCCL communicators of our own (torch.distributed does not expose its ncclComm_t): rank 0 draws
+        an ncclUniqueId, torch.distributed carries its 128 bytes to everybody, ncclCommInitRank builds the
+        world communicator and ncclCommSplit the process-row / process-column ones -- exactly what a
+        non-Python consumer does with its own bootstrap -- then libgpnative_rccl.so wraps the three in
+        the callback table."""
+        ct, nat = self._ct, self._native
+        rccl = ct.CDLL("librccl.so")
+
+        class UniqueId(ct.Structure):
+            _fields_ = [("internal", ct.c_char * 128)]
+        uid = UniqueId()
+        if self.rank == 0 and rccl.ncclGetUniqueId(ct.byref(uid)) != 0:
+            raise _ops.NativeError("ncclGetUniqueId failed")
+        blob = [bytes(bytearray(uid)) if self.rank == 0 else None]
+        dist.broadcast_object_list(blob, src=0)
+        ct.memmove(ct.byref(uid), blob[0], 128)
+        world = ct.c_void_p()
+        rccl.ncclCommInitRank.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int, UniqueId, ct.c_int]
+        if rccl.ncclCommInitRank(ct.byref(world), self.world, uid, self.rank) != 0:
+            raise _ops.NativeError("ncclCommInitRank failed")
+        my_r, my_c = divmod(self.rank, self.pc)
+        row, col = ct.c_void_p(), ct.c_void_p()
+        rccl.ncclCommSplit.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.POINTER(ct.c_void_p), ct.c_void_p]
+        if rccl.ncclCommSplit(world, my_r, my_c, ct.byref(row), None) != 0:      # colour = process row, key = column index
+            raise _ops.NativeError("ncclCommSplit (process row) failed")
+        if rccl.ncclCommSplit(world, my_c, my_r, ct.byref(col), None) != 0:      # colour = process column, key = row index
+            raise _ops.NativeError("ncclCommSplit (process column) failed")
+        table = nat.rccl_lib().gpn_rccl_comm_create(row, col, world)
+        if not table:
+            raise _ops.NativeError("gpn_rccl_comm_create failed")
+        table.contents.flags = 1 if force else 0
+        self._keep = [rccl, world, row, col, table]
+        return table.contents
 
     def _torch_table(self, force):
         ct, nat = self._ct, self._native

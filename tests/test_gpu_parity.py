@@ -600,12 +600,15 @@ def test_block_cyclic_over_rccl_world1(device):
     backward issued through RCCL (single-member groups, GPN_FORCE_COMM=1) -- the calls, buffer
     shapes and stream hand-overs are the ones an 8-GPU run makes."""
     import re
-    out = _torchrun(1, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_FORCE_COMM": "1", "GPN_DIST_GRAD": "1"})
+    out = _torchrun(1, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_FORCE_COMM": "1", "GPN_DIST_GRAD": "1", "GPN_CDRIVER": "1",
+                                                                     "GPN_RCCL": "1"})
     assert out.returncode == 0, out.stderr[-3000:]
     assert "backend=nccl" in out.stdout, out.stdout
     vals = [float(v) for v in re.findall(r"lml=(-?[0-9.]+)", out.stdout)]
     case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
-    assert len(vals) == 4, out.stdout
+    # 3 timed evaluations + the gradient call (torch.distributed/RCCL) + 2 of the C driver over its own
+    # RCCL communicators (ncclCommInitRank + ncclCommSplit, bootstrapped through torch.distributed)
+    assert len(vals) == 6 and out.stdout.count("cdriver:") == 2, out.stdout
     for v in vals:
         assert abs(v - case["lml"]) < 1e-8, (v, case["lml"])
 

@@ -7,7 +7,8 @@ Env: GPN_SHARED_GPU=1   every rank on cuda:0 with gloo collectives (multi-rank o
      GPN_FORCE_COMM=1   issue the row/column collectives even in single-member groups (drives the RCCL calls at world 1)
      GPN_PHANTOM=r/w    do the work of rank r of a w-rank grid with the collectives skipped (timing only)
      GPN_NATIVE=1       also time the single-GPU native factorisation of the same matrix
-     GPN_CDRIVER=1      also the C-ABI driver (gpn_dist_lml_forward) over torch.distributed callbacks"""
+     GPN_CDRIVER=1      also the C-ABI driver (gpn_dist_lml_forward) over torch.distributed callbacks,
+                        or with GPN_RCCL=1 over its own RCCL communicators (libgpnative_rccl.so) -- the form for real multi-GPU runs"""
 import os, sys, time
 import torch
 import torch.distributed as dist
@@ -70,7 +71,8 @@ if os.environ.get("GPN_NATIVE") == "1" and g.rank == 0:
         torch.cuda.synchronize()
         print("native single-GPU: lml=%.8f  %.1f ms" % (terms[2].item(), (time.time() - t0) * 1e3), flush=True)
 if os.environ.get("GPN_CDRIVER") == "1":
-    c = gdist.NativeDistLML(X, Y, "Rbf", tile=T, comm="torch", force_comm=os.environ.get("GPN_FORCE_COMM") == "1")
+    c = gdist.NativeDistLML(X, Y, "Rbf", tile=T, comm="rccl" if os.environ.get("GPN_RCCL") == "1" else "torch",
+                            force_comm=os.environ.get("GPN_FORCE_COMM") == "1")
     for it in range(2):
         torch.cuda.synchronize()
         t0 = time.time()
