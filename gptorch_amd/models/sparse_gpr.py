@@ -108,17 +108,112 @@ def _chunks(n, nc):
 
 class _State:
     """what one evaluation of the bound leaves behind (all M-sized)."""
-    __slots__ = ("f_uu", "fB", "AAT", "Aerr", "s2", "tr", "terms", "n", "n_all", "yy_all")
+    __slots__ = ("f_uu", "fB", "AAT", "Aerr", "s2", "tr", "terms", "n", "n_all", "yy_all", "trkff")
 
 
-def _vfe_forward(kind, x, err, Z, var, ls, s2):
+class _NativeAsm:
+    """K(x_c, Z), K(Z) and their gradient sweeps for a kernel with a native kind: the fused assembly
+    kernel and the native sweeps (gpn_kernel_grad, gpn_kernel_grad_x2)."""
+
+    def __init__(self, kind, var, ls):
+        self.kind, self.var, self.ls = kind, var, ls
+
+    def factor_uu(self, Z):
+        return _ops.kernel_factor(self.kind, Z, self.var, self.ls, None)          # L = chol(K(Z)) (+ladder)
+
+    def kuf(self, xc, Z, out, ldk):
+        _ops.kernel_matrix(self.kind, xc, Z, self.var, self.ls, out=out, ldk=ldk)
+
+    def trkff(self, x):
+        return x.shape[0] * self.var[0]                                           # Kdiag = variance (kernels.py:174-179)
+
+    # -- backward: accumulators for (variance, length_scales, Z)
+    def begin(self, Z):
+        self.g_var = torch.zeros(1, dtype=torch.float64, device=Z.device)
+        self.g_ls = torch.zeros_like(self.ls)
+        self.g_Z = torch.zeros_like(Z)
+
+    def grad_uu(self, Z, Guu):
+        gv, gl = _backward.kernel_backward(self.kind, Z, None, self.var, self.ls, Guu)
+        self.g_var += gv
+        self.g_ls += gl
+        _backward.kernel_backward_x2(self.kind, Z, Z, self.var, self.ls, Guu, scale=2.0, out=self.g_Z)
+
+    def grad_uf(self, xc, Z, G):
+        gv, gl = _backward.kernel_backward(self.kind, xc, Z, self.var, self.ls, G)
+        self.g_var += gv
+        self.g_ls += gl
+        _backward.kernel_backward_x2(self.kind, xc, Z, self.var, self.ls, G, out=self.g_Z)
+
+    def grad_trkff(self, coef, n_all):
+        self.g_var += coef * n_all                                                 # d tr Kff / d variance = N
+
+    def tensors(self):
+        return [self.g_var, self.g_ls, self.g_Z]
+
+
+class _GenericAsm:
+    """The same for ANY kernel object (sparse_gpr.py:126-129 takes whatever `self.kernel` is: sums,
+    products, Linear, ...): K(x_c, Z) and K(Z) come from the kernel's own `K` (whose stationary
+    leaves are the native assembly), and the gradient of sum(G * K) goes back through the kernel's own
+    autograd nodes, chunk by chunk -- to the RAW parameters directly, in `params` order."""
+
+    def __init__(self, kernel, params):
+        self.kernel, self.params = kernel, params
+
+    def factor_uu(self, Z):
+        with torch.no_grad():
+            return _ops.cholesky_factor(self.kernel.K(Z))
+
+    def kuf(self, xc, Z, out, ldk):
+        with torch.no_grad():
+            out[:xc.shape[0], :Z.shape[0]] = self.kernel.K(xc, Z)
+
+    def trkff(self, x):
+        with torch.no_grad():
+            return self.kernel.Kdiag(x).sum()
+
+    def begin(self, Z):
+        self.g_params = [torch.zeros_like(p) for p in self.params]
+        self.g_Z = torch.zeros_like(Z)
+
+    def _pull(self, out, G, Zg):
+        grads = torch.autograd.grad(out, self.params + [Zg], grad_outputs=G, allow_unused=True)
+        for acc, g in zip(self.g_params + [self.g_Z], grads):
+            if g is not None:
+                acc += g
+
+    def grad_uu(self, Z, Guu):
+        with torch.enable_grad():
+            Zg = Z.detach().requires_grad_(True)
+            self._pull(self.kernel.K(Zg), Guu, Zg)
+
+    def grad_uf(self, xc, Z, G):
+        with torch.enable_grad():
+            Zg = Z.detach().requires_grad_(True)
+            self._pull(self.kernel.K(xc, Zg), G, Zg)
+
+    def grad_trkff(self, coef, n_all):
+        # row shards: every rank differentiates the diagonal of ITS rows; the all-reduce sums them
+        with torch.enable_grad():
+            tr = self.kernel.Kdiag(self._x).sum()
+            grads = torch.autograd.grad(tr, self.params, allow_unused=True)
+        for acc, g in zip(self.g_params, grads):
+            if g is not None:
+                acc += coef * g
+
+    def tensors(self):
+        return self.g_params + [self.g_Z]
+
+
+def _vfe_forward(asm, x, err, Z, s2):
     """streamed evaluation of sparse_gpr.py:126-137 -> _State."""
     dev = x.device
     n, dy = err.shape
     m = Z.shape[0]
     st = _State()
     st.n, st.s2 = n, s2
-    st.f_uu = f_uu = _ops.kernel_factor(kind, Z, var, ls, None)          # L = chol(K(Z)) (+ladder)
+    st.f_uu = f_uu = asm.factor_uu(Z)
     fB = _ops.Factor(m, dy, dev)
     st.AAT = AAT = torch.zeros_like(fB.A)
     mp = _ops.round_up(m, 16)
@@ -150,7 +245,7 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
             stream = _ops._stream(dev)
             if r < nc:                                                     # ragged tail: stale entries -> 0
                 At.zero_(), A.zero_(), errT.zero_()
-            _ops.kernel_matrix(kind, x[c0:c0 + r], Z, var, ls, out=At, ldk=f_uu.ld)
+            asm.kuf(x[c0:c0 + r], Z, At, f_uu.ld)
             f_uu.solve_right_lt(At, r)                                     # A_c^T = Kuf_c^T L^-T
             _ops._native.check(lib.gpn_transpose(stream, _ops._ptr(At), r, m, At.stride(0), _ops._ptr(A), nc),
                                "gpn_transpose")
@@ -189,13 +284,14 @@ def _vfe_forward(kind, x, err, Z, var, ls, s2):
         torch.sum(aerr_parts, dim=0, out=Aerr)
         del parts
     # row shards: one all-reduce of the M-sized sums and of (N, |err|^2)
-    scal = torch.tensor([float(n), 0.0], dtype=torch.float64, device=dev)
+    scal = torch.tensor([float(n), 0.0, 0.0], dtype=torch.float64, device=dev)
     scal[1] = err.pow(2).sum()
+    scal[2] = asm.trkff(x)                                                 # tr Kff (sparse_gpr.py:139-141)
     if SHARD_GROUP is not None:
         _all_reduce(AAT)
         _all_reduce(Aerr)
         _all_reduce(scal)
-    st.n_all, st.yy_all = int(round(scal[0].item())), scal[1]
+    st.n_all, st.yy_all, st.trkff = int(round(scal[0].item())), scal[1], scal[2]
     st.Aerr = Aerr[:m]
     st.tr = AAT.diagonal()[:m].sum()
 
@@ -220,8 +316,10 @@ def _sandwich(U, W, m):
     return R
 
 
-def _vfe_backward(kind, x, err, Z, var, ls, st):
-    """-> dF/d(variance [1], length_scales [nls], noise [1], Z [M, D]) for the CONSTRAINED values."""
+def _vfe_backward(asm, x, err, Z, st):
+    """-> dF/d noise [1] (constrained value); the kernel / inducing-point gradients are left in `asm`
+    (native kinds: w.r.t. the constrained variance / length-scales and Z; any other kernel: w.r.t. its
+    raw parameters and Z)."""
     dev = x.device
     n, p = err.shape
     m, s = Z.shape[0], st.s2
@@ -248,11 +346,9 @@ def _vfe_backward(kind, x, err, Z, var, ls, st):
     gt = _ops.gemm_nt(bt, U, p, m, mp, tri=_ops.TRI_B_UPPER)              # gamma^T = beta^T L^-1
 
     # K(Z, Z) part (identical on every rank of a sharded run: counted on the first one only)
-    g_var, g_ls = _backward.kernel_backward(kind, Z, None, var, ls, Guu[:m, :m])
-    g_var, g_ls = g_var.clone(), g_ls.clone()
-    g_Z = _backward.kernel_backward_x2(kind, Z, Z, var, ls, Guu[:m, :m], scale=2.0)
-    if _shard_rank() != 0:
-        g_var.zero_(), g_ls.zero_(), g_Z.zero_()
+    asm.begin(Z)
+    if _shard_rank() == 0:
+        asm.grad_uu(Z, Guu[:m, :m])
 
     # K(x, Z) part, streamed:  G_c = 1/s [K(x_c, Z) | err_c] [P | gamma]^T
     ldk = mp + pp
@@ -264,24 +360,35 @@ def _vfe_backward(kind, x, err, Z, var, ls, st):
     G = torch.empty(nc, mp, dtype=torch.float64, device=dev)
     for c0, r in _chunks(n, nc):
         xc = x[c0:c0 + r]
-        _ops.kernel_matrix(kind, xc, Z, var, ls, out=Kx, ldk=ldk)
+        asm.kuf(xc, Z, Kx, ldk)
         Kx[:r, mp:mp + p] = err[c0:c0 + r]
         _ops.gemm_nt(Kx, Bq, r, m, ldk, alpha=1.0 / s, C=G)
-        gv, gl = _backward.kernel_backward(kind, xc, Z, var, ls, G[:r, :m])
-        g_var += gv
-        g_ls += gl
-        _backward.kernel_backward_x2(kind, xc, Z, var, ls, G[:r, :m], out=g_Z)
+        asm.grad_uf(xc, Z, G[:r, :m])
+    asm._x = x
+    asm.grad_trkff(-0.5 * p / s, n if SHARD_GROUP is not None else st.n_all)   # -p/(2s) d tr Kff (this rank's rows)
 
     if SHARD_GROUP is not None:                                            # sum the row shards' contributions
-        _all_reduce(g_var), _all_reduce(g_ls), _all_reduce(g_Z)
+        for t in asm.tensors():
+            _all_reduce(t)
     n_all = st.n_all
-    g_var = g_var - 0.5 * p * n_all / s                                    # tr Kff = N * variance
     c2 = st.terms[1] / (s * s)
     b = beta[:m, :p]
     quad = (b * st.Aerr).sum() / s - (b * b).sum()                         # beta^T (B - I) beta
     g_noise = (0.5 * p / s) * (m - Binv.diagonal().sum()) - c2 / s + 0.5 * quad / s - 0.5 * p * st.tr / s \
-        - 0.5 * p * n_all / s + 0.5 * (st.yy_all + p * n_all * var[0]) / (s * s)
-    return g_var, g_ls, g_noise.reshape(1), g_Z
+        - 0.5 * p * n_all / s + 0.5 * (st.yy_all + p * st.trkff) / (s * s)
+    return g_noise.reshape(1)
+
+
+def _elbo(st, p, s2):
+    """sparse_gpr.py:139-151 from the M-sized state."""
+    n = st.n_all                                                           # N of the whole data set
+    elbo = -0.5 * p * n * math.log(2.0 * math.pi)
+    elbo = elbo - p * st.terms[0]
+    elbo = elbo - 0.5 * p * n * math.log(s2)
+    elbo = elbo - 0.5 * (st.yy_all + p * st.trkff) / s2
+    elbo = elbo + 0.5 * st.terms[1] / (s2 * s2)                            # c = LB^-1 (A err) / s2
+    elbo = elbo + 0.5 * p * st.tr
+    return elbo
 
 
 class _VFEBound(torch.autograd.Function):
@@ -290,27 +397,43 @@ class _VFEBound(torch.autograd.Function):
     @staticmethod
     def forward(ctx, variance, length_scales, noise, Z, kind, x, err, holder):
         s2 = float(noise.item())
-        st = _vfe_forward(kind, x, err, Z.detach(), variance.detach(), length_scales.detach(), s2)
-        n, p = st.n_all, err.shape[1]                                   # N of the whole data set
-        elbo = -0.5 * p * n * math.log(2.0 * math.pi)
-        elbo = elbo - p * st.terms[0]
-        elbo = elbo - 0.5 * p * n * math.log(s2)
-        elbo = elbo - 0.5 * (st.yy_all + p * n * variance.detach()[0]) / s2   # Kdiag = variance
-        elbo = elbo + 0.5 * st.terms[1] / (s2 * s2)                     # c = LB^-1 (A err) / s2
-        elbo = elbo + 0.5 * p * st.tr
-        ctx.kind, ctx.x, ctx.err, ctx.st = kind, x, err, st
-        ctx.save_for_backward(variance, length_scales, Z)
+        asm = _NativeAsm(kind, variance.detach(), length_scales.detach())
+        st = _vfe_forward(asm, x, err, Z.detach(), s2)
+        ctx.asm, ctx.x, ctx.err, ctx.st = asm, x, err, st
+        ctx.save_for_backward(length_scales, Z)
         holder["state"] = st
-        return elbo
+        return _elbo(st, err.shape[1], s2)
 
     @staticmethod
     def backward(ctx, grad_out):
-        variance, length_scales, Z = ctx.saved_tensors
-        g_var, g_ls, g_noise, g_Z = _vfe_backward(ctx.kind, ctx.x, ctx.err, Z.detach(), variance.detach(),
-                                                  length_scales.detach(), ctx.st)
+        length_scales, Z = ctx.saved_tensors
+        g_noise = _vfe_backward(ctx.asm, ctx.x, ctx.err, Z.detach(), ctx.st)
+        g_var, g_ls, g_Z = ctx.asm.tensors()
         g = grad_out
         return (g * g_var, g * g_ls.reshape(length_scales.shape), g * g_noise, g * g_Z,
                 None, None, None, None)
+
+
+class _VFEBoundGeneric(torch.autograd.Function):
+    """The same bound for any kernel object: node over (noise, Z, *raw kernel parameters)."""
+
+    @staticmethod
+    def forward(ctx, noise, Z, kernel, x, err, holder, *params):
+        s2 = float(noise.item())
+        asm = _GenericAsm(kernel, list(params))
+        st = _vfe_forward(asm, x, err, Z.detach(), s2)
+        ctx.asm, ctx.x, ctx.err, ctx.st = asm, x, err, st
+        ctx.save_for_backward(Z)
+        holder["state"] = st
+        return _elbo(st, err.shape[1], s2)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        Z, = ctx.saved_tensors
+        g_noise = _vfe_backward(ctx.asm, ctx.x, ctx.err, Z.detach(), ctx.st)
+        *g_params, g_Z = ctx.asm.tensors()
+        g = grad_out
+        return (g * g_noise, g * g_Z, None, None, None, None) + tuple(g * t for t in g_params)
 
 
 class VFE(_InducingPointsGP):
@@ -318,19 +441,23 @@ class VFE(_InducingPointsGP):
         super().__init__(*args, **kwargs)
         assert isinstance(self.mean_function, Zero), "Mean functions not implemented for VFE yet."
 
-    def _kind(self):
+    def _native_kernel(self):
+        """the kernel if it is one of the native stationary kinds (fused assembly + native sweeps),
+        else None (sums / products / Linear / static kernels: the kernel's own K and autograd)."""
         from .. import kernels
         k = self.kernel
-        if not isinstance(k, kernels.Stationary) or k._kind is None:
-            raise NotImplementedError("gptorch_amd.VFE supports the native stationary kernels")
-        return k
+        return k if isinstance(k, kernels.Stationary) and k._kind is not None else None
 
     def _bound(self, x):
-        k = self._kind()
+        k = self._native_kernel()
         holder = {}
-        elbo = _VFEBound.apply(k.variance.transform(), k.length_scales.transform(),
-                               self.likelihood.variance.transform(), self.Z, k._kind, x,
-                               self.Y, holder)                           # sparse_gpr.py:125 quirk: err = self.Y
+        s2 = self.likelihood.variance.transform()
+        if k is not None:
+            elbo = _VFEBound.apply(k.variance.transform(), k.length_scales.transform(), s2, self.Z, k._kind, x,
+                                   self.Y, holder)                       # sparse_gpr.py:125 quirk: err = self.Y
+        else:
+            params = [p for p in self.kernel.parameters() if p.requires_grad]
+            elbo = _VFEBoundGeneric.apply(s2, self.Z, self.kernel, x, self.Y, holder, *params)
         return elbo, holder["state"]
 
     def log_likelihood(self, x=None, y=None):
@@ -344,23 +471,22 @@ class VFE(_InducingPointsGP):
     def _predict(self, x_new, diag=True, x=None):
         """sparse_gpr.py:155-195."""
         x = x if x is not None else self.X
-        k = self._kind()
+        kern = self.kernel
         with torch.no_grad():
             _, st = self._bound(x)
             f_uu, fB, s2 = st.f_uu, st.fB, st.s2
-            var, ls = k.variance.transform(), k.length_scales.transform()
             ns, m, dy = x_new.shape[0], self.Z.shape[0], self.Y.shape[1]
             T1 = _ops.padded_like_factor(f_uu, ns)                                    # tmp1^T = K(x*, Z) L^-T
-            _ops.kernel_matrix(k._kind, x_new, self.Z.detach(), var, ls, out=T1, ldk=f_uu.ld)
+            T1[:ns, :m] = kern.K(x_new, self.Z.detach())
             f_uu.solve_right_lt(T1, ns)
             T2 = T1.clone()
             fB.solve_right_lt(T2, ns)                                                 # tmp2^T = tmp1^T LB^-T
             kp = _ops.round_up(m, 16)
             mean = _ops.gemm_nt(T2, fB.A[m:], ns, dy, kp) / s2                        # tmp2^T c
             if diag:
-                v = k.Kdiag(x_new).detach() - _ops.row_sumsq(T1, ns, m) + _ops.row_sumsq(T2, ns, m)
+                v = kern.Kdiag(x_new).detach() - _ops.row_sumsq(T1, ns, m) + _ops.row_sumsq(T2, ns, m)
                 return mean, v[:, None].expand_as(mean)
-            cov = _ops.kernel_matrix(k._kind, x_new, None, var, ls)
+            cov = kern.K(x_new).clone()
             _ops.gemm_nt(T2, T2, ns, ns, kp, alpha=1.0, beta=1.0, C=cov)
             _ops.gemm_nt(T1, T1, ns, ns, kp, alpha=-1.0, beta=1.0, C=cov)
         return mean, cov

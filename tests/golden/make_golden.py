@@ -415,6 +415,36 @@ def gen_composite(out):
     print("composite:", [(c["name"], c["loss"], sorted(c["grads"])) for c in cases])
 
 
+def gen_sparse_composite(out):
+    """VFE over kernels without a single native kind (sparse_gpr.py:126-129 takes any kernel object):
+    bound, raw-parameter / inducing-point gradients and predictions from the reference."""
+    from gptorch.models.sparse_gpr import VFE
+    n, d, m = 700, 3, 40
+    x, y = rng.make_regression(n, d, 1, seed=0)
+    z = rng.normal(61, (m, d))
+    xs = rng.normal(62, (12, d))
+    specs = {"rbf_plus_linear": lambda: rk.Rbf(d, variance=1.1, length_scales=1.4) + rk.Linear(d, variance=np.array([0.2, 0.4, 0.6])),
+             "m52_times_rbf": lambda: rk.Matern52(d, variance=0.9, length_scales=2.0) * rk.Rbf(d, variance=1.2, length_scales=np.array([1.0, 2.0, 3.0]), ARD=True)}
+    cases = []
+    for name, mk in specs.items():
+        def build():
+            return VFE(x, y, mk(), inducing_points=z.copy(), likelihood=rl.Gaussian(variance=0.05), mean_function=rm.Zero(1))
+        mm = build()
+        with torch.no_grad():
+            elbo = float(mm.log_likelihood().item())
+            mu, var = mm._predict(torch.tensor(xs))
+            _, cov = mm._predict(torch.tensor(xs), diag=False)
+        mg = build()                      # _predict froze Z (sparse_gpr.py:165)
+        mg.zero_grad()
+        mg.loss().backward()
+        grads = {nm: p.grad.tolist() for nm, p in mg.named_parameters() if p.grad is not None}
+        cases.append(dict(name=name, n=n, d=d, m=m, noise=0.05, seed_z=61, seed_xs=62, elbo=elbo, grads=grads,
+                          mean=mu.tolist(), var=var.tolist(), cov=cov.tolist()))
+    with open(os.path.join(out, "vfe_composite_cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("sparse composite:", [(c["name"], c["elbo"], sorted(c["grads"])) for c in cases])
+
+
 def gen_c2_grad(out):
     """BASELINE config 2 (N = 8192, D = 8, Rbf): d loss / d raw parameters from autograd through the
     reference (gpr.py:47-67 + PyTorch's CholeskyBackward0 ...), ~15 s -- the full-size gradient pin."""
@@ -495,7 +525,7 @@ if __name__ == "__main__":
     steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
                  lml=lambda: gen_lml(HERE, args.big), adam=lambda: gen_adam(HERE),
                  func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE),
-                 comp=lambda: gen_composite(HERE), c2grad=lambda: gen_c2_grad(HERE), lbfgs=lambda: gen_lbfgs(HERE))
+                 comp=lambda: gen_composite(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), lbfgs=lambda: gen_lbfgs(HERE))
     for k, fn in steps.items():
         if not args.only or k in args.only.split(","):
             fn()

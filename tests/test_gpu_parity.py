@@ -1333,6 +1333,41 @@ def test_c5_full_size_properties(device, monkeypatch):
         assert abs(e - elbo0) < 1e-9 * abs(elbo0), (chunk, lanes, split, e, elbo0)
 
 
+@pytest.mark.parametrize("idx", [0, 1])
+def test_vfe_with_composite_kernels(device, idx):
+    """VFE over kernels without a single native kind (sparse_gpr.py:126-129 takes any kernel object):
+    K(x_c, Z) / K(Z) from the kernel's own `K`, the streamed closed-form backward handing
+    dF/dKuf chunks back through the kernel's own autograd nodes -- bound, every raw-parameter and
+    inducing-point gradient, predictions vs the reference (vfe_composite_cases.json)."""
+    from gptorch_amd.models import VFE
+    case = load_json("vfe_composite_cases.json")[idx]
+    d = case["d"]
+    x, y = rng.make_regression(case["n"], d, 1, seed=0)
+    z = rng.normal(case["seed_z"], (case["m"], d))
+    mk = {"rbf_plus_linear": lambda: kernels.Rbf(d, variance=1.1, length_scales=1.4) + kernels.Linear(d, variance=np.array([0.2, 0.4, 0.6])),
+          "m52_times_rbf": lambda: kernels.Matern52(d, variance=0.9, length_scales=2.0)
+          * kernels.Rbf(d, variance=1.2, length_scales=np.array([1.0, 2.0, 3.0]), ARD=True)}[case["name"]]
+    m = VFE(x, y, mk(), inducing_points=z.copy(), likelihood=likelihoods.Gaussian(variance=case["noise"]),
+            mean_function=mean_functions.Zero(1))
+    m.cuda()
+    loss = m.loss()
+    assert abs(-loss.item() - case["elbo"]) < 1e-9 * max(1.0, abs(case["elbo"]))
+    loss.backward()
+    got = {n: p.grad.cpu().numpy() for n, p in m.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(case["grads"])
+    for n, r in case["grads"].items():
+        r = np.asarray(r)
+        assert np.abs(got[n].reshape(r.shape) - r).max() < 1e-7 * max(1.0, np.abs(r).max()), (n, got[n], r)
+    xs = torch.tensor(rng.normal(case["seed_xs"], (12, d)), device=device)
+    mu, var = m._predict(xs)
+    _, cov = m._predict(xs, diag=False)
+    # K(Z) of these kernels on 40 random inducing points has cond ~ 1e9: the reference's own predictions
+    # carry cond * eps ~ 1e-7 of rounding (the bound and its gradients above are far less sensitive)
+    assert (mu.cpu() - torch.tensor(case["mean"])).abs().max().item() < 2e-7
+    assert (var.cpu() - torch.tensor(case["var"])).abs().max().item() < 2e-7
+    assert (cov.cpu() - torch.tensor(case["cov"])).abs().max().item() < 2e-7
+
+
 def test_vfe_split_k_accumulation(device, monkeypatch):
     """The A A^T accumulation of the sparse bound switches to split-K partial accumulators
     (gpn_gemm_nt_batched) when a chunk is long and M^2 has few tiles: N = 40000 = one 32768-row chunk
