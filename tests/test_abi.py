@@ -103,6 +103,23 @@ def _build_c_consumer(out_path):
     return str(out_path)
 
 
+def _build_c_dist_consumer(out_path):
+    import subprocess
+    lib_dir = os.path.dirname(_native.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", os.path.join(ROOT, "examples", "dist_consumer.c"), "-I" + os.path.join(ROOT, "include"),
+           "-I/opt/rocm/include", "-L" + lib_dir, "-lgpnative", "-lgpnative_rccl", "-L/opt/rocm/lib", "-lrccl", "-lamdhip64",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", str(out_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return str(out_path)
+
+
+def test_c_dist_consumer_links(tmp_path):
+    """examples/dist_consumer.c (C99, gcc): gpn_dist_lml_forward + the RCCL adapter's callback table link
+    from plain C against libgpnative.so + libgpnative_rccl.so + librccl.  (RUN in the gpu suite.)"""
+    _build_c_dist_consumer(tmp_path / "dist_consumer")
+
+
 def test_header_is_plain_c_and_a_c_consumer_links(tmp_path):
     """include/gpnative.h compiles as C99 and examples/lml_consumer.c (gcc, no hipcc, no Python)
     links against libgpnative.so: the boundary really is a C ABI.  (It is RUN in the gpu suite.)"""

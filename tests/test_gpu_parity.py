@@ -1239,6 +1239,23 @@ def test_c_consumer_matches_the_shell(device, tmp_path):
     assert np.abs(got - want).max() < 1e-9 * np.abs(want).max(), (got, want)
 
 
+def test_c_dist_consumer_runs(device, tmp_path):
+    """examples/dist_consumer.c -- a C99 program with its own RCCL bootstrap (ncclCommInitRank +
+    ncclCommSplit), the adapter's callback table and gpn_dist_lml_forward, no Python in the process --
+    on the box's one GPU (1 x 1 grid, collectives forced through RCCL): the reference's LML of the
+    same generated inputs."""
+    import re
+    import subprocess
+    from tests.test_abi import _build_c_dist_consumer
+    exe = _build_c_dist_consumer(tmp_path / "dist_consumer")
+    r = subprocess.run([exe, "2048", "8", "512"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    mm = re.search(r"lml=(\S+) info=(\S+)", r.stdout)
+    case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
+    # the C program's libm Box-Muller may differ from numpy's in the last bit of an input: 1e-9 relative
+    assert float(mm.group(2)) == 0 and abs(float(mm.group(1)) - case["lml"]) < 1e-9 * abs(case["lml"]), r.stdout
+
+
 def test_repeated_evaluations_are_bitwise_identical(device):
     """Idempotence / race check: the leaf kernel hands blocks between its pivot wave and its tile
     waves through LDS (one hardware + one software barrier per panel) and the factorisation forks
