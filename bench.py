@@ -286,6 +286,7 @@ def run_single(args, device):
     roofs = rooflines(lib, w, args.steps, step)
     attach_traffic(roofs.get("roofline"), "gemm_bytes_per_launch", args.workload)
     attach_traffic(roofs.get("roofline_k_assembly"), "kmat_bytes_per_launch", args.workload)
+    attach_traffic(roofs.get("roofline_syrk"), "syrk_bytes_per_launch", args.workload)
 
     if not args.no_extras:
         def leg(name, fn):

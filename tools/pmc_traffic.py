@@ -7,6 +7,17 @@ kernel's operand traffic is LDS-DMA dwordx4, so it is doubled; WRITE_SIZE is tak
 usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> <workload>"""
 import collections, csv, json, sys
 
+def per_grid(path, counter, match):
+    """{grid size: [launches, summed counter]} of the kernels whose name contains `match`"""
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and match in r["Kernel_Name"]:
+            g = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)))
+            d[g][0] += 1
+            d[g][1] += float(r["Counter_Value"])
+    return d
+
+
 def per_kernel(path, counter):
     d = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
@@ -31,5 +42,23 @@ out = {"workload": sys.argv[4], "kernel": "gemm_nt_kernel (all variants)", "laun
        "fetch_bytes_per_launch_corrected_x2": bf / max(nf, 1), "write_bytes_per_launch": bw / max(nw, 1),
        "gemm_bytes_per_launch": bf / max(nf, 1) + bw / max(nw, 1),
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --no-extras --no-cpu-baseline`; KB->B; FETCH x2 (gfx950 wide-read correction)"}
+# the SYRK trailing updates alone (bench.py roofline_syrk): per evaluation they are the launches of the 128x128-tile
+# (C2: 64x64-tile) kernel with the largest grids -- 15 at C3, 5 at C2 (one per panel but the last)
+nsyrk = {"c3": 15, "c2": 5, "c4": 31}.get(sys.argv[4])
+if nsyrk:
+    import math
+    match = "gemm_nt_kernel<"        # 128x128-tile launches and, for the last panels, 64x64-tile ones
+    fg, wg = per_grid(sys.argv[1], "FETCH_SIZE", match), per_grid(sys.argv[2], "WRITE_SIZE", match)
+
+    def triangular(g):          # lower-tile launches have mt (mt + 1) / 2 workgroups of 256 threads
+        w = g // 256
+        t = (math.isqrt(8 * w + 1) - 1) // 2
+        return g % 256 == 0 and t * (t + 1) // 2 == w and t >= 8
+    top = [g for g in fg if triangular(g)]
+    nl = sum(fg[g][0] for g in top)
+    if nl and all(g in wg for g in top):
+        out["syrk_launches"] = nl
+        out["syrk_bytes_per_launch"] = sum(fg[g][1] for g in top) * 2048.0 / nl + sum(wg[g][1] for g in top) * 1024.0 / sum(wg[g][0] for g in top)
+        out["syrk_note"] = "all lower-tile launches (triangular grids of >= 36 workgroups; expected %d per evaluation); FETCH x2 as above" % nsyrk
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
