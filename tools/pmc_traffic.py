@@ -53,12 +53,14 @@ if nsyrk:
     def triangular(g):          # lower-tile launches have mt (mt + 1) / 2 workgroups of 256 threads
         w = g // 256
         t = (math.isqrt(8 * w + 1) - 1) // 2
-        return g % 256 == 0 and t * (t + 1) // 2 == w and t >= 8
+        # in-panel (rectangular) launches stay below ~1030 workgroups at C3/C4 and ~260 at C2: above that a
+        # triangular grid is a SYRK trailing update (only the last, smallest one per evaluation falls under it)
+        return g % 256 == 0 and t * (t + 1) // 2 == w and w > (300 if sys.argv[4] == "c2" else 1100)
     top = [g for g in fg if triangular(g)]
     nl = sum(fg[g][0] for g in top)
     if nl and all(g in wg for g in top):
         out["syrk_launches"] = nl
         out["syrk_bytes_per_launch"] = sum(fg[g][1] for g in top) * 2048.0 / nl + sum(wg[g][1] for g in top) * 1024.0 / sum(wg[g][0] for g in top)
-        out["syrk_note"] = "all lower-tile launches (triangular grids of >= 36 workgroups; expected %d per evaluation); FETCH x2 as above" % nsyrk
+        out["syrk_note"] = "lower-tile launches = triangular grids above the in-panel launch sizes (%d per evaluation minus the last, smallest one); FETCH x2 as above" % nsyrk
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
