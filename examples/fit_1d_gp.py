@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Switching a gptorch script to gptorch_amd: the workflow of the reference's 1-D regression example
+(GPR over a sum kernel -- or a sparse VFE model --, scipy L-BFGS-B, predictions and posterior samples) on an MI355X.  Only the
+import lines differ from a gptorch script -- and `model.cuda()` is mandatory here (there is no CPU path).
+
+    python examples/fit_1d_gp.py [--sparse] [--n 100]
+"""
+import argparse
+
+import numpy as np
+import torch
+
+from gptorch_amd import kernels            # was: from gptorch import kernels
+from gptorch_amd.models import GPR, VFE    # was: from gptorch.models.gpr import GPR / sparse_gpr import VFE
+
+
+def target(x):
+    return np.sin(2.0 * np.pi * x) + np.cos(3.5 * np.pi * x) - 3.0 * x + 5.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sparse", action="store_true", help="variational sparse GP (VFE) instead of the exact one")
+    ap.add_argument("--n", type=int, default=100)
+    args = ap.parse_args()
+    rs = np.random.RandomState(42)
+    x = np.linspace(0.0, 1.0, args.n).reshape(-1, 1)
+    y = target(x) + 0.1 * rs.randn(args.n, 1)
+
+    if args.sparse:      # K(Z) of a sum with rank-one terms on 20 points is singular to working precision: Matern52 here
+        model = VFE(x, y, kernels.Matern52(1), num_inducing_points=20)
+    else:
+        model = GPR(x, y, kernels.Linear(1) + kernels.Rbf(1) + kernels.Constant(1))
+    model.cuda()
+    model.optimize(method="L-BFGS-B", max_iter=100)
+    print(model)
+
+    x_test = np.linspace(-1.0, 2.0, 200).reshape(-1, 1)
+    with torch.no_grad():
+        mu, var = model.predict_y(x_test)
+        samples = model.predict_y_samples(x_test, n_samples=5)
+    inside = np.abs(mu[50:150] - target(x_test[50:150])) < 3.0 * np.sqrt(var[50:150])
+    print("predictive mean within 3 sigma of the truth on [0.25, 1.25]: %.0f %%; samples %s"
+          % (100.0 * inside.mean(), samples.shape))
+
+
+if __name__ == "__main__":
+    main()
