@@ -77,8 +77,10 @@ __device__ __forceinline__ void k_and_base(double r2, double var, double& K, dou
   }
 }
 
-// NCH = number of 16-coordinate chunks (d <= 16*NCH); LML = G formed from Kinv + a
-template <int KIND, int NCH, bool LML>
+// NCH = number of 16-coordinate chunks (d <= 16*NCH); LML = G formed from Kinv + a;
+// ISO = one shared length-scale: sum_d S_d = sum_ij G'_ij r2_ij, so the second pass over the coordinates
+// (and its one accumulator per dimension: 32-128 VGPRs) is not needed at all
+template <int KIND, int NCH, bool LML, bool ISO>
 __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
   __shared__ __attribute__((aligned(16))) double xs[NCH * GDC][GT];
   __shared__ __attribute__((aligned(16))) double ys[NCH * GDC][GT];
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
 
   // G' = weight * G * B, plus the variance / noise sums
   const double var = p.variance[0];
-  double gb[4][4];
-  double s_var = 0.0, s_tr = 0.0;
+  double gb[ISO ? 1 : 4][ISO ? 1 : 4];
+  double s_var = 0.0, s_tr = 0.0, s_iso = 0.0;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int row = i0 + ty * 4 + a;
@@ -167,16 +169,17 @@ __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
       double K, B;
       k_and_base<KIND>(r2[a][b], var, K, B);
       s_var = fma(g, K, s_var);
-      gb[a][b] = g * B;
+      if constexpr (ISO) s_iso = fma(g * B, r2[a][b], s_iso);
+      else gb[a][b] = g * B;
     }
   }
 
   // pass 2: per-dimension sums  S_d = sum G'_ij * s_d
-  double acc[NCH * GDC];
+  double acc[ISO ? 1 : NCH * GDC];
 #pragma unroll
-  for (int dd = 0; dd < NCH * GDC; ++dd) acc[dd] = 0.0;
+  for (int dd = 0; dd < (ISO ? 1 : NCH * GDC); ++dd) acc[dd] = 0.0;
 #pragma unroll
-  for (int dd = 0; dd < NCH * GDC; ++dd) {
+  for (int dd = 0; dd < (ISO ? 0 : NCH * GDC); ++dd) {
     if (dd < p.d) {
       const d2 xa = *reinterpret_cast<const d2*>(&xs[dd][ty * 4]);
       const d2 xb = *reinterpret_cast<const d2*>(&xs[dd][ty * 4 + 2]);
@@ -211,7 +214,10 @@ __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
   double* out = p.partial + (int64_t)blockIdx.x * p.nout;
   const double tv = block_sum(s_var);
   if (tid == 0) out[0] = tv / var;                         // dK/dvar = K / var
-  if (p.nls == 1) {
+  if constexpr (ISO) {
+    const double t = block_sum(s_iso);
+    if (tid == 0) out[1] = t / p.ls[0];
+  } else if (p.nls == 1) {
     double s = 0.0;
 #pragma unroll
     for (int dd = 0; dd < NCH * GDC; ++dd) s += acc[dd];
@@ -404,13 +410,18 @@ static int launch_sweep(hipStream_t s, const GradArgs& a, int64_t nblocks) {
   int rec = -1;
   if (profile_on())   // algorithmic bytes: the gradient matrix is read once (lower triangle for the LML sweep)
     rec = profile_begin(s, 8.0 * (LML ? 0.5 * a.n * (a.n + 1.0) : (double)a.n * a.m) + 8.0 * (a.n + (LML ? 0 : a.m)) * a.d, PROF_GRAD);
+  const bool iso = a.nls == 1;
+#define GPN_SWEEP(N_) \
+  if (iso) hipLaunchKernelGGL((grad_sweep_kernel<KIND, N_, LML, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a); \
+  else hipLaunchKernelGGL((grad_sweep_kernel<KIND, N_, LML, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
   switch (nch) {
-    case 1: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 1, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 2, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 3, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((grad_sweep_kernel<KIND, 4, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
+    case 1: GPN_SWEEP(1) break;
+    case 2: GPN_SWEEP(2) break;
+    case 3: GPN_SWEEP(3) break;
+    case 4: GPN_SWEEP(4) break;
     default: hipLaunchKernelGGL((grad_sweep_chunked_kernel<KIND, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
   }
+#undef GPN_SWEEP
   if (rec >= 0) profile_end(s, rec);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
