@@ -127,11 +127,15 @@ class NativeTileOps:
     def sumsq(self, A, m, n):
         return _ops.row_sumsq(A, m, n).sum()
 
+    def row_sumsq(self, A, m, n):
+        """-> [m]: sum_c A[r, c]^2 over the first n columns."""
+        return _ops.row_sumsq(A, m, n)
+
 
 class BlockCyclicGP:
     """Distributed LML for a stationary kernel.  All ranks call every method collectively."""
 
-    def __init__(self, X, Y, kind, tile=2048, grid=None, ops=None, group=None, phantom=None, force_comm=False):
+    def __init__(self, X, Y, kind, tile=2048, grid=None, ops=None, group=None, phantom=None, force_comm=False, share=None):
         """force_comm: issue the row / column collectives even where a sub-communicator has a single
         member (world 1, or Pr = 1) -- a test hook that drives the RCCL calls on a 1-GPU box."""
         live = dist.is_available() and dist.is_initialized() and phantom is None
@@ -156,7 +160,9 @@ class BlockCyclicGP:
         self.row_group = self.col_group = None
         self.xrow = self.comm and (self.pc > 1 or force_comm)      # panels travel along process rows
         self.xcol = self.comm and (self.pr > 1 or force_comm)      # ... and down process columns
-        if self.comm:
+        if share is not None:      # a second engine on the same grid (predict): reuse the sub-communicators
+            self.row_group, self.col_group = share.row_group, share.col_group
+        elif self.comm:
             for r in range(self.pr):
                 ranks = [r * self.pc + c for c in range(self.pc)]
                 g = dist.new_group(ranks) if self.xrow else None
@@ -189,6 +195,8 @@ class BlockCyclicGP:
         self.kinv = None
         self._alloc_inverse = False
         self.info = 0
+        self.lml_rows = self.dy        # leading rows of the residual segment that enter |alpha|^2 (the rest: predict)
+        self.last_a = None             # a^T = (Kyy^-1 (y - m))^T [dy, n], replicated, after backward()
         self.with_inverse = False      # carry I through the factorisation (-> U = L^-T) for the backward
         self._dirty = False            # a failed factorisation may have left non-finite padding
 
@@ -437,7 +445,7 @@ class BlockCyclicGP:
                 li = (J - self.my_r) // self.pr
                 st[0] += ops.log_diag_sum(self.A[li * T:, lj * T:], self.rows_of(J))
         if self.has_res and self.ncol_t:
-            st[1] += ops.sumsq(self.A[self.res_off:], self.dy, self.cidx.numel())
+            st[1] += ops.sumsq(self.A[self.res_off:], self.lml_rows, self.cidx.numel())
         st[2:] += self.info_t.to(torch.float64)
         if self.comm:
             dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
@@ -453,7 +461,8 @@ class BlockCyclicGP:
 
     def lml(self):
         """LML of gpr.py:63-67 from the distributed factor (the two sums were all-reduced by factor())."""
-        v = -0.5 * self._sumsq - self.dy * self._logdet - 0.5 * self.dy * self.n * math.log(2.0 * math.pi)
+        p = self.lml_rows
+        v = -0.5 * self._sumsq - p * self._logdet - 0.5 * p * self.n * math.log(2.0 * math.pi)
         return torch.tensor(v, dtype=torch.float64, device=self.X.device)
 
     # -- backward (closed form on the same grid; SURVEY 8(e)) ---------------------------------
@@ -523,6 +532,7 @@ class BlockCyclicGP:
             aT[:, self.ridx] = part[:dy, :nrr]
         if self.comm:
             dist.all_reduce(aT, op=dist.ReduceOp.SUM, group=self.group)
+        self.last_a = aT
         C = self._kinv_local()
         acc = torch.zeros(2 + nls, dtype=torch.float64, device=dev)
         kpad = _ops.round_up(dy, 16)
@@ -552,6 +562,50 @@ class BlockCyclicGP:
         if self.comm:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
         return acc
+
+    def predict(self, variance, length_scales, noise, resid, x_new, diag=True, max_tries=10):
+        """GPR._predict (gpr.py:88-117) on the grid, for a zero mean function: (A^T V [n*, dy], var) with
+        A = L^-1 K(X, x*), V = L^-1 (y - m); var = Kdiag - colsumsq(A) [n*] or K(x*) - A^T A [n*, n*].
+        The test points ride through ONE factorisation as further residual rows: K(x*, X) appended to
+        (y - m)^T comes out as A^T exactly like alpha^T does, distributed over the tile columns of the
+        process row that holds the residual; mean and variance are column-partial sums, one all-reduce.
+        (The reference re-factorises on every predict call as well, gpr.py:104.)"""
+        ops, dy, dev = self.ops, self.dy, self.X.device
+        ns = x_new.shape[0]
+        Ks = ops.zeros(self.n, ns)
+        ops.kernel_block(self.kind, self.X, x_new, variance, length_scales, Ks)
+        R = torch.cat([resid, Ks], 1).contiguous()
+        eng = BlockCyclicGP(self.X, R, self.kind, tile=self.T, grid=(self.pr, self.pc), ops=ops, group=self.group,
+                            phantom=None if (self.comm or self.world == 1) else (self.rank, self.world), share=self)
+        eng.comm, eng.xrow, eng.xcol = self.comm, self.xrow, self.xcol
+        eng.lml_rows = dy
+        eng.log_likelihood(variance, length_scales, noise, R, max_tries)
+        self.info, self.jitter_rung = eng.info, eng.jitter_rung
+        ncr = eng.cidx.numel()
+        mean = torch.zeros(ns, dy, dtype=torch.float64, device=dev)
+        out = torch.zeros((ns,) if diag else (ns, ns), dtype=torch.float64, device=dev)
+        if eng.has_res and ncr:
+            rows = eng.A[eng.res_off:]
+            alphaT, AT = rows, rows[dy:]                       # [dy, ld], [ns, ld] (views; K padding is zero)
+            mp = ops.zeros(_ops.round_up(ns, 16), _ops.round_up(dy, 16))
+            ops.update(mp, AT, alphaT, ns, dy, ncr, lower=False, alpha=1.0, beta=0.0)
+            mean += mp[:ns, :dy]
+            if diag:
+                out += ops.row_sumsq(AT, ns, ncr)
+            else:
+                g = ops.zeros(_ops.round_up(ns, 16), _ops.round_up(ns, 16))
+                ops.update(g, AT, AT, ns, ns, ncr, lower=False, alpha=1.0, beta=0.0)
+                out += g[:ns, :ns]
+        if self.comm:
+            dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        if diag:
+            var = variance.reshape(()) - out                   # Kdiag = variance (kernels.py:174-179)
+        else:
+            kss = ops.zeros(ns, ns)
+            ops.kernel_block(self.kind, x_new, x_new, variance, length_scales, kss)
+            var = kss - out
+        return mean, var
 
     def log_likelihood_and_grad(self, variance, length_scales, noise, resid, max_tries=10):
         """(LML, [dLML/dvariance, dLML/dlength_scales..., dLML/dnoise]) with the factorisation

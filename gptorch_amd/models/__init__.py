@@ -2,3 +2,4 @@
 from .base import GPModel  # noqa: F401
 from .gpr import GPR, batched_log_likelihood  # noqa: F401
 from .sparse_gpr import VFE  # noqa: F401
+from .dist_gpr import DistGPR  # noqa: F401

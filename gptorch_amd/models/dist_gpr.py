@@ -1,0 +1,84 @@
+"""
+Exact GP regression for N beyond one GPU's HBM with the call surface of gptorch.models.GPR
+(gptorch/models/gpr.py:26-117): `loss()` / `log_likelihood()` with autograd, `optimize()`,
+`predict_f` / `predict_y` -- over the 2-D block-cyclic engine of gptorch_amd/dist.py, one process per
+GPU (`torch.distributed`, backend "nccl" = RCCL).  The reference has no counterpart
+(models/base.py:33 "Assume single GPU"); every rank constructs the same model on the same data and
+calls every method collectively, exactly as it would call GPR's on one GPU:
+
+    dist.init_process_group("nccl", device_id=device)
+    model = DistGPR(x, y, kernels.Rbf(d)); model.cuda()
+    model.optimize(method="Adam", max_iter=50)          # identical parameter trajectories on all ranks
+    mu, var = model.predict_y(x_test)
+
+log_likelihood is one autograd node: forward = distributed assembly + factorisation (the residual
+riding along), backward = the closed form on the same grid (U = L^-T carried as identity rows,
+Kyy^-1 = U U^T with panels of U travelling like factorisation panels, per-rank sweeps, D + 2 scalars
+all-reduced).  Prediction sends the test points through one more factorisation as extra residual
+rows.  Native stationary kernels only (the distributed assembly is the fused native kernel).
+"""
+import torch
+
+from .. import kernels
+from .gpr import GPR
+
+
+class _DistLogLik(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, variance, length_scales, noise, resid, engine):
+        need = any(ctx.needs_input_grad[:4])
+        if need:
+            lml, g = engine.log_likelihood_and_grad(variance.detach(), length_scales.detach(), noise.detach(), resid.detach())
+            nls = length_scales.numel()
+            ctx.g_var, ctx.g_ls, ctx.g_noise = g[0:1].clone(), g[1:1 + nls].clone(), g[1 + nls:2 + nls].clone()
+            ctx.g_resid = -engine.last_a.t().contiguous()          # dLML/d(y - m) = -a
+            ctx.ls_shape = length_scales.shape
+        else:
+            lml = engine.log_likelihood(variance.detach(), length_scales.detach(), noise.detach(), resid.detach())
+        return lml.reshape(1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        go = grad_out.reshape(())
+        return (go * ctx.g_var, go * ctx.g_ls.reshape(ctx.ls_shape), go * ctx.g_noise,
+                go * ctx.g_resid if ctx.needs_input_grad[3] else None, None)
+
+
+class DistGPR(GPR):
+    def __init__(self, x, y, kernel, mean_function=None, likelihood=None, name="dist_gpr", tile=2048, grid=None, tile_ops=None):
+        super().__init__(x, y, kernel, mean_function=mean_function, likelihood=likelihood, name=name)
+        if not (isinstance(kernel, kernels.Stationary) and kernel._kind is not None):
+            raise NotImplementedError("DistGPR assembles its tiles with the native stationary kernels (Rbf, Matern52, ...)")
+        self._tile, self._grid, self._tile_ops = int(tile), grid, tile_ops
+        self._engine = None
+
+    def _eng(self):
+        from .. import dist as gdist
+        e = self._engine
+        if e is None or e.X.device != self.X.device:
+            e = gdist.BlockCyclicGP(self.X, self.Y, self.kernel._kind, tile=self._tile, grid=self._grid, ops=self._tile_ops)
+            self._engine = e
+        return e
+
+    def log_likelihood(self, x=None, y=None):
+        """gpr.py:47-67 on the grid; shape (1,).  (x, y default to the training data -- other data would
+        need an engine of its own.)"""
+        if x is not None or y is not None:
+            raise NotImplementedError("DistGPR.log_likelihood evaluates the model's own (x, y)")
+        k = self.kernel
+        resid = self.Y - self.mean_function(self.X)
+        return _DistLogLik.apply(k.variance.transform(), k.length_scales.transform(), self.likelihood.variance.transform(),
+                                 resid, self._eng())
+
+    def _predict(self, x_new, diag=True, x=None):
+        """gpr.py:88-117 on the grid: mean [n*, dy]; var [n*, dy] (diag) or cov [n*, n*]."""
+        if x is not None:
+            raise NotImplementedError("DistGPR predicts from the model's own training inputs")
+        k = self.kernel
+        with torch.no_grad():
+            resid = self.Y - self.mean_function(self.X)
+            mean, v = self._eng().predict(k.variance.transform(), k.length_scales.transform(), self.likelihood.variance.transform(),
+                                          resid, x_new, diag=diag)
+            mean_f = mean + self.mean_function(x_new)
+            var_f = v[:, None].expand_as(mean_f) if diag else v
+        return mean_f, var_f

@@ -49,9 +49,10 @@ class CpuTileOps:
         dst[:rows, :cols] = src[:rows, :cols]
 
     def kernel_grad(self, kind, Xi, Xj, variance, ls, G):
-        v = variance.clone().requires_grad_(True)
-        l = ls.clone().requires_grad_(True)
-        (orc.kernel_K(kind, Xi, Xj, v, l) * G).sum().backward()
+        with torch.enable_grad():          # (called from inside an autograd.Function's forward by DistGPR)
+            v = variance.detach().clone().requires_grad_(True)
+            l = ls.detach().clone().requires_grad_(True)
+            (orc.kernel_K(kind, Xi, Xj, v, l) * G.detach()).sum().backward()
         return torch.cat([v.grad, l.grad])
 
     def log_diag_sum(self, A, n):
@@ -59,6 +60,9 @@ class CpuTileOps:
 
     def sumsq(self, A, m, n):
         return A[:m, :n].pow(2).sum()
+
+    def row_sumsq(self, A, m, n):
+        return A[:m, :n].pow(2).sum(1)
 
 
 def _free_port():
@@ -200,3 +204,59 @@ def test_block_cyclic_buffers_are_reused_and_ladder_replays(tmp_path):
     with torch.no_grad():
         ref_j = orc.GPROracle(x, y, kind="Rbf", noise=-1e-3 + 1e-2).log_likelihood().item()
     assert v[6] == 8 and abs(v[1] - ref_j) < 1e-8 * abs(ref_j)      # -1e-3 + 10^(-10+8) is the first positive shift
+
+
+def _dist_gpr_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gptorch_amd import kernels, likelihoods, mean_functions
+        from gptorch_amd.models import DistGPR
+        n, d, dy = 600, 3, 2
+        x, y = rng.make_regression(n, d, dy, seed=0)
+        mean = mean_functions.Constant(dy, val=torch.tensor([0.3, -0.2], dtype=torch.float64))
+        m = DistGPR(x, y, kernels.Matern52(d, variance=1.3, length_scales=np.array([1.1, 1.7, 2.3]), ARD=True),
+                    likelihood=likelihoods.Gaussian(variance=0.05), mean_function=mean, tile=128, tile_ops=CpuTileOps())
+        loss = m.loss()
+        loss.backward()
+        grads = [m.kernel.variance.grad.numpy(), m.kernel.length_scales.grad.numpy(), m.likelihood.variance.grad.numpy(),
+                 m.mean_function.val.grad.numpy()]
+        xs = rng.normal(9, (7, d))
+        mu, var = m.predict_f(xs)
+        _, cov = m.predict_y(xs, diag=False)
+        losses, _ = m.optimize(method="Adam", max_iter=3, verbose=False)
+        if rank == 0:
+            np.savez(out_path, loss=loss.item(), g0=grads[0], g1=grads[1], g2=grads[2], g3=grads[3], mu=mu, var=var, cov=cov, losses=losses)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_dist_gpr_model_matches_oracle(tmp_path, world):
+    """gptorch_amd.models.DistGPR -- GPR's call surface (loss + autograd incl. a trainable mean function,
+    predict_f / predict_y diag and full, optimize) over the block-cyclic engine: loss, raw-parameter
+    gradients, predictions and three Adam steps against the CPU oracle of the reference path."""
+    import contextlib, io
+    out = str(tmp_path / "m.npz")
+    with contextlib.redirect_stdout(io.StringIO()):
+        mp.spawn(_dist_gpr_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    z = np.load(out)
+    n, d, dy = 600, 3, 2
+    x, y = rng.make_regression(n, d, dy, seed=0)
+    o = orc.GPROracle(x, y, kind="Matern52", variance=1.3, length_scales=np.array([1.1, 1.7, 2.3]), noise=0.05, ARD=True, mean=[0.3, -0.2])
+    o.mean_val.requires_grad_(True)
+    lo = o.loss()
+    lo.backward()
+    assert np.abs(z["g3"] - o.mean_val.grad.numpy()).max() < 1e-8 * max(1.0, o.mean_val.grad.abs().max().item())
+    assert abs(z["loss"] - lo.item()) < 1e-9 * abs(lo.item())
+    for got, ref in [(z["g0"], o.raw_variance.grad), (z["g1"], o.raw_length_scales.grad), (z["g2"], o.raw_noise.grad)]:
+        assert np.abs(got - ref.numpy()).max() < 1e-8 * max(1.0, ref.abs().max().item()), (got, ref)
+    xs = rng.normal(9, (7, d))
+    with torch.no_grad():
+        omu, ovar = o.predict_f(xs)
+        _, ocov = o.predict_y(xs, diag=False)
+    assert np.abs(z["mu"] - omu.numpy()).max() < 1e-9 and np.abs(z["var"] - ovar.numpy()).max() < 1e-9
+    assert np.abs(z["cov"] - ocov.numpy()).max() < 1e-9
+    assert z["losses"].shape == (3,) and abs(z["losses"][0] - lo.item()) < 1e-9 * abs(lo.item()) and z["losses"][2] < z["losses"][0]

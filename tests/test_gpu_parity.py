@@ -1430,3 +1430,17 @@ def test_example_script_runs(device):
                            capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, PYTHONPATH=root))
         assert r.returncode == 0, r.stderr[-2000:]
         assert "predictive mean within 3 sigma" in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dist_gpr_model_native_shared_gpu(device, world):
+    """gptorch_amd.models.DistGPR (GPR's call surface over the block-cyclic engine) with the product's
+    native tile ops, `world` ranks sharing cuda:0 over gloo: loss, raw-parameter gradients and
+    predictions (diag and full covariance) against the single-GPU GPR on the same data."""
+    import re
+    out = _torchrun(world, ["tools/dist_gpr_check.py", "3000", "4", "512"], {"GPN_SHARED_GPU": "1"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("dist_gpr_check")][-1]
+    errs = {k: float(v) for k, v in re.findall(r"(\w+)=([0-9.e+-]+)", line.split(":", 1)[1])}
+    assert errs["loss"] < 1e-12 and errs["mean"] < 1e-9 and errs["var"] < 1e-9 and errs["cov"] < 1e-9, line
+    assert errs["g_variance"] < 1e-8 and errs["g_length_scales"] < 1e-8 and errs["g_noise"] < 1e-8, line
