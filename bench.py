@@ -480,6 +480,19 @@ def run_multi(args, rank, local_rank, world, device):
             extra["single_gpu_same_run"] = single
             extra["speedup_vs_single_gpu_same_run"] = single["ms_per_step"] * 1e-3 / sec
             extra["lml_abs_diff_vs_single_gpu"] = abs(lml - single["lml"])
+        if args.dist_backward:
+            # opt-in: one distributed loss + closed-form backward (U = L^-T carried on the grid, Kyy^-1 = U U^T,
+            # per-rank sweeps) of the same model -- 2x the local matrix and ~3x the evaluation's time
+            try:
+                barrier()
+                t0 = time.perf_counter()
+                lml_b, grad = g.log_likelihood_and_grad(var, ls, nz, Y)
+                barrier()
+                tb = max_over_ranks(time.perf_counter() - t0)
+                extra["dist_loss_backward"] = {"config": w["name"].replace("LML eval", "LML + closed-form gradients") + ", block-cyclic over %d GPUs" % world,
+                                               "ms_per_step": tb * 1e3, "lml": float(lml_b.item()), "grads_constrained": [float(v) for v in grad.tolist()]}
+            except Exception as exc:
+                notes["dist_backward_error"] = repr(exc)
         # labelled extra: independent C2 replicas, one model per GPU, no collective (GP-fits/s at small N)
         try:
             mr, _, _ = build_model(WORKLOADS["c2"], seed=rank, device=device)
@@ -532,6 +545,7 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c3 on one GPU; c4 (block-cyclic) on several")
     ap.add_argument("--tile", type=int, default=2048, help="block-cyclic tile size (N > 1 GPUs)")
+    ap.add_argument("--dist-backward", action="store_true", help="(N > 1 GPUs) also time one distributed loss + backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + rooflines only (profiling runs)")
     ap.add_argument("--test-shared-gpu", action="store_true",

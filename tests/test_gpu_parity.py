@@ -620,7 +620,7 @@ def test_bench_multi_rank_line_shared_gpu(device):
     reference's C2 LML and agree with the single-GPU evaluation of the same run."""
     import json
     out = _torchrun(2, ["bench.py", "--gpus", "2", "--workload", "c2", "--tile", "1024", "--steps", "2", "--warmup", "1",
-                        "--test-shared-gpu"], {})
+                        "--test-shared-gpu", "--dist-backward"], {})
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["world_size_reported_by_backend"] == 2
@@ -629,6 +629,13 @@ def test_bench_multi_rank_line_shared_gpu(device):
     assert abs(line["lml"] - case["lml"]) < 1e-8, (line["lml"], case["lml"])
     assert line["lml_abs_diff_vs_single_gpu"] < 1e-8
     assert line["replicas_c2"]["value"] > 0 and line["single_gpu_same_run"]["value"] > 0
+    # --dist-backward: the distributed closed-form gradients of the same model against the full-size reference golden
+    gref = load_json("lml_c2_grad.json")
+    db = line["dist_loss_backward"]
+    assert abs(db["lml"] - case["lml"]) < 1e-8
+    want = [-gref["grad_loss"]["kernel.variance"][0] / case["variance"], -gref["grad_loss"]["kernel.length_scales"][0] / case["length_scales"],
+            -gref["grad_loss"]["likelihood.variance"][0] / case["noise"]]      # golden: d loss / d log(theta)
+    assert np.abs(np.asarray(db["grads_constrained"]) - np.asarray(want)).max() < 1e-7 * np.abs(want).max(), (db, want)
 
 
 def test_c_driver_single_rank_and_rccl_adapter(device):
