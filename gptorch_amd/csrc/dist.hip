@@ -195,14 +195,18 @@ struct DistRun {
     const bool mine = (k % g.pr) == g.my_r;
     double* Lp = W + L.diag;
     double* Wp = Lp + T * T;
-    const double* Lsrc = Lp;
-    int64_t ldl = T;
     int32_t* info = reinterpret_cast<int32_t*>(W + L.info) + k;
     if (mine) {
-      double* Lt = colk + (g.rows_le(k, g.my_r) - 1) * T * g.ld;
-      ok(gpn_potrf_lower(s, Lt, nk, 0, g.ld, Wp, info));
-      if (xcol()) ok(gpn_copy_matrix(s, Lt, nk, nk, g.ld, Lp, T, 0));
-      else { Lsrc = Lt; ldl = g.ld; }
+      const int64_t d0 = (g.rows_le(k, g.my_r) - 1) * T;
+      double* Lt = colk + d0 * g.ld;
+      if (!xcol()) {
+        // nobody else needs L_kk (Pr = 1): my panel rows ride along as extra rows of the same call, so the tile's
+        // leaf chain runs underneath their solves / updates instead of alone on the chip
+        ok(gpn_potrf_lower_panel(s, Lt, nk, hi - (d0 + nk), g.ld, Wp, info));
+        return;
+      }
+      ok(gpn_potrf_lower_panel(s, Lt, nk, 0, g.ld, Wp, info));
+      ok(gpn_copy_matrix(s, Lt, nk, nk, g.ld, Lp, T, 0));
     }
     if (xcol() && rc == GPN_OK) {
       // short, and everything after it depends on it -- but it goes through the column stream like the
@@ -213,7 +217,7 @@ struct DistRun {
       hip(hipEventRecord(ax->diag_done, ax->col_s), "panel_phase");
       hip(hipStreamWaitEvent(s, ax->diag_done, 0), "panel_phase");
     }
-    if (m > 0 && rc == GPN_OK) ok(gpn_trsm_right_lt(s, Lsrc, nk, ldl, Wp, colk + lo * g.ld, m, g.ld));
+    if (m > 0 && rc == GPN_OK) ok(gpn_trsm_right_lt(s, Lp, nk, T, Wp, colk + lo * g.ld, m, g.ld));
   }
 
   // step 3 (asynchronous on the row stream): -> left operand buffer

@@ -514,6 +514,11 @@ struct Ctx {
   double* winv;
   int32_t* info;
   int rc;
+  // corner = true (factor buffers): the trailing update is one lower-tile square over the matrix rows AND the
+  // extra rows, so the e x e corner right of column n accumulates -R R^T garbage (the buffer has room for it).
+  // corner = false (a tile column of a larger matrix, gpn_potrf_lower_panel): nothing right of column n is
+  // touched -- the extra rows get a rectangular update of their own.
+  bool corner = true;
 };
 
 static inline int64_t split_point(int64_t n) {
@@ -559,7 +564,14 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   const int64_t m = n - h + e;
   trsm_rec(c, A21, m, c.lda, A, c.lda, h, col0, c.winv);
   if (c.rc != GPN_OK) return;
-  c.rc = gemm_nt(c.s, m, m, h, -1.0, A21, c.lda, A21, c.lda, 1.0, A21 + h, c.lda, 1);
+  if (c.corner || e == 0) {
+    c.rc = gemm_nt(c.s, m, m, h, -1.0, A21, c.lda, A21, c.lda, 1.0, A21 + h, c.lda, 1);
+  } else {
+    const int64_t ms = n - h;
+    c.rc = gemm_nt(c.s, ms, ms, h, -1.0, A21, c.lda, A21, c.lda, 1.0, A21 + h, c.lda, 1);
+    if (c.rc == GPN_OK)
+      c.rc = gemm_nt(c.s, e, ms, h, -1.0, A21 + ms * c.lda, c.lda, A21, c.lda, 1.0, A21 + ms * c.lda + h, c.lda, 0);
+  }
   potrf_rec(c, A21 + h, n - h, e, col0 + h);
 }
 
@@ -686,7 +698,14 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
     const int64_t m = n + e - pend;
     if (pend < n) {
       double* P = A + pend * lda + p0;             // [m, pw] solved panel below the diagonal square
-      c.rc = gemm_nt(c.s, m, m, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+      if (c.corner || e == 0) {
+        c.rc = gemm_nt(c.s, m, m, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+      } else {
+        const int64_t ms = n - pend;               // matrix rows / columns left; the e extra rows: rectangular
+        c.rc = gemm_nt(c.s, ms, ms, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+        if (c.rc == GPN_OK)
+          c.rc = gemm_nt(c.s, e, ms, round_up(pw, 16), -1.0, P + ms * lda, lda, P, lda, 1.0, A + n * lda + pend, lda, 0);
+      }
     }
   }
 }
@@ -889,6 +908,28 @@ extern "C" int gpn_release_stream(void* stream) {
   auto it = g_aux.find(static_cast<hipStream_t>(stream));
   if (it != g_aux.end()) { drop(it->second); g_aux.erase(it); }
   return GPN_OK;
+}
+
+// A tile column of a larger matrix: the n x n block at A is factored in place and the e rows below it
+// (any number: they are a panel of the enclosing matrix, not right-hand sides with room beside them) come
+// out as R L^-T, with NOTHING right of column n read or written -- lda >= round_up(n, 128) suffices.
+// Same drivers and in-panel look-ahead as gpn_potrf_lower, so the leaf chain of the tile runs underneath
+// the updates of all e rows instead of alone on the chip.  (gptorch_amd/dist.py, csrc/dist.hip.)
+extern "C" int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
+                                     double* winv, int32_t* info) {
+  if (!A) return -2;
+  if (n < 0) return -3;
+  if (e < 0) return -4;
+  if (lda < round_up(n, LEAF) || (lda % LEAF) != 0) return -5;
+  if (!winv) return -6;
+  if (!info) return -7;
+  if (reinterpret_cast<uintptr_t>(A) & 15) return GPN_E_ALIGN;
+  if (n == 0) return GPN_OK;
+  Ctx c{static_cast<hipStream_t>(stream), lda, winv, info, GPN_OK};
+  c.corner = false;
+  if (g_potrf_variant == 1 || n <= 2 * LEAF) potrf_rec(c, A, n, e, 0);
+  else potrf_lookahead(c, A, n, e);
+  return c.rc;
 }
 
 extern "C" int gpn_debug_set_potrf_variant(int v) {

@@ -91,10 +91,11 @@ class NativeTileOps:
         return int(_ops._native.lib().gpn_winv_bytes(n)) // 8
 
     def potrf(self, A, n, e, winv, info):
-        """in-place lower Cholesky of A[:n,:n] carrying the e rows below it; info: int32 view."""
-        st = _ops._native.lib().gpn_potrf_lower(_ops._stream(A.device), _ops._ptr(A), n, e, A.stride(0),
-                                                _ops._ptr(winv), _ops._ptr(info))
-        _ops._native.check(st, "gpn_potrf_lower")
+        """in-place lower Cholesky of the tile A[:n,:n]; the e rows below it (panel rows of the enclosing
+        matrix on this GPU) come out as R L^-T; nothing right of column n is touched; info: int32 view."""
+        st = _ops._native.lib().gpn_potrf_lower_panel(_ops._stream(A.device), _ops._ptr(A), n, e, A.stride(0),
+                                                      _ops._ptr(winv), _ops._ptr(info))
+        _ops._native.check(st, "gpn_potrf_lower_panel")
 
     def trsm(self, L, winv, n, B, m):
         """B[:m,:n] <- B L^-T."""
@@ -327,10 +328,14 @@ class BlockCyclicGP:
         if diag_mine:
             d0 = (self._rows_le(k) - 1) * T
             L = colk[d0:]
+            if not exchange:
+                # nobody else needs L_kk (Pr = 1): my panel rows ride along as extra rows of the SAME call, so the
+                # tile's leaf chain runs underneath their solves / updates instead of alone on the chip
+                self.ops.potrf(L, nk, hi - (d0 + nk), Wp, self.info_t[k:k + 1])
+                return
             self.ops.potrf(L, nk, 0, Wp, self.info_t[k:k + 1])
-            if exchange:
-                ops.copy(Lp, L, nk, nk)
-                L = Lp
+            ops.copy(Lp, L, nk, nk)
+            L = Lp
         if exchange:
             self._bcast(self.diag, (k % self.pr) * self.pc + ck, self.col_group)
         if m:

@@ -98,6 +98,13 @@ int gpn_pack_rhs(void* stream, const double* Y, const double* M, int64_t n, int 
 int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
                     double* winv, int32_t* info);
 
+/* The same factorisation for a tile column of a LARGER matrix: the e rows below the n x n block (any
+ * number -- a panel of the enclosing matrix) come out as R L^-T and nothing right of column n is read or
+ * written; lda >= round_up(n, 128).  What the block-cyclic drivers call on a diagonal tile whose panel
+ * rows live on the same GPU (gptorch_amd/dist.py, gpn_dist_lml_forward). */
+int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
+                          double* winv, int32_t* info);
+
 /* Panel width the driver uses for an n x n factorisation (0 = the recursive driver): each panel ends
  * with one lower-tile K = width contraction -- the SYRK trailing update priced by bench.py. */
 int64_t gpn_potrf_panel_width(int64_t n);

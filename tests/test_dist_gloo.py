@@ -29,11 +29,12 @@ class CpuTileOps:
         return 1
 
     def potrf(self, A, n, e, winv, info):
-        assert e == 0
         L, inf = torch.linalg.cholesky_ex(A[:n, :n])
         info[0] = int(inf)
         if int(inf) == 0:
             A[:n, :n] = L
+            if e:
+                A[n:n + e, :n] = torch.linalg.solve_triangular(L, A[n:n + e, :n].t(), upper=False).t()
 
     def trsm(self, L, winv, n, B, m):
         B[:m, :n] = torch.linalg.solve_triangular(L[:n, :n], B[:m, :n].t(), upper=False).t()
