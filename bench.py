@@ -321,6 +321,24 @@ def run_single(args, device):
                             res[k2] = r2[k2]
                 if with_backward:
                     res["loss_backward"] = backward_leg(lib, m, ww, max(2, steps // 4) if ww["n"] <= 8192 else 2)
+                if key == "c2":
+                    # configs[1] reads "kernel build + Cholesky + predict": GPR.predict_f at 1024 test points
+                    # (gpr.py:88-117) -- with the factor cached between calls, and re-factorising every call as
+                    # the reference does (gpr.py:104)
+                    from gptorch_amd import rng
+                    xs = torch.tensor(rng.normal(7, (1024, ww["d"])), device=device)
+
+                    def pred():
+                        with torch.no_grad():
+                            return m._predict(xs)
+
+                    def pred_refactor():
+                        m._predict_cache = None
+                        return pred()
+                    tp, _ = timed(pred, 10, 3)
+                    tr, _ = timed(pred_refactor, 5, 1)
+                    res["predict"] = {"config": "C2: GPR._predict at 1024 test points, diag variance", "ms_cached_factor": tp * 1e3,
+                                      "ms_with_refactorisation": tr * 1e3}
                 return res
             return run
 
