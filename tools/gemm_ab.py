@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """GPU-box tool: same-box A/B of contraction-kernel variants (gpn_debug_set_gemm_variant) with a
-correctness check of every variant against the first one.   python tools/gemm_ab.py 0,4,9 [M N K lower ...]"""
+correctness check of every variant against the first one.   python tools/gemm_ab.py 0,3,4 [M N K lower ...]"""
 import os, sys
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from gptorch_amd import _ops, _native  # noqa: E402
 
-variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,4,9").split(",")]
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,3,4").split(",")]
 shapes = [(8192, 8192, 8192, 0), (8192, 8192, 2048, 0), (30720, 30720, 2048, 1), (16384, 16384, 4096, 1), (6656, 6656, 1536, 1), (12345, 777, 1024, 0)]
 if len(sys.argv) > 2:
     a = [int(v) for v in sys.argv[2:]]
