@@ -68,6 +68,10 @@ class DistComm(ctypes.Structure):
 
 SIGNATURES.update({
     "gpn_dist_work_bytes": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int64]),
+    "gpn_dist_grad_work_bytes": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int64]),
+    "gpn_dist_lml_grad": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
+                                  c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                  c_void_p, c_void_p]),
     "gpn_dist_lml_forward": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                      c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
 })

@@ -31,8 +31,8 @@ struct DistGeom {
   int rank, pr, pc, my_r, my_c;
   int64_t n, T, nt;
   int dy;
-  int64_t nrow_t, ncol_t, res_off, rows, ld;
-  bool has_res;
+  int64_t nrow_t, ncol_t, res_off, id_off, rows, ld;
+  bool has_res, with_inv;
   int64_t rows_of(int64_t I) const { return I == nt ? dy : std::min<int64_t>(T, n - I * T); }
   int64_t rows_le(int64_t k, int r) const {          // how many of process row r's tile rows have index <= k
     const int64_t cnt = (nt - r + pr - 1) / pr;
@@ -51,7 +51,7 @@ struct DistGeom {
   }
 };
 
-static int make_geom(DistGeom& g, int rank, int pr, int pc, int64_t n, int dy, int64_t tile) {
+static int make_geom(DistGeom& g, int rank, int pr, int pc, int64_t n, int dy, int64_t tile, bool with_inv = false) {
   if (pr < 1 || pc < 1 || pc % pr) return -4;
   if (rank < 0 || rank >= pr * pc) return -3;
   if (tile < LEAF || tile % LEAF) return -15;
@@ -62,7 +62,9 @@ static int make_geom(DistGeom& g, int rank, int pr, int pc, int64_t n, int dy, i
   g.ncol_t = g.nt > g.my_c ? (g.nt - g.my_c + pc - 1) / pc : 0;
   g.has_res = (g.nt % pr) == g.my_r;
   g.res_off = g.nrow_t * tile;
-  g.rows = g.res_off + (g.has_res ? round_up(dy, LEAF) : 0) + LEAF;
+  g.with_inv = with_inv;
+  g.id_off = g.res_off + (g.has_res ? round_up(dy, LEAF) : 0);     // identity blocks (backward only): block i -> U_i,:
+  g.rows = g.id_off + (with_inv ? g.nrow_t * tile : 0) + LEAF;
   g.ld = std::max<int64_t>(g.ncol_t, 1) * tile;
   return GPN_OK;
 }
@@ -70,6 +72,8 @@ static int make_geom(DistGeom& g, int rank, int pr, int pc, int64_t n, int dy, i
 // workspace layout (doubles)
 struct DistLayout {
   int64_t A, left[2], right[2], diag, winv, xrow, xcol, stats, info, sums, total;
+  // backward only
+  int64_t kinv, alphaT, aT, al, part, arow, acol, gwork, gout, acc;
 };
 static DistLayout make_layout(const DistGeom& g, int d) {
   DistLayout L;
@@ -88,6 +92,19 @@ static DistLayout make_layout(const DistGeom& g, int d) {
   L.stats = take(3 * (g.ncol_t + 1) + g.dy + 8);      // lml_reduce triples per diagonal tile, residual row sums
   L.info = take(g.nt + 8);                            // int32 per tile column (stored in double-sized slots)
   L.sums = take(g.nt + 8);                            // all-reduced vector: log-det, |alpha|^2, info per tile
+  if (g.with_inv) {
+    const int64_t kp = round_up(g.dy, 16), rpad = std::max<int64_t>(g.nrow_t, 1) * T;
+    L.kinv = take((rpad + LEAF) * g.ld);                // Kyy^-1 -> G, my tiles, same layout as the matrix segment
+    L.alphaT = take((int64_t)g.dy * g.n);               // alpha^T, replicated
+    L.aT = take((int64_t)g.dy * g.n);                   // a^T = (Kyy^-1 (y - m))^T, replicated
+    L.al = take(kp * g.ld);                             // alpha^T of my tile columns (local column order)
+    L.part = take(kp * rpad);                           // my partial of a^T (local row order)
+    L.arow = take((rpad + 16) * kp);                    // a of my tile rows / columns, K-padded
+    L.acol = take((std::max<int64_t>(g.ncol_t, 1) * T + 16) * kp);
+    L.gwork = take(gpn_grad_work_bytes(rpad, T, d, 0) / 8 + 8);
+    L.gout = take(d + 8);
+    L.acc = take(d + 8);
+  }
   L.total = o;
   return L;
 }
@@ -164,6 +181,43 @@ __global__ void dist_finish_kernel(const double* sums, int nt, int64_t T, int64_
   out4[3] = info;
 }
 
+// identity block: ones on the diagonal of an n x n tile
+__global__ void dist_set_identity_kernel(double* A, int64_t ld, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[i * ld + i] = 1.0;
+}
+// out[p, c] = aT[c, gidx(p)] for the rows of my tile rows (or tile columns): tile q of mine is global tile
+// first + q * stride, so gidx(p) = (first + (p / T) * stride) * T + p % T;  out is [*, kpad] row-major, zero beyond dy
+__global__ void dist_a_pad_kernel(const double* aT, int64_t n, int dy, int64_t T, int first, int stride, int64_t nreal,
+                                  double* out, int kpad) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nreal) return;
+  const int64_t gi = ((int64_t)first + (p / T) * stride) * T + p % T;
+  for (int c = 0; c < dy; ++c) out[p * kpad + c] = aT[(int64_t)c * n + gi];
+}
+// acc[slot] += trace of the n x n block G
+__global__ void dist_trace_add_kernel(const double* G, int64_t ld, int64_t n, double* acc, int slot) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += G[i * ld + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[slot] += red[0];
+}
+__global__ void dist_axpy_kernel(double* acc, const double* x, double scale, int cnt) {
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) acc[i] += scale * x[i];
+}
+// grad_resid[i, c] = -aT[c, i]   (dLML/d(y - m) = -a)
+__global__ void dist_neg_transpose_kernel(const double* aT, int64_t n, int dy, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int c = 0; c < dy; ++c) out[i * dy + c] = -aT[(int64_t)c * n + i];
+}
+
 struct DistRun {
   hipStream_t s;
   DistAux* ax;
@@ -180,7 +234,8 @@ struct DistRun {
 
   void active(int64_t k, int64_t& lo, int64_t& hi) const {
     lo = g.rows_le(k, g.my_r) * g.T;
-    hi = std::max(lo, g.res_off + (g.has_res ? g.dy : 0));
+    hi = g.with_inv ? g.id_off + g.rows_le(k, g.my_r) * g.T : g.res_off + (g.has_res ? g.dy : 0);
+    hi = std::max(lo, hi);
   }
 
   // steps 1-2
@@ -222,9 +277,13 @@ struct DistRun {
 
   // step 3 (asynchronous on the row stream): -> left operand buffer
   double* start_rows(int64_t k, bool& pending) {
-    const int64_t T = g.T, nk = g.rows_of(k), ck = k % g.pc;
     int64_t lo, hi;
     active(k, lo, hi);
+    return start_rows(k, lo, hi, pending);
+  }
+  // ... of an explicit local row range [lo, hi) of tile column k (the backward sends the identity blocks)
+  double* start_rows(int64_t k, int64_t lo, int64_t hi, bool& pending) {
+    const int64_t T = g.T, nk = g.rows_of(k), ck = k % g.pc;
     const int64_t m = hi - lo;
     double* buf = W + L.left[k & 1];
     pending = false;
@@ -247,13 +306,17 @@ struct DistRun {
 
   // step 4 (asynchronous on the column stream, after step 3 has completed): -> right operand
   double* start_cols(int64_t k, double* left, bool& pending) {
+    const int rs = g.my_c % g.pr;
+    const int64_t lj0 = g.cols_le(k), count = g.ncol_t - lj0;
+    const int64_t J0 = lj0 * g.pc + g.my_c;
+    return start_cols(k, left, count > 0 ? (J0 - rs) / g.pr - g.rows_le(k, rs) : 0, count, pending);
+  }
+  // ... `count` tiles starting at slot `first` of process row (c mod Pr)'s left buffer, every (Pc/Pr)-th
+  double* start_cols(int64_t k, double* left, int64_t first, int64_t count, bool& pending) {
     const int64_t T = g.T;
     pending = false;
     const int rs = g.my_c % g.pr;
-    const int64_t lj0 = g.cols_le(k), count = g.ncol_t - lj0;
     if (count <= 0 || rc != GPN_OK) return W + L.right[k & 1];
-    const int64_t J0 = lj0 * g.pc + g.my_c;
-    const int64_t first = (J0 - rs) / g.pr - g.rows_le(k, rs);
     const int64_t step = g.pc / g.pr;
     const bool src = g.my_r == rs;
     double* buf;
@@ -304,18 +367,14 @@ struct DistRun {
 
 using namespace gpn;
 
-extern "C" int64_t gpn_dist_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile) {
-  DistGeom g;
-  if (make_geom(g, rank, pr, pc, n, dy, tile) != GPN_OK || d <= 0 || dy <= 0) return -1;
-  return make_layout(g, d).total * (int64_t)sizeof(double);
-}
-
-extern "C" int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
-                                    const double* X, int64_t n, int d, const double* Y, int dy,
-                                    const double* variance, const double* length_scales, int nls, const double* noise,
-                                    int64_t tile, double* work, int64_t work_bytes, double* out4) {
+// shared body of the two entry points: assembly + factorisation (+ the closed-form backward on the grid)
+static int dist_evaluate(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                         const double* X, int64_t n, int d, const double* Y, int dy,
+                         const double* variance, const double* length_scales, int nls, const double* noise,
+                         int64_t tile, double* work, int64_t work_bytes, double* out4, bool with_grad,
+                         double* grads, double* grad_resid) {
   DistRun R;
-  int rc = make_geom(R.g, rank, pr, pc, n, dy, tile);
+  int rc = make_geom(R.g, rank, pr, pc, n, dy, tile, with_grad);
   if (rc != GPN_OK) return rc;
   if (pr * pc > 1 && (!comm || !comm->bcast || !comm->allreduce)) return -2;
   if (kind < GPN_RBF || kind > GPN_PERIODIC) return -6;
@@ -328,6 +387,7 @@ extern "C" int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int
   if (nls != 1 && nls != d) return -14;
   if (!work) return -16;
   if (!out4) return -18;
+  if (with_grad && !grads) return -19;
   R.L = make_layout(R.g, d);
   if (work_bytes < R.L.total * (int64_t)sizeof(double)) return -17;
   if (reinterpret_cast<uintptr_t>(work) & 255) return GPN_E_ALIGN;
@@ -360,6 +420,12 @@ extern "C" int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int
     if (g.has_res) {                                     // residual rows: (y)^T of this tile column
       rc = gpn_pack_rhs(stream, Y + J * T * dy, nullptr, nJ, dy, A + g.res_off * g.ld + lj * T, g.ld);
       if (rc != GPN_OK) return rc;
+    }
+    if (g.with_inv && J % g.pr == g.my_r) {              // identity block J: I at tile column J (-> U_J,: from there on)
+      const int64_t li = (J - g.my_r) / g.pr;
+      hipLaunchKernelGGL(dist_set_identity_kernel, dim3((unsigned)((nJ + 255) / 256)), dim3(256), 0, s,
+                         A + (g.id_off + li * T) * g.ld + lj * T, g.ld, nJ);
+      GPN_LAUNCH_CHECK();
     }
     const int64_t li0 = g.rows_le(J - 1, g.my_r);
     int64_t r0 = li0 * T;
@@ -435,5 +501,132 @@ extern "C" int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int
   }
   hipLaunchKernelGGL(dist_finish_kernel, dim3(1), dim3(64), 0, s, sums, (int)nt, T, n, dy, out4);
   GPN_LAUNCH_CHECK();
+  if (!with_grad) return GPN_OK;
+
+  // ---- backward on the same grid (gptorch_amd/dist.py BlockCyclicGP.backward) ------------------
+  // a = Kyy^-1 (y - m) = U alpha,  G = 1/2 (a a^T - dy Kyy^-1),  dLML/dtheta = sum G o dKyy/dtheta
+  const int kp = (int)round_up(dy, 16);
+  double *alphaT = work + L.alphaT, *aT = work + L.aT, *al = work + L.al, *part = work + L.part;
+  const int64_t rpad = std::max<int64_t>(g.nrow_t, 1) * T;
+  // (1) alpha^T replicated: every residual holder contributes its tile columns, one all-reduce
+  if (g.has_res)
+    for (int64_t lj = 0; lj < g.ncol_t; ++lj) {
+      const int64_t J = g.my_c + lj * g.pc;
+      GPN_HIP_CHECK(hipMemcpy2DAsync(alphaT + J * T, (size_t)n * 8, A + g.res_off * g.ld + lj * T, (size_t)g.ld * 8,
+                                     (size_t)g.rows_of(J) * 8, (size_t)dy, hipMemcpyDeviceToDevice, s));
+    }
+  if (R.comm) { rc = R.comm->allreduce(R.comm->ctx, alphaT, (int64_t)dy * n, s); if (rc != GPN_OK) return rc; }
+  // (2) a^T = alpha^T U^T: my identity rows x my tile columns give a partial sum
+  for (int64_t lj = 0; lj < g.ncol_t; ++lj) {
+    const int64_t J = g.my_c + lj * g.pc;
+    GPN_HIP_CHECK(hipMemcpy2DAsync(al + lj * T, (size_t)g.ld * 8, alphaT + J * T, (size_t)n * 8, (size_t)g.rows_of(J) * 8, (size_t)dy,
+                                   hipMemcpyDeviceToDevice, s));
+  }
+  if (nrr > 0 && ncr > 0) {
+    rc = gemm_nt(s, dy, nrr, g.ld, 1.0, al, g.ld, A + g.id_off * g.ld, g.ld, 0.0, part, rpad, 0);
+    if (rc != GPN_OK) return rc;
+    for (int64_t li = 0; li < g.nrow_t; ++li) {
+      const int64_t I = g.my_r + li * g.pr;
+      GPN_HIP_CHECK(hipMemcpy2DAsync(aT + I * T, (size_t)n * 8, part + li * T, (size_t)rpad * 8, (size_t)g.rows_of(I) * 8, (size_t)dy,
+                                     hipMemcpyDeviceToDevice, s));
+    }
+  }
+  if (R.comm) { rc = R.comm->allreduce(R.comm->ctx, aT, (int64_t)dy * n, s); if (rc != GPN_OK) return rc; }
+  // (3) Kyy^-1 = U U^T on the owners of the matrix tiles: tile column K of U travels like a factorisation panel
+  double* Kinv = work + L.kinv;
+  {
+    const int rs = g.my_c % g.pr;
+    const int64_t first = (g.my_c - rs) / g.pr;          // slot of tile J = c in process row rs's buffer
+    bool rp = false, cp = false;
+    double* lft = R.start_rows(0, g.id_off, g.id_off + g.rows_le(0, g.my_r) * T, rp);
+    for (int64_t K = 0; K < nt && R.rc == GPN_OK; ++K) {
+      const int64_t nK = round_up(g.rows_of(K), 16);
+      R.wait_rows(K, rp);
+      const int64_t ncol = g.cols_le(K);
+      double* rgt = R.start_cols(K, lft, first, ncol, cp);
+      R.wait_cols(K, cp);
+      double* nlft = nullptr;
+      bool nrp = false;
+      if (K + 1 < nt) nlft = R.start_rows(K + 1, g.id_off, g.id_off + g.rows_le(K + 1, g.my_r) * T, nrp);
+      const int64_t hi = g.rows_le(K, g.my_r) * T;
+      for (int64_t lj = 0; lj < ncol && R.rc == GPN_OK; ++lj) {
+        const int64_t J = lj * g.pc + g.my_c, nJ = g.rows_of(J);
+        const int64_t r0 = g.rows_le(J - 1, g.my_r) * T;
+        if (r0 < hi) R.ok(gemm_nt(s, hi - r0, nJ, nK, 1.0, lft + r0 * T, T, rgt + lj * T * T, T, 1.0, Kinv + r0 * g.ld + lj * T, g.ld, 0));
+      }
+      lft = nlft;
+      rp = nrp;
+    }
+    if (R.rc != GPN_OK) return R.rc;
+  }
+  // (4) G in place over the stacked rows of every local tile column, contracted with dK/dtheta by the native sweep
+  double *arow = work + L.arow, *acol = work + L.acol, *gwork = work + L.gwork, *gout = work + L.gout, *acc = work + L.acc;
+  if (nrr > 0) {
+    hipLaunchKernelGGL(dist_a_pad_kernel, dim3((unsigned)((nrr + 255) / 256)), dim3(256), 0, s, aT, n, dy, T, g.my_r, g.pr, nrr, arow, kp);
+    GPN_LAUNCH_CHECK();
+  }
+  if (ncr > 0) {
+    hipLaunchKernelGGL(dist_a_pad_kernel, dim3((unsigned)((ncr + 255) / 256)), dim3(256), 0, s, aT, n, dy, T, g.my_c, g.pc, ncr, acol, kp);
+    GPN_LAUNCH_CHECK();
+  }
+  for (int64_t lj = 0; lj < g.ncol_t; ++lj) {
+    const int64_t J = g.my_c + lj * g.pc, nJ = g.rows_of(J);
+    const int64_t li0 = g.rows_le(J - 1, g.my_r);
+    int64_t r0 = li0 * T;
+    if (r0 >= nrr) continue;
+    const double* xj = Xcol + lj * T * d;
+    rc = gemm_nt(s, nrr - r0, nJ, kp, 0.5, arow + r0 * kp, kp, acol + lj * T * kp, kp, -0.5 * dy, Kinv + r0 * g.ld + lj * T, g.ld, 0);
+    if (rc != GPN_OK) return rc;
+    if (li0 * g.pr + g.my_r == J) {                     // diagonal tile: counted once; d/d noise = tr G
+      double* G = Kinv + r0 * g.ld + lj * T;
+      hipLaunchKernelGGL(dist_trace_add_kernel, dim3(1), dim3(256), 0, s, G, g.ld, nJ, acc, 1 + nls);
+      GPN_LAUNCH_CHECK();
+      rc = gpn_kernel_grad(stream, kind, Xrow + r0 * d, nJ, xj, nJ, d, variance, length_scales, nls, G, g.ld, gwork, gout);
+      if (rc != GPN_OK) return rc;
+      hipLaunchKernelGGL(dist_axpy_kernel, dim3(1), dim3(256), 0, s, acc, gout, 1.0, 1 + nls);
+      GPN_LAUNCH_CHECK();
+      r0 += T;
+    }
+    if (r0 < nrr) {                                      // symmetric partners (J, I): x 2
+      rc = gpn_kernel_grad(stream, kind, Xrow + r0 * d, nrr - r0, xj, nJ, d, variance, length_scales, nls,
+                           Kinv + r0 * g.ld + lj * T, g.ld, gwork, gout);
+      if (rc != GPN_OK) return rc;
+      hipLaunchKernelGGL(dist_axpy_kernel, dim3(1), dim3(256), 0, s, acc, gout, 2.0, 1 + nls);
+      GPN_LAUNCH_CHECK();
+    }
+  }
+  if (R.comm) { rc = R.comm->allreduce(R.comm->ctx, acc, 2 + nls, s); if (rc != GPN_OK) return rc; }
+  GPN_HIP_CHECK(hipMemcpyAsync(grads, acc, (size_t)(2 + nls) * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (grad_resid) {
+    hipLaunchKernelGGL(dist_neg_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, aT, n, dy, grad_resid);
+    GPN_LAUNCH_CHECK();
+  }
   return GPN_OK;
+}
+
+extern "C" int64_t gpn_dist_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile) {
+  DistGeom g;
+  if (make_geom(g, rank, pr, pc, n, dy, tile) != GPN_OK || d <= 0 || dy <= 0) return -1;
+  return make_layout(g, d).total * (int64_t)sizeof(double);
+}
+extern "C" int64_t gpn_dist_grad_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile) {
+  DistGeom g;
+  if (make_geom(g, rank, pr, pc, n, dy, tile, true) != GPN_OK || d <= 0 || dy <= 0) return -1;
+  return make_layout(g, d).total * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                                    const double* X, int64_t n, int d, const double* Y, int dy,
+                                    const double* variance, const double* length_scales, int nls, const double* noise,
+                                    int64_t tile, double* work, int64_t work_bytes, double* out4) {
+  return dist_evaluate(stream, comm, rank, pr, pc, kind, X, n, d, Y, dy, variance, length_scales, nls, noise, tile, work, work_bytes,
+                       out4, false, nullptr, nullptr);
+}
+
+extern "C" int gpn_dist_lml_grad(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                                 const double* X, int64_t n, int d, const double* Y, int dy,
+                                 const double* variance, const double* length_scales, int nls, const double* noise,
+                                 int64_t tile, double* work, int64_t work_bytes, double* out4, double* grads, double* grad_resid) {
+  return dist_evaluate(stream, comm, rank, pr, pc, kind, X, n, d, Y, dy, variance, length_scales, nls, noise, tile, work, work_bytes,
+                       out4, true, grads, grad_resid);
 }

@@ -663,6 +663,7 @@ class NativeDistLML:
         if nbytes < 0:
             raise ValueError("bad grid / tile for gpn_dist_lml_forward")
         self.work = torch.empty(nbytes // 8, dtype=torch.float64, device=X.device)
+        self.work_is_grad_sized = False
         self.out = torch.zeros(4, dtype=torch.float64, device=X.device)
         self.info = 0
         self.table = None
@@ -720,10 +721,9 @@ class NativeDistLML:
             g = dist.new_group([r * self.pc + c for r in range(self.pr)]) if (self.pr > 1 or force) else None
             if c == my_c:
                 col_group = g
-        base, work = self.work.data_ptr(), self.work
-
         def view(ptr, count):
-            off = (ptr - base) // 8
+            work = self.work                       # looked up per call: the workspace may have been re-allocated
+            off = (ptr - work.data_ptr()) // 8
             assert 0 <= off and off + count <= work.numel()
             return work[off:off + count]
 
@@ -770,6 +770,42 @@ class NativeDistLML:
         if self.info < 0:
             raise _ops.NativeError("a tile factorisation reported an internal status (not a property of the matrix)")
         return host
+
+    def log_likelihood_and_grad(self, variance, length_scales, noise, max_tries=10):
+        """(LML, [dLML/dvariance, dLML/dlength_scales..., dLML/dnoise], dLML/d(y - m) [n, dy]) through
+        gpn_dist_lml_grad: forward + closed-form backward on the grid in ONE library call per attempt."""
+        lib = self._native.lib()
+        if not self.work_is_grad_sized:        # the callbacks map pointers into self.work: grow it in place of the old one
+            nbytes = int(lib.gpn_dist_grad_work_bytes(self.rank, self.pr, self.pc, self.n, self.d, self.dy, self.T))
+            self.work.resize_(nbytes // 8)
+            self.work_is_grad_sized = True
+        nls = length_scales.numel()
+        grads = torch.zeros(2 + nls, dtype=torch.float64, device=self.X.device)
+        g_resid = torch.zeros(self.n, self.dy, dtype=torch.float64, device=self.X.device)
+
+        def attempt(nz):
+            var, ls, nzc = (_ops._c(t.detach()) for t in (variance, length_scales, nz))
+            st = lib.gpn_dist_lml_grad(_ops._stream(self.X.device), self._ct.byref(self.table) if self.table is not None else None,
+                                       self.rank, self.pr, self.pc, _ops.KINDS[self.kind], _ops._ptr(self.X), self.n, self.d,
+                                       _ops._ptr(self.Y), self.dy, _ops._ptr(var), _ops._ptr(ls), nls, _ops._ptr(nzc),
+                                       self.T, _ops._ptr(self.work), self.work.numel() * 8, _ops._ptr(self.out), _ops._ptr(grads),
+                                       _ops._ptr(g_resid))
+            self._native.check(st, "gpn_dist_lml_grad")
+            host = self.out.cpu()
+            self.info = int(host[3])
+            if self.info < 0:
+                raise _ops.NativeError("a tile factorisation reported an internal status (not a property of the matrix)")
+            return host
+        host = attempt(noise)
+        self.jitter_rung = -1
+        for i in range(max_tries):
+            if self.info == 0:
+                break
+            self.jitter_rung = i
+            host = attempt(noise + 10.0 ** (-max_tries + i))
+        if self.info != 0:
+            raise RuntimeError("Max tries exceeded.")
+        return host[2].to(self.X.device), grads, g_resid
 
     def log_likelihood(self, variance, length_scales, noise, max_tries=10):
         """LML with the jitter ladder of functions.py:20-43 on the all-reduced info word."""

@@ -273,6 +273,19 @@ int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int rank, int 
                          const double* X, int64_t n, int d, const double* Y, int dy,
                          const double* variance, const double* length_scales, int nls, const double* noise,
                          int64_t tile, double* work, int64_t work_bytes, double* out4);
+/* The same evaluation PLUS its closed-form backward on the same grid (what autograd gives the reference under
+ * gpr.py:47-67; gptorch_amd/dist.py BlockCyclicGP.log_likelihood_and_grad): the factorisation also carries
+ * identity blocks, so U = L^-T falls out of the same panel solves / updates; Kyy^-1 = U U^T is accumulated with the
+ * tile columns of U travelling like factorisation panels; every rank contracts its own tiles of
+ * G = 1/2 (a a^T - dy Kyy^-1) with dK/dtheta (gpn_kernel_grad) and 2 + nls scalars are all-reduced.
+ * grads (device, [2 + nls]): dLML/d variance, dLML/d length_scales, dLML/d noise w.r.t. the CONSTRAINED values;
+ * grad_resid (device, [n, dy], may be NULL) = dLML/d(y - m) = -a.  Identical on every rank.  Meaningful only when
+ * out4[3] == 0.  Workspace: gpn_dist_grad_work_bytes (about 3x the forward's local matrix). */
+int64_t gpn_dist_grad_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile);
+int gpn_dist_lml_grad(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                      const double* X, int64_t n, int d, const double* Y, int dy,
+                      const double* variance, const double* length_scales, int nls, const double* noise,
+                      int64_t tile, double* work, int64_t work_bytes, double* out4, double* grads, double* grad_resid);
 /* libgpnative_rccl.so only: a callback table over RCCL communicators (ncclComm_t passed as void*):
  * `row` spans this rank's process row with rank-in-communicator = process-column index, `col` its
  * process column with rank-in-communicator = process-row index, `world` all ranks.  row / col may be

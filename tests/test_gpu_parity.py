@@ -606,9 +606,13 @@ def test_block_cyclic_over_rccl_world1(device):
     assert "backend=nccl" in out.stdout, out.stdout
     vals = [float(v) for v in re.findall(r"lml=(-?[0-9.]+)", out.stdout)]
     case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
-    # 3 timed evaluations + the gradient call (torch.distributed/RCCL) + 2 of the C driver over its own
-    # RCCL communicators (ncclCommInitRank + ncclCommSplit, bootstrapped through torch.distributed)
-    assert len(vals) == 6 and out.stdout.count("cdriver:") == 2, out.stdout
+    # 3 timed evaluations + the gradient call (torch.distributed/RCCL) + 2 evaluations and one forward+backward
+    # (gpn_dist_lml_grad) of the C driver over its own RCCL communicators (ncclCommInitRank + ncclCommSplit,
+    # bootstrapped through torch.distributed)
+    assert len(vals) == 7 and out.stdout.count("cdriver:") == 2 and out.stdout.count("cdriver grad:") == 1, out.stdout
+    gpy = [float(t) for t in re.search(r"^grad: lml=\S+\s+(.*?)\s+[0-9.]+ ms", out.stdout, re.M).group(1).split()]
+    gc = [float(t) for t in re.search(r"cdriver grad: lml=\S+\s+(.*?)\s+resid_grad_norm", out.stdout).group(1).split()]
+    assert np.abs(np.asarray(gpy) - np.asarray(gc)).max() < 1e-9 * np.abs(gpy).max(), (gpy, gc)
     for v in vals:
         assert abs(v - case["lml"]) < 1e-8, (v, case["lml"])
 
@@ -690,13 +694,27 @@ def test_c_driver_multi_rank_shared_gpu(device, world):
     run torch.distributed/gloo collectives (tools/dist_bench.py GPN_CDRIVER=1) -- the panel loop,
     packing, look-ahead and exchange order are the library's own."""
     import re
-    out = _torchrun(world, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_SHARED_GPU": "1", "GPN_CDRIVER": "1"})
+    out = _torchrun(world, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_SHARED_GPU": "1", "GPN_CDRIVER": "1", "GPN_DIST_GRAD": "1"})
     assert out.returncode == 0, out.stderr[-3000:]
     vals = [float(v) for v in re.findall(r"cdriver: lml=(-?[0-9.]+)", out.stdout)]
     case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
     assert len(vals) == 2, out.stdout
     for v in vals:
         assert abs(v - case["lml"]) < 1e-8, (v, case["lml"])
+    # gpn_dist_lml_grad: forward + closed-form backward on the grid in one C call, vs the oracle's closed form
+    mm = re.search(r"cdriver grad: lml=(\S+)\s+(.*?)\s+resid_grad_norm=(\S+)", out.stdout)
+    assert mm, out.stdout
+    assert abs(float(mm.group(1)) - case["lml"]) < 1e-8
+    g = [float(t) for t in mm.group(2).split()]
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    ref = orc.lml_closed_form_grads("Rbf", x, y, 1.0, case["length_scales"], 1e-2)
+    ref_g = np.array([float(ref[1]) / 1.0, float(np.asarray(ref[2]).ravel()[0]) / case["length_scales"], float(ref[3]) / 1e-2])
+    assert np.abs(np.asarray(g) - ref_g).max() < 1e-7 * np.abs(ref_g).max(), (g, ref_g)
+    # dLML/d(y - m) = -a = -Kyy^-1 y: its norm from the oracle's factor
+    o = orc.GPROracle(x, y, kind="Rbf", variance=1.0, length_scales=case["length_scales"], noise=1e-2)
+    with torch.no_grad():
+        a = torch.cholesky_solve(o.Y, orc.cholesky(o.compute_kyy(o.X)))
+    assert abs(float(mm.group(3)) - a.norm().item()) < 1e-8 * a.norm().item()
 
 
 # ---- VFE (sparse_gpr.py:92-195; BASELINE config 5) -------------------------------

@@ -80,5 +80,13 @@ if os.environ.get("GPN_CDRIVER") == "1":
         torch.cuda.synchronize()
         if c.rank == 0:
             print("cdriver: lml=%.8f  %.1f ms  grid=%dx%d" % (lml.item(), (time.time() - t0) * 1e3, c.pr, c.pc), flush=True)
+    if os.environ.get("GPN_DIST_GRAD") == "1":      # forward + closed-form backward in one C call (gpn_dist_lml_grad)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        lml, grad, g_resid = c.log_likelihood_and_grad(one, ls, 0.01 * one)
+        torch.cuda.synchronize()
+        if c.rank == 0:
+            print("cdriver grad: lml=%.8f  %s  resid_grad_norm=%.10e  %.1f ms" % (
+                lml.item(), " ".join("%.10e" % v for v in grad.tolist()), g_resid.norm().item(), (time.time() - t0) * 1e3), flush=True)
 if dist.is_initialized():
     dist.destroy_process_group()
