@@ -277,7 +277,7 @@ def gemm_nt(A, B, M, N, K, alpha=1.0, beta=0.0, C=None, lower=False, tri=0):
     if C is None:
         C = torch.empty(M, N, dtype=torch.float64, device=A.device)
     st = _native.lib().gpn_gemm_nt(_stream(A.device), M, N, K, alpha, _ptr(A), A.stride(0), _ptr(B), B.stride(0),
-                                   beta, _ptr(C), C.stride(0), 1 if lower else 0, tri)
+                                   beta, _ptr(C), C.stride(0), int(lower), tri)       # lower: False/True or 2 = trapezoid
     _native.check(st, "gpn_gemm_nt")
     return C
 

@@ -354,11 +354,9 @@ struct DistRun {
       int64_t r0 = std::max(li0 * T, lo);
       if (r0 >= hi) continue;
       const double* B = right + (lj - base) * T * T;
-      if (li0 < g.nrow_t && li0 * g.pr + g.my_r == J) {
-        ok(gemm_nt(s, nJ, nJ, nk, -1.0, left + (r0 - lo) * T, T, B, T, 1.0, A + r0 * g.ld + lj * T, g.ld, 1));
-        r0 += T;
-      }
-      if (hi > r0) ok(gemm_nt(s, hi - r0, nJ, nk, -1.0, left + (r0 - lo) * T, T, B, T, 1.0, A + r0 * g.ld + lj * T, g.ld, 0));
+      // a column that starts with my diagonal tile: ONE "trapezoid" launch (lower-only top square + the rows below)
+      const bool diag = li0 < g.nrow_t && li0 * g.pr + g.my_r == J && hi - r0 >= nJ;
+      ok(gemm_nt(s, hi - r0, nJ, nk, -1.0, left + (r0 - lo) * T, T, B, T, 1.0, A + r0 * g.ld + lj * T, g.ld, diag ? 2 : 0));
     }
   }
 };

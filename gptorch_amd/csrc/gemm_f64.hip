@@ -118,7 +118,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     bid -= z * nwg;
     p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC;
   }
-  if (p.lower) tile_of_block_lower(bid, nwg, p.mt, spread, ti, tj);
+  if (p.lower == 2) {
+    // trapezoid (M >= N): the N x N top square lower-tile only, the (M - N) x N rectangle below it whole -- one tile
+    // column of a block-cyclic trailing update incl. its diagonal tile.  The rectangle's tiles come first (they are
+    // the bulk), in the grouped order of the full-rectangle case; the triangle's nt (nt + 1) / 2 tiles last.
+    const int rect = (p.mt - p.nt) * p.nt;
+    const int q = xcd_remap(bid, nwg);
+    if (q < rect) {
+      tile_of_block(q, rect, p.mt - p.nt, p.nt, true, ti, tj);
+      ti += p.nt;
+    } else {
+      tile_of_block_lower(q - rect, nwg - rect, p.nt, true, ti, tj);
+    }
+  } else if (p.lower) tile_of_block_lower(bid, nwg, p.mt, spread, ti, tj);
   else tile_of_block(bid, nwg, p.mt, p.nt, spread, ti, tj);
 
   const int tid = threadIdx.x;
@@ -318,7 +330,8 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
-  const int grid = (a.lower ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
+  const int grid = (a.lower == 2 ? (a.mt - a.nt) * a.nt + a.nt * (a.nt + 1) / 2
+                    : a.lower    ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
   const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
   static std::atomic<int> attr_set{-1};      // per template instance; racing threads set the same value
@@ -331,8 +344,9 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   int rec = -1;
   if (prof) {
     // executed flops: tiles actually computed x 2*BM*BN*K
-    const double tiles = (a.lower ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt) * std::max(1, a.batch);
-    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : (a.lower ? PROF_GEMM_SYRK : PROF_GEMM));
+    const double tiles = (a.lower == 2 ? (double)(a.mt - a.nt) * a.nt + 0.5 * a.nt * (a.nt + 1.0)
+                          : a.lower    ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt) * std::max(1, a.batch);
+    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : (a.lower == 1 ? PROF_GEMM_SYRK : PROF_GEMM));
     rec = profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K, cls);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
@@ -380,7 +394,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   // slots) better tail quantisation wins (M = 7168 lower, K = 1024: 56.8 vs 62.0).
   auto tiles = [&](int64_t b) {
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
-    return (lower ? mt * (mt + 1) / 2 : mt * nt) * batch;
+    return (lower == 2 ? (mt - nt) * nt + nt * (nt + 1) / 2 : lower ? mt * (mt + 1) / 2 : mt * nt) * batch;
   };
   // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer.  U U^T (lower):
   // N = 8192 3.02 (64) vs 3.12 ms (128), N = 12288 10.3 vs 9.8, N = 16384 25.3 vs 22.7; the
@@ -444,7 +458,9 @@ extern "C" int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double
   if (M < 0) return -2;
   if (N < 0) return -3;
   if (K < 0 || (K % 16) != 0) return -4;
-  if (lower && M != N) return -13;
+  if (lower < 0 || lower > 2) return -13;
+  if (lower == 1 && M != N) return -13;
+  if (lower == 2 && (M < N || tri)) return -13;
   if ((lda & 1) || (ldb & 1)) return GPN_E_ALIGN;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GPN_E_ALIGN;
   if (K == 0) {

@@ -104,7 +104,8 @@ class NativeTileOps:
         _ops._native.check(st, "gpn_trsm_right_lt")
 
     def update(self, C, A, B, m, n, k, lower, alpha=-1.0, beta=1.0):
-        """C[:m,:n] = alpha A[:m,:k] B[:n,:k]^T + beta C (lower: only j <= i)."""
+        """C[:m,:n] = alpha A[:m,:k] B[:n,:k]^T + beta C (lower = True: only j <= i; lower = 2, m >= n: only j <= i
+        inside the top n x n square, the rows below it whole)."""
         _ops.gemm_nt(A, B, m, n, _ops.round_up(k, 16), alpha=alpha, beta=beta, C=C, lower=lower)
 
     def copy(self, dst, src, rows, cols):
@@ -403,11 +404,9 @@ class BlockCyclicGP:
             if r0 >= hi:
                 continue
             B = right[(lj - base) * T:]
-            if li0 < self.nrow_t and li0 * self.pr + self.my_r == J:
-                ops.update(A[r0:, lj * T:], left[r0 - lo:], B, nJ, nJ, nk, lower=True)
-                r0 += T
-            if hi > r0:
-                ops.update(A[r0:, lj * T:], left[r0 - lo:], B, hi - r0, nJ, nk, lower=False)
+            diag = li0 < self.nrow_t and li0 * self.pr + self.my_r == J
+            # a column that starts with my diagonal tile: ONE "trapezoid" launch (lower-only top square + the rows below)
+            ops.update(A[r0:, lj * T:], left[r0 - lo:], B, hi - r0, nJ, nk, lower=2 if (diag and hi - r0 >= nJ) else False)
 
     def factor(self):
         """right-looking block-cyclic Cholesky carrying the residual row, with look-ahead (module

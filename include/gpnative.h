@@ -141,6 +141,9 @@ int gpn_lml_reduce(void* stream, const double* A, int64_t n, int64_t e, int64_t 
  * range MUST be zero): A_UPPER: A[i,k] = 0 for k < i; A_LOWER: A[i,k] = 0 for k > i
  * (to tile granularity: k >= 128*ceil((i+1)/128)); likewise for B with its row index j. */
 enum { GPN_TRI_A_UPPER = 1, GPN_TRI_A_LOWER = 2, GPN_TRI_B_UPPER = 4, GPN_TRI_B_LOWER = 8 };
+/* lower == 2 ("trapezoid", M >= N, tri == 0): the N x N top square is treated as with lower == 1 and the
+ * (M - N) x N rectangle below it is computed whole -- one tile column of a block-cyclic trailing update including
+ * its diagonal tile, in ONE launch. */
 int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
                 const double* A, int64_t lda, const double* B, int64_t ldb,
                 double beta, double* C, int64_t ldc, int lower, int tri);

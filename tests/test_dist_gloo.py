@@ -41,7 +41,7 @@ class CpuTileOps:
 
     def update(self, C, A, B, m, n, k, lower, alpha=-1.0, beta=1.0):
         upd = alpha * (A[:m, :k] @ B[:n, :k].t())
-        if lower:
+        if lower:            # True: square, entries j <= i only; 2: trapezoid = that for the top n x n, everything below it
             C[:m, :n] = torch.where(torch.ones(m, n).tril().bool(), upd + beta * C[:m, :n], C[:m, :n])
         else:
             C[:m, :n] = upd + beta * C[:m, :n]

@@ -53,6 +53,28 @@ def test_syrk_lower(device, n, K):
     assert torch.equal(torch.triu(C, 1), torch.triu(C0, 1))
 
 
+@pytest.mark.parametrize("variant", [0, 3, 4, 6])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (2048 + 640, 2048, 256), (9000, 512, 128), (700, 200, 48), (5000, 72, 64), (33000, 2048, 32)])
+def test_trapezoid_launch(device, variant, M, N, K):
+    """lower = 2: the N x N top square lower-tile only (entries above its diagonal untouched), the rows below it
+    whole -- one tile column of a block-cyclic trailing update incl. its diagonal tile, in one launch; every tile
+    shape, exact integer data."""
+    _native.lib().gpn_debug_set_gemm_variant(variant)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(M + 3 * N + K)
+        A = torch.randint(-4, 5, (M, K), generator=g).double().to(device)
+        B = torch.randint(-4, 5, (N, K), generator=g).double().to(device)
+        C0 = torch.randint(-4, 5, (M, N), generator=g).double().to(device)
+        C = C0.clone()
+        _ops.gemm_nt(_pad_rows(A), _pad_rows(B), M, N, K, alpha=-1.0, beta=1.0, C=C, lower=2)
+        full = C0 - A @ B.t()
+        keep = torch.ones(M, N, dtype=torch.bool, device=device).tril()       # j <= i (all of the rows below the square)
+        assert torch.equal(C[keep], full[keep])
+        assert torch.equal(C[~keep], C0[~keep])
+    finally:
+        _native.lib().gpn_debug_set_gemm_variant(0)
+
+
 def test_gemm_random_fp64(device):
     torch.manual_seed(0)
     M, N, K = 700, 900, 1024
