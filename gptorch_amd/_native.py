@@ -33,6 +33,8 @@ SIGNATURES = {
     "gpn_lml_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "gpn_gemm_nt": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64,
                             c_void_p, c_int64, c_double, c_void_p, c_int64, c_int, c_int]),
+    "gpn_gemm_nt_stair": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64,
+                                  c_void_p, c_int64, c_double, c_void_p, c_int64, c_int64, c_int]),
     "gpn_gemm_nt_batched": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64,
                                     c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64, c_int, c_int, c_int]),
     "gpn_trtri_upper": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64]),

@@ -282,6 +282,16 @@ def gemm_nt(A, B, M, N, K, alpha=1.0, beta=0.0, C=None, lower=False, tri=0):
     return C
 
 
+def gemm_nt_stair(A, B, C, M, nblocks, blk, K, step, diag, alpha=-1.0, beta=1.0):
+    """staircase contraction (gpnative.h gpn_gemm_nt_stair): C[M, nblocks*blk] = alpha A B^T + beta C where column
+    block b only has the rows from b*step on and, with diag, a lower-only first square."""
+    _req(A, B, C)
+    st = _native.lib().gpn_gemm_nt_stair(_stream(A.device), M, nblocks, blk, K, alpha, _ptr(A), A.stride(0), _ptr(B), B.stride(0),
+                                         beta, _ptr(C), C.stride(0), step, 1 if diag else 0)
+    _native.check(st, "gpn_gemm_nt_stair")
+    return C
+
+
 def matmul_nt(A, B, alpha=1.0):
     """alpha * A @ B^T for arbitrary 2-D fp64 device tensors through the native contraction (pads K to
     a multiple of 16 and re-packs operands that are not 16-byte aligned row-major); for the

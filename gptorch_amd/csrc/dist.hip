@@ -341,23 +341,21 @@ struct DistRun {
     pending = false;
   }
 
-  // step 5 on my local tile columns [from, to)
+  // step 5 on my local tile columns [from, to): ONE staircase launch -- every tile column starts Pc/Pr tile rows below
+  // its left neighbour, and where the diagonal tiles are mine (c mod Pr = r) each column's first tile is lower-only
   void update(int64_t k, const double* left, const double* right, int64_t from, int64_t to) {
     const int64_t T = g.T, nk = round_up(g.rows_of(k), 16);
     int64_t lo, hi;
     active(k, lo, hi);
     const int64_t base = g.cols_le(k);
-    double* A = W + L.A;
-    for (int64_t lj = std::max(from, base); lj < std::min(to, g.ncol_t) && rc == GPN_OK; ++lj) {
-      const int64_t J = lj * g.pc + g.my_c, nJ = g.rows_of(J);
-      const int64_t li0 = g.rows_le(J - 1, g.my_r);
-      int64_t r0 = std::max(li0 * T, lo);
-      if (r0 >= hi) continue;
-      const double* B = right + (lj - base) * T * T;
-      // a column that starts with my diagonal tile: ONE "trapezoid" launch (lower-only top square + the rows below)
-      const bool diag = li0 < g.nrow_t && li0 * g.pr + g.my_r == J && hi - r0 >= nJ;
-      ok(gemm_nt(s, hi - r0, nJ, nk, -1.0, left + (r0 - lo) * T, T, B, T, 1.0, A + r0 * g.ld + lj * T, g.ld, diag ? 2 : 0));
-    }
+    const int64_t a = std::max(from, base), b = std::min(to, g.ncol_t);
+    if (b <= a || rc != GPN_OK) return;
+    const int64_t J = a * g.pc + g.my_c;
+    const int64_t r0 = g.rows_le(J - 1, g.my_r) * T;     // >= lo: J > k
+    if (r0 >= hi) return;
+    const int diag = (g.my_c % g.pr) == g.my_r;
+    ok(gemm_nt_stair(s, hi - r0, b - a, T, nk, -1.0, left + (r0 - lo) * T, T, right + (a - base) * T * T, T, 1.0,
+                     W + L.A + r0 * g.ld + a * T, g.ld, (g.pc / g.pr) * T, diag));
   }
 };
 

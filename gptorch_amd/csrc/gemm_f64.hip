@@ -37,7 +37,10 @@ struct GemmArgs {
   int64_t lda, ldb, ldc;
   int M, N, K;
   int mt, nt;       // tile counts
-  int lower;
+  int lower;        // 0 full, 1 lower-tile square, 2 trapezoid, 3 staircase (st_* below)
+  // staircase: C is M x (nb * st_blk); column block b (st_blk columns) only has the rows from b * st_step on, and with
+  // st_diag its first st_blk x st_blk square is lower-only -- the local tile columns of one block-cyclic trailing update
+  int st_blk, st_step, st_diag;
   int tri;          // GPN_TRI_* structure flags: skip the K range where an operand is known zero
   double alpha, beta;
   // strided batch: problem z uses A + z*sA, B + z*sB, C + z*sC (batch identical shapes in ONE launch)
@@ -118,7 +121,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     bid -= z * nwg;
     p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC;
   }
-  if (p.lower == 2) {
+  int diag_off = 0;       // lower launches: the entry (row, col) is on or below ITS diagonal iff col + diag_off <= row
+  bool stair_diag_tile = false;
+  if (p.lower == 3) {
+    int q = xcd_remap(bid, nwg);
+    const int bt = p.st_blk / BN, nb = p.nt / bt, stept = p.st_step / BM;
+    int b = 0, sbt = 0, rows_t = 0, cnt = 0;
+    for (; b < nb; ++b) {
+      sbt = b * stept;
+      rows_t = max(p.mt - sbt, 0);
+      cnt = rows_t * bt - ((p.st_diag && rows_t >= bt) ? bt * (bt - 1) / 2 : 0);
+      if (q < cnt) break;
+      q -= cnt;
+    }
+    if (p.st_diag && rows_t >= bt) {
+      const int rect = (rows_t - bt) * bt;
+      if (q < rect) {
+        tile_of_block(q, rect, rows_t - bt, bt, true, ti, tj);
+        ti += sbt + bt;
+      } else {
+        tile_of_block_lower(q - rect, bt * (bt + 1) / 2, bt, true, ti, tj);
+        stair_diag_tile = ti == tj;
+        ti += sbt;
+      }
+    } else {
+      tile_of_block(q, cnt, rows_t, bt, true, ti, tj);
+      ti += sbt;
+    }
+    tj += b * bt;
+    diag_off = sbt * BM - b * bt * BN;
+  } else if (p.lower == 2) {
     // trapezoid (M >= N): the N x N top square lower-tile only, the (M - N) x N rectangle below it whole -- one tile
     // column of a block-cyclic trailing update incl. its diagonal tile.  The rectangle's tiles come first (they are
     // the bulk), in the grouped order of the full-rectangle case; the triangle's nt (nt + 1) / 2 tiles last.
@@ -291,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
   // epilogue: reg r of lane l is C[(l>>4) + 4r][l&15] of its 16x16 tile
   const int crow = lane >> 4, ccol = lane & 15;
-  const bool diag_tile = p.lower && (ti == tj);
+  const bool diag_tile = p.lower == 3 ? stair_diag_tile : (p.lower && (ti == tj));
   // beta != 0: ALL loads of one row of 16x16 tiles are issued before the first use (one HBM
   // round trip per TN*4 elements); element-by-element load -> fma -> store serialises 16+ round
   // trips per tile, which is most of the run time of a K = 128 update
@@ -306,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wave_m * WM + i * 16 + crow + 4 * r;
-        ok[j][r] = row < p.M && col < p.N && (!diag_tile || col <= row);
+        ok[j][r] = row < p.M && col < p.N && (!diag_tile || col + diag_off <= row);
         cold[j][r] = 0.0;
         if (use_c && ok[j][r]) cold[j][r] = p.C[(int64_t)row * p.ldc + col];
       }
@@ -325,13 +357,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
 static int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
 
+// workgroups of a staircase launch with b x b tiles
+static int64_t stair_tiles(int64_t M, int64_t N, int st_blk, int st_step, int st_diag, int64_t b) {
+  const int64_t mt = (M + b - 1) / b, bt = st_blk / b, nb = N / st_blk, stept = st_step / b;
+  int64_t total = 0;
+  for (int64_t k = 0; k < nb; ++k) {
+    const int64_t rows_t = std::max<int64_t>(mt - k * stept, 0);
+    total += rows_t * bt - ((st_diag && rows_t >= bt) ? bt * (bt - 1) / 2 : 0);
+  }
+  return total;
+}
+
 template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
 static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.N + BN - 1) / BN;
-  const int grid = (a.lower == 2 ? (a.mt - a.nt) * a.nt + a.nt * (a.nt + 1) / 2
-                    : a.lower    ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
+  if (a.lower == 3 && (BM != BN || a.st_blk % BN || a.st_step % BM)) return GPN_E_UNSUPPORTED;
+  const int grid = (a.lower == 3   ? (int)stair_tiles(a.M, a.N, a.st_blk, a.st_step, a.st_diag, BM)
+                    : a.lower == 2 ? (a.mt - a.nt) * a.nt + a.nt * (a.nt + 1) / 2
+                    : a.lower      ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
+  if (grid <= 0) return GPN_OK;
   const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
   static std::atomic<int> attr_set{-1};      // per template instance; racing threads set the same value
@@ -344,8 +390,9 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   int rec = -1;
   if (prof) {
     // executed flops: tiles actually computed x 2*BM*BN*K
-    const double tiles = (a.lower == 2 ? (double)(a.mt - a.nt) * a.nt + 0.5 * a.nt * (a.nt + 1.0)
-                          : a.lower    ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt) * std::max(1, a.batch);
+    const double tiles = (a.lower == 3   ? (double)stair_tiles(a.M, a.N, a.st_blk, a.st_step, a.st_diag, BM)
+                          : a.lower == 2 ? (double)(a.mt - a.nt) * a.nt + 0.5 * a.nt * (a.nt + 1.0)
+                          : a.lower      ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt) * std::max(1, a.batch);
     const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : (a.lower == 1 ? PROF_GEMM_SYRK : PROF_GEMM));
     rec = profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K, cls);
   }
@@ -357,10 +404,11 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
 
 static int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
 
+struct Stair { int blk = 0, step = 0, diag = 0; };
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC);
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair());
 
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
@@ -374,10 +422,18 @@ int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha
   return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0, tri, 0, batch, sA, sB, sC);
 }
 
+int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,
+                  const double* A, int64_t lda, const double* B, int64_t ldb,
+                  double beta, double* C, int64_t ldc, int64_t step, int diag) {
+  Stair st;
+  st.blk = (int)blk; st.step = (int)step; st.diag = diag ? 1 : 0;
+  return gemm_nt_impl(s, M, nblocks * blk, K, alpha, A, lda, B, ldb, beta, C, ldc, 3, 0, 0, 1, 0, 0, 0, st);
+}
+
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC) {
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st) {
   if (M <= 0 || N <= 0 || batch <= 0) return GPN_OK;
   GemmArgs a;
   a.batch = batch; a.sA = sA; a.sB = sB; a.sC = sC;
@@ -386,6 +442,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.mt = a.nt = 0;
   a.lower = lower;
+  a.st_blk = st.blk; a.st_step = st.step; a.st_diag = st.diag;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
   // Tile choice (same-box sweep, tools/ab_layout.py): 128x128 tiles (2 workgroups / CU, half the
@@ -394,6 +451,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   // slots) better tail quantisation wins (M = 7168 lower, K = 1024: 56.8 vs 62.0).
   auto tiles = [&](int64_t b) {
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
+    if (lower == 3) return stair_tiles(M, N, st.blk, st.step, st.diag, b);
     return (lower == 2 ? (mt - nt) * nt + nt * (nt + 1) / 2 : lower ? mt * (mt + 1) / 2 : mt * nt) * batch;
   };
   // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer.  U U^T (lower):
@@ -427,6 +485,21 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
 }
 
 }  // namespace gpn
+
+extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,
+                                 const double* A, int64_t lda, const double* B, int64_t ldb,
+                                 double beta, double* C, int64_t ldc, int64_t step, int diag) {
+  if (M < 0) return -2;
+  if (nblocks < 0) return -3;
+  if (blk <= 0 || (blk % 128)) return -4;
+  if (K <= 0 || (K % 16)) return -5;
+  if (step < 0 || (step % 128)) return -14;
+  if (diag && M < blk) return -15;
+  if ((lda & 1) || (ldb & 1)) return GPN_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GPN_E_ALIGN;
+  if (M == 0 || nblocks == 0) return GPN_OK;
+  return gpn::gemm_nt_stair(static_cast<hipStream_t>(stream), M, nblocks, blk, K, alpha, A, lda, B, ldb, beta, C, ldc, step, diag);
+}
 
 extern "C" int gpn_debug_set_gemm_variant(int v) {
   gpn::g_gemm_variant = v & 0xff;

@@ -29,6 +29,12 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
             double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0);
 
+// staircase: C is M x (nblocks * blk); column block b has the rows from b * step on; diag: its first blk x blk square
+// is lower-only (gpnative.h gpn_gemm_nt_stair)
+int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,
+                  const double* A, int64_t lda, const double* B, int64_t ldb,
+                  double beta, double* C, int64_t ldc, int64_t step, int diag);
+
 // `batch` problems of identical shape at constant strides (elements) in one launch
 int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                     const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,

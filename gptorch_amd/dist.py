@@ -108,6 +108,11 @@ class NativeTileOps:
         inside the top n x n square, the rows below it whole)."""
         _ops.gemm_nt(A, B, m, n, _ops.round_up(k, 16), alpha=alpha, beta=beta, C=C, lower=lower)
 
+    def update_stair(self, C, A, B, m, nb, blk, k, step, diag):
+        """C[:m, :nb*blk] -= A[:m,:k] B[:nb*blk,:k]^T restricted to the staircase: column block b has the rows from
+        b*step on; diag: its first blk x blk square is lower-only (gpn_gemm_nt_stair)."""
+        _ops.gemm_nt_stair(A, B, C, m, nb, blk, _ops.round_up(k, 16), step, diag)
+
     def copy(self, dst, src, rows, cols):
         """dst[:rows,:cols] <- src[:rows,:cols] (both strided row-major views)."""
         st = _ops._native.lib().gpn_copy_matrix(_ops._stream(dst.device), _ops._ptr(src), rows, cols, src.stride(0),
@@ -389,24 +394,23 @@ class BlockCyclicGP:
         return buf, [w]
 
     def _update(self, k, left, right, lj_from, lj_to):
-        """step 5 restricted to my local tile columns [lj_from, lj_to): per column one contraction
-        over the stacked rows below the diagonal tile, plus a lower-only one for a diagonal tile."""
-        ops, T = self.ops, self.T
+        """step 5 restricted to my local tile columns [lj_from, lj_to): ONE staircase launch -- every tile column
+        starts Pc/Pr tile rows below its left neighbour (my first tile row at or below the diagonal), and where the
+        diagonal tiles are mine (c mod Pr = r) each column's first tile is lower-only."""
+        T = self.T
         nk = self.rows_of(k)
         lo, hi = self._active(k)
         base = self._cols_le(k)
-        A = self.A
-        for lj in range(max(lj_from, base), min(lj_to, self.ncol_t)):
-            J = lj * self.pc + self.my_c
-            nJ = self.rows_of(J)
-            li0 = self._rows_le(J - 1)
-            r0 = max(li0 * T, lo)
-            if r0 >= hi:
-                continue
-            B = right[(lj - base) * T:]
-            diag = li0 < self.nrow_t and li0 * self.pr + self.my_r == J
-            # a column that starts with my diagonal tile: ONE "trapezoid" launch (lower-only top square + the rows below)
-            ops.update(A[r0:, lj * T:], left[r0 - lo:], B, hi - r0, nJ, nk, lower=2 if (diag and hi - r0 >= nJ) else False)
+        a, b = max(lj_from, base), min(lj_to, self.ncol_t)
+        if b <= a:
+            return
+        J = a * self.pc + self.my_c
+        r0 = self._rows_le(J - 1) * T                    # >= lo: J > k
+        if r0 >= hi:
+            return
+        diag = (self.my_c % self.pr) == self.my_r
+        self.ops.update_stair(self.A[r0:, a * T:], left[r0 - lo:], right[(a - base) * T:], hi - r0, b - a, T, nk,
+                              (self.pc // self.pr) * T, diag)
 
     def factor(self):
         """right-looking block-cyclic Cholesky carrying the residual row, with look-ahead (module

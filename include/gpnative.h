@@ -148,6 +148,15 @@ int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
                 const double* A, int64_t lda, const double* B, int64_t ldb,
                 double beta, double* C, int64_t ldc, int lower, int tri);
 
+/* "Staircase": C is M x (nblocks * blk) and column block b (blk columns, blk % 128 == 0) only has the rows from
+ * b * step on (step % 128 == 0); with diag != 0 the first blk x blk square of every block is lower-only (entries
+ * above its diagonal are not written).  All the local tile columns of one block-cyclic trailing update -- each
+ * starting Pc/Pr tile rows below its left neighbour -- in ONE launch (gptorch_amd/dist.py, csrc/dist.hip), instead
+ * of one launch with its own partial last round per tile column.  B is [nblocks * blk, K]. */
+int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,
+                      const double* A, int64_t lda, const double* B, int64_t ldb,
+                      double beta, double* C, int64_t ldc, int64_t step, int diag);
+
 /* `batch` problems of identical shape in ONE launch: problem z uses A + z*sA, B + z*sB, C + z*sC
  * (strides in elements; sA, sB even).  With sA = sB = K and one set of rows this is a split-K
  * contraction into `batch` partial results -- how the sparse model's M x M accumulation

@@ -46,6 +46,13 @@ class CpuTileOps:
         else:
             C[:m, :n] = upd + beta * C[:m, :n]
 
+    def update_stair(self, C, A, B, m, nb, blk, k, step, diag):
+        for b in range(nb):
+            r0 = b * step
+            if r0 >= m:
+                break
+            self.update(C[r0:, b * blk:], A[r0:], B[b * blk:], m - r0, blk, k, lower=2 if diag else False)
+
     def copy(self, dst, src, rows, cols):
         dst[:rows, :cols] = src[:rows, :cols]
 

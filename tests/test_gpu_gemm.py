@@ -75,6 +75,36 @@ def test_trapezoid_launch(device, variant, M, N, K):
         _native.lib().gpn_debug_set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("M,nb,blk,K,step,diag", [(1024, 1, 256, 64, 0, 1), (3000, 4, 256, 128, 512, 1), (3000, 4, 256, 128, 256, 0),
+                                                  (2500, 6, 128, 48, 512, 1), (9000, 3, 2048, 256, 2048, 1), (20000, 5, 512, 64, 1024, 0),
+                                                  (1500, 8, 128, 32, 256, 1)])
+def test_staircase_launch(device, variant, M, nb, blk, K, step, diag):
+    """gpn_gemm_nt_stair: column block b has the rows from b*step on (those above stay untouched), with diag a
+    lower-only first square -- the local tile columns of a block-cyclic trailing update in ONE launch; incl. blocks
+    that start below the last row (no work) and every tile shape; exact integer data."""
+    _native.lib().gpn_debug_set_gemm_variant(variant)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(M + 5 * nb + blk + K + step)
+        N = nb * blk
+        A = torch.randint(-4, 5, (M, K), generator=g).double().to(device)
+        B = torch.randint(-4, 5, (N, K), generator=g).double().to(device)
+        C0 = torch.randint(-4, 5, (M, N), generator=g).double().to(device)
+        C = C0.clone()
+        _ops.gemm_nt_stair(_pad_rows(A), _pad_rows(B), C, M, nb, blk, K, step, diag)
+        full = C0 - A @ B.t()
+        rows = torch.arange(M, device=device)[:, None]
+        cols = torch.arange(N, device=device)[None, :]
+        start = (cols // blk) * step
+        keep = rows >= start
+        if diag:
+            keep = keep & ((cols % blk) <= (rows - start))
+        assert torch.equal(C[keep], full[keep])
+        assert torch.equal(C[~keep], C0[~keep])
+    finally:
+        _native.lib().gpn_debug_set_gemm_variant(0)
+
+
 def test_gemm_random_fp64(device):
     torch.manual_seed(0)
     M, N, K = 700, 900, 1024
