@@ -545,11 +545,9 @@ static int dist_evaluate(void* stream, const gpn_dist_comm* comm, int rank, int 
       bool nrp = false;
       if (K + 1 < nt) nlft = R.start_rows(K + 1, g.id_off, g.id_off + g.rows_le(K + 1, g.my_r) * T, nrp);
       const int64_t hi = g.rows_le(K, g.my_r) * T;
-      for (int64_t lj = 0; lj < ncol && R.rc == GPN_OK; ++lj) {
-        const int64_t J = lj * g.pc + g.my_c, nJ = g.rows_of(J);
-        const int64_t r0 = g.rows_le(J - 1, g.my_r) * T;
-        if (r0 < hi) R.ok(gemm_nt(s, hi - r0, nJ, nK, 1.0, lft + r0 * T, T, rgt + lj * T * T, T, 1.0, Kinv + r0 * g.ld + lj * T, g.ld, 0));
-      }
+      const int64_t r0 = g.rows_le((int64_t)g.my_c - 1, g.my_r) * T;   // my first tile column starts here, the next Pc/Pr tiles lower
+      if (ncol > 0 && r0 < hi)
+        R.ok(gemm_nt_stair(s, hi - r0, ncol, T, nK, 1.0, lft + r0 * T, T, rgt, T, 1.0, Kinv + r0 * g.ld, g.ld, (g.pc / g.pr) * T, 0));
       lft = nlft;
       rp = nrp;
     }

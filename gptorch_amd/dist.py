@@ -108,10 +108,10 @@ class NativeTileOps:
         inside the top n x n square, the rows below it whole)."""
         _ops.gemm_nt(A, B, m, n, _ops.round_up(k, 16), alpha=alpha, beta=beta, C=C, lower=lower)
 
-    def update_stair(self, C, A, B, m, nb, blk, k, step, diag):
-        """C[:m, :nb*blk] -= A[:m,:k] B[:nb*blk,:k]^T restricted to the staircase: column block b has the rows from
-        b*step on; diag: its first blk x blk square is lower-only (gpn_gemm_nt_stair)."""
-        _ops.gemm_nt_stair(A, B, C, m, nb, blk, _ops.round_up(k, 16), step, diag)
+    def update_stair(self, C, A, B, m, nb, blk, k, step, diag, alpha=-1.0):
+        """C[:m, :nb*blk] += alpha A[:m,:k] B[:nb*blk,:k]^T restricted to the staircase: column block b has the rows
+        from b*step on; diag: its first blk x blk square is lower-only (gpn_gemm_nt_stair)."""
+        _ops.gemm_nt_stair(A, B, C, m, nb, blk, _ops.round_up(k, 16), step, diag, alpha=alpha)
 
     def copy(self, dst, src, rows, cols):
         """dst[:rows,:cols] <- src[:rows,:cols] (both strided row-major views)."""
@@ -503,12 +503,9 @@ class BlockCyclicGP:
             self._wait(works)
             nleft, works = start(K + 1) if K + 1 < nt else (None, [])
             hi = self._rows_le(K) * T                              # rows I <= K of the result
-            for lj in range(ncol):
-                J = lj * self.pc + self.my_c
-                nJ = self.rows_of(J)
-                r0 = self._rows_le(J - 1) * T
-                if r0 < hi:
-                    ops.update(C[r0:, lj * T:], left[r0:], right[lj * T:], hi - r0, nJ, nK, lower=False, alpha=1.0)
+            r0 = self._rows_le(self.my_c - 1) * T                  # my first tile column starts here, the next Pc/Pr tiles lower
+            if ncol and r0 < hi:
+                ops.update_stair(C[r0:], left[r0:], right, hi - r0, ncol, T, nK, (self.pc // self.pr) * T, False, alpha=1.0)
             left = nleft
         return C
 

@@ -46,12 +46,12 @@ class CpuTileOps:
         else:
             C[:m, :n] = upd + beta * C[:m, :n]
 
-    def update_stair(self, C, A, B, m, nb, blk, k, step, diag):
+    def update_stair(self, C, A, B, m, nb, blk, k, step, diag, alpha=-1.0):
         for b in range(nb):
             r0 = b * step
             if r0 >= m:
                 break
-            self.update(C[r0:, b * blk:], A[r0:], B[b * blk:], m - r0, blk, k, lower=2 if diag else False)
+            self.update(C[r0:, b * blk:], A[r0:], B[b * blk:], m - r0, blk, k, lower=2 if diag else False, alpha=alpha)
 
     def copy(self, dst, src, rows, cols):
         dst[:rows, :cols] = src[:rows, :cols]
