@@ -23,6 +23,7 @@
 //    share operand panels in its 4 MiB L2; `lower` drops tiles above the diagonal.
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include "gpn_common.h"
 
 namespace gpn {
@@ -101,7 +102,7 @@ __device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bo
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, int SPREAD = 0>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       const int idx = wave + 4 * i;
       const double* src = src_base[i] + k0;
       if constexpr (DMA) {
-        if (idx < NBLK) {
+        if (NBLK % 4 == 0 || idx < NBLK) {   // NBLK % 4 == 0: every wave has PER_WAVE pieces, no branch in the loop
           char* dst = smem + s * STAGE + idx * 1024;
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)src,
@@ -229,6 +230,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       } else {
         stage_regs[i] = src_ok[i] ? *reinterpret_cast<const d2*>(src) : d2{0.0, 0.0};
       }
+    }
+  };
+  // one LDS-DMA piece of K-step `t` (SPREAD: the pieces are issued between the MFMA groups of step t - 1)
+  auto stage_issue_piece = [&](int i, int t, int s) {
+    if constexpr (DMA) {
+      const int idx = wave + 4 * i;
+      char* dst = smem + s * STAGE + idx * 1024;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src_base[i] + t * BK),
+          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
   auto stage_commit = [&](int s) {
@@ -243,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
   // BLOW: B is lower-triangular (panel solve against an inverted leaf block, B[j][k] = 0 for
   // k > j): a 16-column tile needs no K beyond its last column -- skipped per (tile, 8-k group)
-  auto compute = [&](int s, int k0) {
+  auto compute = [&](int s, int k0, auto issue_c, int tnext = 0, int snext = 0) {
+    constexpr bool issue = decltype(issue_c)::value;   // SPREAD: also issue the pieces of K-step `tnext`
     const char* base = smem + s * STAGE;
 #pragma unroll
     for (int kg8 = 0; kg8 < 2; ++kg8) {
@@ -266,12 +278,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
           }
+          if constexpr (SPREAD == 1) {
+            // one piece behind each group of 2 TN MFMAs, over the whole K-step
+            static_assert(SPREAD != 1 || PER_WAVE % (2 * TM) == 0, "pieces per MFMA group");
+            constexpr int PG = PER_WAVE / (2 * TM);
+            if constexpr (issue) {
+#pragma unroll
+              for (int q = 0; q < PG; ++q) stage_issue_piece((kg8 * TM + i) * PG + q, tnext, snext);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (SPREAD == 2) {
+            // all pieces inside the first half of the K-step's MFMAs
+            constexpr int PG = PER_WAVE / TM;
+            if (kg8 == 0) {
+              if constexpr (issue) {
+#pragma unroll
+                for (int q = 0; q < PG; ++q) stage_issue_piece(i * PG + q, tnext, snext);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
       }
     }
   };
@@ -290,13 +323,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       stage_issue(t0, t0 & 1);
       stage_commit(t0 & 1);
     }
-    for (int t = t0; t < nk; ++t) {
-      const int s = t & 1;
-      __syncthreads();  // K-step t has landed (vmcnt(0)); every wave is done reading stage s^1
-      if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
-      compute(s, t * BK);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) stage_commit(s ^ 1);
+    if constexpr (SPREAD != 0) {
+      // the pieces of K-step t + 1 go out between the MFMA groups of step t (last step peeled: nothing to issue)
+      for (int t = t0; t + 1 < nk; ++t) {
+        const int s = t & 1;
+        __syncthreads();
+        compute(s, t * BK, std::true_type{}, t + 1, s ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (t0 < nk) {
+        __syncthreads();
+        compute((nk - 1) & 1, (nk - 1) * BK, std::false_type{});
+      }
+    } else {
+      for (int t = t0; t < nk; ++t) {
+        const int s = t & 1;
+        __syncthreads();  // K-step t has landed (vmcnt(0)); every wave is done reading stage s^1
+        if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
+        compute(s, t * BK, std::false_type{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nk) stage_commit(s ^ 1);
+      }
     }
   } else {
     // Deep LDS-DMA ring for latency-bound launches (few, small workgroups): NS-1 K-steps
@@ -316,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       }
       __builtin_amdgcn_s_barrier();
       if (t + AHEAD < nk) stage_issue(t + AHEAD, (t - t0 + AHEAD) % NS);   // slot last read in step t-1
-      compute(slot, t * BK);
+      compute(slot, t * BK, std::false_type{});
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -368,7 +415,7 @@ static int64_t stair_tiles(int64_t M, int64_t N, int st_blk, int st_step, int st
   return total;
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, int SPREAD = 0>
 static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
@@ -379,7 +426,7 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
                     : a.lower      ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
   if (grid <= 0) return GPN_OK;
   const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW>;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW, SPREAD>;
   static std::atomic<int> attr_set{-1};      // per template instance; racing threads set the same value
   if (attr_set.load(std::memory_order_acquire) != smem) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -470,6 +517,10 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   if (g_gemm_variant == 4) return launch<64, 64, 32, 32, true>(s, a);
   if (g_gemm_variant == 5) return launch<64, 64, 32, 32, true, 8>(s, a);
   if (g_gemm_variant == 6) return launch<32, 32, 16, 16, true, 8>(s, a);
+  if (g_gemm_variant == 7) return launch<128, 128, 64, 64, true, 2, false, 1>(s, a);   // A/B: LDS-DMA pieces spread over the MFMA groups
+  if (g_gemm_variant == 8) return launch<128, 128, 64, 64, true, 2, false, 2>(s, a);
+  if (g_gemm_variant == 9) return launch<64, 64, 32, 32, true, 2, false, 1>(s, a);
+  if (g_gemm_variant == 10) return launch<64, 64, 32, 32, true, 2, false, 2>(s, a);
   // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
   // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
   if (g_gemm_variant == 0 && (M <= 32 || N <= 32)) return launch<32, 32, 16, 16, true, 8>(s, a);
