@@ -18,6 +18,9 @@
 //    A and B, so the product is unchanged).
 //  * 128x128 block tile, 4 waves each 64x64 (16 accumulator tiles = 128 VGPRs),
 //    BK = 16, two LDS stages (64 KB) => 2 workgroups per CU, one barrier / K-step.
+//  * software-pipelined K loop (PIPE): operand fragments double-buffered in registers and
+//    requested half a K-step ahead, barrier between the two halves, the LDS-DMA pieces of
+//    step t+2 between the MFMA groups -- a wave's MFMA stream waits only for the barrier.
 //  * blockIdx -> tile: bijective XCD remap (blocks b, b+8 share an XCD/L2) then
 //    grouped ordering (8 tile-rows per group) so the tiles resident on one XCD
 //    share operand panels in its 4 MiB L2; `lower` drops tiles above the diagonal.
@@ -102,7 +105,7 @@ __device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bo
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, int SPREAD = 0>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       }
     }
   };
-  // one LDS-DMA piece of K-step `t` (SPREAD: the pieces are issued between the MFMA groups of step t - 1)
+  // one LDS-DMA piece of K-step `t` (PIPE: the pieces go out between the MFMA groups of step t - 2's second half)
   auto stage_issue_piece = [&](int i, int t, int s) {
     if constexpr (DMA) {
       const int idx = wave + 4 * i;
@@ -254,8 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 
   // BLOW: B is lower-triangular (panel solve against an inverted leaf block, B[j][k] = 0 for
   // k > j): a 16-column tile needs no K beyond its last column -- skipped per (tile, 8-k group)
-  auto compute = [&](int s, int k0, auto issue_c, int tnext = 0, int snext = 0) {
-    constexpr bool issue = decltype(issue_c)::value;   // SPREAD: also issue the pieces of K-step `tnext`
+  auto compute = [&](int s, int k0) {
     const char* base = smem + s * STAGE;
 #pragma unroll
     for (int kg8 = 0; kg8 < 2; ++kg8) {
@@ -278,33 +280,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
           }
-          if constexpr (SPREAD == 1) {
-            // one piece behind each group of 2 TN MFMAs, over the whole K-step
-            static_assert(SPREAD != 1 || PER_WAVE % (2 * TM) == 0, "pieces per MFMA group");
-            constexpr int PG = PER_WAVE / (2 * TM);
-            if constexpr (issue) {
-#pragma unroll
-              for (int q = 0; q < PG; ++q) stage_issue_piece((kg8 * TM + i) * PG + q, tnext, snext);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          } else if constexpr (SPREAD == 2) {
-            // all pieces inside the first half of the K-step's MFMAs
-            constexpr int PG = PER_WAVE / TM;
-            if (kg8 == 0) {
-              if constexpr (issue) {
-#pragma unroll
-                for (int q = 0; q < PG; ++q) stage_issue_piece(i * PG + q, tnext, snext);
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
       }
     }
   };
@@ -319,28 +300,86 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   const int t0 = k_lo / BK;
   const int nk = max(t0, (k_hi + BK - 1) / BK);
   if constexpr (NS == 2) {
-    if (t0 < nk) {
-      stage_issue(t0, t0 & 1);
-      stage_commit(t0 & 1);
-    }
-    if constexpr (SPREAD != 0) {
-      // the pieces of K-step t + 1 go out between the MFMA groups of step t (last step peeled: nothing to issue)
-      for (int t = t0; t + 1 < nk; ++t) {
+    if constexpr (PIPE) {
+      // Software-pipelined K loop (the default for the two big tile shapes).  A K-step is two halves of 8 k's;
+      // the operand fragments of each half are read from LDS most of a half (3 of 4 MFMA groups at 128x128) before
+      // their MFMAs into a second register set (+32 VGPRs: 212 at 128x128, still 2 workgroups / CU), the barrier
+      // sits BETWEEN the halves, and the LDS-DMA pieces of step t + 2 go out between the MFMA groups of the second
+      // half -- a wave's MFMA stream waits for nothing but the barrier.  Same summation order as the plain loop
+      // (bit-identical results).  Same-box medians, tools/gemm_ab.py: 8192^3 70.1 -> 73.0 TFLOP/s, M = 30720 lower
+      // K = 2048 (C3's first trailing update) 68.6 -> 70.3, M = 61440 lower K = 1024 66.7 -> 68.7; 64x64 tiles:
+      // 8192^2 x 2048 66.6 -> 68.1, M = 6656 lower K = 1536 (C2's) 62.7 -> 65.1, 30912 x 128 x 1920 (in-panel at C3)
+      // 57.0 -> 60.0.  (Only moving the DMA issue between the MFMAs, without the register double-buffering, changed
+      // nothing: 68.2 vs 68.2; and with every K-step re-reading L2-resident lines -- a timing-only build -- the
+      // pipelined loop gains another 0.5 %: neither the DMA issue slots nor the fabric are what is left.)
+      static_assert(DMA && !BLOW && PER_WAVE % TM == 0, "pipelined loop: LDS-DMA staging, whole pieces per MFMA group");
+      d2 a0[TM], b0[TN], a1[TM], b1[TN];
+      auto read_ops = [&](int s, int kg8, d2 (&a)[TM], d2 (&b)[TN]) {
+        const char* base = smem + s * STAGE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const d2*>(base + (wave_m * TM + i) * 2048 + (kg8 ? (roff0 ^ 64) : roff0));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const d2*>(base + (A_BLOCKS + (wave_n * TN + j) * 2) * 1024 + (kg8 ? (roff0 ^ 64) : roff0));
+      };
+      // MFMA groups [i_lo, i_hi) of one half K-step (a group = one row of 16x16 tiles = 2 TN MFMAs); `issue`: PG
+      // LDS-DMA pieces of K-step `tnext` behind each group
+      auto mfma_groups = [&](d2 (&a)[TM], d2 (&b)[TN], int i_lo, int i_hi, auto issue_c, int tnext, int snext) {
+        constexpr bool issue = decltype(issue_c)::value;
+        constexpr int PG = PER_WAVE / TM;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (i < i_lo || i >= i_hi) continue;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          }
+          if constexpr (issue) {
+#pragma unroll
+            for (int q = 0; q < PG; ++q) stage_issue_piece(i * PG + q, tnext, snext);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+      // one K-step.  The fragments of a half are requested right after the FIRST MFMA group of the half before, so
+      // the wait in front of a half only ever covers reads that are 3 groups old (the compiler's lgkmcnt(0) is free)
+      auto kstep = [&](int t, auto issue_c, bool read_next) {
         const int s = t & 1;
-        __syncthreads();
-        compute(s, t * BK, std::true_type{}, t + 1, s ^ 1);
+        mfma_groups(a0, b0, 0, 1, std::false_type{}, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-      }
+        read_ops(s, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_groups(a0, b0, 1, TM, std::false_type{}, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();            // step t + 1 has landed; every wave has its fragments of stage s in registers
+        mfma_groups(a1, b1, 0, 1, issue_c, t + 2, s);
+        __builtin_amdgcn_sched_barrier(0);
+        if (read_next) read_ops(s ^ 1, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_groups(a1, b1, 1, TM, issue_c, t + 2, s);
+        __builtin_amdgcn_sched_barrier(0);
+      };
       if (t0 < nk) {
+        stage_issue(t0, t0 & 1);
         __syncthreads();
-        compute((nk - 1) & 1, (nk - 1) * BK, std::false_type{});
+        read_ops(t0 & 1, 0, a0, b0);
+        if (t0 + 1 < nk) stage_issue(t0 + 1, (t0 + 1) & 1);
+        int t = t0;
+        for (; t + 2 < nk; ++t) kstep(t, std::true_type{}, true);
+        for (; t < nk; ++t) kstep(t, std::false_type{}, t + 1 < nk);   // last two steps: nothing left to issue
       }
     } else {
+      if (t0 < nk) {
+        stage_issue(t0, t0 & 1);
+        stage_commit(t0 & 1);
+      }
       for (int t = t0; t < nk; ++t) {
         const int s = t & 1;
         __syncthreads();  // K-step t has landed (vmcnt(0)); every wave is done reading stage s^1
         if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
-        compute(s, t * BK, std::false_type{});
+        compute(s, t * BK);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < nk) stage_commit(s ^ 1);
       }
@@ -363,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
       }
       __builtin_amdgcn_s_barrier();
       if (t + AHEAD < nk) stage_issue(t + AHEAD, (t - t0 + AHEAD) % NS);   // slot last read in step t-1
-      compute(slot, t * BK, std::false_type{});
+      compute(slot, t * BK);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -415,7 +454,7 @@ static int64_t stair_tiles(int64_t M, int64_t N, int st_blk, int st_step, int st
   return total;
 }
 
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, int SPREAD = 0>
+template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, bool PIPE = false>
 static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   GemmArgs a = a0;
   a.mt = (a.M + BM - 1) / BM;
@@ -426,7 +465,7 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
                     : a.lower      ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
   if (grid <= 0) return GPN_OK;
   const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW, SPREAD>;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW, PIPE>;
   static std::atomic<int> attr_set{-1};      // per template instance; racing threads set the same value
   if (attr_set.load(std::memory_order_acquire) != smem) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -492,20 +531,24 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   a.st_blk = st.blk; a.st_step = st.step; a.st_diag = st.diag;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
-  // Tile choice (same-box sweep, tools/ab_layout.py): 128x128 tiles (2 workgroups / CU, half the
-  // L2->LDS traffic per flop) win once there are >= 8 rounds of them (M = 61440 lower, K = 1024:
-  // 66.0 vs 62.5 TFLOP/s; 8192^2 x 4096: 68.2 vs 66.4); below that the 64x64 tiles' (5 / CU, 1280
-  // slots) better tail quantisation wins (M = 7168 lower, K = 1024: 56.8 vs 62.0).
+  // Tile choice (same-box sweeps, tools/gemm_ab.py): 128x128 tiles (2 workgroups / CU, 512 slots, half the L2->LDS
+  // traffic per flop) win once there are >= 8 rounds of them (M = 61440 lower, K = 1024: 68.7 vs 66.5 TFLOP/s;
+  // 8192^2 x 4096: 70+ vs 68); below that the 64x64 tiles' (5 / CU, 1280 slots) better tail quantisation wins
+  // (lower K = 2048: M = 10240 62.7 vs 66.3, 12288 64.1 vs 67.4, 18432 68.3 vs 68.1, 24576 69.4 vs 68.3).
+  // A rule that also priced the partial last round of the 512 slots (a 128-tile launch of 16.1 rounds loses 5 %)
+  // measured neutral on whole evaluations and worse on the VFE accumulation (C3 193.0 vs 192.9 ms, C4 1423 vs 1426,
+  // C5 600 vs 563, tools/workload_ab.py) -- the simple threshold stays.
   auto tiles = [&](int64_t b) {
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
     if (lower == 3) return stair_tiles(M, N, st.blk, st.step, st.diag, b);
     return (lower == 2 ? (mt - nt) * nt + nt * (nt + 1) / 2 : lower ? mt * (mt + 1) / 2 : mt * nt) * batch;
   };
+  const int64_t t128 = tiles(128), t64 = tiles(64);
   // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer.  U U^T (lower):
   // N = 8192 3.02 (64) vs 3.12 ms (128), N = 12288 10.3 vs 9.8, N = 16384 25.3 vs 22.7; the
   // triangular inversion's rectangular products stay on 64x64 tiles up to N = 16384 (28.0 vs 29.2 ms).
-  const bool small = tri ? !(K >= 8192 && tiles(128) >= (lower ? 4096 : 8192) && M > 64 && N > 64)
-                         : !(K >= 512 && tiles(128) >= 4096 && M > 64 && N > 64);
+  const bool small = tri ? !(K >= 8192 && t128 >= (lower ? 4096 : 8192) && M > 64 && N > 64)
+                         : !(K >= 512 && t128 >= 4096 && M > 64 && N > 64);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
@@ -513,24 +556,25 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
     if (g_gemm_variant == 2) return launch<64, 128, 32, 64, true>(s, a, 1);
     return (tri & GPN_TRI_B_LOWER) ? launch<32, 128, 16, 64, true, 4, true>(s, a, 1) : launch<32, 128, 16, 64, true, 4>(s, a, 1);
   }
-  if (g_gemm_variant == 3) return launch<128, 128, 64, 64, true>(s, a);        // A/B: force a tile shape
+  if (g_gemm_variant == 3) return launch<128, 128, 64, 64, true>(s, a);        // A/B: force a tile shape (3..6: the plain K loop)
   if (g_gemm_variant == 4) return launch<64, 64, 32, 32, true>(s, a);
   if (g_gemm_variant == 5) return launch<64, 64, 32, 32, true, 8>(s, a);
   if (g_gemm_variant == 6) return launch<32, 32, 16, 16, true, 8>(s, a);
-  if (g_gemm_variant == 7) return launch<128, 128, 64, 64, true, 2, false, 1>(s, a);   // A/B: LDS-DMA pieces spread over the MFMA groups
-  if (g_gemm_variant == 8) return launch<128, 128, 64, 64, true, 2, false, 2>(s, a);
-  if (g_gemm_variant == 9) return launch<64, 64, 32, 32, true, 2, false, 1>(s, a);
-  if (g_gemm_variant == 10) return launch<64, 64, 32, 32, true, 2, false, 2>(s, a);
+  if (g_gemm_variant == 7) return launch<128, 128, 64, 64, true, 2, false, true>(s, a);   // A/B: pipelined K loop
+  if (g_gemm_variant == 8) return launch<64, 64, 32, 32, true, 2, false, true>(s, a);
   // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
   // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
-  if (g_gemm_variant == 0 && (M <= 32 || N <= 32)) return launch<32, 32, 16, 16, true, 8>(s, a);
-  if (g_gemm_variant == 0 && (tiles(64) <= 64 || (N <= 128 && tiles(64) <= 128))) {   // (M = 4096, N = 128, K = 128: 8.1 vs 10.9 us)
+  // 21: A/B of whole workloads (tools/workload_ab.py) -- the shipped dispatch with the plain K loop
+  const bool std_path = g_gemm_variant == 0 || g_gemm_variant == 21;
+  if (std_path && (M <= 32 || N <= 32)) return launch<32, 32, 16, 16, true, 8>(s, a);
+  if (std_path && (t64 <= 64 || (N <= 128 && t64 <= 128))) {   // (M = 4096, N = 128, K = 128: 8.1 vs 10.9 us)
     // a handful of workgroups: per-CU MFMA rate and DMA latency are the limits -> 4x more,
     // 4x smaller workgroups (32x32 tiles) with 8 K-steps of LDS-DMA in flight
     return launch<32, 32, 16, 16, true, 8>(s, a);
   }
-  if (g_gemm_variant == 0) {
-    return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true>(s, a);
+  if (std_path) {
+    if (g_gemm_variant == 21) return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true>(s, a);
+    return small ? launch<64, 64, 32, 32, true, 2, false, true>(s, a) : launch<128, 128, 64, 64, true, 2, false, true>(s, a);
   }
   return small ? launch<64, 64, 32, 32, false>(s, a) : launch<128, 128, 64, 64, false>(s, a);
 }

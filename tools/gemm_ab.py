@@ -12,6 +12,7 @@ shapes = [(8192, 8192, 8192, 0), (8192, 8192, 2048, 0), (30720, 30720, 2048, 1),
 if len(sys.argv) > 2:
     a = [int(v) for v in sys.argv[2:]]
     shapes = [tuple(a[i:i + 4]) for i in range(0, len(a), 4)]
+ROUNDS = int(os.environ.get("GPN_AB_ROUNDS", "5"))
 dev = torch.device("cuda:0")
 lib = _native.lib()
 for (M, N, K, lower) in shapes:
@@ -21,24 +22,31 @@ for (M, N, K, lower) in shapes:
     C0 = torch.randn(M, N, dtype=torch.float64, device=dev)
     ref = None
     line = "M=%6d N=%6d K=%5d lower=%d:" % (M, N, K, lower)
+    flops = (M * (M + 1) if lower else 2.0 * M * N) * K
+    times = {v: [] for v in variants}
+    errs = {}
+    C = C0.clone()
+    for rnd in range(ROUNDS):                    # variants interleaved round by round: clock / box drift hits all alike
+        for v in variants:
+            lib.gpn_debug_set_gemm_variant(v)
+            if rnd == 0:
+                C.copy_(C0)
+                _ops.gemm_nt(A, B, M, N, K, alpha=-1.0, beta=1.0, C=C, lower=bool(lower))
+                torch.cuda.synchronize()
+                errs[v] = 0.0 if ref is None else (torch.tril(C - ref) if lower else (C - ref)).abs().max().item()
+                if ref is None:
+                    ref = C.clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                _ops.gemm_nt(A, B, M, N, K, alpha=-1.0, beta=1.0, C=C, lower=bool(lower))
+            e1.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / 5)
     for v in variants:
-        lib.gpn_debug_set_gemm_variant(v)
-        C = C0.clone()
-        _ops.gemm_nt(A, B, M, N, K, alpha=-1.0, beta=1.0, C=C, lower=bool(lower))
-        torch.cuda.synchronize()
-        err = 0.0 if ref is None else (torch.tril(C - ref) if lower else (C - ref)).abs().max().item()
-        if ref is None:
-            ref = C.clone()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            _ops.gemm_nt(A, B, M, N, K, alpha=-1.0, beta=1.0, C=C, lower=bool(lower))
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
-        flops = (M * (M + 1) if lower else 2.0 * M * N) * K
-        line += "   v%d %8.3f ms %6.2f TF (maxdiff %.1e)" % (v, ms, flops / ms / 1e9, err)
-        del C
+        ms = sorted(times[v])[len(times[v]) // 2]
+        line += "   v%d %8.3f ms %6.2f TF [%5.2f-%5.2f] (maxdiff %.1e)" % (
+            v, ms, flops / ms / 1e9, flops / max(times[v]) / 1e9, flops / min(times[v]) / 1e9, errs[v])
     print(line, flush=True)
-    del A, B, C0, ref
+    del A, B, C0, ref, C
 lib.gpn_debug_set_gemm_variant(0)
