@@ -16,8 +16,9 @@
 //    g = l>>4, so one b128 read feeds two MFMAs (first MFMA sums k = {0,2,4,6},
 //    second k = {1,3,5,7}: the k order inside a K-step is a permutation shared by
 //    A and B, so the product is unchanged).
-//  * 128x128 block tile, 4 waves each 64x64 (16 accumulator tiles = 128 VGPRs),
-//    BK = 16, two LDS stages (64 KB) => 2 workgroups per CU, one barrier / K-step.
+//  * 128x128 block tile as 8 waves of 32x64 (8 accumulator tiles = 64 VGPRs per wave),
+//    BK = 16, two LDS stages (64 KB) => 2 workgroups per CU = 4 waves / SIMD, one barrier
+//    / K-step.  (Until late round 2: 4 waves of 64x64, 2 / SIMD -- 3-4 % slower.)
 //  * software-pipelined K loop (PIPE): operand fragments double-buffered in registers and
 //    requested half a K-step ahead, barrier between the two halves, the LDS-DMA pieces of
 //    step t+2 between the MFMA groups -- a wave's MFMA stream waits only for the barrier.
@@ -106,13 +107,14 @@ __device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bo
 }
 
 template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, bool PIPE = false>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(GemmArgs p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
   constexpr int BK = 16;
   constexpr int A_BLOCKS = (BM / 16) * 2, B_BLOCKS = (BN / 16) * 2;
   constexpr int NBLK = A_BLOCKS + B_BLOCKS;      // 1 KiB fragment blocks per K-step
-  constexpr int PER_WAVE = (NBLK + 3) / 4;
+  constexpr int NWAVES = (BM / WM) * (BN / WN);  // 4, or 8 (128x128 tile as 64x32 wave tiles: 4 waves / SIMD at 2 workgroups / CU)
+  constexpr int PER_WAVE = (NBLK + NWAVES - 1) / NWAVES;
   constexpr int STAGE = NBLK * 1024;             // bytes
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   bool src_ok[PER_WAVE];
 #pragma unroll
   for (int i = 0; i < PER_WAVE; ++i) {
-    const int idx = wave + 4 * i;
+    const int idx = wave + NWAVES * i;
     const bool isA = idx < A_BLOCKS;
     const int b = isA ? idx : idx - A_BLOCKS;
     const int rg = b >> 1, half = b & 1;
@@ -221,10 +223,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     const int k0 = t * BK;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
-      const int idx = wave + 4 * i;
+      const int idx = wave + NWAVES * i;
       const double* src = src_base[i] + k0;
       if constexpr (DMA) {
-        if (NBLK % 4 == 0 || idx < NBLK) {   // NBLK % 4 == 0: every wave has PER_WAVE pieces, no branch in the loop
+        if (NBLK % NWAVES == 0 || idx < NBLK) {   // NBLK % NWAVES == 0: every wave has PER_WAVE pieces, no branch in the loop
           char* dst = smem + s * STAGE + idx * 1024;
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)src,
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   // one LDS-DMA piece of K-step `t` (PIPE: the pieces go out between the MFMA groups of step t - 2's second half)
   auto stage_issue_piece = [&](int i, int t, int s) {
     if constexpr (DMA) {
-      const int idx = wave + 4 * i;
+      const int idx = wave + NWAVES * i;
       char* dst = smem + s * STAGE + idx * 1024;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(src_base[i] + t * BK),
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     if constexpr (!DMA) {
 #pragma unroll
       for (int i = 0; i < PER_WAVE; ++i) {
-        const int idx = wave + 4 * i;
+        const int idx = wave + NWAVES * i;
         if (idx < NBLK) *reinterpret_cast<d2*>(smem + s * STAGE + idx * 1024 + lane * 16) = stage_regs[i];
       }
     }
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     // outstanding, then a raw s_barrier (a __syncthreads() would drain the ring: vmcnt(0)).
     // Every wave issues exactly PER_WAVE DMAs per K-step, so the count is exact.
     static_assert(DMA, "the ring is LDS-DMA only");
-    static_assert(NBLK % 4 == 0, "equal DMA count per wave");
+    static_assert(NBLK % NWAVES == 0, "equal DMA count per wave");
     constexpr int AHEAD = NS - 1;
     for (int t = t0; t < min(nk, t0 + AHEAD); ++t) stage_issue(t, (t - t0) % NS);
     for (int t = t0; t < nk; ++t) {
@@ -482,7 +484,7 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
     const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : (a.lower == 1 ? PROF_GEMM_SYRK : PROF_GEMM));
     rec = profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K, cls);
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), smem, s, a);
   if (prof) profile_end(s, rec);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
@@ -531,13 +533,14 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   a.st_blk = st.blk; a.st_step = st.step; a.st_diag = st.diag;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
-  // Tile choice (same-box sweeps, tools/gemm_ab.py): 128x128 tiles (2 workgroups / CU, 512 slots, half the L2->LDS
-  // traffic per flop) win once there are >= 8 rounds of them (M = 61440 lower, K = 1024: 68.7 vs 66.5 TFLOP/s;
-  // 8192^2 x 4096: 70+ vs 68); below that the 64x64 tiles' (5 / CU, 1280 slots) better tail quantisation wins
-  // (lower K = 2048: M = 10240 62.7 vs 66.3, 12288 64.1 vs 67.4, 18432 68.3 vs 68.1, 24576 69.4 vs 68.3).
-  // A rule that also priced the partial last round of the 512 slots (a 128-tile launch of 16.1 rounds loses 5 %)
-  // measured neutral on whole evaluations and worse on the VFE accumulation (C3 193.0 vs 192.9 ms, C4 1423 vs 1426,
-  // C5 600 vs 563, tools/workload_ab.py) -- the simple threshold stays.
+  // Tile choice (same-box sweeps, tools/gemm_ab.py).  The big tile is 128x128 as EIGHT waves of 32x64 (2 workgroups
+  // / CU = 4 waves / SIMD, 126 VGPRs, 64 KB LDS, half the L2->LDS traffic per flop of the small tile): with the
+  // pipelined loop 8192^3 72.9 TFLOP/s, M = 30720 lower K = 2048 (C3's first trailing update) 72.0, M = 61440 lower
+  // K = 1024 71.1 -- against 72.5 / 69.9 / 68.1 for the same tile as four 64x64 waves (2 / SIMD) and 71.4 / 70.6 for
+  // eight 64x32 waves.  It wins once there are >= 8 rounds of its 512 slots; below that the 64x64 tile's (5 / CU,
+  // 1280 slots) better tail quantisation wins: lower K = 2048 M = 8192 64.7 vs 67.3, 10240 70.3 vs 68.6, 12288 68.5
+  // vs 67.4.  Rules that also priced the partial last round of the 512 slots measured neutral or worse on whole
+  // evaluations (tools/workload_ab.py: C3 184.3 vs 184.5 ms, C2 6.85 vs 6.79, C5 600 vs 563 with an earlier form).
   auto tiles = [&](int64_t b) {
     const int64_t mt = (M + b - 1) / b, nt = (N + b - 1) / b;
     if (lower == 3) return stair_tiles(M, N, st.blk, st.step, st.diag, b);
@@ -562,9 +565,12 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   if (g_gemm_variant == 6) return launch<32, 32, 16, 16, true, 8>(s, a);
   if (g_gemm_variant == 7) return launch<128, 128, 64, 64, true, 2, false, true>(s, a);   // A/B: pipelined K loop
   if (g_gemm_variant == 8) return launch<64, 64, 32, 32, true, 2, false, true>(s, a);
+  if (g_gemm_variant == 9) return launch<128, 128, 64, 32, true, 2, false, true>(s, a);   // 8 waves x (64x32), pipelined
+  if (g_gemm_variant == 10) return launch<128, 128, 64, 32, true, 2, false, false>(s, a); // 8 waves x (64x32), plain loop
+  if (g_gemm_variant == 11) return launch<128, 128, 32, 64, true, 2, false, true>(s, a);  // 8 waves x (32x64), pipelined
   // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
   // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
-  // 21: A/B of whole workloads (tools/workload_ab.py) -- the shipped dispatch with the plain K loop
+  // 21: A/B of whole workloads (tools/workload_ab.py): the shipped dispatch with the 4-wave 128x128 kernel
   const bool std_path = g_gemm_variant == 0 || g_gemm_variant == 21;
   if (std_path && (M <= 32 || N <= 32)) return launch<32, 32, 16, 16, true, 8>(s, a);
   if (std_path && (t64 <= 64 || (N <= 128 && t64 <= 128))) {   // (M = 4096, N = 128, K = 128: 8.1 vs 10.9 us)
@@ -573,8 +579,9 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
     return launch<32, 32, 16, 16, true, 8>(s, a);
   }
   if (std_path) {
-    if (g_gemm_variant == 21) return small ? launch<64, 64, 32, 32, true>(s, a) : launch<128, 128, 64, 64, true>(s, a);
-    return small ? launch<64, 64, 32, 32, true, 2, false, true>(s, a) : launch<128, 128, 64, 64, true, 2, false, true>(s, a);
+    if (small) return launch<64, 64, 32, 32, true, 2, false, true>(s, a);
+    if (g_gemm_variant == 21) return launch<128, 128, 64, 64, true, 2, false, true>(s, a);
+    return launch<128, 128, 32, 64, true, 2, false, true>(s, a);
   }
   return small ? launch<64, 64, 32, 32, false>(s, a) : launch<128, 128, 64, 64, false>(s, a);
 }
