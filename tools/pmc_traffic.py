@@ -8,11 +8,17 @@ usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.c
 import collections, csv, json, sys
 
 def per_grid(path, counter, match):
-    """{grid size: [launches, summed counter]} of the kernels whose name contains `match`"""
+    """{workgroups per launch: [launches, summed counter]} of the kernels whose name contains `match`"""
     d = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and match in r["Kernel_Name"]:
             g = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)))
+            wgs = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 0)) or 0)
+            if not wgs:        # the big tile runs as 8 waves (128, 128, 32, 64), every other variant as 4
+                wgs = 512 if "<128, 128, 32, 64" in r["Kernel_Name"] or "<128, 128, 64, 32" in r["Kernel_Name"] else 256
+            if g % wgs:
+                continue
+            g //= wgs
             d[g][0] += 1
             d[g][1] += float(r["Counter_Value"])
     return d
@@ -50,12 +56,11 @@ if nsyrk:
     match = "gemm_nt_kernel<"        # 128x128-tile launches and, for the last panels, 64x64-tile ones
     fg, wg = per_grid(sys.argv[1], "FETCH_SIZE", match), per_grid(sys.argv[2], "WRITE_SIZE", match)
 
-    def triangular(g):          # lower-tile launches have mt (mt + 1) / 2 workgroups of 256 threads
-        w = g // 256
+    def triangular(w):          # lower-tile launches have mt (mt + 1) / 2 workgroups
         t = (math.isqrt(8 * w + 1) - 1) // 2
         # in-panel (rectangular) launches stay below ~1030 workgroups at C3/C4 and ~260 at C2: above that a
         # triangular grid is a SYRK trailing update (only the last, smallest one per evaluation falls under it)
-        return g % 256 == 0 and t * (t + 1) // 2 == w and w > (300 if sys.argv[4] == "c2" else 1100)
+        return t * (t + 1) // 2 == w and w > (300 if sys.argv[4] == "c2" else 1100)
     top = [g for g in fg if triangular(g)]
     nl = sum(fg[g][0] for g in top)
     if nl and all(g in wg for g in top):
