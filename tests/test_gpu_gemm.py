@@ -53,7 +53,7 @@ def test_syrk_lower(device, n, K):
     assert torch.equal(torch.triu(C, 1), torch.triu(C0, 1))
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 6])
+@pytest.mark.parametrize("variant", [0, 3, 4, 6, 8, 11])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (2048 + 640, 2048, 256), (9000, 512, 128), (700, 200, 48), (5000, 72, 64), (33000, 2048, 32)])
 def test_trapezoid_launch(device, variant, M, N, K):
     """lower = 2: the N x N top square lower-tile only (entries above its diagonal untouched), the rows below it
@@ -75,7 +75,7 @@ def test_trapezoid_launch(device, variant, M, N, K):
         _native.lib().gpn_debug_set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4])
+@pytest.mark.parametrize("variant", [0, 3, 4, 8, 11])
 @pytest.mark.parametrize("M,nb,blk,K,step,diag", [(1024, 1, 256, 64, 0, 1), (3000, 4, 256, 128, 512, 1), (3000, 4, 256, 128, 256, 0),
                                                   (2500, 6, 128, 48, 512, 1), (9000, 3, 2048, 256, 2048, 1), (20000, 5, 512, 64, 1024, 0),
                                                   (1500, 8, 128, 32, 256, 1)])
@@ -115,7 +115,7 @@ def test_gemm_random_fp64(device):
     assert (C - ref).abs().max().item() < 1e-11
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7, 8, 9, 10, 11])   # 7..11: the pipelined loop / 8-wave forms (8 and 11 ship)
 @pytest.mark.parametrize("M,N,K,lower", [(333, 257, 80, False), (1000, 700, 144, False), (129, 127, 16, False),
                                          (777, 777, 96, True), (1100, 1100, 64, True), (130, 130, 32, True)])
 def test_every_tile_shape_on_ragged_sizes(device, variant, M, N, K, lower):
@@ -141,7 +141,7 @@ def test_every_tile_shape_on_ragged_sizes(device, variant, M, N, K, lower):
         _native.lib().gpn_debug_set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 6])
+@pytest.mark.parametrize("variant", [0, 3, 4, 6, 8, 11])
 @pytest.mark.parametrize("n", [200, 777, 1300])
 def test_k_clipped_triangular_operands(device, variant, n):
     """GPN_TRI_* flags (the K range of a tile is clipped where an operand is structurally zero) on
