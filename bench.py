@@ -598,8 +598,20 @@ def main():
         dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
     try:
         run_multi(args, rank, local_rank, world, device)
+    except Exception as exc:
+        # never leave the driver without a line: an unmeasured run says so (value null) with the reason
+        if rank == 0:
+            print(json.dumps({"metric": "GP log-marginal-likelihood evals/sec (Cholesky+solve) at NxD fp64", "value": None,
+                              "unit": "LML evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": WORKLOADS[args.workload]["name"] + ", ONE model 2-D block-cyclic over %d GPUs" % world},
+                              "error": repr(exc)}), flush=True)
+        raise
     finally:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":
