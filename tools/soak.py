@@ -3,7 +3,8 @@
 bitwise-identical LML and gradients every time (the leaf kernel hands blocks between its pivot
 wave and its tile waves through LDS with one hardware and one software barrier per panel, and
 the factorisation forks onto a second stream: a race would show up as a flipped last bit).
-usage: soak.py [evaluations at N=8192 = 1500] [evaluations at N=1000 = 4000]"""
+usage: soak.py [evaluations at N=8192 = 1500] [evaluations at N=1000 = 4000] [evaluations at N=16384 = 0]
+(the third leg is the one that reaches the 8-wave 128x128 contraction tile: 7260 tiles in its first trailing update)"""
 import os
 import sys
 import time
@@ -19,6 +20,7 @@ from gptorch_amd.models import GPR, batched_log_likelihood  # noqa: E402
 dev = torch.device("cuda:0")
 n_big = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 n_small = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
+n_large = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 
 
 def soak(model, reps, label, grads_every=0):
@@ -54,6 +56,12 @@ x, y = rng.make_regression(1000, 5, 2, seed=4)
 m1 = GPR(x, y, kernels.Matern52(5, variance=1.1, length_scales=1.5), likelihood=likelihoods.Gaussian(variance=0.02))
 m1.cuda()
 bad += soak(m1, n_small, "N=1000 D=5 dy=2 Matern52 (ragged)", grads_every=7)
+if n_large:
+    w = dict(name="n16384", kind="Matern52", n=16384, d=8, dy=1, variance=1.0, length_scales=8.0 ** 0.5, noise=1e-2)
+    ml, _, _ = bench.build_model(w, 3, dev)
+    bad += soak(ml, n_large, "N=16384 D=8 Matern52 (8-wave tile)", grads_every=10)
+    del ml
+    torch.cuda.empty_cache()
 # two evaluations in flight on two streams
 models = [bench.build_model(bench.WORKLOADS["c2"], 50 + r, dev)[0] for r in range(4)]
 ref = None
