@@ -5,12 +5,13 @@
  *   gcc -std=c99 examples/dist_consumer.c -Iinclude -I/opt/rocm/include -Lgptorch_amd/lib -lgpnative \
  *       -lgpnative_rccl -L/opt/rocm/lib -lrccl -lamdhip64 -Wl,-rpath,$PWD/gptorch_amd/lib \
  *       -Wl,-rpath,/opt/rocm/lib -lm -o build/dist_consumer
- *   build/dist_consumer <n> <d> <tile> [<rank> <Pr> <Pc> <id-file>]
+ *   build/dist_consumer <n> <d> <tile> [<rank> <Pr> <Pc> <id-file> [<nonce>]]
  *
  * With no grid arguments it runs the 1 x 1 grid on one GPU with the collectives FORCED through RCCL
  * (single-member communicators), i.e. every ncclBroadcast / ncclAllReduce of a real run.  With a
- * grid, rank 0 writes the ncclUniqueId to <id-file> and the other ranks read it (one process per
- * GPU, HIP device = rank).  Prints "lml=<value> info=<value>"; the inputs are those of
+ * grid, rank 0 publishes the ncclUniqueId at <id-file> (written aside and renamed into place, tagged with the
+ * launcher's <nonce>) and the other ranks wait for THIS run's file (one process per GPU, HIP device = rank).
+ * GPN_DIST_SCHEDULE=mesh selects the point-to-point panel exchange of the adapter (GPN_DIST_MESH_EXCHANGE).  Prints "lml=<value> info=<value>"; the inputs are those of
  * gptorch_amd/rng.py, so the value is the one the Python shell gives
  * (tests/test_gpu_parity.py::test_c_dist_consumer_runs). */
 #define __HIP_PLATFORM_AMD__ 1
@@ -65,14 +66,34 @@ int main(int argc, char** argv) {
   CHECK(hipSetDevice(grid ? rank : 0));
   /* communicators: world, then split by grid coordinate */
   ncclUniqueId id;
+  /* The id travels through a file: rank 0 writes [nonce | id] to "<idfile>.tmp" and rename()s it into place (readers
+   * never see a partial write); the other ranks poll until the file carries THIS run's nonce (argv[8], any string the
+   * launcher makes up, e.g. its pid -- a file left behind by an earlier run is ignored, not joined). */
+  char nonce[32] = {0}, seen[32];
+  if (argc > 8) strncpy(nonce, argv[8], sizeof(nonce) - 1);
   if (rank == 0) {
     NCCL(ncclGetUniqueId(&id));
-    if (grid) { FILE* f = fopen(argv[7], "wb"); fwrite(&id, sizeof(id), 1, f); fclose(f); }
+    if (grid) {
+      char tmp[4096];
+      snprintf(tmp, sizeof(tmp), "%s.tmp", argv[7]);
+      remove(argv[7]);
+      FILE* f = fopen(tmp, "wb");
+      if (!f || fwrite(nonce, sizeof(nonce), 1, f) != 1 || fwrite(&id, sizeof(id), 1, f) != 1 || fclose(f) != 0 || rename(tmp, argv[7]) != 0) {
+        fprintf(stderr, "cannot publish the unique id at %s\n", argv[7]);
+        return 5;
+      }
+    }
   } else {
-    FILE* f = NULL;
-    for (int tries = 0; tries < 600 && !(f = fopen(argv[7], "rb")); ++tries) usleep(100000);
-    if (!f || fread(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "no unique id\n"); return 5; }
-    fclose(f);
+    int got = 0;
+    for (int tries = 0; tries < 600 && !got; ++tries) {
+      FILE* f = fopen(argv[7], "rb");
+      if (f) {
+        got = fread(seen, sizeof(seen), 1, f) == 1 && fread(&id, sizeof(id), 1, f) == 1 && memcmp(seen, nonce, sizeof(nonce)) == 0;
+        fclose(f);
+      }
+      if (!got) usleep(100000);
+    }
+    if (!got) { fprintf(stderr, "no unique id for this run at %s\n", argv[7]); return 5; }
   }
   ncclComm_t world, row, col;
   NCCL(ncclCommInitRank(&world, pr * pc, id, rank));

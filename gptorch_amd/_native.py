@@ -82,7 +82,9 @@ RCCL_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpnative_rccl.so")
 RCCL_SIGNATURES = {
     "gpn_rccl_comm_create": (ctypes.POINTER(DistComm), [c_void_p, c_void_p, c_void_p]),
     "gpn_rccl_comm_destroy": (None, [ctypes.POINTER(DistComm)]),
+    "gpn_mesh_plan": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int64, ctypes.POINTER(c_int64), c_int64]),
 }
+DIST_FORCE_COLLECTIVES, DIST_MESH_EXCHANGE = 1, 2      # gpn_dist_comm.flags
 _rccl_lib = None
 
 

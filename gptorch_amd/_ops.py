@@ -152,9 +152,10 @@ class Factor:
 JITTER_TRIES = 10  # functions.py:21 max_tries
 
 
-def _ladder(attempt):
-    """functions.py:20-43: plain try, then +10^(-10+i) I for i = 0..9, then
+def _ladder(attempt, tries=None):
+    """functions.py:20-43: plain try, then +10^(-max_tries+i) I for i = 0..max_tries-1 (max_tries = 10 by default), then
     RuntimeError("Max tries exceeded.").  `attempt(jitter)` -> info."""
+    tries = JITTER_TRIES if tries is None else int(tries)
     def run(jitter):
         info = attempt(jitter)
         if info < 0:
@@ -165,8 +166,8 @@ def _ladder(attempt):
 
     if run(None) == 0:
         return -1
-    for i in range(JITTER_TRIES):
-        if run(10.0 ** (-JITTER_TRIES + i)) == 0:
+    for i in range(tries):
+        if run(10.0 ** (-tries + i)) == 0:
             return i
     raise RuntimeError("Max tries exceeded.")
 

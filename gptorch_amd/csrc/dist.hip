@@ -123,13 +123,23 @@ static DistAux* dist_aux_for(hipStream_t s) {
   auto it = g_dist_aux.find(s);
   if (it != g_dist_aux.end()) return &it->second;
   DistAux a;
-  if (hipStreamCreateWithFlags(&a.row_s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  if (hipStreamCreateWithFlags(&a.col_s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.ready, hipEventDisableTiming) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.diag_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-  for (int i = 0; i < 2; ++i) {
-    if (hipEventCreateWithFlags(&a.row_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&a.col_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+  bool good = hipStreamCreateWithFlags(&a.row_s, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&a.col_s, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&a.ready, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&a.diag_done, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 2 && good; ++i)
+    good = hipEventCreateWithFlags(&a.row_done[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&a.col_done[i], hipEventDisableTiming) == hipSuccess;
+  if (!good) {                       // free what was created before the failing call
+    if (a.row_s) (void)hipStreamDestroy(a.row_s);
+    if (a.col_s) (void)hipStreamDestroy(a.col_s);
+    if (a.ready) (void)hipEventDestroy(a.ready);
+    if (a.diag_done) (void)hipEventDestroy(a.diag_done);
+    for (int i = 0; i < 2; ++i) {
+      if (a.row_done[i]) (void)hipEventDestroy(a.row_done[i]);
+      if (a.col_done[i]) (void)hipEventDestroy(a.col_done[i]);
+    }
+    return nullptr;
   }
   return &g_dist_aux.emplace(s, a).first->second;
 }
@@ -323,9 +333,10 @@ struct DistRun {
     if (src && step == 1) buf = left + first * T * T;                     // already contiguous
     else {
       buf = W + L.right[k & 1];
-      if (src)   // every step-th tile of my left buffer -> consecutive tiles: ONE strided 2-D copy (tile = T*T doubles)
-        hip(hipMemcpy2DAsync(buf, (size_t)T * T * sizeof(double), left + first * T * T, (size_t)step * T * T * sizeof(double),
-                             (size_t)T * T * sizeof(double), (size_t)count, hipMemcpyDeviceToDevice, s), "start_cols gather");
+      if (src)   // every step-th tile of my left buffer -> consecutive tiles: ONE strided copy launch with a tile (T*T doubles) as
+                 // a "row" (not hipMemcpy2DAsync: its pitch is limited to the device's memPitch, about 2 GiB -- a 1 x 8
+                 // grid with tile 8192 would need 4.3 GB)
+        ok(gpn_copy_matrix(s, left + first * T * T, count, T * T, step * T * T, buf, T * T, 0));
     }
     if (xcol() && rc == GPN_OK) {
       hip(hipEventRecord(ax->ready, s), "start_cols");
@@ -363,7 +374,11 @@ struct DistRun {
 
 using namespace gpn;
 
-// shared body of the two entry points: assembly + factorisation (+ the closed-form backward on the grid)
+// shared body of the two entry points: assembly + factorisation (+ the closed-form backward on the grid).
+// Error behaviour on a multi-rank grid: a non-zero status means this rank stopped issuing the evaluation's collectives part-way
+// (nothing is waited for here: a broadcast whose peers never arrive would block a drain for ever).  The other ranks of its
+// process row / column are then blocked inside the transport: the caller must abort the communicators (ncclCommAbort) on every
+// rank before reusing them -- include/gpnative.h says the same.
 static int dist_evaluate(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
                          const double* X, int64_t n, int d, const double* Y, int dy,
                          const double* variance, const double* length_scales, int nls, const double* noise,
@@ -398,8 +413,15 @@ static int dist_evaluate(void* stream, const gpn_dist_comm* comm, int rank, int 
   hipStream_t s = R.s;
 
   // ---- assembly: X rows in my tile-row / tile-column order, then one rectangular K per local tile column
-  GPN_HIP_CHECK(hipMemsetAsync(work, 0, (size_t)R.L.total * sizeof(double), s));
+  // The workspace's contents are arbitrary on entry.  What has to be zero: everything but the REAL rows of the matrix
+  // segment (ragged-tile padding rows, residual and identity segments, Kyy^-1 accumulator, panel buffers, statistics)
+  // and, in those rows, the padding columns of a ragged last tile column.  The tiles of the real rows at or below the
+  // diagonal are overwritten by the assembly; the tiles above it are never read.  (At 1 x 1 and N = 65536 the matrix
+  // segment is 34 GB: clearing it every evaluation was 10 ms.)
   const int64_t nrr = g.nreal_rows(), ncr = g.nreal_cols();
+  GPN_HIP_CHECK(hipMemsetAsync(work + L.A + nrr * g.ld, 0, (size_t)(R.L.total - (L.A + nrr * g.ld)) * sizeof(double), s));
+  if (nrr > 0 && ncr < g.ld)
+    GPN_HIP_CHECK(hipMemset2DAsync(work + L.A + ncr, (size_t)g.ld * sizeof(double), 0, (size_t)(g.ld - ncr) * sizeof(double), (size_t)nrr, s));
   double* Xrow = work + L.xrow;
   double* Xcol = work + L.xcol;
   for (int64_t li = 0; li < g.nrow_t; ++li) {          // tile rows are T-row blocks of X at stride Pr*T

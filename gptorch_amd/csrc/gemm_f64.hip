@@ -597,6 +597,11 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
   if (K <= 0 || (K % 16)) return -5;
   if (step < 0 || (step % 128)) return -14;
   if (diag && M < blk) return -15;
+  if (diag)      // a lower-only first square needs all blk rows of its block: a block that starts inside the last blk rows
+    for (int64_t b = 1; b < nblocks; ++b) {          // would get the rectangular treatment and write above its diagonal
+      const int64_t rows = M - b * step;
+      if (rows > 0 && rows < blk) return -15;
+    }
   if ((lda & 1) || (ldb & 1)) return GPN_E_ALIGN;
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GPN_E_ALIGN;
   if (M == 0 || nblocks == 0) return GPN_OK;

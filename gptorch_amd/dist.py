@@ -66,12 +66,117 @@ from . import _ops
 LEAF = _ops.LEAF
 
 
+MESH_STAGES = 4            # pipeline depth of the scatter + all-gather form of the mesh broadcast
+MESH_DIRECT_BYTES = 4 << 20  # below this a panel goes root -> every peer directly (one hop, latency-bound)
+
+
+def mesh_plan(members, root, me, count, stages=MESH_STAGES, direct_below=None):
+    """Point-to-point schedule of ONE broadcast of `count` elements from `root` inside the
+    sub-communicator `members` (global ranks), as seen by rank `me`: a list of stages, each a list of
+    ("send" | "recv", peer, offset, length) that are issued as one grouped call (ncclGroupStart/End,
+    dist.batch_isend_irecv).  xGMI is a full mesh of point-to-point links, so every (sender, receiver)
+    pair of a stage uses its own link ("do not route these through a ring"):
+
+      * small panels (count < direct_below) or a single peer: the root sends the whole buffer to every
+        peer directly -- one hop, q = len(members) - 1 links in parallel;
+      * otherwise scatter + all-gather, pipelined: the buffer is cut into `stages` slices of q pieces;
+        in stage t the root sends piece (t, i) to peer i while peer i forwards piece (t-1, i), which it
+        received one stage earlier, to the q - 1 other peers.  Every link carries count / q elements
+        (a ring carries `count` over each of its links), in stages + 1 grouped calls.
+
+    The plan is a pure function of its arguments and identical on every member, so sends and receives
+    match by construction (tests/test_dist_gloo.py::test_mesh_plan_is_consistent checks it exhaustively).
+    The same function is restated in C in csrc/rccl_adapter.cpp (`mesh_bcast`)."""
+    peers = [m for m in members if m != root]
+    q = len(peers)
+    if q == 0 or count <= 0:
+        return []
+    if direct_below is None:
+        import os
+        direct_below = int(os.environ.get("GPN_DIST_MESH_DIRECT_BYTES", MESH_DIRECT_BYTES)) // 8
+    if q == 1 or count < direct_below:
+        if me == root:
+            return [[("send", p, 0, count) for p in peers]]
+        return [[("recv", root, 0, count)]]
+    S = max(1, min(int(stages), count // q))
+    npieces = S * q
+    base, extra = divmod(count, npieces)
+
+    def piece(t, i):               # slice t, piece i -> (offset, length); the first `extra` pieces are one longer
+        idx = t * q + i
+        return idx * base + min(idx, extra), base + (1 if idx < extra else 0)
+
+    plan = []
+    for t in range(S + 1):
+        ops = []
+        if me == root:
+            if t < S:
+                ops += [("send", p, *piece(t, i)) for i, p in enumerate(peers)]
+        else:
+            i = peers.index(me)
+            if t < S:
+                ops.append(("recv", root, *piece(t, i)))
+            if t >= 1:
+                ops += [("send", p, *piece(t - 1, i)) for p in peers if p != me]
+                ops += [("recv", p, *piece(t - 1, j)) for j, p in enumerate(peers) if p != me]
+        plan.append([o for o in ops if o[3] > 0])     # (a stage may be empty for one member: count < number of pieces)
+    return plan
+
+
+def mesh_broadcast(t, src, me, members, group, stages=None, stats=None):
+    """execute `mesh_plan` for the contiguous tensor `t` with torch.distributed point-to-point ops (one
+    dist.batch_isend_irecv = one ncclGroupStart/End per stage).  -> list of Work still in flight (stream-ordered
+    backends); [] when the transport completed on the host.  stats: object with sent_bytes / recv_bytes counters."""
+    flat = t.view(-1)
+    es = t.element_size()
+    # a stage forwards what the stage before received: on a stream-ordered backend (RCCL) the grouped calls
+    # are queued back to back on the communicator's stream; a host-side transport (gloo) has to complete a
+    # stage before the next one may read its pieces
+    stream_ordered = dist.get_backend(group) == "nccl"
+    staged = t.is_cuda and not stream_ordered      # gloo moves host memory only (shared-GPU test mode): stage the pieces
+    works = []
+    for stage in mesh_plan(members, src, me, flat.numel(), MESH_STAGES if stages is None else stages):
+        if not stage:
+            continue
+        ops, landed = [], []
+        for kind, peer, off, ln in stage:
+            view = flat[off:off + ln]
+            if kind == "send":
+                if stats is not None:
+                    stats.sent_bytes[peer] = stats.sent_bytes.get(peer, 0) + ln * es
+                ops.append(dist.P2POp(dist.isend, view.cpu() if staged else view, peer, group=group))
+            else:
+                if stats is not None:
+                    stats.recv_bytes += ln * es
+                host = torch.empty(ln, dtype=t.dtype) if staged else view
+                if staged:
+                    landed.append((view, host))
+                ops.append(dist.P2POp(dist.irecv, host, peer, group=group))
+        ws = dist.batch_isend_irecv(ops)
+        if not stream_ordered:
+            for w in ws:
+                w.wait()
+            for view, host in landed:
+                view.copy_(host)
+        else:
+            works += ws
+    return works
+
+
 def choose_grid(world):
     """Pr x Pc with Pr <= Pc, as square as possible: 1x1, 1x2, 2x2, 2x4."""
     pr = int(math.sqrt(world))
     while world % pr:
         pr -= 1
     return pr, world // pr
+
+
+def _flatten(works):
+    for w in works:
+        if isinstance(w, (list, tuple)):
+            yield from _flatten(w)
+        else:
+            yield w
 
 
 class NativeTileOps:
@@ -142,9 +247,24 @@ class NativeTileOps:
 class BlockCyclicGP:
     """Distributed LML for a stationary kernel.  All ranks call every method collectively."""
 
-    def __init__(self, X, Y, kind, tile=2048, grid=None, ops=None, group=None, phantom=None, force_comm=False, share=None):
+    def __init__(self, X, Y, kind, tile=2048, grid=None, ops=None, group=None, phantom=None, force_comm=False, share=None,
+                 schedule=None):
         """force_comm: issue the row / column collectives even where a sub-communicator has a single
-        member (world 1, or Pr = 1) -- a test hook that drives the RCCL calls on a 1-GPU box."""
+        member (world 1, or Pr = 1) -- a test hook that drives the RCCL calls on a 1-GPU box.
+        schedule: how a panel travels inside a row / column sub-communicator -- "bcast" = the
+        backend's broadcast (RCCL picks the route: a ring / tree), "mesh" = grouped point-to-point
+        sends over the direct xGMI links (`mesh_plan`); default from GPN_DIST_SCHEDULE, else "bcast".
+        Both move the same bytes into the same buffers: results are bit-identical."""
+        import os
+        self.schedule = schedule or os.environ.get("GPN_DIST_SCHEDULE", "bcast")
+        if self.schedule not in ("bcast", "mesh"):
+            raise ValueError("schedule must be 'bcast' or 'mesh'")
+        self.mesh_stages = int(os.environ.get("GPN_DIST_MESH_STAGES", MESH_STAGES))
+        self.comm_timing = False       # record an event pair around every wait on a collective (exposed_comm_ms)
+        self._wait_events = []
+        self.sent_bytes = {}           # global peer rank -> payload bytes this rank sent it ("mesh"; reset_comm_stats)
+        self.bcast_root_bytes = 0      # payload bytes this rank was the root of ("bcast": the route is the backend's)
+        self.recv_bytes = 0            # payload bytes this rank received in row / column exchanges
         live = dist.is_available() and dist.is_initialized() and phantom is None
         self.rank = dist.get_rank(group) if live else 0
         self.world = dist.get_world_size(group) if live else 1
@@ -167,6 +287,8 @@ class BlockCyclicGP:
         self.row_group = self.col_group = None
         self.xrow = self.comm and (self.pc > 1 or force_comm)      # panels travel along process rows
         self.xcol = self.comm and (self.pr > 1 or force_comm)      # ... and down process columns
+        self.row_ranks = [self.my_r * self.pc + c for c in range(self.pc)]       # global ranks of my process row ...
+        self.col_ranks = [r * self.pc + self.my_c for r in range(self.pr)]       # ... and of my process column
         if share is not None:      # a second engine on the same grid (predict): reuse the sub-communicators
             self.row_group, self.col_group = share.row_group, share.col_group
         elif self.comm:
@@ -271,16 +393,54 @@ class BlockCyclicGP:
 
     # -- collectives ----------------------------------------------------------------
     def _bcast(self, t, src, group, async_op=False):
-        """broadcast a contiguous tensor inside a row / column sub-communicator; -> Work or None."""
+        """broadcast a contiguous tensor inside a row / column sub-communicator; -> Work, list of Work or None.
+        schedule "mesh": the grouped point-to-point plan of `mesh_plan` (one dist.batch_isend_irecv per stage)."""
         if not self.comm or group is None:
             return None
-        return dist.broadcast(t, src=src, group=group, async_op=async_op)
-
-    @staticmethod
-    def _wait(works):
+        nbytes = t.numel() * t.element_size()
+        members = self.row_ranks if group is self.row_group else self.col_ranks
+        if self.schedule == "bcast" or len(members) == 1:
+            if src == self.rank:
+                self.bcast_root_bytes += nbytes * (len(members) - 1)
+            else:
+                self.recv_bytes += nbytes
+            w = dist.broadcast(t, src=src, group=group, async_op=async_op)
+            return w if async_op else None
+        works = mesh_broadcast(t, src, self.rank, members, group, self.mesh_stages, self)
+        if async_op:
+            return works
         for w in works:
-            if w is not None:
+            w.wait()
+        return None
+
+    def _wait(self, works):
+        """make the compute stream wait for the collectives in `works`; with comm_timing an event pair around the
+        wait measures how long the stream stood still for them (the exposed part of the exchange)."""
+        works = [w for w in _flatten(works) if w is not None]
+        if not works:
+            return
+        if self.comm_timing and self.X.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for w in works:
                 w.wait()
+            e1.record()
+            self._wait_events.append((e0, e1))
+        else:
+            for w in works:
+                w.wait()
+
+    def reset_comm_stats(self):
+        self._wait_events, self.sent_bytes, self.bcast_root_bytes, self.recv_bytes = [], {}, 0, 0
+
+    def comm_stats(self):
+        """-> dict: exposed_comm_ms (sum over the recorded waits; synchronises), bytes sent per peer, bytes received."""
+        ms = 0.0
+        if self._wait_events:
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        return {"exposed_comm_ms": ms, "waits": len(self._wait_events), "sent_bytes_per_peer": dict(self.sent_bytes),
+                "bcast_root_bytes": self.bcast_root_bytes, "recv_bytes": self.recv_bytes}
 
     # -- assembly ---------------------------------------------------------------
     def assemble(self, variance, length_scales, noise, resid):
@@ -343,7 +503,7 @@ class BlockCyclicGP:
             ops.copy(Lp, L, nk, nk)
             L = Lp
         if exchange:
-            self._bcast(self.diag, (k % self.pr) * self.pc + ck, self.col_group)
+            self._wait([self._bcast(self.diag, (k % self.pr) * self.pc + ck, self.col_group, async_op=True)])
         if m:
             ops.trsm(L, Wp, nk, colk[lo:], m)
 
@@ -581,7 +741,8 @@ class BlockCyclicGP:
         ops.kernel_block(self.kind, self.X, x_new, variance, length_scales, Ks)
         R = torch.cat([resid, Ks], 1).contiguous()
         eng = BlockCyclicGP(self.X, R, self.kind, tile=self.T, grid=(self.pr, self.pc), ops=ops, group=self.group,
-                            phantom=None if (self.comm or self.world == 1) else (self.rank, self.world), share=self)
+                            phantom=None if (self.comm or self.world == 1) else (self.rank, self.world), share=self,
+                            schedule=self.schedule)
         eng.comm, eng.xrow, eng.xcol = self.comm, self.xrow, self.xcol
         eng.lml_rows = dy
         eng.log_likelihood(variance, length_scales, noise, R, max_tries)
@@ -645,8 +806,13 @@ class NativeDistLML:
     "torch" (callbacks over torch.distributed collectives -- any backend; how the test-suite runs
     several ranks on one GPU over gloo)."""
 
-    def __init__(self, X, Y, kind, tile=2048, grid=None, comm="torch", force_comm=False):
+    def __init__(self, X, Y, kind, tile=2048, grid=None, comm="torch", force_comm=False, schedule=None):
+        """schedule "mesh": GPN_DIST_MESH_EXCHANGE in the table's flags -- the RCCL adapter then moves panels by grouped
+        ncclSend / ncclRecv over the direct links (csrc/rccl_adapter.cpp), the torch transport by `mesh_broadcast`."""
         import ctypes
+        import os
+        self.schedule = schedule or os.environ.get("GPN_DIST_SCHEDULE", "bcast")
+        self.sent_bytes, self.recv_bytes = {}, 0
         from . import _native
         self._ct, self._native = ctypes, _native
         live = dist.is_available() and dist.is_initialized()
@@ -705,7 +871,7 @@ class NativeDistLML:
         table = nat.rccl_lib().gpn_rccl_comm_create(row, col, world)
         if not table:
             raise _ops.NativeError("gpn_rccl_comm_create failed")
-        table.contents.flags = 1 if force else 0
+        table.contents.flags = (nat.DIST_FORCE_COLLECTIVES if force else 0) | (nat.DIST_MESH_EXCHANGE if self.schedule == "mesh" else 0)
         self._keep = [rccl, world, row, col, table]
         return table.contents
 
@@ -730,10 +896,14 @@ class NativeDistLML:
         def bcast(ctx, which, buf, count, root, stream):
             try:
                 torch.cuda.synchronize()          # the table's contract is stream order; this transport is host-side
-                if which == 0:
-                    dist.broadcast(view(buf, count), src=my_r * self.pc + root, group=row_group)
+                src = my_r * self.pc + root if which == 0 else root * self.pc + my_c
+                group = row_group if which == 0 else col_group
+                members = [my_r * self.pc + c for c in range(self.pc)] if which == 0 else [r * self.pc + my_c for r in range(self.pr)]
+                if self.schedule == "mesh" and len(members) > 1:
+                    for w in mesh_broadcast(view(buf, count), src, self.rank, members, group, None, self):
+                        w.wait()
                 else:
-                    dist.broadcast(view(buf, count), src=root * self.pc + my_c, group=col_group)
+                    dist.broadcast(view(buf, count), src=src, group=group)
                 torch.cuda.synchronize()
                 return 0
             except Exception:                     # never let an exception cross the C frame
@@ -754,7 +924,7 @@ class NativeDistLML:
 
         b, a = nat.BCAST_FN(bcast), nat.ALLREDUCE_FN(allreduce)
         self._keep = [b, a]                       # the C side holds raw pointers to these
-        return nat.DistComm(None, b, a, 1 if force else 0)
+        return nat.DistComm(None, b, a, (nat.DIST_FORCE_COLLECTIVES if force else 0) | (nat.DIST_MESH_EXCHANGE if self.schedule == "mesh" else 0))
 
     def _evaluate(self, variance, length_scales, noise):
         ct = self._ct

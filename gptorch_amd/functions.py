@@ -32,11 +32,13 @@ def jit_op(op, x, max_tries: int = 10, verbose: bool = False):
         try:
             out[:] = [op(xj)]
             return 0
-        except RuntimeError:
+        except Exception as exc:          # the reference catches Exception on the initial try (functions.py:30) and
+            if jitter is not None and not isinstance(exc, RuntimeError):     # RuntimeError on the jittered ones (:38)
+                raise
             if verbose:
                 print("Op {} failed ({})".format(getattr(op, "__name__", "op"), "initial try" if jitter is None else "jitter %g" % jitter))
             return 1
-    _ops._ladder(attempt)
+    _ops._ladder(attempt, tries=max_tries)
     return out[0]
 
 

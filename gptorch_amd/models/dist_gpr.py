@@ -45,18 +45,20 @@ class _DistLogLik(torch.autograd.Function):
 
 
 class DistGPR(GPR):
-    def __init__(self, x, y, kernel, mean_function=None, likelihood=None, name="dist_gpr", tile=2048, grid=None, tile_ops=None):
+    def __init__(self, x, y, kernel, mean_function=None, likelihood=None, name="dist_gpr", tile=2048, grid=None, tile_ops=None, schedule=None):
         super().__init__(x, y, kernel, mean_function=mean_function, likelihood=likelihood, name=name)
         if not (isinstance(kernel, kernels.Stationary) and kernel._kind is not None):
             raise NotImplementedError("DistGPR assembles its tiles with the native stationary kernels (Rbf, Matern52, ...)")
         self._tile, self._grid, self._tile_ops = int(tile), grid, tile_ops
+        self._schedule = schedule        # panel exchange: "bcast" | "mesh" (dist.BlockCyclicGP); None = GPN_DIST_SCHEDULE / "bcast"
         self._engine = None
 
     def _eng(self):
         from .. import dist as gdist
         e = self._engine
         if e is None or e.X.device != self.X.device:
-            e = gdist.BlockCyclicGP(self.X, self.Y, self.kernel._kind, tile=self._tile, grid=self._grid, ops=self._tile_ops)
+            e = gdist.BlockCyclicGP(self.X, self.Y, self.kernel._kind, tile=self._tile, grid=self._grid, ops=self._tile_ops,
+                                    schedule=self._schedule)
             self._engine = e
         return e
 

@@ -152,7 +152,8 @@ int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
  * b * step on (step % 128 == 0); with diag != 0 the first blk x blk square of every block is lower-only (entries
  * above its diagonal are not written).  All the local tile columns of one block-cyclic trailing update -- each
  * starting Pc/Pr tile rows below its left neighbour -- in ONE launch (gptorch_amd/dist.py, csrc/dist.hip), instead
- * of one launch with its own partial last round per tile column.  B is [nblocks * blk, K]. */
+ * of one launch with its own partial last round per tile column.  B is [nblocks * blk, K].  With diag every block that
+ * has rows at all must have at least blk of them (status -15 otherwise: a partial diagonal square is not supported). */
 int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,
                       const double* A, int64_t lda, const double* B, int64_t ldb,
                       double beta, double* C, int64_t ldc, int64_t step, int diag);
@@ -267,7 +268,11 @@ int gpn_predict(void* stream, int kind, const double* X, int64_t n, int d,
  *       rank's process ROW (which = 0; root = the source's process-column index 0..Pc-1) or process
  *       COLUMN (which = 1; root = the source's process-row index 0..Pr-1) sub-communicator;
  *   allreduce(ctx, buf, count, stream): in-place sum over all Pr*Pc ranks. */
-enum { GPN_DIST_FORCE_COLLECTIVES = 1 /* issue them in single-member communicators too (tests) */ };
+enum { GPN_DIST_FORCE_COLLECTIVES = 1, /* issue them in single-member communicators too (tests) */
+       GPN_DIST_MESH_EXCHANGE = 2      /* transports that know two routes (libgpnative_rccl.so): move a panel by grouped
+                                          point-to-point transfers over the direct xGMI links (root -> every peer for
+                                          small panels, pipelined scatter + all-gather for large ones: gpn_mesh_plan)
+                                          instead of the library broadcast.  Same bytes, same buffers: bit-identical. */ };
 typedef struct gpn_dist_comm {
   void* ctx;
   int (*bcast)(void* ctx, int which, double* buf, int64_t count, int root, void* stream);
@@ -280,7 +285,10 @@ int64_t gpn_dist_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, 
 /* out4 (device): [0] = sum log L_ii, [1] = |alpha|^2, [2] = LML (gpr.py:63-67), [3] = LAPACK-style
  * info of the WHOLE matrix as a double (0 = ok, j > 0 = first failing pivot: replay with
  * noise + 10^(-10+i) as functions.py:20-43 does; GPN_INFO_INTERNAL = internal failure), identical on
- * every rank.  comm may be NULL for a 1 x 1 grid.  No host synchronisation. */
+ * every rank.  comm may be NULL for a 1 x 1 grid.  No host synchronisation.
+ * Errors on a multi-rank grid: a non-zero status (bad argument aside) means this rank stopped issuing the evaluation's
+ * collectives part-way; its peers may be blocked inside the transport.  Nothing is drained (a collective whose peers never
+ * arrive cannot complete): abort the communicators on every rank (ncclCommAbort) before reusing them. */
 int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
                          const double* X, int64_t n, int d, const double* Y, int dy,
                          const double* variance, const double* length_scales, int nls, const double* noise,
@@ -305,6 +313,13 @@ int gpn_dist_lml_grad(void* stream, const gpn_dist_comm* comm, int rank, int pr,
  * communicators themselves stay the caller's). */
 gpn_dist_comm* gpn_rccl_comm_create(void* row, void* col, void* world);
 void gpn_rccl_comm_destroy(gpn_dist_comm* comm);
+/* libgpnative_rccl.so only: the point-to-point schedule of ONE mesh broadcast (GPN_DIST_MESH_EXCHANGE) of `count`
+ * doubles from member `root` of a p-member communicator, as seen by member `me`: quintuples (stage, kind 0 = send /
+ * 1 = recv, peer, offset, length) into ops[5 * cap]; one stage = one ncclGroupStart/End.  Returns the number of
+ * quintuples (call again with a larger buffer if > cap), < 0: bad arguments.  Pure host function (no RCCL call) --
+ * the same plan as gptorch_amd/dist.py mesh_plan, checked against it by tests/test_abi.py.  Defaults used by the
+ * adapter: stages = 4, direct_below = 4 MiB / 8 (GPN_DIST_MESH_STAGES / GPN_DIST_MESH_DIRECT_BYTES override). */
+int64_t gpn_mesh_plan(int p, int root, int me, int64_t count, int stages, int64_t direct_below, int64_t* ops, int64_t cap);
 
 /* ---- small utilities -------------------------------------------------------- */
 /* dst[r, c] = src[c, r] for src[rows, cols] */

@@ -56,6 +56,9 @@ def test_argument_validation_without_launch():
     """bad arguments are rejected with -(argument index) / GPN_E_* before any HIP call."""
     lib = _native.lib()
     null = None
+    # staircase with lower-only first squares: a block with fewer than blk rows (M = 3000, blk = step = 2048, 2 blocks) is refused
+    assert lib.gpn_gemm_nt_stair(null, 3000, 2, 2048, 16, -1.0, null, 16, null, 16, 1.0, null, 4096, 2048, 1) == -15
+    assert lib.gpn_gemm_nt_stair(null, 1000, 1, 2048, 16, -1.0, null, 16, null, 16, 1.0, null, 4096, 2048, 1) == -15
     assert lib.gpn_gemm_nt(null, 16, 16, 10, 1.0, null, 16, null, 16, 0.0, null, 16, 0, 0) == -4     # K % 16
     assert lib.gpn_gemm_nt(null, 16, 8, 16, 1.0, null, 16, null, 16, 0.0, null, 16, 1, 0) == -13    # lower, M != N
     assert lib.gpn_gemm_nt(null, 16, 16, 16, 1.0, null, 15, null, 16, 0.0, null, 16, 0, 0) == -101  # odd lda
@@ -124,3 +127,28 @@ def test_header_is_plain_c_and_a_c_consumer_links(tmp_path):
     """include/gpnative.h compiles as C99 and examples/lml_consumer.c (gcc, no hipcc, no Python)
     links against libgpnative.so: the boundary really is a C ABI.  (It is RUN in the gpu suite.)"""
     _build_c_consumer(tmp_path / "lml_consumer")
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 8])
+def test_c_mesh_plan_equals_python_plan(p):
+    """gpn_mesh_plan (libgpnative_rccl.so: what the adapter's grouped ncclSend / ncclRecv loop executes) is the same
+    schedule as gptorch_amd.dist.mesh_plan (checked for consistency by tests/test_dist_gloo.py) for every member, root,
+    ragged counts, both forms and a too-small output buffer."""
+    from gptorch_amd import dist as gdist
+    rccl = _native.rccl_lib()
+    members = list(range(p))
+    for root in members:
+        for count, stages, direct in [(0, 4, 0), (1, 4, 0), (5, 4, 0), (97, 4, 0), (1000, 3, 0), (1000, 4, 4096), (64, 64, 0),
+                                      (268435456, 4, 524288)]:
+            for me in members:
+                want = []
+                for t, stage in enumerate(gdist.mesh_plan(members, root, me, count, stages, direct)):
+                    want += [(t, 0 if kind == "send" else 1, peer, off, ln) for kind, peer, off, ln in stage]
+                buf = (ctypes.c_int64 * (5 * 2))()
+                n = rccl.gpn_mesh_plan(p, root, me, count, stages, direct, buf, 2)
+                assert n == len(want)
+                buf = (ctypes.c_int64 * (5 * max(n, 1)))()
+                assert rccl.gpn_mesh_plan(p, root, me, count, stages, direct, buf, n) == n
+                got = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
+                assert got == want, (p, root, me, count)
+    assert rccl.gpn_mesh_plan(2, 2, 0, 10, 4, 0, None, 0) == -1

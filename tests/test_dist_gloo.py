@@ -268,3 +268,82 @@ def test_dist_gpr_model_matches_oracle(tmp_path, world):
     assert np.abs(z["mu"] - omu.numpy()).max() < 1e-9 and np.abs(z["var"] - ovar.numpy()).max() < 1e-9
     assert np.abs(z["cov"] - ocov.numpy()).max() < 1e-9
     assert z["losses"].shape == (3,) and abs(z["losses"][0] - lo.item()) < 1e-9 * abs(lo.item()) and z["losses"][2] < z["losses"][0]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# mesh exchange schedule (grouped point-to-point sends over the direct links instead of the backend's broadcast)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 8])
+def test_mesh_plan_is_consistent(p):
+    """`mesh_plan` simulated for every member at once: every send has exactly one matching receive in the same
+    stage (same peer pair, offset, length), a rank only forwards elements it already holds, every rank ends up
+    with the whole buffer, and no link (ordered pair) carries more than ~count/(p-1) elements in the
+    scatter + all-gather form -- for direct fan-out, ragged counts and more stages than elements."""
+    members = [3 + 2 * i for i in range(p)]                 # global ranks need not be 0..p-1
+    for root in members:
+        for count, stages, direct in [(0, 4, 0), (1, 4, 0), (5, 4, 0), (97, 4, 0), (1000, 3, 0), (1000, 4, 4096), (64, 64, 0)]:
+            plans = {m: gdist.mesh_plan(members, root, m, count, stages, direct) for m in members}
+            have = {m: np.zeros(count, bool) for m in members}
+            have[root][:] = True
+            link = {}
+            nstage = max(len(pl) for pl in plans.values()) if plans else 0
+            # members take part in different numbers of stages (the root stops one early): align by stage index
+            # from the start for the root and the peers alike -- a peer's first stage is the root's first stage
+            for t in range(nstage):
+                sends, recvs = [], []
+                for m in members:
+                    if t < len(plans[m]):
+                        for kind, peer, off, ln in plans[m][t]:
+                            assert peer in members and peer != m and ln > 0 and 0 <= off and off + ln <= count
+                            (sends if kind == "send" else recvs).append((m, peer, off, ln) if kind == "send" else (peer, m, off, ln))
+                assert sorted(sends) == sorted(recvs), (p, root, count, t)
+                for a, b, off, ln in sends:
+                    assert have[a][off:off + ln].all(), "forwarding data not yet received"
+                    link[(a, b)] = link.get((a, b), 0) + ln
+                for a, b, off, ln in sends:
+                    have[b][off:off + ln] = True
+            for m in members:
+                assert have[m].all(), (p, root, count, m)
+            q = p - 1
+            if q >= 2 and count >= 4096 // 8 and direct == 0:
+                assert max(link.values()) <= count // q + stages + 1
+
+
+def _mesh_worker(rank, world, port, n, tile, dy, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GPN_DIST_MESH_STAGES"] = "3"
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, y = rng.make_regression(n, 3, dy, seed=0)
+        X, Y = torch.tensor(x), torch.tensor(y)
+        var, ls, nz = (torch.tensor([v], dtype=torch.float64) for v in (1.3, 1.7, 0.05))
+        res = []
+        old = gdist.MESH_DIRECT_BYTES
+        for schedule, direct in (("bcast", old), ("mesh", 0), ("mesh", 1 << 40)):     # scatter+all-gather form, direct fan-out form
+            gdist.MESH_DIRECT_BYTES = direct
+            g = gdist.BlockCyclicGP(X, Y, "Rbf", tile=tile, ops=CpuTileOps(), schedule=schedule)
+            lml, grad = g.log_likelihood_and_grad(var, ls, nz, Y)
+            mu, v = g.predict(var, ls, nz, Y, torch.tensor(rng.normal(4, (5, 3))))
+            res.append(np.concatenate([[float(lml)], grad.numpy(), mu.numpy().ravel(), v.numpy().ravel()]))
+            st = g.comm_stats()
+            if schedule == "mesh" and world > 1:
+                assert st["bcast_root_bytes"] == 0 and sum(st["sent_bytes_per_peer"].values()) > 0
+                assert all(p != rank for p in st["sent_bytes_per_peer"])
+        gdist.MESH_DIRECT_BYTES = old
+        if rank == 0:
+            np.save(out_path, np.stack(res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,tile,dy", [(2, 300, 128, 1), (4, 700, 128, 2), (8, 1100, 128, 1)])
+def test_mesh_schedule_is_bit_identical(tmp_path, world, n, tile, dy):
+    """the mesh exchange (grouped isend/irecv: scatter + all-gather, and the direct fan-out used for small panels)
+    delivers exactly the bytes of the backend's broadcast: LML, gradients and predictions agree bit for bit with
+    schedule "bcast" on grids 1x2, 2x2 and 2x4."""
+    out = str(tmp_path / "mesh.npy")
+    mp.spawn(_mesh_worker, args=(world, _free_port(), n, tile, dy, out), nprocs=world, join=True)
+    r = np.load(out)
+    assert np.array_equal(r[0], r[1]) and np.array_equal(r[0], r[2])

@@ -633,6 +633,13 @@ def test_bench_multi_rank_line_shared_gpu(device):
     assert abs(line["lml"] - case["lml"]) < 1e-8, (line["lml"], case["lml"])
     assert line["lml_abs_diff_vs_single_gpu"] < 1e-8
     assert line["replicas_c2"]["value"] > 0 and line["single_gpu_same_run"]["value"] > 0
+    # both exchange schedules were timed in the run, are bit-identical, and both reproduce the C2 golden
+    sch = line["exchange_schedules"]
+    assert set(sch) == {"bcast", "mesh"} and line["exchange_schedule"] in sch, line.get("notes")
+    assert sch["bcast"]["lml"] == sch["mesh"]["lml"] and abs(sch["mesh"]["lml"] - case["lml"]) < 1e-8
+    assert len(line["exposed_comm_ms_per_rank"]) == 2 and all(v >= 0 for v in line["exposed_comm_ms_per_rank"])
+    assert sch["mesh"]["p2p_sent_gb_per_rank"][0] > 0 and sch["bcast"]["bcast_root_payload_gb_per_rank"][0] > 0
+    assert abs(line["speedup_vs_single_gpu_same_run"] - line["single_gpu_same_run"]["ms_per_step"] / line["ms_per_step"]) < 1e-9
     # --dist-backward: the distributed closed-form gradients of the same model against the full-size reference golden
     gref = load_json("lml_c2_grad.json")
     db = line["dist_loss_backward"]
@@ -640,6 +647,27 @@ def test_bench_multi_rank_line_shared_gpu(device):
     want = [-gref["grad_loss"]["kernel.variance"][0] / case["variance"], -gref["grad_loss"]["kernel.length_scales"][0] / case["length_scales"],
             -gref["grad_loss"]["likelihood.variance"][0] / case["noise"]]      # golden: d loss / d log(theta)
     assert np.abs(np.asarray(db["grads_constrained"]) - np.asarray(want)).max() < 1e-7 * np.abs(want).max(), (db, want)
+
+
+def test_bench_launches_its_own_ranks(device):
+    """`python bench.py --gpus 2 ...` with NO launcher and no RANK / WORLD_SIZE in the environment (the way the driver
+    starts the N = 1 run): bench.py must start its ranks itself as a child torch.distributed.run, relay the one JSON
+    line and the exit code."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c1", "--tile", "128", "--steps", "2",
+                          "--warmup", "1", "--test-shared-gpu", "--no-extras"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    case = [c for c in LML if c["name"] == "C1_rbf_512_2"][0]
+    assert d["n_gpus"] == 2 and d["world_size_reported_by_backend"] == 2 and d["scaling"] == "strong"
+    assert abs(d["lml"] - case["lml"]) < 1e-8 and set(d["exchange_schedules"]) == {"bcast", "mesh"}
 
 
 def test_c_driver_single_rank_and_rccl_adapter(device):
@@ -687,15 +715,20 @@ def test_c_driver_single_rank_and_rccl_adapter(device):
         rccl.ncclCommDestroy(comm)
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_c_driver_multi_rank_shared_gpu(device, world):
+@pytest.mark.parametrize("world,schedule", [(2, "bcast"), (4, "bcast"), (8, "bcast"), (4, "mesh"), (8, "mesh")])
+def test_c_driver_multi_rank_shared_gpu(device, world, schedule):
     """the C-ABI driver on grids 1x2, 2x2 and 2x4 (the 8-GPU grid: every second tile of the row exchange
     gathered for the column exchange): `world` processes share cuda:0, the communicator callbacks
     run torch.distributed/gloo collectives (tools/dist_bench.py GPN_CDRIVER=1) -- the panel loop,
     packing, look-ahead and exchange order are the library's own."""
     import re
-    out = _torchrun(world, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_SHARED_GPU": "1", "GPN_CDRIVER": "1", "GPN_DIST_GRAD": "1"})
+    # schedule "mesh": GPN_DIST_MESH_EXCHANGE in the table's flags -- both engines (Python and C driver) then move their
+    # panels by the grouped point-to-point plan (small direct threshold so that the scatter + all-gather form runs too)
+    out = _torchrun(world, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_SHARED_GPU": "1", "GPN_CDRIVER": "1", "GPN_DIST_GRAD": "1",
+                                                                         "GPN_DIST_SCHEDULE": schedule, "GPN_DIST_MESH_DIRECT_BYTES": "65536"})
     assert out.returncode == 0, out.stderr[-3000:]
+    py_vals = [float(v) for v in re.findall(r"backend=gloo: lml=(-?[0-9.]+)", out.stdout)]
+    assert len(py_vals) == 3 and all(abs(v - [c for c in LML if c["name"] == "rbf_2048_8"][0]["lml"]) < 1e-8 for v in py_vals), out.stdout
     vals = [float(v) for v in re.findall(r"cdriver: lml=(-?[0-9.]+)", out.stdout)]
     case = [c for c in LML if c["name"] == "rbf_2048_8"][0]
     assert len(vals) == 2, out.stdout
@@ -1285,7 +1318,16 @@ def test_c_dist_consumer_runs(device, tmp_path):
         except subprocess.TimeoutExpired:
             continue
     if r is None:
-        pytest.xfail("the RCCL bootstrap of the C process did not complete within 120 s, twice, on this box")
+        # a bootstrap that hangs twice is a FAILURE of the C / RCCL path on this box, not an expected outcome: show what
+        # RCCL says about it
+        try:
+            dbg = subprocess.run([exe, "2048", "8", "512"], capture_output=True, text=True, timeout=60,
+                                 env=dict(os.environ, NCCL_SOCKET_IFNAME="lo", NCCL_DEBUG="INFO"))
+            tail = dbg.stdout[-3000:] + dbg.stderr[-3000:]
+        except subprocess.TimeoutExpired as exc:
+            tail = ((exc.stdout or b"")[-3000:] + (exc.stderr or b"")[-3000:]).decode(errors="replace") if isinstance(exc.stdout, bytes) or isinstance(exc.stderr, bytes) \
+                else str(exc.stdout)[-3000:] + str(exc.stderr)[-3000:]
+        pytest.fail("the RCCL bootstrap of the C process did not complete within 120 s, twice; NCCL_DEBUG=INFO of a third run:\n" + tail)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     mm = re.search(r"lml=(\S+) info=(\S+)", r.stdout)
     case = [c for c in LML if c["name"] == "rbf_2048_8"][0]

@@ -125,6 +125,30 @@ def test_jit_op_is_the_same_ladder():
         raise RuntimeError("no")
     with pytest.raises(RuntimeError, match="Max tries exceeded."):
         functions.jit_op(never, torch.eye(2, dtype=torch.float64))
+    # max_tries sets both the number of rungs and the first jitter, 10^(-max_tries + i) (functions.py:34-36)
+    seen.clear()
+    functions.jit_op(lambda m: op(m) if m[0, 0].item() < 1.005 else m, torch.eye(2, dtype=torch.float64), max_tries=3)
+    assert seen == [1.0, 1.0 + 1e-3] and True
+    calls = []
+
+    def counting(m):
+        calls.append(m[0, 0].item())
+        raise RuntimeError("no")
+    with pytest.raises(RuntimeError, match="Max tries exceeded."):
+        functions.jit_op(counting, torch.eye(2, dtype=torch.float64), max_tries=3)
+    assert calls == [1.0, 1.0 + 1e-3, 1.0 + 1e-2, 1.0 + 1e-1]
+    # the reference catches any Exception on the initial try but only RuntimeError on the jittered ones (functions.py:30, 38)
+
+    def value_error_first(m):
+        if m[0, 0].item() == 1.0:
+            raise ValueError("initial")
+        return m
+    assert functions.jit_op(value_error_first, torch.eye(2, dtype=torch.float64))[0, 0].item() == 1.0 + 1e-10
+
+    def value_error_later(m):
+        raise (RuntimeError("first") if m[0, 0].item() == 1.0 else ValueError("later"))
+    with pytest.raises(ValueError):
+        functions.jit_op(value_error_later, torch.eye(2, dtype=torch.float64))
     with pytest.raises(NativeError):          # the differentiable surface has no CPU path either
         gptorch_amd.util.squared_distance(torch.zeros(3, 2, dtype=torch.float64))
 
