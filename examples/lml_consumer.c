@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
   CHECK(hipStreamCreate(&s));
   GPN(gpn_lml_forward(s, GPN_RBF, X, n, d, Y, NULL, dy, th, th + 1, 1, th + 2, A, lda, winv, info, out3));
   GPN(gpn_lml_backward(s, GPN_RBF, X, n, d, th, th + 1, 1, A, lda, winv, dy, work, grads, NULL));
-  GPN(gpn_predict(s, GPN_RBF, X, n, d, Xs, ns, th, th + 1, 1, A, lda, winv, dy, 0, pwork, mean, var));
+  GPN(gpn_predict(s, GPN_RBF, X, n, d, Xs, ns, NULL /* zero mean function */, th, th + 1, 1, A, lda, winv, dy, 0, pwork, mean, var));
   CHECK(hipStreamSynchronize(s));
 
   int32_t hinfo;

@@ -1,0 +1,251 @@
+"""
+Composite covariance functions on the native path (csrc/kexpr.hip).
+
+gptorch composes kernels with `+` and `*` (kernels.py:286-306 Sum / Product); its own example model is
+`Linear + Rbf + Constant` (examples/regression_1d.py:34-53).  The reference evaluates such a tree with
+elementwise torch ops on dense N x M matrices.  Here a tree whose leaves are native terms -- a stationary
+kernel with a native kind (kernels.py:108-235), Linear (238-265), Constant / Bias (95-105), White (83-92) --
+is expanded into a SUM OF PRODUCTS of leaf instances and handed to gpn_kernel_matrix_expr, which writes the
+matrix once (for GPR: straight into the factor buffer); gradients come from gpn_kernel_expr_grad, one sweep per
+leaf instance, re-computing everything from the points.
+
+  Program          the expanded expression + the packing of all leaf parameters into one device vector
+  kernel_matrix    K(X, X2) of a Program (forward only)
+  ExprK            Kernel.K of a composite as ONE autograd node (parameter gradients; not w.r.t. the points)
+  ExprLogLik       GPR.log_likelihood (gpr.py:47-67) over a composite kernel as one autograd node: fused
+                   assembly -> native factorisation -> closed-form backward with the expression sweeps
+"""
+import ctypes
+
+import torch
+
+from . import _native, _ops
+from ._ops import _c, _ptr, _stream
+
+
+class Program:
+    """sum-of-products form of a kernel tree.  `leaves`: the distinct leaf kernel objects in first-visit order;
+    `groups`: list of lists of leaf indices (one list per product).  Parameters are packed leaf by leaf:
+    [variance(s), length-scale(s)] in their CONSTRAINED values."""
+
+    def __init__(self, leaves, groups):
+        self.leaves, self.groups = leaves, groups
+        if sum(len(g) for g in groups) > _native.EXPR_MAX_TERMS or len(groups) > _native.EXPR_MAX_GROUPS:
+            raise ValueError("expression too large for the fused evaluation")
+        self.offsets = []            # per leaf: (var_off, nvar, ls_off, nls)
+        off = 0
+        for k in leaves:
+            nvar = k.variance.numel()
+            nls = k.length_scales.numel() if hasattr(k, "length_scales") else 0
+            self.offsets.append((off, nvar, off + nvar, nls))
+            off += nvar + nls
+        self.ntheta = off
+        inst = [li for g in groups for li in g]                     # term instances, group by group
+        self.instances = inst
+        self.terms = (_native.ExprTerm * len(inst))()
+        for i, li in enumerate(inst):
+            k = leaves[li]
+            var_off, nvar, ls_off, nls = self.offsets[li]
+            self.terms[i] = _native.ExprTerm(_leaf_type(k), _ops.KINDS.get(getattr(k, "_kind", None) or "Rbf", 0), var_off, ls_off,
+                                             max(nls, 1), max(nvar, 1))
+        starts, pos = [0], 0
+        for g in groups:
+            pos += len(g)
+            starts.append(pos)
+        self.gstart = (ctypes.c_int * len(starts))(*starts)
+        self.ngroups = len(groups)
+
+    def params(self):
+        """the leaves' parameter tensors in packing order (constrained values, autograd-connected)."""
+        out = []
+        for k in self.leaves:
+            out.append(k.variance.transform())
+            if hasattr(k, "length_scales"):
+                out.append(k.length_scales.transform())
+        return out
+
+    def theta(self, params):
+        return torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+
+    def grad_supported(self, d):
+        """per-dimension parameters keep one accumulator per input in registers: d <= 16 (kexpr.hip)."""
+        return all(d <= 16 or (nvar == 1 and nls <= 1) for (_, nvar, _, nls) in self.offsets)
+
+    def scatter(self, per_instance, params):
+        """per-instance gradient vectors -> one gradient per parameter tensor (instances of one leaf add up)."""
+        flat = torch.zeros(self.ntheta, dtype=torch.float64, device=params[0].device)
+        for i, li in enumerate(self.instances):
+            var_off, nvar, ls_off, nls = self.offsets[li]
+            g = per_instance[i]
+            flat[var_off:var_off + nvar] += g[:nvar]
+            if nls:
+                flat[ls_off:ls_off + nls] += g[nvar:nvar + nls]
+        out, off = [], 0
+        for p in params:
+            out.append(flat[off:off + p.numel()].reshape(p.shape))
+            off += p.numel()
+        return out
+
+
+def _leaf_type(k):
+    from . import kernels
+    if isinstance(k, kernels.Stationary):
+        return _native.TERM_STATIONARY
+    if isinstance(k, kernels.Linear):
+        return _native.TERM_LINEAR
+    if isinstance(k, kernels.White):
+        return _native.TERM_WHITE
+    return _native.TERM_CONSTANT
+
+
+def build(kernel):
+    """-> Program for a tree of Sum / Product over native leaves, or None (some leaf has no native term, the
+    expansion is too large, or the kernel is a single stationary leaf, which has its own fused path)."""
+    from . import kernels
+
+    def expand(k):                      # -> list of products, each a list of leaf objects
+        if isinstance(k, kernels.Sum):
+            a, b = expand(k.kern1), expand(k.kern2)
+            return None if a is None or b is None else a + b
+        if isinstance(k, kernels.Product):
+            a, b = expand(k.kern1), expand(k.kern2)
+            if a is None or b is None or len(a) * len(b) > _native.EXPR_MAX_GROUPS:
+                return None
+            return [x + y for x in a for y in b]
+        native_stationary = isinstance(k, kernels.Stationary) and type(k).K is kernels.Stationary.K and k._kind in _ops.KINDS \
+            and k._kind != "SqDist"
+        simple = type(k) in (kernels.Linear, kernels.White, kernels.Constant, kernels.Bias)
+        return [[k]] if (native_stationary or simple) else None
+
+    sop = expand(kernel)
+    if sop is None:
+        return None
+    leaves = []
+    for prod in sop:
+        for k in prod:
+            if not any(k is q for q in leaves):
+                leaves.append(k)
+    groups = [[next(i for i, q in enumerate(leaves) if q is k) for k in prod] for prod in sop]
+    try:
+        return Program(leaves, groups)
+    except ValueError:
+        return None
+
+
+def kernel_matrix(prog, theta, X, X2=None, noise=None, out=None, ldk=None, lower=False):
+    """K(X, X2) of the expression as a new [n, m] tensor, or written into `out` (leading dimension ldk; lower: only the
+    tiles on / below the diagonal; noise: added on the diagonal of K(X))."""
+    _ops._req(X, X2, theta, noise)
+    X = _c(X.detach())
+    n, d = X.shape
+    if X2 is not None:
+        X2 = _c(X2.detach())
+        m = X2.shape[0]
+        if X2.shape[1] != d:
+            raise ValueError("X and X2 must have the same input dimension")
+    else:
+        m = n
+    if out is None:
+        out = torch.empty(n, m, dtype=torch.float64, device=X.device)
+        ldk = m
+    noise = None if noise is None else _c(noise.detach())
+    st = _native.lib().gpn_kernel_matrix_expr(_stream(X.device), prog.terms, len(prog.instances), prog.gstart, prog.ngroups, _ptr(theta),
+                                              _ptr(X), n, _ptr(X2), m, d, _ptr(noise), _ops.GPN_LOWER if lower else _ops.GPN_FULL,
+                                              _ptr(out), ldk)
+    _native.check(st, "gpn_kernel_matrix_expr")
+    return out
+
+
+def _sweeps(prog, theta, X, X2, G, ldg, at=None, ldat=0, dy=0):
+    """one gpn_kernel_expr_grad per leaf instance -> (list of per-instance gradient vectors, trace(W) or None)."""
+    lib = _native.lib()
+    X = _c(X.detach())
+    n, d = X.shape
+    X2c = None if X2 is None else _c(X2.detach())
+    m = n if X2c is None else X2c.shape[0]
+    lml = at is not None
+    work = torch.empty(max(1, int(lib.gpn_kernel_expr_grad_work_bytes(n, m, d, 1 if lml else 0)) // 8), dtype=torch.float64, device=X.device)
+    outs, trace = [], None
+    for i, li in enumerate(prog.instances):
+        _, nvar, _, nls = prog.offsets[li]
+        want_trace = 1 if (lml and i == 0) else 0
+        out = torch.empty(nvar + nls + want_trace, dtype=torch.float64, device=X.device)
+        st = lib.gpn_kernel_expr_grad(_stream(X.device), prog.terms, len(prog.instances), prog.gstart, prog.ngroups, _ptr(theta), i,
+                                      _ptr(X), n, _ptr(X2c), m, d, _ptr(G), ldg, _ptr(at), ldat, dy, want_trace, _ptr(work), _ptr(out))
+        _native.check(st, "gpn_kernel_expr_grad")
+        if want_trace:
+            trace = out[nvar + nls:nvar + nls + 1]
+        outs.append(out)
+    return outs, trace
+
+
+class ExprK(torch.autograd.Function):
+    """Kernel.K(X, X2) of a composite kernel: one fused assembly; backward = one sweep per leaf instance against the
+    incoming dense gradient.  Gradients w.r.t. the parameters only (callers that differentiate w.r.t. the points use the
+    composed path)."""
+
+    @staticmethod
+    def forward(ctx, X, X2, prog, *params):
+        theta = prog.theta(params)
+        ctx.prog, ctx.has_x2 = prog, X2 is not None
+        ctx.save_for_backward(X, X2 if X2 is not None else X, theta, *params)
+        return kernel_matrix(prog, theta, X, X2)
+
+    @staticmethod
+    def backward(ctx, gK):
+        from . import _backward
+        X, X2, theta, *params = ctx.saved_tensors
+        g = _backward._rowmajor(gK)
+        outs, _ = _sweeps(ctx.prog, theta, X, X2 if ctx.has_x2 else None, g, g.stride(0))
+        return (None, None, None) + tuple(ctx.prog.scatter(outs, params))
+
+
+class ExprLogLik(torch.autograd.Function):
+    """GPR.log_likelihood (gpr.py:47-67) for a composite kernel as ONE autograd node: the expression is assembled straight
+    into the factor buffer (one N x N write, noise on the diagonal), the factorisation carries the residual as extra
+    rows, and the backward is the closed form  dLML/dtheta = sum G o dKyy/dtheta  with  G = 1/2 (a a^T - dy Kyy^-1)
+    formed on the fly inside the expression sweeps -- no dense N x N tensor passes through autograd."""
+
+    @staticmethod
+    def forward(ctx, X, R, noise, prog, holder, *params):
+        theta = prog.theta(params)
+        n, e = R.shape
+        f = holder.get("factor")
+        if f is None or f.n != n or f.e != e or f.device != X.device:
+            f = _ops.Factor(n, e, X.device)
+        holder["factor"] = f
+        nz0 = _c(noise.detach())
+
+        def attempt(jitter):
+            kernel_matrix(prog, theta, X, None, noise=nz0 if jitter is None else nz0 + jitter, out=f.A, ldk=f.ld, lower=True)
+            f.pack_rhs(R)
+            return f.potrf()
+
+        f.jitter_rung = _ops._ladder(attempt)
+        ctx.prog, ctx.factor, ctx.generation = prog, f, f.generation
+        ctx.save_for_backward(X, R, noise, theta, *params)
+        return f.lml_terms()[2:3].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _backward
+        X, R, noise, theta, *params = ctx.saved_tensors
+        f, prog = ctx.factor, ctx.prog
+        if f.generation != ctx.generation:           # the reusable buffer was refactorised since: rebuild privately
+            f = _ops.Factor(R.shape[0], R.shape[1], X.device)
+
+            def attempt(jitter):
+                nz = _c(noise.detach())
+                kernel_matrix(prog, theta, X, None, noise=nz if jitter is None else nz + jitter, out=f.A, ldk=f.ld, lower=True)
+                f.pack_rhs(R)
+                return f.potrf()
+            _ops._ladder(attempt)
+        n, dy = f.n, f.e
+        U = _backward._upper_inverse(f)
+        Kinv = _backward._kinv_lower(f, U)
+        at = _ops.gemm_nt(f.A[n:], U, dy, n, _ops.round_up(n, 16), tri=_ops.TRI_B_UPPER)       # a^T = alpha^T U^T  [dy, n]
+        outs, trace = _sweeps(prog, theta, X, None, Kinv, Kinv.stride(0), at=at, ldat=at.stride(0), dy=dy)
+        go = grad_out.reshape(())
+        g_params = [go * g for g in prog.scatter(outs, params)]
+        return (None, -go * at.t() if ctx.needs_input_grad[1] else None, go * trace if ctx.needs_input_grad[2] else None,
+                None, None) + tuple(g_params)

@@ -49,16 +49,35 @@ SIGNATURES = {
                                    c_int, c_void_p, c_int64, c_double, c_int, c_void_p, c_void_p]),
     "gpn_lml_forward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                 c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "gpn_lml_refine_work_bytes": (c_int64, [c_int64, c_int]),
+    "gpn_lml_refine": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                               c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_lml_backward_work_bytes": (c_int64, [c_int64, c_int, c_int]),
     "gpn_lml_backward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                  c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gpn_predict_work_bytes": (c_int64, [c_int64, c_int64, c_int]),
-    "gpn_predict": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+    "gpn_predict": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                             c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gpn_transpose": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64]),
     "gpn_copy_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "gpn_row_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
 }
+class ExprTerm(ctypes.Structure):
+    """include/gpnative.h gpn_expr_term: one leaf of a sum-of-products covariance expression."""
+    _fields_ = [("type", c_int), ("kind", c_int), ("var_off", c_int), ("ls_off", c_int), ("nls", c_int), ("nvar", c_int)]
+
+
+TERM_STATIONARY, TERM_LINEAR, TERM_CONSTANT, TERM_WHITE = 0, 1, 2, 3
+EXPR_MAX_TERMS, EXPR_MAX_GROUPS = 16, 8
+SIGNATURES.update({
+    "gpn_kernel_matrix_expr": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p,
+                                       c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64]),
+    "gpn_kernel_expr_grad_work_bytes": (c_int64, [c_int64, c_int64, c_int, c_int]),
+    "gpn_kernel_expr_grad": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_int,
+                                     c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                                     c_void_p, c_void_p]),
+})
+
 # callback table of the distributed driver (include/gpnative.h gpn_dist_comm)
 BCAST_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)

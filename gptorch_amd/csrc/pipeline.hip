@@ -119,7 +119,7 @@ extern "C" int64_t gpn_predict_work_bytes(int64_t n, int64_t ns, int dy) {
 }
 
 extern "C" int gpn_predict(void* stream, int kind, const double* X, int64_t n, int d,
-                           const double* Xs, int64_t ns,
+                           const double* Xs, int64_t ns, const double* Ms,
                            const double* variance, const double* length_scales, int nls,
                            const double* A, int64_t lda, const double* winv, int dy, int full_cov,
                            double* work, double* mean, double* var) {
@@ -145,7 +145,9 @@ extern "C" int gpn_predict(void* stream, int kind, const double* X, int64_t n, i
     if (rc != GPN_OK) return rc;
   }
   const int64_t kp = round_up(n, 16);
-  rc = gpn_gemm_nt(stream, ns, dy, kp, 1.0, Bt, lda, A + n * lda, lda, 0.0, mean, dy, 0, 0);   // A^T V
+  // mean = m(x*) + A^T V (gpr.py:107-108): the mean function's values at the test points, if any, are the C operand
+  if (Ms) GPN_HIP_CHECK(hipMemcpyAsync(mean, Ms, (size_t)ns * dy * sizeof(double), hipMemcpyDeviceToDevice, s));
+  rc = gpn_gemm_nt(stream, ns, dy, kp, 1.0, Bt, lda, A + n * lda, lda, Ms ? 1.0 : 0.0, mean, dy, 0, 0);   // (+) A^T V
   if (rc != GPN_OK) return rc;
   if (!full_cov) {
     rc = gpn_row_sumsq(stream, Bt, ns, n, lda, var);

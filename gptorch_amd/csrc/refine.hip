@@ -1,0 +1,408 @@
+// gpn_lml_refine: one step of iterative refinement of the quadratic form y^T Kyy^-1 y of
+// GPR.log_likelihood (gpr.py:61-67: alpha = L^-1 (y - m), LML = -1/2 |alpha|^2 - ...).
+//
+// Why.  north_star asks for the LML within 1e-8 ABSOLUTE of the reference's CPU value.  At BASELINE config 3
+// (N = 32768, |LML| = 1.5e5) that is 7e-14 relative -- the rounding level of any fp64 factorisation: with
+// L L^T = Kyy + E the computed |alpha|^2 is y^T (Kyy + E)^-1 y = exact - a^T E a, |a|^2 = 9.5e6, and both MKL's
+// factor (3.4e-9 off) and ours (7.6e-9 off, the other way) are a few 1e-9 away from the exact value
+// (tests/golden/make_c3_extended.py).  One refinement step removes the factor's error from the value:
+//     a_hat = L^-T alpha                       (back-substitution: any approximate solution will do)
+//     r     = (y - m) - Kyy a_hat              (Kyy RE-COMPUTED from the points, entry for entry the
+//                                               arithmetic of the assembly; accumulated in double-double)
+//     y^T Kyy^-1 y = y^T a_hat + a_hat^T r + r^T Kyy^-1 r,   the last term is O(|E|^2) and dropped
+// so the result depends on the factorisation only to second order (and no longer on its summation order).
+// Cost: a pass over L (HBM) in N/128 dependent launches + one pass of kernel evaluations (vector ALU), about 3 %
+// of an evaluation at N = 32768; the shell applies it from GPN_REFINE_MIN_N rows on (gptorch_amd/_ops.py).
+//
+// Kernels: backsub_step_kernel (one launch per 128-column block, right-looking: s_j -= L_kj^T a_k for all columns left
+// of block k, and the workgroup that owns block k-1 goes on to a_{k-1} = W_{k-1}^T s_{k-1} with the stored leaf inverse),
+// refine_resid_kernel<KIND> (64 x 64 tiles of
+// Kyy times a_hat, row strips split into column segments; error-free products and sums: Ogita-Rump-Oishi Dot2),
+// refine_finish_kernel (r, the two dot products and the LML, one workgroup, double-double throughout).
+#include "gpn_common.h"
+#include "kernel_fn.h"
+
+namespace gpn {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ---- double-double accumulation (explicitly rounded intrinsics: never contracted into FMAs by the compiler) ----
+struct dd { double hi, lo; };
+__device__ __forceinline__ void two_sum(double a, double b, double& s, double& e) {
+  s = __dadd_rn(a, b);
+  const double bb = __dsub_rn(s, a);
+  e = __dadd_rn(__dsub_rn(a, __dsub_rn(s, bb)), __dsub_rn(b, bb));
+}
+__device__ __forceinline__ void dd_fma(dd& acc, double a, double b) {        // acc += a * b, error-free product and sum
+  const double p = __dmul_rn(a, b);
+  const double ep = __fma_rn(a, b, -p);
+  double s, es;
+  two_sum(acc.hi, p, s, es);
+  acc.hi = s;
+  acc.lo = __dadd_rn(acc.lo, __dadd_rn(es, ep));
+}
+__device__ __forceinline__ void dd_add(dd& acc, const dd x) {
+  double s, e;
+  two_sum(acc.hi, x.hi, s, e);
+  acc.hi = s;
+  acc.lo = __dadd_rn(acc.lo, __dadd_rn(e, x.lo));
+}
+
+constexpr int RT = 64;        // tile edge of the residual kernel (= kmat.hip's KT)
+constexpr int RDC = 16;       // coordinates staged per pass (= kmat.hip's DC: the same summation order over d)
+constexpr int RDY = 2;        // right-hand sides per pass when dy > 1
+constexpr int BS_COLS = 128;  // columns per workgroup of the back-substitution update = one leaf block
+
+// s <- alpha^T (the first n entries of the factor buffer's extra rows; what is right of them is the corner that
+// accumulated -alpha alpha^T), zero padded to lds
+__global__ void refine_init_kernel(const double* A, int64_t lda, int64_t n, int dy, double* s, int64_t lds) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= lds) return;
+  for (int c = 0; c < dy; ++c) s[(int64_t)c * lds + i] = i < n ? A[(n + c) * lda + i] : 0.0;
+}
+
+// One step of the back-substitution L^T a = alpha, right-looking over 128-wide blocks, ONE launch per block and nothing
+// else on the chain:
+//   * every workgroup owns one leaf block j < k of columns and applies  s_j -= L[block k rows, block j cols]^T a_k
+//     (a_k was stored by the launch before; all 32 x 16-byte loads of a thread are issued before the first use, so the
+//     launch costs one memory round trip);
+//   * workgroup 0 owns block k-1, whose s is FINAL after this update (blocks k+1 ... nb-1 were applied by the earlier
+//     launches): it goes on to a_{k-1} = W_{k-1}^T s_{k-1} with the stored leaf inverse W = L_{k-1,k-1}^-1 and stores it
+//     for the next launch -- the 128 x 128 product never gets a launch (or a redundant copy per workgroup) of its own.
+// k = nb (first launch, one workgroup): no update, a_{nb-1} from alpha.  NRHS right-hand sides c0 .. c0+NRHS-1.
+template <int NRHS>
+__global__ __launch_bounds__(256) void backsub_step_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ winv,
+                                                           int k, int nb, int64_t n, int dy, int c0, double* __restrict__ s,
+                                                           double* __restrict__ a, int64_t lds) {
+  __shared__ double ak[NRHS][LEAF];
+  __shared__ double part[4][NRHS][BS_COLS];
+  __shared__ double sj[NRHS][LEAF];
+  const int t = threadIdx.x;
+  const int nc = min(NRHS, dy - c0);
+  const int jb = k - 1 - (int)blockIdx.x;                  // my column block (workgroup 0: block k-1)
+  const int64_t col0 = (int64_t)jb * LEAF;
+  const int cp = t & 63, g = t >> 6;                       // column pair (2 cp, 2 cp + 1), row group g: rows 32 g .. 32 g + 31
+  double upd0[NRHS], upd1[NRHS];
+#pragma unroll
+  for (int c = 0; c < NRHS; ++c) upd0[c] = upd1[c] = 0.0;
+  if (k < nb) {
+    const int64_t r0 = (int64_t)k * LEAF;
+    const int kb = (int)min((int64_t)LEAF, n - r0);        // ragged last block: the rows behind it are the extra rows, not L
+    const d2* Lp = reinterpret_cast<const d2*>(A + (r0 + g * 32) * lda + col0 + 2 * cp);
+    d2 l[32];
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) l[rr] = (g * 32 + rr < kb) ? Lp[(int64_t)rr * (lda / 2)] : d2{0.0, 0.0};
+    if (t < LEAF)
+      for (int c = 0; c < nc; ++c) ak[c][t] = a[(int64_t)(c0 + c) * lds + r0 + t];
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr)
+#pragma unroll
+      for (int c = 0; c < NRHS; ++c) {
+        const double av = ak[c][g * 32 + rr];
+        upd0[c] = fma(l[rr].x, av, upd0[c]);
+        upd1[c] = fma(l[rr].y, av, upd1[c]);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < NRHS; ++c) {
+    part[g][c][2 * cp] = upd0[c];
+    part[g][c][2 * cp + 1] = upd1[c];
+  }
+  __syncthreads();
+  if (t < LEAF)
+    for (int c = 0; c < nc; ++c) {
+      const int64_t idx = (int64_t)(c0 + c) * lds + col0 + t;
+      const double v = s[idx] - ((part[0][c][t] + part[1][c][t]) + (part[2][c][t] + part[3][c][t]));
+      if (k < nb) s[idx] = v;
+      sj[c][t] = v;
+    }
+  if (blockIdx.x != 0) return;
+  __syncthreads();
+  // a_j[i] = sum_{r >= i} W[r][i] s_j[r]  (W lower triangular; rows past a ragged block's end are padding)
+  const double* W = winv + (int64_t)jb * LEAF * LEAF;
+  const int jbn = (int)min((int64_t)LEAF, n - col0);
+  d2 w[32];
+#pragma unroll
+  for (int rr = 0; rr < 32; ++rr) {
+    const int r = g * 32 + rr;
+    w[rr] = (r < jbn && r >= 2 * cp) ? *reinterpret_cast<const d2*>(W + (int64_t)r * LEAF + 2 * cp) : d2{0.0, 0.0};
+  }
+  double acc0[NRHS], acc1[NRHS];
+#pragma unroll
+  for (int c = 0; c < NRHS; ++c) acc0[c] = acc1[c] = 0.0;
+#pragma unroll
+  for (int rr = 0; rr < 32; ++rr) {
+    const int r = g * 32 + rr;
+#pragma unroll
+    for (int c = 0; c < NRHS; ++c) {
+      const double sv = sj[c][r];
+      acc0[c] = fma(w[rr].x, sv, acc0[c]);
+      acc1[c] = (r >= 2 * cp + 1) ? fma(w[rr].y, sv, acc1[c]) : acc1[c];   // (W[2cp][2cp+1] is above the diagonal)
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NRHS; ++c) {
+    part[g][c][2 * cp] = acc0[c];
+    part[g][c][2 * cp + 1] = acc1[c];
+  }
+  __syncthreads();
+  if (t < LEAF)
+    for (int c = 0; c < nc; ++c)
+      a[(int64_t)(c0 + c) * lds + col0 + t] = t < jbn ? (part[0][c][t] + part[1][c][t]) + (part[2][c][t] + part[3][c][t]) : 0.0;
+}
+
+struct RefineArgs {
+  const double* X;
+  const double* variance;
+  const double* ls;
+  const double* noise;
+  const double* a;       // [dy][lds]
+  double* partial;       // [nseg][dy][lds][2]
+  int64_t lds;
+  int n, d, nls, dy, nseg, tiles_per_seg;
+};
+
+// partial[seg][c][row] = sum over the column tiles of segment `seg` of Kyy[row, col] * a[c][col] in double-double.
+// Tile structure, staging and the order of the sum over coordinates are kmat_kernel's, so that every entry is
+// bit for bit the one the assembly wrote into the factor buffer.
+template <int KIND, int NRHS>
+__global__ __launch_bounds__(256) void refine_resid_kernel(RefineArgs p) {
+  __shared__ __attribute__((aligned(16))) double xs[RDC][RT];
+  __shared__ __attribute__((aligned(16))) double ys[RDC][RT];
+  __shared__ double inv_ell[RDC];
+  __shared__ double av[NRHS][RT];
+  __shared__ double red[2][RT][17];
+  const int ti = blockIdx.x, seg = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int i0 = ti * RT;
+  const int ntile = (p.n + RT - 1) / RT;
+  const int tj0 = seg * p.tiles_per_seg, tj1 = min(ntile, tj0 + p.tiles_per_seg);
+  const double var = p.variance[0], noise = p.noise[0];
+
+  for (int c0 = 0; c0 < p.dy; c0 += NRHS) {
+    const int nc = min(NRHS, p.dy - c0);
+    dd racc[4][NRHS];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < NRHS; ++c) racc[a][c] = dd{0.0, 0.0};
+
+    for (int tj = tj0; tj < tj1; ++tj) {
+      const int j0 = tj * RT;
+      double acc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+      // the assembly computes entry (i, j), i >= j, from (x_i - x_j); (x_j - x_i)^2 is the same number, so the upper
+      // triangle needs no swap of the operands
+      for (int d0 = 0; d0 < p.d; d0 += RDC) {
+        if (tid < RDC) {
+          const int dd_ = d0 + tid;
+          inv_ell[tid] = dd_ < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : dd_] : 0.0;
+        }
+        __syncthreads();
+        {
+          const int pt = tid >> 2, c4 = (tid & 3) * 4;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int dd_ = d0 + c4 + c;
+            double vx = 0.0, vy = 0.0;
+            if (dd_ < p.d) {
+              const double ie = inv_ell[c4 + c];
+              if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd_] * ie;
+              if (j0 + pt < p.n) vy = p.X[(int64_t)(j0 + pt) * p.d + dd_] * ie;
+            }
+            xs[c4 + c][pt] = vx;
+            ys[c4 + c][pt] = vy;
+          }
+        }
+        if (d0 == 0 && tid < RT)
+          for (int c = 0; c < nc; ++c) av[c][tid] = j0 + tid < p.n ? p.a[(int64_t)(c0 + c) * p.lds + j0 + tid] : 0.0;
+        __syncthreads();
+        const int dmax = min(RDC, p.d - d0);
+        for (int dd_ = 0; dd_ < dmax; ++dd_) {
+          const d2 xa = *reinterpret_cast<const d2*>(&xs[dd_][ty * 4]);
+          const d2 xb = *reinterpret_cast<const d2*>(&xs[dd_][ty * 4 + 2]);
+          const d2 ya = *reinterpret_cast<const d2*>(&ys[dd_][tx * 2]);
+          const d2 yb = *reinterpret_cast<const d2*>(&ys[dd_][32 + tx * 2]);
+          const double xr[4] = {xa.x, xa.y, xb.x, xb.y};
+          const double yc[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const double df = xr[a] - yc[b];
+              acc[a][b] = fma(df, df, acc[a][b]);
+            }
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int row = i0 + ty * 4 + a;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int cl = (b >> 1) * 32 + tx * 2 + (b & 1);
+          const int col = j0 + cl;
+          double v = kernel_of_r2<KIND>(acc[a][b], var);
+          if (row == col) v += noise;
+          if (row >= p.n || col >= p.n) v = 0.0;
+#pragma unroll
+          for (int c = 0; c < NRHS; ++c)
+            if (NRHS == 1 || c < nc) dd_fma(racc[a][c], v, av[c][cl]);
+        }
+      }
+      // (av / xs / ys are rewritten only behind the barriers at the top of the next tile's staging)
+    }
+    // reduce the 16 tx lanes of a row in a fixed order
+    for (int c = 0; c < nc; ++c) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        red[0][ty * 4 + a][tx] = racc[a][c].hi;
+        red[1][ty * 4 + a][tx] = racc[a][c].lo;
+      }
+      __syncthreads();
+      if (tid < RT && i0 + tid < p.n) {
+        dd sum{red[0][tid][0], red[1][tid][0]};
+        for (int q = 1; q < 16; ++q) dd_add(sum, dd{red[0][tid][q], red[1][tid][q]});
+        double* out = p.partial + (((int64_t)seg * p.dy + (c0 + c)) * p.lds + i0 + tid) * 2;
+        out[0] = sum.hi;
+        out[1] = sum.lo;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// r = (y - m) - sum_seg partial;  quad = sum_c sum_i a_i ((y - m)_i + r_i);  out3[1] = quad, out3[2] = LML (gpr.py:63-67)
+__global__ __launch_bounds__(1024) void refine_finish_kernel(const double* Y, const double* M, const double* a, const double* partial,
+                                                             int64_t n, int dy, int nseg, int64_t lds, double* out3, double* resid_norm) {
+  constexpr int NT = 1024;
+  __shared__ double rh[NT], rl[NT], rn[NT];
+  const int tid = threadIdx.x;
+  dd q{0.0, 0.0};
+  double rmax = 0.0;
+  for (int c = 0; c < dy; ++c)
+    for (int64_t i = tid; i < n; i += NT) {
+      dd ka{0.0, 0.0};
+      for (int sgm = 0; sgm < nseg; ++sgm) {
+        const double* pp = partial + (((int64_t)sgm * dy + c) * lds + i) * 2;
+        dd_add(ka, dd{pp[0], pp[1]});
+      }
+      double y = Y[i * dy + c];
+      if (M) y -= M[i * dy + c];                       // (one rounding, as in the extra rows the factorisation consumed)
+      // t = y + r = 2 y - Kyy a, as a double-double
+      dd tt{0.0, 0.0};
+      dd_add(tt, dd{-ka.hi, -ka.lo});
+      dd_add(tt, dd{y, 0.0});
+      rmax = fmax(rmax, fabs(tt.hi));                  // |r_i| (diagnostic)
+      dd_add(tt, dd{y, 0.0});
+      const double ai = a[(int64_t)c * lds + i];
+      dd_fma(q, ai, tt.hi);
+      q.lo = fma(ai, tt.lo, q.lo);
+    }
+  rh[tid] = q.hi; rl[tid] = q.lo; rn[tid] = rmax;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if (tid < s) {
+      dd x{rh[tid], rl[tid]};
+      dd_add(x, dd{rh[tid + s], rl[tid + s]});
+      rh[tid] = x.hi; rl[tid] = x.lo;
+      rn[tid] = fmax(rn[tid], rn[tid + s]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double quad = rh[0] + rl[0];
+    const double logdet = out3[0];
+    out3[1] = quad;
+    out3[2] = -0.5 * quad - (double)dy * logdet - 0.5 * (double)dy * (double)n * 1.8378770664093454836;
+    if (resid_norm) resid_norm[0] = rn[0];
+  }
+}
+
+struct RefineLayout { int64_t lds, s, a, partial, norm, total; int nseg, tiles_per_seg; };
+static RefineLayout refine_layout(int64_t n, int dy) {
+  RefineLayout L;
+  L.lds = round_up(n, LEAF);
+  const int64_t ntile = (n + RT - 1) / RT;
+  // enough workgroups for ~8 per CU: row tiles x segments >= 2048, at least 8 column tiles per segment
+  int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(2048 / std::max<int64_t>(ntile, 1), ntile / 8));
+  L.tiles_per_seg = (int)((ntile + nseg - 1) / nseg);
+  L.nseg = (int)((ntile + L.tiles_per_seg - 1) / L.tiles_per_seg);
+  L.s = 0;
+  L.a = L.s + (int64_t)dy * L.lds;
+  L.partial = L.a + (int64_t)dy * L.lds;
+  L.norm = L.partial + (int64_t)L.nseg * dy * L.lds * 2;
+  L.total = L.norm + 8;
+  return L;
+}
+
+}  // namespace gpn
+
+using namespace gpn;
+
+extern "C" int64_t gpn_lml_refine_work_bytes(int64_t n, int dy) {
+  if (n < 0 || dy <= 0) return 0;
+  return refine_layout(n, dy).total * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n, int d,
+                              const double* Y, const double* M, int dy,
+                              const double* variance, const double* length_scales, int nls, const double* noise,
+                              const double* A, int64_t lda, const double* winv, double* work, double* out3) {
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
+  if (!X) return -3;
+  if (n < 0) return -4;
+  if (d <= 0) return -5;
+  if (!Y) return -6;
+  if (dy <= 0) return -8;
+  if (!variance || !length_scales) return -9;
+  if (nls != 1 && nls != d) return -11;
+  if (!noise) return -12;
+  if (!A) return -13;
+  if (lda != gpn_factor_ld(n, dy)) return -14;
+  if (!winv) return -15;
+  if (!work) return -16;
+  if (!out3) return -17;
+  if (n == 0) return GPN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const RefineLayout L = refine_layout(n, dy);
+  double* sv = work + L.s;
+  double* av = work + L.a;
+  hipLaunchKernelGGL(refine_init_kernel, dim3((unsigned)((L.lds + 255) / 256)), dim3(256), 0, s, A, lda, n, dy, sv, L.lds);
+  GPN_LAUNCH_CHECK();
+  const int nb = (int)((n + LEAF - 1) / LEAF);
+  for (int c0 = 0; c0 < dy; c0 += (dy == 1 ? 1 : RDY))
+    for (int k = nb; k >= 1; --k) {                 // launch k: update blocks < k by a_k (k < nb), then a_{k-1}
+      if (dy == 1) hipLaunchKernelGGL(backsub_step_kernel<1>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
+      else hipLaunchKernelGGL(backsub_step_kernel<RDY>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
+    }
+  GPN_LAUNCH_CHECK();
+  RefineArgs p;
+  p.X = X; p.variance = variance; p.ls = length_scales; p.noise = noise; p.a = av;
+  p.partial = work + L.partial; p.lds = L.lds;
+  p.n = (int)n; p.d = d; p.nls = nls; p.dy = dy; p.nseg = L.nseg; p.tiles_per_seg = L.tiles_per_seg;
+  const dim3 grid((unsigned)((n + RT - 1) / RT), (unsigned)L.nseg);
+#define GPN_RESID(KIND)                                                                             \
+  do {                                                                                              \
+    if (dy == 1) hipLaunchKernelGGL((refine_resid_kernel<KIND, 1>), grid, dim3(256), 0, s, p);      \
+    else hipLaunchKernelGGL((refine_resid_kernel<KIND, RDY>), grid, dim3(256), 0, s, p);            \
+  } while (0)
+  switch (kind) {
+    case GPN_RBF: GPN_RESID(GPN_RBF); break;
+    case GPN_MATERN52: GPN_RESID(GPN_MATERN52); break;
+    case GPN_MATERN32: GPN_RESID(GPN_MATERN32); break;
+    case GPN_EXP: GPN_RESID(GPN_EXP); break;
+    default: GPN_RESID(GPN_PERIODIC); break;
+  }
+#undef GPN_RESID
+  GPN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(1024), 0, s, Y, M, av, work + L.partial, n, dy, L.nseg, L.lds, out3, work + L.norm);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}

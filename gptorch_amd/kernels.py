@@ -286,18 +286,43 @@ class Linear(Kernel):
 
 
 class Combination(Kernel):
+    """kernels.py:268-283.  A tree of Sum / Product whose leaves are native terms (stationary kinds, Linear, Constant /
+    Bias, White) is evaluated by ONE fused pass (csrc/kexpr.hip through gptorch_amd/_expr.py: the matrix is written
+    once, the backward is one sweep per leaf); anything else -- a leaf without a native term, inputs that require
+    gradients themselves -- composes the children's matrices the way the reference does."""
+
     def __init__(self, k1, k2):
         if not k1.input_dim == k2.input_dim:
             raise ValueError("Kernels must have same input dimension")
         super().__init__(k1.input_dim)
         self.kern1, self.kern2 = k1, k2
 
+    def fused_program(self):
+        """the expression program of this tree (gptorch_amd._expr.Program) or None; rebuilt on every call (cheap: a
+        dozen Python objects) so that a tree edited after construction is never evaluated from a stale program."""
+        from . import _expr
+        return _expr.build(self)
+
+    def _fused_K(self, X, X2):
+        if isinstance(X, np.ndarray):
+            X = as_tensor(X).to(self.kern1.variance.device)
+        if isinstance(X2, np.ndarray):
+            X2 = as_tensor(X2).to(self.kern1.variance.device)
+        if not X.is_cuda or X.requires_grad or (X2 is not None and X2.requires_grad):
+            return None
+        from . import _expr
+        prog = self.fused_program()
+        if prog is None or not prog.grad_supported(X.shape[1]):
+            return None
+        return _expr.ExprK.apply(X, X2, prog, *prog.params())
+
 
 class Sum(Combination):
     """kernels.py:286-295."""
 
     def K(self, X, X2=None):
-        return self.kern1.K(X, X2) + self.kern2.K(X, X2)
+        K = self._fused_K(X, X2)
+        return K if K is not None else self.kern1.K(X, X2) + self.kern2.K(X, X2)
 
     def Kdiag(self, X):
         return self.kern1.Kdiag(X) + self.kern2.Kdiag(X)
@@ -307,7 +332,8 @@ class Product(Combination):
     """kernels.py:298-306."""
 
     def K(self, X, X2=None):
-        return self.kern1.K(X, X2) * self.kern2.K(X, X2)
+        K = self._fused_K(X, X2)
+        return K if K is not None else self.kern1.K(X, X2) * self.kern2.K(X, X2)
 
     def Kdiag(self, X):
         return self.kern1.Kdiag(X) * self.kern2.Kdiag(X)

@@ -30,6 +30,14 @@ class GPR(GPModel):
         k = self.kernel
         return k if isinstance(k, kernels.Stationary) and k._kind is not None else None
 
+    def _expression(self, x):
+        """the fused-expression program of a composite kernel (gptorch_amd._expr) or None (dense-K path)."""
+        k = self.kernel
+        if not isinstance(k, kernels.Combination) or not x.is_cuda or x.requires_grad:
+            return None
+        prog = k.fused_program()
+        return prog if prog is not None and prog.grad_supported(x.shape[1]) else None
+
     def log_likelihood(self, x=None, y=None):
         """gpr.py:47-67; returns a tensor of shape (1,)."""
         x = x if x is not None else self.X
@@ -39,6 +47,12 @@ class GPR(GPModel):
         k = self._stationary()
         resid = y - self.mean_function(x)
         if k is None:
+            prog = self._expression(x)
+            if prog is not None:
+                # composite kernel with native leaves (e.g. the reference's example Linear + Rbf + Constant,
+                # examples/regression_1d.py:34-53): fused assembly into the factor buffer, expression sweeps in the backward
+                from .. import _expr
+                return _expr.ExprLogLik.apply(x, resid, self.likelihood.variance.transform(), prog, self._holder, *prog.params())
             return _ops.DenseLogLik.apply(self.kernel.K(x), resid, self.likelihood.variance.transform())
         return _ops.GPRLogLik.apply(x, resid, k.variance.transform(), k.length_scales.transform(),
                                     self.likelihood.variance.transform(), k._kind, self._holder)
@@ -100,9 +114,8 @@ class GPR(GPModel):
         with torch.no_grad():
             # from the third prediction with the same factor on, the right-solve chain is replaced
             # by one contraction with the explicit inverse (built once, n^3/3 flops)
-            mean, v = _ops.gpr_predict(k._kind, x, x_new, var, ls, f, diag=diag,
-                                       use_inverse=self._predict_calls >= INVERSE_AFTER_CALLS)
-            mean_f = mean + self.mean_function(x_new)
+            mean_f, v = _ops.gpr_predict(k._kind, x, x_new, var, ls, f, diag=diag,
+                                         use_inverse=self._predict_calls >= INVERSE_AFTER_CALLS, mean_new=self.mean_function(x_new))
             var_f = v[:, None].expand_as(mean_f) if diag else v
         return mean_f, var_f
 

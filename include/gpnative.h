@@ -211,6 +211,45 @@ int gpn_kernel_grad_x2(void* stream, int kind, const double* X, int64_t n, const
                        const double* G, int64_t ldg, double scale, int accumulate,
                        double* work, double* out);
 
+/* ---- composite covariance functions (kernels.py:286-306 Sum / Product over the leaves below) in one pass --------
+ * The reference composes `k1 + k2`, `k1 * k2` with elementwise torch ops on dense N x M matrices, one assembly chain per
+ * leaf -- e.g. its own example model Linear + Rbf + Constant (examples/regression_1d.py:34-53).  Here the expression is
+ * expanded by the caller into a SUM OF PRODUCTS of leaf terms,  K = sum_g prod_{t in group g} term_t,  and evaluated per
+ * tile: the matrix is written once (uplo / noise / ldk exactly as gpn_kernel_matrix, so a GPR over a composite kernel
+ * assembles straight into the factor buffer).  Leaves: a stationary kernel (kernels.py:108-235; kind = GPN_RBF ...
+ * GPN_PERIODIC, variance at theta[var_off], length-scale(s) at theta[ls_off .. +nls), nls in {1, d}); Linear
+ * (kernels.py:238-265: sum_d x_d v_d x'_d, v at theta[var_off .. +nvar), nvar in {1, d}); Constant / Bias
+ * (kernels.py:95-105: theta[var_off]); White (kernels.py:83-92: theta[var_off] on the diagonal of K(X), 0 for K(X, X2)).
+ * theta: ONE device array holding every leaf's constrained parameter values. */
+enum { GPN_TERM_STATIONARY = 0, GPN_TERM_LINEAR = 1, GPN_TERM_CONSTANT = 2, GPN_TERM_WHITE = 3 };
+enum { GPN_EXPR_MAX_TERMS = 16, GPN_EXPR_MAX_GROUPS = 8 };
+typedef struct gpn_expr_term {
+  int type;      /* GPN_TERM_* */
+  int kind;      /* stationary: GPN_RBF ... GPN_PERIODIC */
+  int var_off;   /* offset of the variance(s) in theta */
+  int ls_off;    /* stationary: offset of the length-scale(s) in theta */
+  int nls;       /* stationary: 1 or d */
+  int nvar;      /* linear: 1 or d (1 otherwise) */
+} gpn_expr_term;
+/* terms[nterms] (host), group_start[ngroups + 1] (host): group g = terms group_start[g] .. group_start[g+1]-1. */
+int gpn_kernel_matrix_expr(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                           const double* theta, const double* X, int64_t n, const double* X2, int64_t m, int d,
+                           const double* noise, int uplo, double* K, int64_t ldk);
+/* The matching backward sweep for ONE leaf instance `target` (index into terms):
+ *     out[p] = sum_ij W_ij * prod_{t' != target in its group} term_t'(x_i, x_j) * d term_target(x_i, x_j) / d theta_p
+ * with p over the target's parameters in the order variance, length-scale(s) (stationary) / variance(s) (linear) /
+ * variance (constant, white), everything re-computed from the points.  W is either a given dense [n, m] matrix G
+ * (at == NULL: the autograd backward of Kernel.K) or, with at != NULL (X2 must be NULL), the closed-form dLML/dKyy =
+ * 1/2 (a a^T - dy Kyy^-1) formed on the fly from G = Kyy^-1 (lower triangle read) and a^T [dy, n]; then want_trace != 0
+ * appends trace(W) (= dLML/d noise) as one more output.  One launch reads W once; a kernel of T leaf instances costs T
+ * launches.  Per-dimension parameters (ARD length-scales, Linear with one variance per input) need d <= 16
+ * (GPN_E_UNSUPPORTED beyond).  work: gpn_kernel_expr_grad_work_bytes(n, m, d, lml) bytes. */
+int64_t gpn_kernel_expr_grad_work_bytes(int64_t n, int64_t m, int d, int lml);
+int gpn_kernel_expr_grad(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                         const double* theta, int target, const double* X, int64_t n, const double* X2, int64_t m, int d,
+                         const double* G, int64_t ldg, const double* at, int64_t ldat, int dy, int want_trace,
+                         double* work, double* out);
+
 /* ---- whole-path entry points: one call per reference method -------------------
  * Fixed sequences of the entry points above on ONE stream (no host synchronisation, no
  * allocation) for callers that do not want to issue them one by one.
@@ -228,6 +267,21 @@ int gpn_lml_forward(void* stream, int kind, const double* X, int64_t n, int d,
                     const double* noise, double* A, int64_t lda, double* winv,
                     int32_t* info, double* out3);
 
+/* gpn_lml_refine: one step of iterative refinement of the quadratic form of gpr.py:61-67, to be called after a
+ * gpn_lml_forward that returned info == 0 (same arguments; A / winv read only).  The factor satisfies
+ * L L^T = Kyy + E, so |alpha|^2 = y^T (Kyy + E)^-1 y carries -a^T E a -- a few 1e-9 ABSOLUTE at N = 32768, where
+ * |LML| = 1.5e5 and north_star's 1e-8 is 7e-14 relative (the reference's own fp64 value is 3.4e-9 from the exact one
+ * there).  This call computes a_hat = L^-T alpha (back-substitution), r = (y - m) - Kyy a_hat with Kyy re-computed
+ * from the points and double-double accumulation, and replaces out3[1] by y^T a_hat + a_hat^T r (exact up to
+ * r^T Kyy^-1 r = O(|E|^2)) and out3[2] by the LML with it; out3[0] (log-det) is kept.  Cost: one pass over L in
+ * n/128 dependent launches + one pass of kernel evaluations (about 3 % of an evaluation at N = 32768); pointless
+ * below N of about 10^4, where the plain value is already within 1e-9.  work: gpn_lml_refine_work_bytes(n, dy). */
+int64_t gpn_lml_refine_work_bytes(int64_t n, int dy);
+int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n, int d,
+                   const double* Y, const double* M, int dy,
+                   const double* variance, const double* length_scales, int nls, const double* noise,
+                   const double* A, int64_t lda, const double* winv, double* work, double* out3);
+
 /* gpn_lml_backward = the autograd backward of gpr.py:47-67 in closed form (what PyTorch's
  * CholeskyBackward0 + TriangularSolveBackward0 + elementwise chain compute for the reference):
  * U = L^-T, Kyy^-1 = U U^T, a = U alpha, one sweep.  grads[0] = dLML/d variance,
@@ -240,14 +294,15 @@ int gpn_lml_backward(void* stream, int kind, const double* X, int64_t n, int d,
                      const double* A, int64_t lda, const double* winv, int dy,
                      double* work, double* grads, double* grad_resid);
 
-/* gpn_predict = GPR._predict (gpr.py:88-117) for a zero mean function, given the factor of
- * gpn_lml_forward: mean [ns, dy] = A^T V with A = L^-1 K(X, x*), V = alpha;
+/* gpn_predict = GPR._predict (gpr.py:88-117), given the factor of gpn_lml_forward (whose extra rows hold
+ * V = L^-1 (Y - m(X)), i.e. the training-side mean function went in through gpn_lml_forward's M):
+ * mean [ns, dy] = Ms + A^T V with A = L^-1 K(X, x*) and Ms [ns, dy] = the mean function at the test points
+ * (gpr.py:107-108; NULL = zero mean, mean_functions.py:42-49);
  * var = [ns] K_diag - colsumsq(A) (full_cov == 0; the reference expands it to [ns, dy])
- * or [ns, ns] K(x*) - A^T A.  A non-zero mean function is added to `mean` by the caller
- * (gpr.py:108).  work: gpn_predict_work_bytes(n, ns, dy) bytes. */
+ * or [ns, ns] K(x*) - A^T A.  work: gpn_predict_work_bytes(n, ns, dy) bytes. */
 int64_t gpn_predict_work_bytes(int64_t n, int64_t ns, int dy);
 int gpn_predict(void* stream, int kind, const double* X, int64_t n, int d,
-                const double* Xs, int64_t ns,
+                const double* Xs, int64_t ns, const double* Ms,
                 const double* variance, const double* length_scales, int nls,
                 const double* A, int64_t lda, const double* winv, int dy, int full_cov,
                 double* work, double* mean, double* var);

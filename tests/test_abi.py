@@ -71,7 +71,7 @@ def test_argument_validation_without_launch():
     assert lib.gpn_lml_forward(null, 0, null, -1, 2, null, null, 1, null, null, 1, null, null, 128, null, null, null) == -4
     assert lib.gpn_lml_forward(null, 0, null, 4, 2, null, null, 1, null, null, 1, null, null, 128, null, null, null) == -6
     assert lib.gpn_lml_backward(null, 0, null, 4, 2, null, null, 1, null, 128, null, 1, null, null, null) == -9
-    assert lib.gpn_predict(null, 0, null, 4, 2, null, 3, null, null, 1, null, 128, null, 1, 0, null, null, null) == -6
+    assert lib.gpn_predict(null, 0, null, 4, 2, null, 3, null, null, null, 1, null, 128, null, 1, 0, null, null, null) == -6
     assert lib.gpn_lml_backward_work_bytes(1000, 2, 3) >= 2 * lib.gpn_factor_rows(1000, 0) * lib.gpn_factor_ld(1000, 0) * 8
     assert lib.gpn_predict_work_bytes(1000, 5, 2) == 128 * lib.gpn_factor_ld(1000, 2) * 8
     # distributed driver: grid / tile validation and workspace sizing are pure host code
