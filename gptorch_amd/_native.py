@@ -93,6 +93,10 @@ SIGNATURES.update({
     "gpn_dist_lml_grad": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_void_p]),
+    "gpn_dist_predict_work_bytes": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int]),
+    "gpn_dist_predict": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
+                                 c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
+                                 c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_dist_lml_forward": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                      c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
 })
@@ -121,38 +125,92 @@ def rccl_lib():
     return _rccl_lib
 
 
-# not part of the public header: debugging switches
+# not part of the public header.  The profiler hooks live in the product library; the A/B switches (kernel / driver
+# variants per calling thread, CU-masked streams, the instrumented leaf) only in the tools' build libgpnative_dbg.so
+# (same sources, -DGPN_DEBUG_SWITCHES): the shipped library carries no mutable debug state.
+PROFILE_SIGNATURES = {
+    "gpn_profile_enable": (c_int, [c_int]),
+    "gpn_profile_collect": (c_int, [ctypes.POINTER(c_double)]),
+    "gpn_profile_collect_classes": (c_int, [ctypes.POINTER(c_double), c_int]),
+}
 DEBUG_SIGNATURES = {
     "gpn_debug_set_gemm_variant": (c_int, [c_int]),
     "gpn_debug_set_potrf_variant": (c_int, [c_int]),
     "gpn_debug_masked_stream": (c_int, [ctypes.POINTER(ctypes.c_uint32), c_int, ctypes.POINTER(c_void_p)]),
     "gpn_debug_leaf_timing": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "gpn_profile_enable": (c_int, [c_int]),
-    "gpn_profile_collect": (c_int, [ctypes.POINTER(c_double)]),
-    "gpn_profile_collect_classes": (c_int, [ctypes.POINTER(c_double), c_int]),
 }
+DEBUG_LIB_PATH = os.path.join(_HERE, "lib", "libgpnative_dbg.so")
 
 _lib = None
+_product_lib = None
+_debug_lib = None
 
 
 class NativeError(RuntimeError):
     pass
 
 
+def _load(path, extra):
+    handle = ctypes.CDLL(path)
+    for name, (res, args) in list(SIGNATURES.items()) + list(PROFILE_SIGNATURES.items()) + list(extra.items()):
+        fn = getattr(handle, name)
+        fn.restype, fn.argtypes = res, args
+    return handle
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises if the library is absent."""
-    global _lib
+    global _lib, _product_lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise NativeError(
                 "libgpnative.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or gptorch_amd/csrc/build.sh). gptorch_amd has no CPU fallback." % LIB_PATH)
-        handle = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
-            fn = getattr(handle, name)
-            fn.restype, fn.argtypes = res, args
-        _lib = handle
+        extra = DEBUG_SIGNATURES if os.path.basename(LIB_PATH).startswith("libgpnative_dbg") else {}
+        _product_lib = _lib = _load(LIB_PATH, extra)
     return _lib
+
+
+class debug_library:
+    """`with _native.debug_library() as lib:` -- inside the block every native call of this process goes through the tools'
+    build libgpnative_dbg.so, whose gpn_debug_set_* switches select kernel / driver variants for the calling thread (A/B
+    tools, forced-variant tests).  On exit the product library is back (and the switches of the debug build are reset)."""
+
+    def __enter__(self):
+        global _lib, _debug_lib
+        lib()
+        if _debug_lib is None:
+            if not os.path.exists(DEBUG_LIB_PATH):
+                raise NativeError("libgpnative_dbg.so not found at %s -- run gptorch_amd/csrc/build.sh" % DEBUG_LIB_PATH)
+            _debug_lib = _load(DEBUG_LIB_PATH, DEBUG_SIGNATURES)
+        _lib = _debug_lib
+        return _debug_lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _debug_lib.gpn_debug_set_gemm_variant(0)
+        _debug_lib.gpn_debug_set_potrf_variant(0)
+        _lib = _product_lib
+        return False
+
+
+_debug_ctx = None
+
+
+def debug_begin():
+    """switch this process to the tools' build (see debug_library) and return its handle; debug_end() switches back."""
+    global _debug_ctx
+    if _debug_ctx is None:
+        _debug_ctx = debug_library()
+        return _debug_ctx.__enter__()
+    return _debug_lib
+
+
+def debug_end():
+    global _debug_ctx
+    if _debug_ctx is not None:
+        _debug_ctx.__exit__(None, None, None)
+        _debug_ctx = None
 
 
 def check(status, what):

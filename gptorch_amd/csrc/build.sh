@@ -16,9 +16,27 @@ for f in "$HERE"/*.hip; do
     pids+=($!)
   fi
 done
+# the tools' build: the three sources that carry A/B switches once more with -DGPN_DEBUG_SWITCHES (per-thread variant
+# setters, masked streams, the instrumented leaf); everything else is shared with the product library, which exports
+# none of it
+DBG="$OBJ/dbg"
+mkdir -p "$DBG"
+for f in "$HERE"/gemm_f64.hip "$HERE"/potrf.hip "$HERE"/profile.hip; do
+  o="$DBG/$(basename "${f%.hip}").o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ]; then
+    $HIPCC $FLAGS -DGPN_DEBUG_SWITCHES -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgpnative.so" "$OBJ"/*.o
 echo "built $OUT/libgpnative.so"
+shared=()
+for o in "$OBJ"/*.o; do
+  case "$(basename "$o")" in gemm_f64.o|potrf.o|profile.o) ;; *) shared+=("$o") ;; esac
+done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgpnative_dbg.so" "${shared[@]}" "$DBG"/*.o
+echo "built $OUT/libgpnative_dbg.so"
 # the RCCL adapter of the gpn_dist_comm callback table (a separate library: libgpnative itself links no
 # communication runtime)
 if [ ! -f "$OUT/libgpnative_rccl.so" ] || [ "$HERE/rccl_adapter.cpp" -nt "$OUT/libgpnative_rccl.so" ] || [ "$HERE/../../include/gpnative.h" -nt "$OUT/libgpnative_rccl.so" ]; then

@@ -374,7 +374,15 @@ struct DistRun {
 
 using namespace gpn;
 
-// shared body of the two entry points: assembly + factorisation (+ the closed-form backward on the grid).
+// var <- variance - var (diag) / var <- Kss - var (full), mean += Ms: the last step of gpr.py:107-117 after the all-reduce
+__global__ void dist_predict_finish_kernel(double* mean, const double* Ms, int64_t nmean, double* var, const double* variance,
+                                           const double* kss, int64_t nvar) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (Ms && i < nmean) mean[i] += Ms[i];
+  if (i < nvar) var[i] = (kss ? kss[i] : variance[0]) - var[i];
+}
+
+// shared body of the entry points: assembly + factorisation (+ the closed-form backward on the grid, or prediction).
 // Error behaviour on a multi-rank grid: a non-zero status means this rank stopped issuing the evaluation's collectives part-way
 // (nothing is waited for here: a broadcast whose peers never arrive would block a drain for ever).  The other ranks of its
 // process row / column are then blocked inside the transport: the caller must abort the communicators (ncclCommAbort) on every
@@ -383,10 +391,15 @@ static int dist_evaluate(void* stream, const gpn_dist_comm* comm, int rank, int 
                          const double* X, int64_t n, int d, const double* Y, int dy,
                          const double* variance, const double* length_scales, int nls, const double* noise,
                          int64_t tile, double* work, int64_t work_bytes, double* out4, bool with_grad,
-                         double* grads, double* grad_resid) {
+                         double* grads, double* grad_resid,
+                         const double* Xs = nullptr, int64_t ns = 0, const double* Ms = nullptr, int full_cov = 0,
+                         double* pmean = nullptr, double* pvar = nullptr) {
   DistRun R;
-  int rc = make_geom(R.g, rank, pr, pc, n, dy, tile, with_grad);
+  // prediction: the ns test points ride through the factorisation as further residual rows (K(x*, X) below (y - m)^T comes
+  // out as A^T = (L^-1 K(X, x*))^T exactly like alpha^T does); the LML terms still count the first dy rows only
+  int rc = make_geom(R.g, rank, pr, pc, n, dy + (int)ns, tile, with_grad);
   if (rc != GPN_OK) return rc;
+  if (ns > 0 && (with_grad || !Xs || !pmean || !pvar)) return -20;
   if (pr * pc > 1 && (!comm || !comm->bcast || !comm->allreduce)) return -2;
   if (kind < GPN_RBF || kind > GPN_PERIODIC) return -6;
   if (!X) return -7;
@@ -400,7 +413,8 @@ static int dist_evaluate(void* stream, const gpn_dist_comm* comm, int rank, int 
   if (!out4) return -18;
   if (with_grad && !grads) return -19;
   R.L = make_layout(R.g, d);
-  if (work_bytes < R.L.total * (int64_t)sizeof(double)) return -17;
+  const int64_t pred_words = ns > 0 ? round_up(ns * dy + (full_cov ? 2 * ns * ns : ns), 32) : 0;   // partials (+ K(x*) for the full covariance)
+  if (work_bytes < (R.L.total + pred_words) * (int64_t)sizeof(double)) return -17;
   if (reinterpret_cast<uintptr_t>(work) & 255) return GPN_E_ALIGN;
   R.s = static_cast<hipStream_t>(stream);
   R.comm = (pr * pc > 1 || (comm && (comm->flags & GPN_DIST_FORCE_COLLECTIVES))) ? comm : nullptr;
@@ -438,6 +452,11 @@ static int dist_evaluate(void* stream, const gpn_dist_comm* comm, int rank, int 
     if (g.has_res) {                                     // residual rows: (y)^T of this tile column
       rc = gpn_pack_rhs(stream, Y + J * T * dy, nullptr, nJ, dy, A + g.res_off * g.ld + lj * T, g.ld);
       if (rc != GPN_OK) return rc;
+      if (ns > 0) {                                      // ... and K(x*, X_J) below them (prediction)
+        rc = gpn_kernel_matrix(stream, kind, Xs, ns, Xcol + lj * T * d, nJ, d, variance, length_scales, nls, nullptr, GPN_FULL,
+                               A + (g.res_off + dy) * g.ld + lj * T, g.ld);
+        if (rc != GPN_OK) return rc;
+      }
     }
     if (g.with_inv && J % g.pr == g.my_r) {              // identity block J: I at tile column J (-> U_J,: from there on)
       const int64_t li = (J - g.my_r) / g.pr;
@@ -519,6 +538,37 @@ static int dist_evaluate(void* stream, const gpn_dist_comm* comm, int rank, int 
   }
   hipLaunchKernelGGL(dist_finish_kernel, dim3(1), dim3(64), 0, s, sums, (int)nt, T, n, dy, out4);
   GPN_LAUNCH_CHECK();
+  if (ns > 0) {
+    // ---- prediction (gpr.py:104-117; gptorch_amd/dist.py BlockCyclicGP.predict): mean = A^T alpha and colsumsq(A) / A^T A are
+    // sums over the tile columns, which are spread over the ranks of the residual's process row: partials + ONE all-reduce
+    double* pm = work + R.L.total;                       // [ns * dy | ns or ns * ns | (full: K(x*))]
+    double* pv = pm + ns * dy;
+    const int64_t nvar = full_cov ? ns * ns : ns;
+    GPN_HIP_CHECK(hipMemsetAsync(pm, 0, (size_t)(ns * dy + nvar) * sizeof(double), s));
+    if (g.has_res && ncr > 0) {
+      const double* alphaT = A + g.res_off * g.ld;       // [dy, ld]  (columns past my real ones are zero)
+      const double* AT = alphaT + (int64_t)dy * g.ld;    // [ns, ld]
+      rc = gemm_nt(s, ns, dy, g.ld, 1.0, AT, g.ld, alphaT, g.ld, 0.0, pm, dy, 0);
+      if (rc != GPN_OK) return rc;
+      if (full_cov) rc = gemm_nt(s, ns, ns, g.ld, 1.0, AT, g.ld, AT, g.ld, 0.0, pv, ns, 0);
+      else rc = gpn_row_sumsq(stream, AT, ns, ncr, g.ld, pv);
+      if (rc != GPN_OK) return rc;
+    }
+    if (R.comm) { rc = R.comm->allreduce(R.comm->ctx, pm, ns * dy + nvar, s); if (rc != GPN_OK) return rc; }
+    double* kss = nullptr;
+    if (full_cov) {
+      kss = pv + nvar;
+      rc = gpn_kernel_matrix(stream, kind, Xs, ns, nullptr, ns, d, variance, length_scales, nls, nullptr, GPN_FULL, kss, ns);
+      if (rc != GPN_OK) return rc;
+    }
+    GPN_HIP_CHECK(hipMemcpyAsync(pmean, pm, (size_t)ns * dy * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GPN_HIP_CHECK(hipMemcpyAsync(pvar, pv, (size_t)nvar * sizeof(double), hipMemcpyDeviceToDevice, s));
+    const int64_t cnt = std::max<int64_t>(ns * dy, nvar);
+    hipLaunchKernelGGL(dist_predict_finish_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, pmean, Ms, ns * dy, pvar,
+                       variance, kss, nvar);
+    GPN_LAUNCH_CHECK();
+    return GPN_OK;
+  }
   if (!with_grad) return GPN_OK;
 
   // ---- backward on the same grid (gptorch_amd/dist.py BlockCyclicGP.backward) ------------------
@@ -629,6 +679,21 @@ extern "C" int64_t gpn_dist_grad_work_bytes(int rank, int pr, int pc, int64_t n,
   DistGeom g;
   if (make_geom(g, rank, pr, pc, n, dy, tile, true) != GPN_OK || d <= 0 || dy <= 0) return -1;
   return make_layout(g, d).total * (int64_t)sizeof(double);
+}
+
+extern "C" int64_t gpn_dist_predict_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t ns, int64_t tile, int full_cov) {
+  DistGeom g;
+  if (ns < 0 || dy <= 0 || d <= 0 || make_geom(g, rank, pr, pc, n, dy + (int)ns, tile) != GPN_OK) return -1;
+  return (make_layout(g, d).total + round_up(ns * dy + (full_cov ? 2 * ns * ns : ns), 32)) * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_dist_predict(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                                const double* X, int64_t n, int d, const double* Y, int dy, const double* Xs, int64_t ns, const double* Ms,
+                                const double* variance, const double* length_scales, int nls, const double* noise,
+                                int64_t tile, int full_cov, double* work, int64_t work_bytes, double* out4, double* mean, double* var) {
+  if (ns <= 0) return -13;
+  return dist_evaluate(stream, comm, rank, pr, pc, kind, X, n, d, Y, dy, variance, length_scales, nls, noise, tile, work, work_bytes,
+                       out4, false, nullptr, nullptr, Xs, ns, Ms, full_cov, mean, var);
 }
 
 extern "C" int gpn_dist_lml_forward(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,

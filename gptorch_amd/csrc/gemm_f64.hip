@@ -443,7 +443,14 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(
   }
 }
 
-static int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
+// A/B switches exist only in the tools' build (libgpnative_dbg.so, -DGPN_DEBUG_SWITCHES): per calling thread, so two
+// threads of one process can hold different variants and a setter never races another thread's launches.  The product
+// library is compiled with the defaults as constants and exports no setter.
+#ifdef GPN_DEBUG_SWITCHES
+static thread_local int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
+#else
+static constexpr int g_smem_pad = 0;
+#endif
 
 // workgroups of a staircase launch with b x b tiles
 static int64_t stair_tiles(int64_t M, int64_t N, int st_blk, int st_step, int st_diag, int64_t b) {
@@ -490,7 +497,11 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   return GPN_OK;
 }
 
-static int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
+#ifdef GPN_DEBUG_SWITCHES
+static thread_local int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
+#else
+static constexpr int g_gemm_variant = 0;
+#endif
 
 struct Stair { int blk = 0, step = 0, diag = 0; };
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
@@ -608,11 +619,13 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
   return gpn::gemm_nt_stair(static_cast<hipStream_t>(stream), M, nblocks, blk, K, alpha, A, lda, B, ldb, beta, C, ldc, step, diag);
 }
 
-extern "C" int gpn_debug_set_gemm_variant(int v) {
+#ifdef GPN_DEBUG_SWITCHES
+extern "C" int gpn_debug_set_gemm_variant(int v) {     // (libgpnative_dbg.so only; the calling thread's launches)
   gpn::g_gemm_variant = v & 0xff;
   gpn::g_smem_pad = v >> 8;           // bits 8..: KiB of LDS padding per workgroup
   return GPN_OK;
 }
+#endif
 
 extern "C" int gpn_gemm_nt_batched(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
                                    const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,

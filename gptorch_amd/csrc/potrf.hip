@@ -506,7 +506,13 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   (void)done;
 }
 
-static int g_leaf_pipe = 1;          // 1 = two-phase leaf (pivot wave advances its own block); 0 = three-phase
+// (A/B switches: libgpnative_dbg.so only, per calling thread -- see gemm_f64.hip)
+#ifdef GPN_DEBUG_SWITCHES
+#define GPN_SWITCH static thread_local int
+#else
+#define GPN_SWITCH static constexpr int
+#endif
+GPN_SWITCH g_leaf_pipe = 1;          // 1 = two-phase leaf (pivot wave advances its own block); 0 = three-phase
 
 struct Ctx {
   hipStream_t s;
@@ -598,7 +604,7 @@ struct Aux {
 };
 static std::mutex g_aux_mutex;
 static std::unordered_map<hipStream_t, Aux> g_aux;
-static int g_potrf_variant = 0;     // 0 = look-ahead panels (default), 1 = plain recursion
+GPN_SWITCH g_potrf_variant = 0;     // 0 = look-ahead panels (default), 1 = plain recursion
 
 static Aux* aux_for(hipStream_t s) {
   std::lock_guard<std::mutex> lock(g_aux_mutex);
@@ -617,8 +623,8 @@ static Aux* aux_for(hipStream_t s) {
   return &g_aux.emplace(s, a).first->second;
 }
 
-static int g_panel_width = 0;        // 0 = by size; debug override
-static int g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
+GPN_SWITCH g_panel_width = 0;        // 0 = by size; debug override
+GPN_SWITCH g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
 // Same-box sweeps (r1z, tools/potrf_ab.py): panel width 1024 / 1536 / 2048 -> C2 7.10 / 7.00 / 7.01 ms,
 // N = 16384 31.9 (1536) vs 32.2 (2048), C3 201.5 / 200.0 / 201.1, C4 1492 / 1473 / 1472; with the
 // left-looking aux update (below) the large sizes prefer 2048: C3 198.1, C4 1454 ms.
@@ -932,6 +938,7 @@ extern "C" int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t
   return c.rc;
 }
 
+#ifdef GPN_DEBUG_SWITCHES
 extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_potrf_variant = v & 1;           // bit 0: plain recursion; bit 2: three-phase leaf; bits 8..: panel width / 128
   g_leaf_pipe = ((v >> 2) & 1) ? 0 : 1;
@@ -950,6 +957,7 @@ extern "C" int gpn_debug_leaf_timing(void* stream, double* A, int64_t lda, doubl
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
+#endif
 
 extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t ldl, double* winv, int32_t* info) {
   if (!L) return -2;

@@ -977,6 +977,43 @@ class NativeDistLML:
             raise RuntimeError("Max tries exceeded.")
         return host[2].to(self.X.device), grads, g_resid
 
+    def predict(self, variance, length_scales, noise, x_new, mean_new=None, diag=True, max_tries=10):
+        """GPR._predict (gpr.py:88-117) through gpn_dist_predict: (mean [n*, dy], var [n*] or cov [n*, n*]), identical on
+        every rank; self.Y is the residual y - m(X), mean_new the mean function at the test points (None = zero).  Same
+        jitter ladder as log_likelihood (the reference re-factorises in every predict call, gpr.py:104)."""
+        ct, lib = self._ct, self._native.lib()
+        xs = _ops._c(x_new.detach())
+        ns = xs.shape[0]
+        nbytes = int(lib.gpn_dist_predict_work_bytes(self.rank, self.pr, self.pc, self.n, self.d, self.dy, ns, self.T, 0 if diag else 1))
+        if self.work.numel() * 8 < nbytes:
+            self.work.resize_(nbytes // 8)          # (in place: the torch transport's callbacks map pointers into self.work)
+        mean = torch.empty(ns, self.dy, dtype=torch.float64, device=self.X.device)
+        var = torch.empty((ns,) if diag else (ns, ns), dtype=torch.float64, device=self.X.device)
+        ms = None if mean_new is None else _ops._c(mean_new.detach().expand(ns, self.dy))
+        v, ls = _ops._c(variance.detach()), _ops._c(length_scales.detach())
+
+        def attempt(nz):
+            nzc = _ops._c(nz.detach())
+            st = lib.gpn_dist_predict(_ops._stream(self.X.device), ct.byref(self.table) if self.table is not None else None,
+                                      self.rank, self.pr, self.pc, _ops.KINDS[self.kind], _ops._ptr(self.X), self.n, self.d,
+                                      _ops._ptr(self.Y), self.dy, _ops._ptr(xs), ns, _ops._ptr(ms), _ops._ptr(v), _ops._ptr(ls), ls.numel(),
+                                      _ops._ptr(nzc), self.T, 0 if diag else 1, _ops._ptr(self.work), self.work.numel() * 8,
+                                      _ops._ptr(self.out), _ops._ptr(mean), _ops._ptr(var))
+            self._native.check(st, "gpn_dist_predict")
+            self.info = int(self.out.cpu()[3])
+            if self.info < 0:
+                raise _ops.NativeError("a tile factorisation reported an internal status (not a property of the matrix)")
+        attempt(noise)
+        self.jitter_rung = -1
+        for i in range(max_tries):
+            if self.info == 0:
+                break
+            self.jitter_rung = i
+            attempt(noise + 10.0 ** (-max_tries + i))
+        if self.info != 0:
+            raise RuntimeError("Max tries exceeded.")
+        return mean, var
+
     def log_likelihood(self, variance, length_scales, noise, max_tries=10):
         """LML with the jitter ladder of functions.py:20-43 on the all-reduced info word."""
         host = self._evaluate(variance, length_scales, noise)

@@ -170,9 +170,21 @@ class GPModel(Model):
             return self.likelihood.predict_mean_variance(mean_f, cov_f)
         return self.likelihood.predict_mean_covariance(mean_f, cov_f)
 
-    def _samples(self, mu, sigma, n_samples):
+    def _samples(self, mu, sigma, n_samples, z=None):
+        """mu + chol(sigma) z for z ~ N(0, I) of shape [n_samples, n_test, dy] (base.py:371-374 / 386-389).  The Cholesky is
+        the native factorisation (functions.cholesky) and all n_samples * dy matrix-vector products go out as ONE native
+        fp64 contraction  Z^T L^T  with the draws as rows (the reference issues a batched matmul).  z: the standard-normal
+        draws, for callers (and tests) that bring their own."""
         chol_s = cholesky(sigma)
-        return mu + chol_s[None, :, :] @ torch.randn(n_samples, *mu.shape, dtype=torch_dtype, device=chol_s.device)
+        if z is None:
+            z = torch.randn(n_samples, *mu.shape, dtype=torch_dtype, device=chol_s.device)
+        if not chol_s.is_cuda:
+            return mu + chol_s[None, :, :] @ z
+        from .. import _ops
+        ns, nt, dy = z.shape
+        zt = z.permute(0, 2, 1).reshape(ns * dy, nt).contiguous()            # one row per (sample, output) pair
+        lz = _ops.matmul_nt(zt, chol_s.detach().contiguous())                 # [ns * dy, nt] = Z^T L^T
+        return mu + lz.reshape(ns, dy, nt).permute(0, 2, 1)
 
     @input_as_tensor
     def predict_f_samples(self, input_new, n_samples=1, **kwargs):

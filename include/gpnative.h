@@ -361,6 +361,18 @@ int gpn_dist_lml_grad(void* stream, const gpn_dist_comm* comm, int rank, int pr,
                       const double* X, int64_t n, int d, const double* Y, int dy,
                       const double* variance, const double* length_scales, int nls, const double* noise,
                       int64_t tile, double* work, int64_t work_bytes, double* out4, double* grads, double* grad_resid);
+/* GPR._predict (gpr.py:88-117) on the grid (gptorch_amd/dist.py BlockCyclicGP.predict): the ns test points ride through ONE
+ * factorisation as further residual rows -- K(x*, X) below (y - m)^T comes out as A^T = (L^-1 K(X, x*))^T exactly like alpha^T
+ * does, spread over the tile columns of the residual's process row -- and mean = Ms + A^T alpha [ns, dy], var = variance -
+ * colsumsq(A) [ns] (full_cov == 0) or K(x*) - A^T A [ns, ns] are column-partial sums and ONE all-reduce.  Y is the residual
+ * y - m(X) [n, dy], Ms the mean function at the test points [ns, dy] (gpr.py:107; NULL = zero); mean / var (device) come out
+ * identical on every rank; out4 as gpn_dist_lml_forward (the reference re-factorises on every predict call as well,
+ * gpr.py:104; a non-zero out4[3] is replayed with jitter by the caller).  work: gpn_dist_predict_work_bytes. */
+int64_t gpn_dist_predict_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t ns, int64_t tile, int full_cov);
+int gpn_dist_predict(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                     const double* X, int64_t n, int d, const double* Y, int dy, const double* Xs, int64_t ns, const double* Ms,
+                     const double* variance, const double* length_scales, int nls, const double* noise,
+                     int64_t tile, int full_cov, double* work, int64_t work_bytes, double* out4, double* mean, double* var);
 /* libgpnative_rccl.so only: a callback table over RCCL communicators (ncclComm_t passed as void*):
  * `row` spans this rank's process row with rank-in-communicator = process-column index, `col` its
  * process column with rank-in-communicator = process-row index, `world` all ranks.  row / col may be

@@ -152,3 +152,15 @@ def test_c_mesh_plan_equals_python_plan(p):
                 got = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]
                 assert got == want, (p, root, me, count)
     assert rccl.gpn_mesh_plan(2, 2, 0, 10, 4, 0, None, 0) == -1
+
+
+def test_product_library_has_no_debug_switches():
+    """the shipped libgpnative.so carries no mutable A/B state: the gpn_debug_* switches exist only in the tools' build
+    libgpnative_dbg.so (same sources, -DGPN_DEBUG_SWITCHES, per calling thread), which still exports the whole C ABI."""
+    prod = ctypes.CDLL(_native.LIB_PATH)
+    dbg = ctypes.CDLL(_native.DEBUG_LIB_PATH)
+    for n in _native.DEBUG_SIGNATURES:
+        assert not hasattr(prod, n), "libgpnative.so exports %s" % n
+        assert hasattr(dbg, n), "libgpnative_dbg.so lacks %s" % n
+    for n in _native.SIGNATURES:
+        assert hasattr(dbg, n)

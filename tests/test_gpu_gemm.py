@@ -22,7 +22,7 @@ def test_gemm_exact_integers(device, variant, M, N, K):
     """Small integers: every product and sum is exact in fp64, so the result must be
     bit-identical whatever the summation order; A != B and asymmetric, which catches
     row/column swaps in the MFMA fragment maps."""
-    _native.lib().gpn_debug_set_gemm_variant(variant)
+    _native.debug_begin().gpn_debug_set_gemm_variant(variant)
     try:
         g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
         A = torch.randint(-8, 9, (M, K), generator=g).double().to(device)
@@ -36,7 +36,7 @@ def test_gemm_exact_integers(device, variant, M, N, K):
         C2 = _ops.gemm_nt(Ap, Bp, M, N, K)
         assert torch.equal(C2, A @ B.t())
     finally:
-        _native.lib().gpn_debug_set_gemm_variant(0)
+        _native.debug_end()
 
 
 @pytest.mark.parametrize("n,K", [(64, 64), (200, 32), (640, 128), (1100, 64)])
@@ -59,7 +59,7 @@ def test_trapezoid_launch(device, variant, M, N, K):
     """lower = 2: the N x N top square lower-tile only (entries above its diagonal untouched), the rows below it
     whole -- one tile column of a block-cyclic trailing update incl. its diagonal tile, in one launch; every tile
     shape, exact integer data."""
-    _native.lib().gpn_debug_set_gemm_variant(variant)
+    _native.debug_begin().gpn_debug_set_gemm_variant(variant)
     try:
         g = torch.Generator(device="cpu").manual_seed(M + 3 * N + K)
         A = torch.randint(-4, 5, (M, K), generator=g).double().to(device)
@@ -72,7 +72,7 @@ def test_trapezoid_launch(device, variant, M, N, K):
         assert torch.equal(C[keep], full[keep])
         assert torch.equal(C[~keep], C0[~keep])
     finally:
-        _native.lib().gpn_debug_set_gemm_variant(0)
+        _native.debug_end()
 
 
 @pytest.mark.parametrize("variant", [0, 3, 4, 8, 11])
@@ -83,7 +83,7 @@ def test_staircase_launch(device, variant, M, nb, blk, K, step, diag):
     """gpn_gemm_nt_stair: column block b has the rows from b*step on (those above stay untouched), with diag a
     lower-only first square -- the local tile columns of a block-cyclic trailing update in ONE launch; incl. blocks
     that start below the last row (no work) and every tile shape; exact integer data."""
-    _native.lib().gpn_debug_set_gemm_variant(variant)
+    _native.debug_begin().gpn_debug_set_gemm_variant(variant)
     try:
         g = torch.Generator(device="cpu").manual_seed(M + 5 * nb + blk + K + step)
         N = nb * blk
@@ -102,7 +102,7 @@ def test_staircase_launch(device, variant, M, nb, blk, K, step, diag):
         assert torch.equal(C[keep], full[keep])
         assert torch.equal(C[~keep], C0[~keep])
     finally:
-        _native.lib().gpn_debug_set_gemm_variant(0)
+        _native.debug_end()
 
 
 def test_gemm_random_fp64(device):
@@ -122,7 +122,7 @@ def test_every_tile_shape_on_ragged_sizes(device, variant, M, N, K, lower):
     """The launcher picks a tile shape by problem size (128x128 from 8 rounds of tiles up, 64x64,
     64x64 / 32x32 with the deep LDS-DMA ring); here each one is FORCED onto small ragged problems
     (sizes that are no multiple of any tile edge) with exact integer data: bit-identical results."""
-    _native.lib().gpn_debug_set_gemm_variant(variant)
+    _native.debug_begin().gpn_debug_set_gemm_variant(variant)
     try:
         g = torch.Generator(device="cpu").manual_seed(variant * 1000 + M + N + K)
         A = torch.randint(-8, 9, (M, K), generator=g).double().to(device)
@@ -138,7 +138,7 @@ def test_every_tile_shape_on_ragged_sizes(device, variant, M, N, K, lower):
         else:
             assert torch.equal(C, ref)
     finally:
-        _native.lib().gpn_debug_set_gemm_variant(0)
+        _native.debug_end()
 
 
 @pytest.mark.parametrize("variant", [0, 3, 4, 6, 8, 11])
@@ -147,7 +147,7 @@ def test_k_clipped_triangular_operands(device, variant, n):
     """GPN_TRI_* flags (the K range of a tile is clipped where an operand is structurally zero) on
     every tile shape: U U^T for an upper-triangular U (the backward's Kyy^-1 product) and B W^T for
     a lower-triangular W, exact integers."""
-    _native.lib().gpn_debug_set_gemm_variant(variant)
+    _native.debug_begin().gpn_debug_set_gemm_variant(variant)
     try:
         g = torch.Generator(device="cpu").manual_seed(variant * 100 + n)
         kp = (n + 15) // 16 * 16
@@ -167,4 +167,4 @@ def test_k_clipped_triangular_operands(device, variant, n):
         X = _ops.gemm_nt(Bm, W, 100, n, kp, tri=_ops.TRI_B_LOWER)
         assert torch.equal(X, Bm[:100, :n] @ W[:n, :n].t())
     finally:
-        _native.lib().gpn_debug_set_gemm_variant(0)
+        _native.debug_end()

@@ -227,11 +227,11 @@ def test_factorisation_drivers_agree(device, n, e):
     R = torch.tensor(rng.normal(6, (n, max(e, 1)))[:, :e], device=device) if e else None
     out = []
     for variant in (1, 0, 8, 0x408):     # recursion | look-ahead (default) | left-looking aux update | + 512-wide panels
-        lib.gpn_debug_set_potrf_variant(variant)
+        _native.debug_begin().gpn_debug_set_potrf_variant(variant)
         try:
             f = _ops.kernel_factor("Matern52", x, one, 2.0 * one, 0.05 * one, R=R)
         finally:
-            lib.gpn_debug_set_potrf_variant(0)
+            _native.debug_end()
         assert int(f.info.item()) == 0
         out.append((f.lower(), f.extra().clone(), f.winv.clone(), f.lml_terms().clone()))
     L1, E1, W1, T1 = out[0]
@@ -671,6 +671,31 @@ def test_bench_launches_its_own_ranks(device):
     assert abs(d["lml"] - case["lml"]) < 1e-8 and set(d["exchange_schedules"]) == {"bcast", "mesh"}
 
 
+def test_sample_values_with_fixed_draws(device):
+    """predict_f_samples / predict_y_samples (base.py:362-390) VALUES: with the standard-normal draws fixed, the samples
+    must be mu + chol(Sigma) z of the reference's predictive mean and covariance (oracle on the CPU), for dy = 2 and
+    several samples -- the native Cholesky of the predictive covariance and the single native contraction that applies
+    it to all draws."""
+    n, d, dy, nt, nsamp = 400, 3, 2, 37, 5
+    x, y = rng.make_regression(n, d, dy, seed=21)
+    m = GPR(x, y, kernels.Matern52(d, variance=1.2, length_scales=1.4), likelihood=likelihoods.Gaussian(variance=0.05))
+    m.cuda()
+    o = orc.GPROracle(x, y, kind="Matern52", variance=1.2, length_scales=1.4, noise=0.05)
+    xs = rng.normal(5, (nt, d))
+    z = rng.normal(6, (nsamp, nt, dy))
+    zt = torch.tensor(z, device=device)
+    for name in ("f", "y"):
+        with torch.no_grad():
+            mu_o, cov_o = (o.predict_f if name == "f" else o.predict_y)(xs, diag=False)
+            want = mu_o[None] + torch.linalg.cholesky(cov_o)[None] @ torch.tensor(z)
+            mu, sigma = (m.predict_f if name == "f" else m.predict_y)(xs, diag=False)
+            got = m._samples(torch.as_tensor(mu, device=device), torch.as_tensor(sigma, device=device), nsamp, z=zt)
+        assert got.shape == (nsamp, nt, dy)
+        assert (got.cpu() - want).abs().max().item() < 1e-8, name
+    s = m.predict_f_samples(xs, n_samples=3)
+    assert tuple(s.shape) == (3, nt, dy)
+
+
 def test_c_driver_single_rank_and_rccl_adapter(device):
     """gpn_dist_lml_forward (csrc/dist.hip), the block-cyclic evaluation behind the C ABI: (1) a 1x1 grid
     without a communicator on ragged multi-tile problems against the goldens; (2) the same call with
@@ -733,8 +758,12 @@ def test_c_driver_multi_rank_shared_gpu(device, world, schedule):
     # schedule "mesh": GPN_DIST_MESH_EXCHANGE in the table's flags -- both engines (Python and C driver) then move their
     # panels by the grouped point-to-point plan (small direct threshold so that the scatter + all-gather form runs too)
     out = _torchrun(world, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_SHARED_GPU": "1", "GPN_CDRIVER": "1", "GPN_DIST_GRAD": "1",
-                                                                         "GPN_DIST_SCHEDULE": schedule, "GPN_DIST_MESH_DIRECT_BYTES": "65536"})
+                                                                         "GPN_DIST_SCHEDULE": schedule, "GPN_DIST_MESH_DIRECT_BYTES": "65536",
+                                                                         "GPN_DIST_PREDICT": "1"})
     assert out.returncode == 0, out.stderr[-3000:]
+    # gpn_dist_predict on the grid (test points as further residual rows, mean function added inside) vs the single-GPU prediction
+    pm = re.search(r"cdriver predict: mean_err=(\S+) var_err=(\S+) cov_err=(\S+)", out.stdout)
+    assert pm and all(float(v) < 1e-9 for v in pm.groups()), out.stdout
     py_vals = [float(v) for v in re.findall(r"backend=gloo: lml=(-?[0-9.]+)", out.stdout)]
     assert len(py_vals) == 3 and all(abs(v - [c for c in LML if c["name"] == "rbf_2048_8"][0]["lml"]) < 1e-8 for v in py_vals), out.stdout
     vals = [float(v) for v in re.findall(r"cdriver: lml=(-?[0-9.]+)", out.stdout)]
@@ -1295,11 +1324,11 @@ def test_c4_full_size_factor_properties(device):
     t = lambda v: torch.tensor([v], dtype=torch.float64, device=device)
     terms = []
     for variant in (1, 0):
-        lib.gpn_debug_set_potrf_variant(variant)
+        _native.debug_begin().gpn_debug_set_potrf_variant(variant)
         try:
             f = _ops.kernel_factor("Rbf", x, t(var), t(ls), t(noise), R=R)
         finally:
-            lib.gpn_debug_set_potrf_variant(0)
+            _native.debug_end()
         assert int(f.info.item()) == 0
         terms.append(f.lml_terms().cpu().numpy().copy())
         if variant == 1:

@@ -31,18 +31,18 @@ def t(fn, reps=5):
 
 
 for v in (0, 3, 4, 0, 3, 4):
-    lib.gpn_debug_set_gemm_variant(v)
+    _native.debug_begin().gpn_debug_set_gemm_variant(v)
     a = t(lambda: _backward._kinv_lower(f, U))
-    lib.gpn_debug_set_gemm_variant(0)
+    _native.debug_end()
     print("Kinv = U U^T (K-clipped SYRK), variant %d: %8.1f us" % (v, a))
 for v in (0, 4, 5, 6):
-    lib.gpn_debug_set_gemm_variant(v)
+    _native.debug_begin().gpn_debug_set_gemm_variant(v)
     a = t(lambda: _ops.gemm_nt(f.A[n:], U, dy, n, _ops.round_up(n, 16), tri=_ops.TRI_B_UPPER))
-    lib.gpn_debug_set_gemm_variant(0)
+    _native.debug_end()
     print("a^T = alpha^T U^T (skinny), variant %d: %8.1f us" % (v, a))
 for v in (0, 3, 4, 0, 3, 4):
-    lib.gpn_debug_set_gemm_variant(v)
+    _native.debug_begin().gpn_debug_set_gemm_variant(v)
     a = t(lambda: _backward._upper_inverse(f, True), 3)
-    lib.gpn_debug_set_gemm_variant(0)
+    _native.debug_end()
     print("U = L^-T (level-wise, incl. zeroing two buffers), variant %d: %8.1f us" % (v, a))
 print("U = L^-T: chain-based recursion %8.1f us" % t(lambda: _backward._upper_inverse(f, False), 3))

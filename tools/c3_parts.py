@@ -21,7 +21,7 @@ idx = [(0, 0), (1, 0), (100, 7), (w["n"] - 1, w["n"] - 2), (20000 % w["n"], 123)
 f = None
 for name, v in [("default", 0), ("right-looking aux", 1 << 5), ("left-looking aux", 1 << 3), ("pw1024", 8 << 8), ("pw1536", 12 << 8),
                 ("pw4096", 32 << 8), ("recursive", 1)]:
-    lib.gpn_debug_set_potrf_variant(v)
+    _native.debug_begin().gpn_debug_set_potrf_variant(v)
     f, terms = _ops.lml_forward(w["kind"], X, Y, var, ls, nz, factor=f)
     torch.cuda.synchronize()
     t0 = time.time()
@@ -33,7 +33,7 @@ for name, v in [("default", 0), ("right-looking aux", 1 << 5), ("left-looking au
     import math
     print(json.dumps({"variant": name, "ms": dt * 1e3, "logdet_half": terms[0].item(), "quad": terms[1].item(), "lml": terms[2].item(),
                       "ld_fsum": math.fsum(d.cpu().tolist()), "quad_fsum": math.fsum((a.cpu().numpy() ** 2).tolist())}), flush=True)
-lib.gpn_debug_set_potrf_variant(0)
+_native.debug_end()
 K = _ops.kernel_matrix(w["kind"], X[:40000], None, var, ls, noise=nz) if w["n"] <= 8192 else None
 from gptorch_amd import kernels
 ks = []

@@ -43,7 +43,7 @@ for layout in (0, 1):
             mask[bit >> 5] &= ~(1 << (bit & 31))
         arr = (ctypes.c_uint32 * 8)(*mask)
         ms_ = ctypes.c_void_p()
-        rc = lib.gpn_debug_masked_stream(arr, 8, ctypes.byref(ms_))
+        rc = _native.debug_begin().gpn_debug_masked_stream(arr, 8, ctypes.byref(ms_))
         if rc != 0:
             print("masked stream creation failed", rc)
             continue

@@ -7,6 +7,7 @@ Env: GPN_SHARED_GPU=1   every rank on cuda:0 with gloo collectives (multi-rank o
      GPN_FORCE_COMM=1   issue the row/column collectives even in single-member groups (drives the RCCL calls at world 1)
      GPN_PHANTOM=r/w    do the work of rank r of a w-rank grid with the collectives skipped (timing only)
      GPN_NATIVE=1       also time the single-GPU native factorisation of the same matrix
+     GPN_DIST_PREDICT=1 (with GPN_CDRIVER=1) also gpn_dist_predict against the single-GPU prediction
      GPN_CDRIVER=1      also the C-ABI driver (gpn_dist_lml_forward) over torch.distributed callbacks,
                         or with GPN_RCCL=1 over its own RCCL communicators (libgpnative_rccl.so) -- the form for real multi-GPU runs"""
 import os, sys, time
@@ -88,5 +89,17 @@ if os.environ.get("GPN_CDRIVER") == "1":
         if c.rank == 0:
             print("cdriver grad: lml=%.8f  %s  resid_grad_norm=%.10e  %.1f ms" % (
                 lml.item(), " ".join("%.10e" % v for v in grad.tolist()), g_resid.norm().item(), (time.time() - t0) * 1e3), flush=True)
+    if os.environ.get("GPN_DIST_PREDICT") == "1":   # gpn_dist_predict vs the single-GPU predict of the same model (rank 0 prints)
+        xs = torch.tensor(rng.normal(9, (40, d)), device=dev)
+        ms = torch.tensor(rng.normal(10, (40, 1)), device=dev)
+        mu, var = c.predict(one, ls, 0.01 * one, xs, mean_new=ms, diag=True)
+        _, cov = c.predict(one, ls, 0.01 * one, xs, mean_new=ms, diag=False)
+        if c.rank == 0:
+            from gptorch_amd import _ops
+            f = _ops.kernel_factor("Rbf", X, one, ls, 0.01 * one, R=Y)
+            mu1, var1 = _ops.gpr_predict("Rbf", X, xs, one, ls, f, diag=True, mean_new=ms)
+            _, cov1 = _ops.gpr_predict("Rbf", X, xs, one, ls, f, diag=False, mean_new=ms)
+            print("cdriver predict: mean_err=%.3e var_err=%.3e cov_err=%.3e" % (
+                (mu - mu1).abs().max().item(), (var - var1).abs().max().item(), (cov - cov1).abs().max().item()), flush=True)
 if dist.is_initialized():
     dist.destroy_process_group()

@@ -28,7 +28,7 @@ for (M, N, K, lower) in shapes:
     C = C0.clone()
     for rnd in range(ROUNDS):                    # variants interleaved round by round: clock / box drift hits all alike
         for v in variants:
-            lib.gpn_debug_set_gemm_variant(v)
+            _native.debug_begin().gpn_debug_set_gemm_variant(v)
             if rnd == 0:
                 C.copy_(C0)
                 _ops.gemm_nt(A, B, M, N, K, alpha=-1.0, beta=1.0, C=C, lower=bool(lower))
@@ -49,4 +49,4 @@ for (M, N, K, lower) in shapes:
             v, ms, flops / ms / 1e9, flops / max(times[v]) / 1e9, flops / min(times[v]) / 1e9, errs[v])
     print(line, flush=True)
     del A, B, C0, ref, C
-lib.gpn_debug_set_gemm_variant(0)
+_native.debug_end()

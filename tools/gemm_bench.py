@@ -33,7 +33,7 @@ def run(M, N, K, lower, reps=5):
 
 if __name__ == "__main__":
     if sys.argv[1:2] == ["--variant"]:
-        _native.lib().gpn_debug_set_gemm_variant(int(sys.argv[2]))
+        _native.debug_begin().gpn_debug_set_gemm_variant(int(sys.argv[2]))
         print("gemm variant", sys.argv[2])
         del sys.argv[1:3]
     args = [int(a) for a in sys.argv[1:]]

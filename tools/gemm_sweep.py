@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 
 
 def t(M, N, K, lower, variant, reps=20):
-    lib.gpn_debug_set_gemm_variant(variant)
+    _native.debug_begin().gpn_debug_set_gemm_variant(variant)
     A = torch.randn(M + 16, K, dtype=torch.float64, device=dev)
     B = A if lower else torch.randn(N + 16, K, dtype=torch.float64, device=dev)
     C = torch.zeros(M, N, dtype=torch.float64, device=dev)
@@ -24,7 +24,7 @@ def t(M, N, K, lower, variant, reps=20):
         _ops.gemm_nt(A, B, M, N, K, alpha=-1.0, beta=1.0, C=C, lower=lower)
     e1.record()
     torch.cuda.synchronize()
-    lib.gpn_debug_set_gemm_variant(0)
+    _native.debug_end()
     return e0.elapsed_time(e1) / reps * 1e3
 
 

@@ -12,7 +12,7 @@ var, ls, nz = k.variance.transform().detach(), k.length_scales.transform().detac
 f = _ops.kernel_factor_async(k._kind, m.X, var, ls, nz, R=resid)
 torch.cuda.synchronize()
 for variant in (0, 1):
-    lib.gpn_debug_set_potrf_variant(variant)
+    _native.debug_begin().gpn_debug_set_potrf_variant(variant)
     ts = []
     for _ in range(8):
         torch.cuda.synchronize()
@@ -23,4 +23,4 @@ for variant in (0, 1):
         t2 = time.perf_counter()
         ts.append(((t1 - t0) * 1e3, (t2 - t0) * 1e3))
     print("variant %d: host enqueue %.2f ms, total %.2f ms" % (variant, min(a for a, b in ts), min(b for a, b in ts)))
-lib.gpn_debug_set_potrf_variant(0)
+_native.debug_end()

@@ -20,7 +20,7 @@ for it in range(3):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    lib.gpn_debug_leaf_timing(_stream(dev), _ptr(f.A), f.ld, _ptr(f.winv), _ptr(f.info), _ptr(diag))
+    _native.debug_begin().gpn_debug_leaf_timing(_stream(dev), _ptr(f.A), f.ld, _ptr(f.winv), _ptr(f.info), _ptr(diag))
     e1.record()
     torch.cuda.synchronize()
     d = diag.cpu().numpy().reshape(9, 8)

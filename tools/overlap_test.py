@@ -65,7 +65,7 @@ def masked(pred):
         if pred(cu):
             words[cu // 32] |= (1 << (cu % 32))
     out = ctypes.c_void_p()
-    st = lib.gpn_debug_masked_stream(words, 8, ctypes.byref(out))
+    st = _native.debug_begin().gpn_debug_masked_stream(words, 8, ctypes.byref(out))
     assert st == 0, (st, lib.gpn_last_hip_error())
     return torch.cuda.ExternalStream(out.value, device=dev)
 

@@ -17,7 +17,7 @@ for wl in (sys.argv[1:] or ["c2", "c3"]):
         w = bench.WORKLOADS[wl]
     m, _, _ = bench.build_model(w, 0, torch.device("cuda:0"))
     for variant in [int(v, 0) for v in os.environ.get("VARIANTS", "1,0,1,0").split(",")]:
-        lib.gpn_debug_set_potrf_variant(variant)
+        _native.debug_begin().gpn_debug_set_potrf_variant(variant)
         with torch.no_grad():
             for _ in range(3):
                 out = m.log_likelihood()
@@ -28,6 +28,6 @@ for wl in (sys.argv[1:] or ["c2", "c3"]):
                 out = m.log_likelihood()
             torch.cuda.synchronize()
         print("%s variant 0x%x: %.3f ms  lml %.10f" % (wl, variant, (time.perf_counter() - t0) / reps * 1e3, out.item()), flush=True)
-    lib.gpn_debug_set_potrf_variant(0)
+    _native.debug_end()
     del m
     torch.cuda.empty_cache()

@@ -7,14 +7,14 @@ lib = _native.lib()
 dev = torch.device("cuda:0")
 m, _, _ = bench.build_model(bench.WORKLOADS["c2"], 0, dev)
 def run(stream, variant):
-    lib.gpn_debug_set_potrf_variant(variant)
+    _native.debug_begin().gpn_debug_set_potrf_variant(variant)
     ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
     with ctx, torch.no_grad():
         for _ in range(3): m.log_likelihood()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): m.log_likelihood()
         torch.cuda.synchronize()
-    lib.gpn_debug_set_potrf_variant(0)
+    _native.debug_end()
     return (time.perf_counter() - t0) / 10 * 1e3
 s_norm = torch.cuda.Stream(device=dev)
 s_hi = torch.cuda.Stream(device=dev, priority=-1)

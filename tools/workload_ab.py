@@ -60,11 +60,11 @@ for leg in legs:
     vals = {}
     for r in range(rounds):
         for v in variants:
-            lib.gpn_debug_set_gemm_variant(v)
+            _native.debug_begin().gpn_debug_set_gemm_variant(v)
             t, o = timed(fn, steps)
             times[v].append(t)
             vals[v] = o.item()
-    lib.gpn_debug_set_gemm_variant(0)
+    _native.debug_end()
     print(leg, "  ".join("v%d %.3f ms [%.3f-%.3f] val %.10f" % (v, sorted(times[v])[len(times[v]) // 2], min(times[v]), max(times[v]), vals[v])
                          for v in variants), flush=True)
     del model
