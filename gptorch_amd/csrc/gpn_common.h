@@ -35,6 +35,11 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
                   const double* A, int64_t lda, const double* B, int64_t ldb,
                   double beta, double* C, int64_t ldc, int64_t step, int diag);
 
+// the in-panel chain's column passes (colpanel.hip): C[m, nb] = A[m, 128] B[nb, 128]^T with B lower triangular (mode 0; C may
+// be A) or C -= A B^T (mode 1); nb <= 128
+int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B, int64_t ldb,
+             double* C, int64_t ldc);
+
 // `batch` problems of identical shape at constant strides (elements) in one launch
 int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                     const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,

@@ -102,6 +102,35 @@ __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
   const int tx = tid & 15, ty = tid >> 4;
   const int i0 = ti * GT, j0 = tj * GT;
 
+  // LML mode: the weight entries G_ij = 1/2 (a_i . a_j - dy Kinv_ij) need Kinv (one 16-byte load per column pair, requested
+  // HERE so that the round trip runs under the distance pass) and a^T at the tile's rows and columns (staged in LDS: read
+  // per entry from global they were 2 dy dependent loads per entry and left the sweep latency-bound -- 50 % VALU-issue, 16 %
+  // of HBM peak, profiles/r2_valu_bound_c3.json)
+  constexpr int ADY = 4;                      // right-hand sides staged at a time
+  __shared__ double a_rows[LML ? ADY : 1][GT], a_cols[LML ? ADY : 1][GT];
+  d2 gk[4][2];
+  const bool gvec = LML && ((p.ldg & 1) == 0) && ((reinterpret_cast<uintptr_t>(p.G) & 15) == 0);
+  if constexpr (LML) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = i0 + ty * 4 + a;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int col = j0 + h * 32 + tx * 2;
+        gk[a][h] = d2{0.0, 0.0};
+        if (row < p.n && col <= row) {          // (col + 1 may lie above the diagonal: loaded, never used)
+          if (gvec) gk[a][h] = *reinterpret_cast<const d2*>(p.G + (int64_t)row * p.ldg + col);
+          else { gk[a][h].x = p.G[(int64_t)row * p.ldg + col]; if (col + 1 <= row) gk[a][h].y = p.G[(int64_t)row * p.ldg + col + 1]; }
+        }
+      }
+    }
+    if (p.dy <= ADY && tid < 2 * GT) {
+      const int pt = tid & (GT - 1);
+      const int idx = (tid < GT ? i0 : j0) + pt;
+      for (int c = 0; c < p.dy; ++c) (tid < GT ? a_rows : a_cols)[c][pt] = idx < p.n ? p.at[(int64_t)c * p.ldat + idx] : 0.0;
+    }
+  }
+
   // stage both point blocks, scaled by the reciprocal length-scales (kernels.py:154-158; one
   // reciprocal per coordinate and workgroup, as in kmat.hip)
   __shared__ double inv_ell[NCH * GDC];
@@ -157,8 +186,14 @@ __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
         if constexpr (LML) {
           if (col <= row) {
             double aa = 0.0;
-            for (int c = 0; c < p.dy; ++c) aa = fma(p.at[(int64_t)c * p.ldat + row], p.at[(int64_t)c * p.ldat + col], aa);
-            g = 0.5 * (aa - (double)p.dy * p.G[(int64_t)row * p.ldg + col]);
+            if (p.dy <= ADY) {
+              const int rl = ty * 4 + a, cl = (b >> 1) * 32 + tx * 2 + (b & 1);
+              for (int c = 0; c < p.dy; ++c) aa = fma(a_rows[c][rl], a_cols[c][cl], aa);
+            } else {
+              for (int c = 0; c < p.dy; ++c) aa = fma(p.at[(int64_t)c * p.ldat + row], p.at[(int64_t)c * p.ldat + col], aa);
+            }
+            const double kinv = (b & 1) ? gk[a][b >> 1].y : gk[a][b >> 1].x;
+            g = 0.5 * (aa - (double)p.dy * kinv);
             if (col == row) s_tr += g;
             else g *= 2.0;   // symmetric partner (col, row)
           }

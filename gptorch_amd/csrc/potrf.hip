@@ -513,6 +513,9 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
 #define GPN_SWITCH static constexpr int
 #endif
 GPN_SWITCH g_leaf_pipe = 1;          // 1 = two-phase leaf (pivot wave advances its own block); 0 = three-phase
+// bit 0: every in-place solve against an inverted leaf block (the chain's and the right-solve recursion's) through
+// colpanel.hip; bit 1: the chain's next-column update too (measured slower: DESIGN 8-1f); 0 = the generic contraction
+GPN_SWITCH g_chain_kernel = 1;
 
 struct Ctx {
   hipStream_t s;
@@ -541,7 +544,8 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
   if (kb <= LEAF) {
     const double* W = winv + (diag0 / LEAF) * (LEAF * LEAF);
     // in place: one LEAF-wide column tile per row block (see file header)
-    c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
+    if (g_chain_kernel & 1) c.rc = colpanel(c.s, 0, m, kb, B, ldb, W, LEAF, B, ldb);
+    else c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
     return;
   }
   const int64_t h = split_point(kb);
@@ -658,7 +662,8 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       const int64_t m = n + e - c1;                // rows below (incl. the extra rows)
       if (m <= 0 || c.rc != GPN_OK) continue;
       double* B = A + c1 * lda + k0;               // [m, kb] <- B W_k^T   (in place)
-      c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
+      if (g_chain_kernel & 1) c.rc = colpanel(c.s, 0, m, kb, B, lda, Wk, LEAF, B, lda);
+      else c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
       if (c.rc != GPN_OK || c1 >= pend) continue;  // last block of the panel: nothing left inside it
       const int64_t nb1 = std::min<int64_t>(LEAF, pend - c1);
       const int64_t c2 = c1 + nb1;
@@ -671,8 +676,10 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       // The aux work is forked AFTER it: launched together, the 1000+ workgroups of the rest
       // update crowd this small launch out (16 us instead of 7); behind it they overlap with
       // the next leaf + solve instead.
-      if (c.rc == GPN_OK)
-        c.rc = gemm_nt(c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
+      if (c.rc == GPN_OK) {
+        if ((g_chain_kernel & 2) && kb == LEAF) c.rc = colpanel(c.s, 1, m, nb1, B, lda, B, lda, A + c1 * lda + c1, lda);
+        else c.rc = gemm_nt(c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
+      }
       if (fork) hip_ok(hipEventRecord(ax->solve[step & 3], c.s));
       if (fork && c.rc == GPN_OK) {                // the rest of the panel on the aux stream
         hip_ok(hipStreamWaitEvent(ax->s1, ax->solve[step & 3], 0));
@@ -942,8 +949,9 @@ extern "C" int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t
 extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_potrf_variant = v & 1;           // bit 0: plain recursion; bit 2: three-phase leaf; bits 8..: panel width / 128
   g_leaf_pipe = ((v >> 2) & 1) ? 0 : 1;
-  g_panel_width = (v >> 8) * LEAF;
+  g_panel_width = ((v >> 8) & 0xff) * LEAF;
   g_aux_left_looking = ((v >> 3) & 1) ? 1 : (((v >> 5) & 1) ? 0 : -1);   // bit 3: force left-looking aux update, bit 5: force right-looking
+  g_chain_kernel = 1 ^ ((v >> 6) & 3);                                   // bit 6: the chain's solve through the generic contraction; bit 7: its next-column update through colpanel.hip
   return GPN_OK;
 }
 

@@ -149,7 +149,7 @@ def batched_log_likelihood(models, streams=None):
     side = any(st is not cur for st in streams)
     if side:
         # host-side fork/join: event waits between a created stream and the legacy default stream
-        # cost ~7 ms per evaluation on this runtime (tools/stream_kind_test2.py), a host sync of an
+        # cost ~7 ms per evaluation on this runtime (tools/stream_kind_test.py waits), a host sync of an
         # idle stream costs nothing
         cur.synchronize()
     pending = []

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""GPU-box tool: tile-shape A/B for the shapes the look-ahead factorisation launches
-(variants: 3 = 128x128, 4 = 64x64 2-stage, 5 = 64x64 8-deep ring, 6 = 32x32 8-deep ring, 0 = heuristic)."""
+"""GPU-box tool: tile-shape A/B of the contraction kernel (tools' build: gpn_debug_set_gemm_variant; 3 = 128x128, 4 = 64x64
+2-stage, 5 = 64x64 8-deep ring, 6 = 32x32 8-deep ring, 0 = the launcher's heuristic).
+    gemm_sweep.py            the shapes the look-ahead factorisation launches (trailing SYRK, next-column, rest-of-panel)
+    gemm_sweep.py large      128x128 vs 64x64 tiles on large contractions (was gemm_sweep2.py)"""
 import os, sys
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -28,6 +30,14 @@ def t(M, N, K, lower, variant, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "large":
+    for (M, N, K, lo) in [(8192, 8192, 8192, 0), (4096, 4096, 4096, 0), (16384, 16384, 16384, 1), (16384, 16384, 4096, 1),
+                          (8192, 8192, 4096, 1), (4096, 4096, 65536, 1), (65536, 4096, 4096, 0), (65536, 2048, 2048, 0),
+                          (16384, 8192, 8192, 0), (4096, 4096, 2048, 1), (24576, 24576, 8192, 1)]:
+        fl = (M * (M + 1.0) if lo else 2.0 * M * N) * K
+        a, b = t(M, N, K, lo, 3, reps=3), t(M, N, K, lo, 4, reps=3)
+        print("M=%6d N=%6d K=%6d lower=%d: 128: %9.1f us (%.1f TF)   64: %9.1f us (%.1f TF)" % (M, N, K, lo, a, fl / a / 1e6, b, fl / b / 1e6), flush=True)
+    sys.exit(0)
 print("== trailing SYRK (lower), K = panel width")
 for K in (1024, 2048):
     for M in ([1024, 2048, 3072, 4096, 5120, 6144, 7168] if K == 1024 else [2048, 6144, 10240, 14336, 22528, 30720]):

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=sparse_gpr.CHUNK_ROWS)
     ap.add_argument("--kind", default="Rbf")
     args = ap.parse_args()
+    if os.environ.get("POTRF_VARIANT"):          # A/B of driver variants through the tools' build (libgpnative_dbg.so)
+        from gptorch_amd import _native
+        _native.debug_begin().gpn_debug_set_potrf_variant(int(os.environ["POTRF_VARIANT"], 0))
     sparse_gpr.CHUNK_ROWS = args.chunk
     n, m, d = args.n, args.m, args.d
     x, y = rng.make_regression(n, d, 1, seed=0)
