@@ -22,11 +22,11 @@ read-back (jitter ladder).  Inputs are resident in HBM before the timed region.
     replicas (`replicas_c2`, labelled, not the headline).
 
 Extra objects on the JSON line (N=1):
-  roofline            -- fp64 MFMA contraction kernel (gemm_nt_kernel), ALL its launches of an
-                         evaluation: algorithmic flops of the factorisation they carry / summed
-                         HIP-event time (events on the launch stream, second pass over the same steps)
-  roofline_syrk       -- only the SYRK trailing updates (the lower-tile K = panel-width contraction
-                         at the end of every panel): north_star's ">= 50 % of fp64 MFMA peak at N=32768"
+  roofline            -- the dominant kernel on one stream: the fp64 MFMA contraction kernel's SYRK trailing updates (the
+                         lower-tile K = panel-width launch at the end of every panel; north_star's ">= 50 % of fp64
+                         MFMA peak at N=32768"): algorithmic flops of those launches / their summed HIP-event time
+                         (events on the launch stream, second pass over the same steps).  = roofline_syrk
+  roofline_all_contractions -- ALL launches of gemm_nt_kernel (two overlapping streams: a lower bound, see its note)
   roofline_k_assembly -- fused distance + kernel + noise assembly, HBM roofline (+ vector-flop model)
   cpu_baseline        -- the CPU oracle (torch-CPU restatement of the reference path,
                          oracle/gp_oracle.py) on this box's host cores: a bounded sample, see `sample`
@@ -378,6 +378,15 @@ def run_single(args, device):
     attach_traffic(roofs.get("roofline"), "gemm_bytes_per_launch", args.workload)
     attach_traffic(roofs.get("roofline_k_assembly"), "kmat_bytes_per_launch", args.workload)
     attach_traffic(roofs.get("roofline_syrk"), "syrk_bytes_per_launch", args.workload)
+    if "roofline_syrk" in roofs:
+        # `roofline` = the DOMINANT kernel on ONE stream: the lower-tile launches of the contraction kernel (the SYRK trailing
+        # updates: ~78 % of an evaluation's wall time at C3, all on the caller's stream, so launches x average duration is a
+        # real time).  The figure over ALL contraction launches sums launches that overlap on the aux stream -- its
+        # kernel_ms_per_step can exceed ms_per_step -- and is kept as a conservative lower bound under its own key.
+        roofs["roofline_all_contractions"] = roofs["roofline"]
+        roofs["roofline_all_contractions"]["note"] = ("sum over launches of two overlapping streams: kernel_ms_per_step is not a "
+                                                      "wall time and frac is a lower bound")
+        roofs["roofline"] = dict(roofs["roofline_syrk"])
 
     if not args.no_extras:
         def leg(name, fn):
@@ -407,7 +416,9 @@ def run_single(args, device):
                     if gl is not None:
                         res["lml_abs_err_vs_reference_golden"] = abs(res["lml"] - gl)
                     r2 = rooflines(lib, ww, steps, st)
-                    for k2 in ("roofline", "roofline_syrk", "roofline_k_assembly"):
+                    if "roofline_syrk" in r2:
+                        r2["roofline_all_contractions"], r2["roofline"] = r2["roofline"], dict(r2["roofline_syrk"])
+                    for k2 in ("roofline", "roofline_syrk", "roofline_all_contractions", "roofline_k_assembly"):
                         if k2 in r2:
                             res[k2] = r2[k2]
                 if with_backward:
@@ -446,8 +457,10 @@ def run_single(args, device):
                 mm.loss().backward()
                 mm.zero_grad()                           # warm-up: allocations, side streams
                 torch.cuda.synchronize()
+                import contextlib
                 t0 = time.perf_counter()
-                losses, _ = mm.optimize(method="Adam", max_iter=50, verbose=False, learning_rate=0.01)
+                with contextlib.redirect_stdout(sys.stderr):      # optimize() reports like the reference (base.py:255-296): not on the JSON's stream
+                    losses, _ = mm.optimize(method="Adam", max_iter=50, verbose=False, learning_rate=0.01)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 return {"config": "C3: GPR+Matern52 N=32768 D=16 fp64, one fit = 50 Adam steps (lr 0.01) of GPModel.optimize",
@@ -575,7 +588,8 @@ def run_multi(args, rank, local_rank, world, device):
     per_schedule, engines = {}, {}
 
     def measure(sched):
-        g = gdist.BlockCyclicGP(X, Y, w["kind"], tile=args.tile, schedule=sched)
+        # (the second engine reuses the first one's row / column sub-communicators: same grid, other schedule)
+        g = gdist.BlockCyclicGP(X, Y, w["kind"], tile=args.tile, schedule=sched, share=next(iter(engines.values()), None))
         engines[sched] = g
 
         def step():

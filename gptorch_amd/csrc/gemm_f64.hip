@@ -42,7 +42,10 @@ struct GemmArgs {
   int64_t lda, ldb, ldc;
   int M, N, K;
   int mt, nt;       // tile counts
-  int lower;        // 0 full, 1 lower-tile square, 2 trapezoid, 3 staircase (st_* below)
+  int lower;        // 0 full, 1 lower-tile square, 2 trapezoid, 3 staircase (st_* below), 4 quarters of the last big tiles (q_*)
+  // lower == 4: this launch computes, as BM x BN = 64 x 64 quarter tiles, the 128 x 128 tiles q_off .. q_off + q_cnt - 1 of a
+  // lower-tile launch with q_mt tile rows (its partial last round: gemm_nt_impl); block b = quarter (b & 3) of tile q_off + b/4
+  int q_off, q_cnt, q_mt;
   // staircase: C is M x (nb * st_blk); column block b (st_blk columns) only has the rows from b * st_step on, and with
   // st_diag its first st_blk x st_blk square is lower-only -- the local tile columns of one block-cyclic trailing update
   int st_blk, st_step, st_diag;
@@ -78,8 +81,12 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, 
 // number of real tiles): groups of 8 tile rows; group g holds the 8g full columns
 // left of the diagonal super-tile (column-major, 8 per column) followed by the
 // 36 tiles of the diagonal super-tile.  Tiles before group g: 32 g^2 + 4 g.
+__device__ __forceinline__ void lower_tile_of_index(int q, int mt, int& ti, int& tj);
 __device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bool spread, int& ti, int& tj) {
-  const int q = spread ? bid : xcd_remap(bid, nwg);
+  lower_tile_of_index(spread ? bid : xcd_remap(bid, nwg), mt, ti, tj);
+}
+// logical index q of the grouped lower enumeration -> tile
+__device__ __forceinline__ void lower_tile_of_index(int q, int mt, int& ti, int& tj) {
   const int G = mt >> 3;
   const int full_total = 32 * G * G + 4 * G;
   int g, h;
@@ -168,6 +175,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(
     } else {
       tile_of_block_lower(q - rect, nwg - rect, p.nt, true, ti, tj);
     }
+  } else if (p.lower == 4) {
+    // quarters of the big tiles of a partial last round: the four quarters of one parent are consecutive logical ids,
+    // i.e. on one XCD (they share the parent's operand panels)
+    const int idx = xcd_remap(bid, nwg);
+    int pi, pj;
+    lower_tile_of_index(p.q_off + (idx >> 2), p.q_mt, pi, pj);
+    ti = 2 * pi + ((idx >> 1) & 1);
+    tj = 2 * pj + (idx & 1);
+    if (tj > ti || ti >= p.mt) return;        // the upper-right quarter of a diagonal parent; a ragged parent's empty half
   } else if (p.lower) tile_of_block_lower(bid, nwg, p.mt, spread, ti, tj);
   else tile_of_block(bid, nwg, p.mt, p.nt, spread, ti, tj);
 
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(
 
   // epilogue: reg r of lane l is C[(l>>4) + 4r][l&15] of its 16x16 tile
   const int crow = lane >> 4, ccol = lane & 15;
-  const bool diag_tile = p.lower == 3 ? stair_diag_tile : (p.lower && (ti == tj));
+  const bool diag_tile = p.lower == 3 ? stair_diag_tile : (p.lower && (ti == tj));     // (lower == 4 included)
   // beta != 0: ALL loads of one row of 16x16 tiles are issued before the first use (one HBM
   // round trip per TN*4 elements); element-by-element load -> fma -> store serialises 16+ round
   // trips per tile, which is most of the run time of a K = 128 update
@@ -471,7 +487,8 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   if (a.lower == 3 && (BM != BN || a.st_blk % BN || a.st_step % BM)) return GPN_E_UNSUPPORTED;
   const int grid = (a.lower == 3   ? (int)stair_tiles(a.M, a.N, a.st_blk, a.st_step, a.st_diag, BM)
                     : a.lower == 2 ? (a.mt - a.nt) * a.nt + a.nt * (a.nt + 1) / 2
-                    : a.lower      ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
+                    : a.lower == 4 ? 4 * a.q_cnt
+                    : a.lower      ? (a.q_cnt > 0 ? a.q_cnt : a.mt * (a.mt + 1) / 2) : a.mt * a.nt) * std::max(1, a.batch);
   if (grid <= 0) return GPN_OK;
   const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW, PIPE>;
@@ -487,8 +504,9 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
     // executed flops: tiles actually computed x 2*BM*BN*K
     const double tiles = (a.lower == 3   ? (double)stair_tiles(a.M, a.N, a.st_blk, a.st_step, a.st_diag, BM)
                           : a.lower == 2 ? (double)(a.mt - a.nt) * a.nt + 0.5 * a.nt * (a.nt + 1.0)
-                          : a.lower      ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt) * std::max(1, a.batch);
-    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : (a.lower == 1 ? PROF_GEMM_SYRK : PROF_GEMM));
+                          : a.lower == 4 ? 4.0 * a.q_cnt
+                          : a.lower      ? (a.q_cnt > 0 ? (double)a.q_cnt : 0.5 * a.mt * (a.mt + 1.0)) : (double)a.mt * a.nt) * std::max(1, a.batch);
+    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : ((a.lower == 1 || a.lower == 4) ? PROF_GEMM_SYRK : PROF_GEMM));
     rec = profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K, cls);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), smem, s, a);
@@ -499,8 +517,10 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
 
 #ifdef GPN_DEBUG_SWITCHES
 static thread_local int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
+static thread_local int g_split_tail = 1;    // 1 = the partial last round of a big lower-tile launch as quarter tiles
 #else
 static constexpr int g_gemm_variant = 0;
+static constexpr int g_split_tail = 1;
 #endif
 
 struct Stair { int blk = 0, step = 0, diag = 0; };
@@ -542,6 +562,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   a.mt = a.nt = 0;
   a.lower = lower;
   a.st_blk = st.blk; a.st_step = st.step; a.st_diag = st.diag;
+  a.q_off = a.q_cnt = a.q_mt = 0;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
   // Tile choice (same-box sweeps, tools/gemm_ab.py).  The big tile is 128x128 as EIGHT waves of 32x64 (2 workgroups
@@ -592,6 +613,21 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   if (std_path) {
     if (small) return launch<64, 64, 32, 32, true, 2, false, true>(s, a);
     if (g_gemm_variant == 21) return launch<128, 128, 64, 64, true, 2, false, true>(s, a);
+    // Partial last round of a lower-tile launch: the 128 x 128 kernel has 512 slots (2 workgroups / CU), so t128 mod 512
+    // tiles keep the chip for one whole tile time (0.44 ms at K = 2048) however few they are.  When their 64 x 64 quarters
+    // fit ONE round of the small kernel's 1280 slots they go out as a second launch of quarter tiles instead (0.27 ms);
+    // every entry keeps its summation order (bit-identical).  C3's ten big trailing updates all qualify (mt a multiple of
+    // 16 => t128 mod 512 in 48 .. 248).  g_split_tail: A/B switch (tools' build).
+    const int64_t rem = t128 % 512;
+    if (g_split_tail && lower == 1 && batch == 1 && rem > 0 && 4 * rem <= 1280) {
+      GemmArgs big = a;
+      big.q_cnt = (int)(t128 - rem);
+      int rc = launch<128, 128, 32, 64, true, 2, false, true>(s, big);
+      if (rc != GPN_OK) return rc;
+      GemmArgs q = a;
+      q.lower = 4; q.q_off = (int)(t128 - rem); q.q_cnt = (int)rem; q.q_mt = (int)((M + 127) / 128);
+      return launch<64, 64, 32, 32, true, 2, false, true>(s, q);
+    }
     return launch<128, 128, 32, 64, true, 2, false, true>(s, a);
   }
   return small ? launch<64, 64, 32, 32, false>(s, a) : launch<128, 128, 64, 64, false>(s, a);
@@ -621,7 +657,8 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
 
 #ifdef GPN_DEBUG_SWITCHES
 extern "C" int gpn_debug_set_gemm_variant(int v) {     // (libgpnative_dbg.so only; the calling thread's launches)
-  gpn::g_gemm_variant = v & 0xff;
+  gpn::g_gemm_variant = v & 0x7f;
+  gpn::g_split_tail = (v & 0x80) ? 0 : 1;   // bit 7: no quarter-tile launch for the partial last round
   gpn::g_smem_pad = v >> 8;           // bits 8..: KiB of LDS padding per workgroup
   return GPN_OK;
 }

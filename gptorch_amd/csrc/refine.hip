@@ -16,8 +16,8 @@
 //
 // Kernels: backsub_step_kernel (one launch per 128-column block, right-looking: s_j -= L_kj^T a_k for all columns left
 // of block k, and the workgroup that owns block k-1 goes on to a_{k-1} = W_{k-1}^T s_{k-1} with the stored leaf inverse),
-// refine_resid_kernel<KIND> (64 x 64 tiles of
-// Kyy times a_hat, row strips split into column segments; error-free products and sums: Ogita-Rump-Oishi Dot2),
+// refine_resid_sym_kernel<KIND> (the 64 x 64 tiles of Kyy on / below the diagonal times a_hat, each used for its rows and for its
+// mirror columns; error-free products and sums: Ogita-Rump-Oishi Dot2) + refine_gather_kernel (per-row sums of the tile partials),
 // refine_finish_kernel (r, the two dot products and the LML, one workgroup, double-double throughout).
 #include "gpn_common.h"
 #include "kernel_fn.h"
@@ -153,127 +153,181 @@ __global__ __launch_bounds__(256) void backsub_step_kernel(const double* __restr
       a[(int64_t)(c0 + c) * lds + col0 + t] = t < jbn ? (part[0][c][t] + part[1][c][t]) + (part[2][c][t] + part[3][c][t]) : 0.0;
 }
 
-struct RefineArgs {
+// Kyy a_hat in double-double, Kyy re-computed from the points: ONE workgroup per 64 x 64 tile on or below the diagonal (the
+// assembly's own enumeration; tile structure, staging and the order of the sum over coordinates are kmat_kernel's, so that
+// every entry is bit for bit the one the assembly wrote into the factor buffer).  Tile (I, J), I > J, is evaluated once and used twice: its rows times a_J go to the row partial of tile
+// row I, its columns times a_I (the mirror entries K[j, i] = K[i, j]) to the column partial of tile row J; a diagonal
+// tile is computed whole and only feeds its row partial.  prow / pcol[tile q][c][64] double-double; refine_gather_kernel
+// adds them up per row in a fixed order.  (The first version evaluated all N^2 entries, one row strip per workgroup: 3.7 ms at
+// C3 against the 1.7 ms of the assembly it mirrors.)
+struct RefineSymArgs {
   const double* X;
   const double* variance;
   const double* ls;
   const double* noise;
   const double* a;       // [dy][lds]
-  double* partial;       // [nseg][dy][lds][2]
+  double* prow;          // [ntri][dy][64][2]
+  double* pcol;          // [ntri][dy][64][2]
   int64_t lds;
-  int n, d, nls, dy, nseg, tiles_per_seg;
+  int n, d, nls, dy;
 };
 
-// partial[seg][c][row] = sum over the column tiles of segment `seg` of Kyy[row, col] * a[c][col] in double-double.
-// Tile structure, staging and the order of the sum over coordinates are kmat_kernel's, so that every entry is
-// bit for bit the one the assembly wrote into the factor buffer.
 template <int KIND, int NRHS>
-__global__ __launch_bounds__(256) void refine_resid_kernel(RefineArgs p) {
+__global__ __launch_bounds__(256) void refine_resid_sym_kernel(RefineSymArgs p) {
   __shared__ __attribute__((aligned(16))) double xs[RDC][RT];
   __shared__ __attribute__((aligned(16))) double ys[RDC][RT];
   __shared__ double inv_ell[RDC];
-  __shared__ double av[NRHS][RT];
+  __shared__ double arow[NRHS][RT], acol[NRHS][RT];
   __shared__ double red[2][RT][17];
-  const int ti = blockIdx.x, seg = blockIdx.y;
+  const int q = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > q) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+  const int tj = q - ti * (ti + 1) / 2;
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
-  const int i0 = ti * RT;
-  const int ntile = (p.n + RT - 1) / RT;
-  const int tj0 = seg * p.tiles_per_seg, tj1 = min(ntile, tj0 + p.tiles_per_seg);
+  const int i0 = ti * RT, j0 = tj * RT;
   const double var = p.variance[0], noise = p.noise[0];
+  const bool offdiag = ti != tj;
 
-  for (int c0 = 0; c0 < p.dy; c0 += NRHS) {
-    const int nc = min(NRHS, p.dy - c0);
-    dd racc[4][NRHS];
+  double acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int c = 0; c < NRHS; ++c) racc[a][c] = dd{0.0, 0.0};
-
-    for (int tj = tj0; tj < tj1; ++tj) {
-      const int j0 = tj * RT;
-      double acc[4][4];
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int d0 = 0; d0 < p.d; d0 += RDC) {
+    if (tid < RDC) {
+      const int dd_ = d0 + tid;
+      inv_ell[tid] = dd_ < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : dd_] : 0.0;
+    }
+    __syncthreads();
+    {
+      const int pt = tid >> 2, c4 = (tid & 3) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int dd_ = d0 + c4 + c;
+        double vx = 0.0, vy = 0.0;
+        if (dd_ < p.d) {
+          const double ie = inv_ell[c4 + c];
+          if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd_] * ie;
+          if (j0 + pt < p.n) vy = p.X[(int64_t)(j0 + pt) * p.d + dd_] * ie;
+        }
+        xs[c4 + c][pt] = vx;
+        ys[c4 + c][pt] = vy;
+      }
+    }
+    __syncthreads();
+    const int dmax = min(RDC, p.d - d0);
+    for (int dd_ = 0; dd_ < dmax; ++dd_) {
+      const d2 xa = *reinterpret_cast<const d2*>(&xs[dd_][ty * 4]);
+      const d2 xb = *reinterpret_cast<const d2*>(&xs[dd_][ty * 4 + 2]);
+      const d2 ya = *reinterpret_cast<const d2*>(&ys[dd_][tx * 2]);
+      const d2 yb = *reinterpret_cast<const d2*>(&ys[dd_][32 + tx * 2]);
+      const double xr[4] = {xa.x, xa.y, xb.x, xb.y};
+      const double yc[4] = {ya.x, ya.y, yb.x, yb.y};
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-      // the assembly computes entry (i, j), i >= j, from (x_i - x_j); (x_j - x_i)^2 is the same number, so the upper
-      // triangle needs no swap of the operands
-      for (int d0 = 0; d0 < p.d; d0 += RDC) {
-        if (tid < RDC) {
-          const int dd_ = d0 + tid;
-          inv_ell[tid] = dd_ < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : dd_] : 0.0;
-        }
-        __syncthreads();
-        {
-          const int pt = tid >> 2, c4 = (tid & 3) * 4;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int dd_ = d0 + c4 + c;
-            double vx = 0.0, vy = 0.0;
-            if (dd_ < p.d) {
-              const double ie = inv_ell[c4 + c];
-              if (i0 + pt < p.n) vx = p.X[(int64_t)(i0 + pt) * p.d + dd_] * ie;
-              if (j0 + pt < p.n) vy = p.X[(int64_t)(j0 + pt) * p.d + dd_] * ie;
-            }
-            xs[c4 + c][pt] = vx;
-            ys[c4 + c][pt] = vy;
-          }
-        }
-        if (d0 == 0 && tid < RT)
-          for (int c = 0; c < nc; ++c) av[c][tid] = j0 + tid < p.n ? p.a[(int64_t)(c0 + c) * p.lds + j0 + tid] : 0.0;
-        __syncthreads();
-        const int dmax = min(RDC, p.d - d0);
-        for (int dd_ = 0; dd_ < dmax; ++dd_) {
-          const d2 xa = *reinterpret_cast<const d2*>(&xs[dd_][ty * 4]);
-          const d2 xb = *reinterpret_cast<const d2*>(&xs[dd_][ty * 4 + 2]);
-          const d2 ya = *reinterpret_cast<const d2*>(&ys[dd_][tx * 2]);
-          const d2 yb = *reinterpret_cast<const d2*>(&ys[dd_][32 + tx * 2]);
-          const double xr[4] = {xa.x, xa.y, xb.x, xb.y};
-          const double yc[4] = {ya.x, ya.y, yb.x, yb.y};
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const double df = xr[a] - yc[b];
-              acc[a][b] = fma(df, df, acc[a][b]);
-            }
-        }
-        __syncthreads();
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int row = i0 + ty * 4 + a;
-#pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const int cl = (b >> 1) * 32 + tx * 2 + (b & 1);
-          const int col = j0 + cl;
-          double v = kernel_of_r2<KIND>(acc[a][b], var);
-          if (row == col) v += noise;
-          if (row >= p.n || col >= p.n) v = 0.0;
-#pragma unroll
-          for (int c = 0; c < NRHS; ++c)
-            if (NRHS == 1 || c < nc) dd_fma(racc[a][c], v, av[c][cl]);
+          const double df = xr[a] - yc[b];
+          acc[a][b] = fma(df, df, acc[a][b]);
         }
-      }
-      // (av / xs / ys are rewritten only behind the barriers at the top of the next tile's staging)
     }
-    // reduce the 16 tx lanes of a row in a fixed order
+    __syncthreads();
+  }
+  // entries (the assembly's arithmetic: kernel_fn.h), noise on the diagonal, nothing outside the matrix
+  double v[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = i0 + ty * 4 + a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = j0 + (b >> 1) * 32 + tx * 2 + (b & 1);
+      double e = kernel_of_r2<KIND>(acc[a][b], var);
+      if (row == col) e += noise;
+      v[a][b] = (row < p.n && col < p.n) ? e : 0.0;
+    }
+  }
+  for (int c0 = 0; c0 < p.dy; c0 += NRHS) {
+    const int nc = min(NRHS, p.dy - c0);
+    __syncthreads();
+    if (tid < 2 * RT) {
+      const int pt = tid & (RT - 1);
+      const int idx = (tid < RT ? i0 : j0) + pt;
+      for (int c = 0; c < nc; ++c) (tid < RT ? arow : acol)[c][pt] = idx < p.n ? p.a[(int64_t)(c0 + c) * p.lds + idx] : 0.0;
+    }
+    __syncthreads();
     for (int c = 0; c < nc; ++c) {
+      // rows of I: sum over my 4 columns of v * a_J[col], then over the 16 tx lanes (fixed order)
+      dd r[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        red[0][ty * 4 + a][tx] = racc[a][c].hi;
-        red[1][ty * 4 + a][tx] = racc[a][c].lo;
+        r[a] = dd{0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dd_fma(r[a], v[a][b], acol[c][(b >> 1) * 32 + tx * 2 + (b & 1)]);
+        red[0][ty * 4 + a][tx] = r[a].hi;
+        red[1][ty * 4 + a][tx] = r[a].lo;
       }
       __syncthreads();
-      if (tid < RT && i0 + tid < p.n) {
+      if (tid < RT) {
         dd sum{red[0][tid][0], red[1][tid][0]};
-        for (int q = 1; q < 16; ++q) dd_add(sum, dd{red[0][tid][q], red[1][tid][q]});
-        double* out = p.partial + (((int64_t)seg * p.dy + (c0 + c)) * p.lds + i0 + tid) * 2;
+        for (int k = 1; k < 16; ++k) dd_add(sum, dd{red[0][tid][k], red[1][tid][k]});
+        double* out = p.prow + (((int64_t)q * p.dy + (c0 + c)) * RT + tid) * 2;
         out[0] = sum.hi;
         out[1] = sum.lo;
       }
       __syncthreads();
+      if (offdiag) {
+        // columns of J (the mirror entries): sum over my 4 rows of v * a_I[row], then over the 16 ty lanes
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          dd cc{0.0, 0.0};
+#pragma unroll
+          for (int a = 0; a < 4; ++a) dd_fma(cc, v[a][b], arow[c][ty * 4 + a]);
+          const int cl = (b >> 1) * 32 + tx * 2 + (b & 1);
+          red[0][cl][ty] = cc.hi;
+          red[1][cl][ty] = cc.lo;
+        }
+        __syncthreads();
+        if (tid < RT) {
+          dd sum{red[0][tid][0], red[1][tid][0]};
+          for (int k = 1; k < 16; ++k) dd_add(sum, dd{red[0][tid][k], red[1][tid][k]});
+          double* out = p.pcol + (((int64_t)q * p.dy + (c0 + c)) * RT + tid) * 2;
+          out[0] = sum.hi;
+          out[1] = sum.lo;
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// ka[c][i] = sum_{J <= T} prow[(T, J)][c][r] + sum_{I > T} pcol[(I, T)][c][r]   (T = i / 64, r = i % 64), double-double,
+// fixed order; 4 lanes per row take every 4th partial and are combined through LDS
+__global__ __launch_bounds__(256) void refine_gather_kernel(const double* prow, const double* pcol, int nt, int dy, int64_t lds,
+                                                            int64_t n, double* ka) {
+  __shared__ double sh[2][4][RT];
+  const int T = blockIdx.x, c = blockIdx.y;
+  const int r = threadIdx.x & (RT - 1), lane4 = threadIdx.x >> 6;
+  dd acc{0.0, 0.0};
+  const int total = nt;                       // T + 1 row partials + (nt - 1 - T) column partials
+  for (int k = lane4; k < total; k += 4) {
+    const double* src;
+    if (k <= T) src = prow + ((((int64_t)T * (T + 1) / 2 + k) * dy + c) * RT + r) * 2;
+    else src = pcol + ((((int64_t)k * (k + 1) / 2 + T) * dy + c) * RT + r) * 2;
+    dd_add(acc, dd{src[0], src[1]});
+  }
+  sh[0][lane4][r] = acc.hi;
+  sh[1][lane4][r] = acc.lo;
+  __syncthreads();
+  if (lane4 == 0) {
+    dd sum{sh[0][0][r], sh[1][0][r]};
+    for (int k = 1; k < 4; ++k) dd_add(sum, dd{sh[0][k][r], sh[1][k][r]});
+    const int64_t i = (int64_t)T * RT + r;
+    if (i < n) {
+      double* out = ka + ((int64_t)c * lds + i) * 2;
+      out[0] = sum.hi;
+      out[1] = sum.lo;
     }
   }
 }
@@ -325,20 +379,22 @@ __global__ __launch_bounds__(1024) void refine_finish_kernel(const double* Y, co
   }
 }
 
-struct RefineLayout { int64_t lds, s, a, partial, norm, total; int nseg, tiles_per_seg; };
+struct RefineLayout { int64_t lds, s, a, partial, norm, prow, pcol, total; int nseg, tiles_per_seg; };
 static RefineLayout refine_layout(int64_t n, int dy) {
   RefineLayout L;
   L.lds = round_up(n, LEAF);
   const int64_t ntile = (n + RT - 1) / RT;
-  // enough workgroups for ~8 per CU: row tiles x segments >= 2048, at least 8 column tiles per segment
-  int nseg = (int)std::max<int64_t>(1, std::min<int64_t>(2048 / std::max<int64_t>(ntile, 1), ntile / 8));
-  L.tiles_per_seg = (int)((ntile + nseg - 1) / nseg);
-  L.nseg = (int)((ntile + L.tiles_per_seg - 1) / L.tiles_per_seg);
+  L.nseg = 1;                 // Kyy a_hat per row (double-double), written by refine_gather_kernel
+  L.tiles_per_seg = (int)ntile;
   L.s = 0;
   L.a = L.s + (int64_t)dy * L.lds;
   L.partial = L.a + (int64_t)dy * L.lds;
   L.norm = L.partial + (int64_t)L.nseg * dy * L.lds * 2;
-  L.total = L.norm + 8;
+  // symmetric pass: one row partial and one column partial per lower tile
+  const int64_t ntri = ntile * (ntile + 1) / 2;
+  L.prow = L.norm + 8;
+  L.pcol = L.prow + ntri * dy * RT * 2;
+  L.total = L.pcol + ntri * dy * RT * 2;
   return L;
 }
 
@@ -383,15 +439,16 @@ extern "C" int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n
       else hipLaunchKernelGGL(backsub_step_kernel<RDY>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
     }
   GPN_LAUNCH_CHECK();
-  RefineArgs p;
+  const int64_t ntile = (n + RT - 1) / RT;
+  RefineSymArgs p;
   p.X = X; p.variance = variance; p.ls = length_scales; p.noise = noise; p.a = av;
-  p.partial = work + L.partial; p.lds = L.lds;
-  p.n = (int)n; p.d = d; p.nls = nls; p.dy = dy; p.nseg = L.nseg; p.tiles_per_seg = L.tiles_per_seg;
-  const dim3 grid((unsigned)((n + RT - 1) / RT), (unsigned)L.nseg);
-#define GPN_RESID(KIND)                                                                             \
-  do {                                                                                              \
-    if (dy == 1) hipLaunchKernelGGL((refine_resid_kernel<KIND, 1>), grid, dim3(256), 0, s, p);      \
-    else hipLaunchKernelGGL((refine_resid_kernel<KIND, RDY>), grid, dim3(256), 0, s, p);            \
+  p.prow = work + L.prow; p.pcol = work + L.pcol; p.lds = L.lds;
+  p.n = (int)n; p.d = d; p.nls = nls; p.dy = dy;
+  const dim3 grid((unsigned)(ntile * (ntile + 1) / 2));
+#define GPN_RESID(KIND)                                                                                 \
+  do {                                                                                                  \
+    if (dy == 1) hipLaunchKernelGGL((refine_resid_sym_kernel<KIND, 1>), grid, dim3(256), 0, s, p);      \
+    else hipLaunchKernelGGL((refine_resid_sym_kernel<KIND, RDY>), grid, dim3(256), 0, s, p);            \
   } while (0)
   switch (kind) {
     case GPN_RBF: GPN_RESID(GPN_RBF); break;
@@ -402,7 +459,11 @@ extern "C" int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n
   }
 #undef GPN_RESID
   GPN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(1024), 0, s, Y, M, av, work + L.partial, n, dy, L.nseg, L.lds, out3, work + L.norm);
+  // Kyy a per row, double-double, into the slot the finish kernel reads as its single segment
+  hipLaunchKernelGGL(refine_gather_kernel, dim3((unsigned)ntile, (unsigned)dy), dim3(256), 0, s, work + L.prow, work + L.pcol, (int)ntile, dy,
+                     L.lds, n, work + L.partial);
+  GPN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(1024), 0, s, Y, M, av, work + L.partial, n, dy, 1, L.lds, out3, work + L.norm);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

@@ -32,10 +32,9 @@ for n in [int(a) for a in sys.argv[1:]] or [128, 256, 896, 1000, 1024, 2048, 250
         a_ref = torch.linalg.solve_triangular(L.t(), alpha.t(), upper=True).t()
         K = _ops.kernel_matrix(kind, X, None, tv, tl, noise=tn)
         ka_ref = (K @ a_ref.t()).t()
-        nseg = (work.numel() - 8 - 2 * dy * lds) // (2 * dy * lds)
-        part = work[2 * dy * lds:2 * dy * lds + nseg * dy * lds * 2].view(nseg, dy, lds, 2)
-        ka_nat = part.sum(0).sum(-1)[:, :n]
+        nseg = 1                                          # refine_gather_kernel's per-row sums (hi, lo)
+        ka_nat = work[2 * dy * lds:2 * dy * lds + dy * lds * 2].view(dy, lds, 2).sum(-1)[:, :n]
         print("n=%5d %-8s d=%2d dy=%d nseg=%d | a err %.2e | Ka err %.2e | quad plain %.12g refined %.12g (rel diff %.2e) | max|r| %.2e"
               % (n, kind, d, dy, nseg, (a_nat - a_ref).abs().max().item() / a_ref.abs().max().item(),
                  (ka_nat - ka_ref).abs().max().item() / ka_ref.abs().max().item(), quad0, out[1].item(),
-                 abs(out[1].item() - quad0) / abs(quad0), work[-8].item()))
+                 abs(out[1].item() - quad0) / abs(quad0), work[2 * dy * lds + dy * lds * 2].item()))
