@@ -266,3 +266,59 @@ def test_rng_is_deterministic():
     c2 = [c for c in load_json("lml_cases.json") if c["name"] == "C2_rbf_8192_8"][0]
     assert rng.checksum(x) == c2["x_checksum"] and rng.checksum(y) == c2["y_checksum"]
     assert abs(x.mean()) < 0.01 and abs(x.std() - 1) < 0.01
+
+
+def test_expression_program_builder():
+    """gptorch_amd._expr.build: a Sum / Product tree (kernels.py:286-306) expands into a sum of products of leaf
+    instances with all leaf parameters packed into one vector -- pure host logic, no GPU."""
+    from gptorch_amd import _expr, _native
+    d = 3
+    rbf, m52 = kernels.Rbf(d, variance=0.7), kernels.Matern52(d, length_scales=np.array([1.0, 2.0, 3.0]), ARD=True)
+    lin, bias = kernels.Linear(d, variance=0.35), kernels.Bias(d, variance=0.2)
+    p = _expr.build((rbf + bias) * (m52 + lin))
+    assert p.groups == [[0, 1], [0, 2], [3, 1], [3, 2]] and [type(k).__name__ for k in p.leaves] == ["Rbf", "Matern52", "Linear", "Bias"]
+    assert p.offsets == [(0, 1, 1, 1), (2, 1, 3, 3), (6, 3, 9, 0), (9, 1, 10, 0)] and p.ntheta == 10
+    assert list(p.gstart) == [0, 2, 4, 6, 8] and len(p.instances) == 8
+    t = p.terms[1]
+    assert (t.type, t.kind, t.var_off, t.ls_off, t.nls) == (_native.TERM_STATIONARY, 1, 2, 3, 3)
+    assert p.terms[3].type == _native.TERM_LINEAR and p.terms[3].nvar == 3 and p.terms[4].type == _native.TERM_CONSTANT
+    assert p.grad_supported(3) and not _expr.build(kernels.Rbf(20, length_scales=np.ones(20), ARD=True) + bias2(20)).grad_supported(20)
+    theta = p.theta(p.params())
+    assert theta.shape == (10,) and abs(theta[0].item() - 0.7) < 1e-15 and torch.allclose(theta[3:6], torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64))
+    # instances of one leaf add their gradients up; White is a leaf, a lone stationary kernel is one too
+    g = p.scatter([torch.ones(2), torch.ones(4), torch.ones(2), torch.ones(3), torch.ones(1), torch.ones(4), torch.ones(1), torch.ones(3)], p.params())
+    assert [float(x.sum()) for x in g] == [2.0, 2.0, 2.0, 6.0, 6.0, 2.0]
+    assert _expr.build(kernels.Matern32(d) + kernels.White(d)).groups == [[0], [1]]
+    wide = rbf + bias
+    for _ in range(3):
+        wide = wide * (kernels.Rbf(d) + kernels.Bias(d))
+    assert _expr.build(wide) is None                     # 16 product groups > 8: composed path
+
+    class Custom(kernels.Kernel):
+        def K(self, X, X2=None):
+            return X @ (X if X2 is None else X2).t()
+    assert _expr.build(rbf + Custom(d)) is None          # a leaf without a native term: composed path
+
+
+def bias2(d):
+    return kernels.Bias(d, variance=0.1)
+
+
+def test_bench_self_launch_reports_a_dead_child(tmp_path):
+    """`python bench.py --gpus 2` with no launcher starts its ranks itself (a child torch.distributed.run).  Here there is no
+    GPU, so the ranks die at once: the parent must relay the child's exit code AND leave one JSON line that says so
+    (value null + the reason) instead of a usage message."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c1", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["scaling"] == "strong" and "without a result line" in d["error"]
