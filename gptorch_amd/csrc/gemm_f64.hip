@@ -517,10 +517,10 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
 
 #ifdef GPN_DEBUG_SWITCHES
 static thread_local int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
-static thread_local int g_split_tail = 1;    // 1 = the partial last round of a big lower-tile launch as quarter tiles
+static thread_local int g_split_tail = 0;    // 1 = the partial last round of a big lower-tile launch as quarter tiles (measured neutral: off)
 #else
 static constexpr int g_gemm_variant = 0;
-static constexpr int g_split_tail = 1;
+static constexpr int g_split_tail = 0;
 #endif
 
 struct Stair { int blk = 0, step = 0, diag = 0; };
@@ -617,7 +617,9 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
     // tiles keep the chip for one whole tile time (0.44 ms at K = 2048) however few they are.  When their 64 x 64 quarters
     // fit ONE round of the small kernel's 1280 slots they go out as a second launch of quarter tiles instead (0.27 ms);
     // every entry keeps its summation order (bit-identical).  C3's ten big trailing updates all qualify (mt a multiple of
-    // 16 => t128 mod 512 in 48 .. 248).  g_split_tail: A/B switch (tools' build).
+    // 16 => t128 mod 512 in 48 .. 248).  Measured NEUTRAL on whole evaluations (C3 186.05 vs 186.28 ms, C4 1363.9 vs 1363.0:
+    // the big kernel's last round is not synchronous, tiles are dealt to slots as they free up), so it is OFF in the product
+    // and kept behind g_split_tail (tools' build, gemm variant bit 7) with its test.
     const int64_t rem = t128 % 512;
     if (g_split_tail && lower == 1 && batch == 1 && rem > 0 && 4 * rem <= 1280) {
       GemmArgs big = a;
@@ -658,7 +660,7 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
 #ifdef GPN_DEBUG_SWITCHES
 extern "C" int gpn_debug_set_gemm_variant(int v) {     // (libgpnative_dbg.so only; the calling thread's launches)
   gpn::g_gemm_variant = v & 0x7f;
-  gpn::g_split_tail = (v & 0x80) ? 0 : 1;   // bit 7: no quarter-tile launch for the partial last round
+  gpn::g_split_tail = (v & 0x80) ? 1 : 0;   // bit 7: quarter-tile launch for the partial last round of big lower-tile launches
   gpn::g_smem_pad = v >> 8;           // bits 8..: KiB of LDS padding per workgroup
   return GPN_OK;
 }

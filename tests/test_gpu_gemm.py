@@ -180,7 +180,11 @@ def test_syrk_big_tile_launch_with_quarter_tile_tail(device, n, K):
     P = torch.randint(-3, 4, (n, K), generator=g).double().to(device)
     Pp = _pad_rows(P)
     C = torch.full((n, n), 7.0, dtype=torch.float64, device=device)
-    _ops.gemm_nt(Pp, Pp, n, n, K, alpha=-1.0, beta=1.0, C=C, lower=True)
+    _native.debug_begin().gpn_debug_set_gemm_variant(0x80)       # the split is off in the product (measured neutral): tools' build
+    try:
+        _ops.gemm_nt(Pp, Pp, n, n, K, alpha=-1.0, beta=1.0, C=C, lower=True)
+    finally:
+        _native.debug_end()
     for r0 in range(0, n, 2048):             # check in row slabs (the full reference would be another 1.1 GB)
         r1 = min(n, r0 + 2048)
         ref = 7.0 - P[r0:r1] @ P[:r1].t()
