@@ -24,9 +24,9 @@ from ._ops import _c, _ptr, _req, _stream, round_up
 def _upper_inverse(f, workspace=True):
     """U = L^-T in a zeroed [rows, ld] buffer (workspace: the level-parallel variant, which
     needs a second zeroed buffer of the same shape while it runs)."""
-    U = torch.zeros(f.rows, f.ld, dtype=torch.float64, device=f.device)
+    U = _ops.zeros(f.rows, f.ld, f.device)
     if workspace and f.n > 2 * _ops.LEAF:
-        S = torch.zeros_like(U)
+        S = _ops.zeros(f.rows, f.ld, f.device)
         st = _native.lib().gpn_trtri_upper_ws(_stream(f.device), _ptr(f.A), f.n, f.ld, _ptr(f.winv), _ptr(U), f.ld,
                                               _ptr(S), f.ld)
         _native.check(st, "gpn_trtri_upper_ws")

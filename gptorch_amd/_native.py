@@ -61,6 +61,7 @@ SIGNATURES = {
     "gpn_transpose": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64]),
     "gpn_copy_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "gpn_row_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "gpn_fill_zero": (c_int, [c_void_p, c_void_p, c_int64]),
 }
 class ExprTerm(ctypes.Structure):
     """include/gpnative.h gpn_expr_term: one leaf of a sum-of-products covariance expression."""

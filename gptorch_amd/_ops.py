@@ -74,6 +74,15 @@ def kernel_matrix(kind, X, X2, variance, length_scales, noise=None, out=None, ld
     return out
 
 
+def zeros(rows, cols, device):
+    """a zeroed [rows, cols] fp64 buffer: torch owns the memory, the library clears it (hipMemsetAsync on the current
+    stream) -- the large factor / inverse buffers are not cleared by an elementwise torch kernel."""
+    t = torch.empty(rows, cols, dtype=torch.float64, device=device)
+    st = _native.lib().gpn_fill_zero(_stream(t.device), _ptr(t), t.numel() * 8)
+    _native.check(st, "gpn_fill_zero")
+    return t
+
+
 # ----------------------------------------------------------------------------
 # factor buffers + Cholesky
 # ----------------------------------------------------------------------------
@@ -87,7 +96,7 @@ class Factor:
         self.n, self.e = int(n), int(e)
         self.ld = int(lib.gpn_factor_ld(n, e))
         self.rows = int(lib.gpn_factor_rows(n, e))
-        self.A = torch.zeros(self.rows, self.ld, dtype=torch.float64, device=device)
+        self.A = zeros(self.rows, self.ld, device)
         self.winv = torch.empty(max(1, int(lib.gpn_winv_bytes(n)) // 8), dtype=torch.float64, device=device)
         self.info = torch.zeros(1, dtype=torch.int32, device=device)
         self.jitter_rung = -1
@@ -375,7 +384,7 @@ def row_sumsq(A, rows, cols):
 
 def padded_like_factor(f, m):
     """zeroed [round_up(m,128), f.ld] buffer for right-hand sides of solve_right_lt."""
-    return torch.zeros(round_up(max(m, 1), LEAF), f.ld, dtype=torch.float64, device=f.device)
+    return zeros(round_up(max(m, 1), LEAF), f.ld, f.device)
 
 
 def trtrs_lower(b, f):
@@ -408,7 +417,7 @@ def lower_inverse(f):
     if W is None:
         from . import _backward
         U = _backward._upper_inverse(f)
-        W = torch.zeros_like(U)
+        W = zeros(U.shape[0], U.shape[1], U.device)
         if f.n:
             st = _native.lib().gpn_transpose(_stream(f.device), _ptr(U), f.n, f.n, f.ld, _ptr(W), f.ld)
             _native.check(st, "gpn_transpose")

@@ -12,3 +12,11 @@ void set_hip_error(hipError_t e, const char* where) {
 extern "C" int gpn_version(void) { return GPN_VERSION; }
 extern "C" const char* gpn_arch(void) { return "gfx950"; }
 extern "C" const char* gpn_last_hip_error(void) { return gpn::g_last_error.c_str(); }
+
+extern "C" int gpn_fill_zero(void* stream, void* dst, int64_t bytes) {
+  if (!dst) return -2;
+  if (bytes < 0) return -3;
+  if (bytes == 0) return GPN_OK;
+  GPN_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t)bytes, static_cast<hipStream_t>(stream)));
+  return GPN_OK;
+}

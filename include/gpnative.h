@@ -389,6 +389,8 @@ void gpn_rccl_comm_destroy(gpn_dist_comm* comm);
 int64_t gpn_mesh_plan(int p, int root, int me, int64_t count, int stages, int64_t direct_below, int64_t* ops, int64_t cap);
 
 /* ---- small utilities -------------------------------------------------------- */
+/* zero `bytes` bytes at dst on the stream (hipMemsetAsync): factor buffers, the backward's U / scratch matrices */
+int gpn_fill_zero(void* stream, void* dst, int64_t bytes);
 /* dst[r, c] = src[c, r] for src[rows, cols] */
 int gpn_transpose(void* stream, const double* src, int64_t rows, int64_t cols, int64_t lds,
                   double* dst, int64_t ldd);
