@@ -46,6 +46,7 @@ struct GemmArgs {
   // lower == 4: this launch computes, as BM x BN = 64 x 64 quarter tiles, the 128 x 128 tiles q_off .. q_off + q_cnt - 1 of a
   // lower-tile launch with q_mt tile rows (its partial last round: gemm_nt_impl); block b = quarter (b & 3) of tile q_off + b/4
   int q_off, q_cnt, q_mt;
+  int lds_pad_kb;   // extra dynamic LDS per workgroup: caps the workgroups per CU of a launch that shares the chip (look-ahead)
   // staircase: C is M x (nb * st_blk); column block b (st_blk columns) only has the rows from b * st_step on, and with
   // st_diag its first st_blk x st_blk square is lower-only -- the local tile columns of one block-cyclic trailing update
   int st_blk, st_step, st_diag;
@@ -490,10 +491,10 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
                     : a.lower == 4 ? 4 * a.q_cnt
                     : a.lower      ? (a.q_cnt > 0 ? a.q_cnt : a.mt * (a.mt + 1) / 2) : a.mt * a.nt) * std::max(1, a.batch);
   if (grid <= 0) return GPN_OK;
-  const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
+  const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + (g_smem_pad + a.lds_pad_kb) * 1024;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW, PIPE>;
-  static std::atomic<int> attr_set{-1};      // per template instance; racing threads set the same value
-  if (attr_set.load(std::memory_order_acquire) != smem) {
+  static std::atomic<int> attr_set{-1};      // per template instance: the largest size asked for so far (the attribute is a maximum)
+  if (attr_set.load(std::memory_order_acquire) < smem) {
     GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set.store(smem, std::memory_order_release);
@@ -527,12 +528,12 @@ struct Stair { int blk = 0, step = 0, diag = 0; };
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair());
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair(), int lds_pad_kb = 0);
 
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
-            double beta, double* C, int64_t ldc, int lower, int tri, int inplace) {
-  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, 1, 0, 0, 0);
+            double beta, double* C, int64_t ldc, int lower, int tri, int inplace, int lds_pad_kb) {
+  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, 1, 0, 0, 0, Stair(), lds_pad_kb);
 }
 
 int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
@@ -552,7 +553,7 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st) {
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st, int lds_pad_kb) {
   if (M <= 0 || N <= 0 || batch <= 0) return GPN_OK;
   GemmArgs a;
   a.batch = batch; a.sA = sA; a.sB = sB; a.sC = sC;
@@ -563,6 +564,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   a.lower = lower;
   a.st_blk = st.blk; a.st_step = st.step; a.st_diag = st.diag;
   a.q_off = a.q_cnt = a.q_mt = 0;
+  a.lds_pad_kb = lds_pad_kb;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
   // Tile choice (same-box sweeps, tools/gemm_ab.py).  The big tile is 128x128 as EIGHT waves of 32x64 (2 workgroups

@@ -27,7 +27,7 @@ void set_hip_error(hipError_t e, const char* where);
 // the factorisation drivers (no argument validation).
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
-            double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0);
+            double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0, int lds_pad_kb = 0);
 
 // staircase: C is M x (nblocks * blk); column block b has the rows from b * step on; diag: its first blk x blk square
 // is lower-only (gpnative.h gpn_gemm_nt_stair)

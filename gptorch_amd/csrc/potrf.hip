@@ -603,6 +603,8 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
 // or winv).
 struct Aux {
   hipStream_t s1 = nullptr;
+  hipStream_t s2 = nullptr;                     // look-ahead over panels (A/B): the bulk of a trailing update
+  hipEvent_t chain_done = nullptr, bulk_done = nullptr;
   hipEvent_t solve[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t rest[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -618,6 +620,11 @@ static Aux* aux_for(hipStream_t s) {
   int least = 0, greatest = 0;     // aux work is off the critical path: lowest priority
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
   if (hipStreamCreateWithPriority(&a.s1, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+#ifdef GPN_DEBUG_SWITCHES
+  if (hipStreamCreateWithPriority(&a.s2, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.chain_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.bulk_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+#endif
   for (int i = 0; i < 4; ++i) {
     if (hipEventCreateWithFlags(&a.solve[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.rest[i], hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -628,6 +635,11 @@ static Aux* aux_for(hipStream_t s) {
 }
 
 GPN_SWITCH g_panel_width = 0;        // 0 = by size; debug override
+// look-ahead over PANELS (A/B, tools' build only): after panel p only the strip of the trailing update that panel p+1 lives in
+// runs on the caller's stream; the rest goes to a second lowest-priority stream, capped to g_bulk_pad KiB of extra LDS per
+// workgroup (= fewer workgroups per CU, so that the chain's kernels always find room), underneath panel p+1's chain
+GPN_SWITCH g_panel_lookahead = 0;
+GPN_SWITCH g_bulk_pad = 32;
 GPN_SWITCH g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
 // Same-box sweeps (r1z, tools/potrf_ab.py): panel width 1024 / 1536 / 2048 -> C2 7.10 / 7.00 / 7.01 ms,
 // N = 16384 31.9 (1536) vs 32.2 (2048), C3 201.5 / 200.0 / 201.1, C4 1492 / 1473 / 1472; with the
@@ -642,7 +654,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
-  bool rest_pending = false;
+  bool rest_pending = false, bulk_pending = false;
   for (int64_t p0 = 0; p0 < n && c.rc == GPN_OK; p0 += PW) {
     const int64_t pw = std::min(PW, n - p0), pend = p0 + pw;
     for (int64_t k0 = p0; k0 < pend && c.rc == GPN_OK; k0 += LEAF, ++step) {
@@ -709,6 +721,33 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       rest_pending = false;
     }
     const int64_t m = n + e - pend;
+    const int64_t pw2 = std::min(PW, n - pend);    // width of the next panel
+    if (g_panel_lookahead && ax->s2 && pend + pw2 < n) {
+      // ---- look-ahead: strip now, bulk on the second stream underneath the next panel's chain
+      double* P = A + pend * lda + p0;
+      const int64_t kp = round_up(pw, 16);
+      if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }   // it wrote these columns
+      hip_ok(hipEventRecord(ax->chain_done, c.s));                                  // panel p is solved
+      // strip: rows >= pend x the next panel's columns (lower-only inside its top square)
+      c.rc = gemm_nt(c.s, m, pw2, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
+      if (c.rc != GPN_OK) break;
+      hip_ok(hipStreamWaitEvent(ax->s2, ax->chain_done, 0));
+      double* P2 = P + pw2 * lda;                  // rows >= pend + pw2 of the solved panel
+      double* C2 = A + (pend + pw2) * lda + pend + pw2;
+      const int64_t m2 = m - pw2;
+      if (c.corner || e == 0) {
+        c.rc = gemm_nt(ax->s2, m2, m2, kp, -1.0, P2, lda, P2, lda, 1.0, C2, lda, 1, 0, 0, g_bulk_pad);
+      } else {
+        const int64_t ms = m2 - e;
+        c.rc = gemm_nt(ax->s2, ms, ms, kp, -1.0, P2, lda, P2, lda, 1.0, C2, lda, 1, 0, 0, g_bulk_pad);
+        if (c.rc == GPN_OK)
+          c.rc = gemm_nt(ax->s2, e, ms, kp, -1.0, P2 + ms * lda, lda, P2, lda, 1.0, C2 + ms * lda, lda, 0, 0, 0, g_bulk_pad);
+      }
+      hip_ok(hipEventRecord(ax->bulk_done, ax->s2));
+      bulk_pending = true;
+      continue;
+    }
+    if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }
     if (pend < n) {
       double* P = A + pend * lda + p0;             // [m, pw] solved panel below the diagonal square
       if (c.corner || e == 0) {
@@ -908,6 +947,9 @@ extern "C" int gpn_release_stream(void* stream) {
   std::lock_guard<std::mutex> lock(g_aux_mutex);
   auto drop = [](Aux& a) {
     if (a.s1) { (void)hipStreamSynchronize(a.s1); (void)hipStreamDestroy(a.s1); }
+    if (a.s2) { (void)hipStreamSynchronize(a.s2); (void)hipStreamDestroy(a.s2); }
+    if (a.chain_done) (void)hipEventDestroy(a.chain_done);
+    if (a.bulk_done) (void)hipEventDestroy(a.bulk_done);
     for (int i = 0; i < 4; ++i) {
       if (a.solve[i]) (void)hipEventDestroy(a.solve[i]);
       if (a.rest[i]) (void)hipEventDestroy(a.rest[i]);
@@ -951,6 +993,8 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_leaf_pipe = ((v >> 2) & 1) ? 0 : 1;
   g_panel_width = ((v >> 8) & 0xff) * LEAF;
   g_aux_left_looking = ((v >> 3) & 1) ? 1 : (((v >> 5) & 1) ? 0 : -1);   // bit 3: force left-looking aux update, bit 5: force right-looking
+  g_panel_lookahead = (v >> 4) & 1;                                      // bit 4: look-ahead over panels (bulk of the trailing update on a second stream)
+  g_bulk_pad = (v >> 16) ? (v >> 16) : 32;                               // bits 16..: its LDS padding in KiB (occupancy cap)
   g_chain_kernel = 1 ^ ((v >> 6) & 3);                                   // bit 6: the chain's solve through the generic contraction; bit 7: its next-column update through colpanel.hip
   return GPN_OK;
 }
