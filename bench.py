@@ -588,6 +588,8 @@ def run_multi(args, rank, local_rank, world, device):
     per_schedule, engines = {}, {}
 
     def measure(sched):
+        if os.environ.get("GPN_BENCH_TEST_HANG_SCHEDULE") == sched and rank == world - 1:
+            time.sleep(3600)                       # test hook: one rank never joins this schedule's collectives
         # (the second engine reuses the first one's row / column sub-communicators: same grid, other schedule)
         g = gdist.BlockCyclicGP(X, Y, w["kind"], tile=args.tile, schedule=sched, share=next(iter(engines.values()), None))
         engines[sched] = g
@@ -737,7 +739,7 @@ def run_multi(args, rank, local_rank, world, device):
     # the remaining schedule(s), under a watchdog: if one does not come back, rank 0 prints the line it has and every
     # rank leaves (a blocked collective cannot be cancelled from Python)
     for sched in schedules[1:]:
-        deadline = 10.0 * t_first + 120.0
+        deadline = float(os.environ.get("GPN_BENCH_WATCHDOG_S", 10.0 * t_first + 120.0))
         done = threading.Event()
 
         def watchdog(sched=sched, deadline=deadline):

@@ -696,6 +696,23 @@ def test_sample_values_with_fixed_draws(device):
     assert tuple(s.shape) == (3, nt, dy)
 
 
+def test_bench_second_schedule_hang_does_not_cost_the_line(device):
+    """the N > 1 run times a second exchange schedule after the first.  If that one never comes back (here: one rank
+    sleeps instead of joining it -- on real hardware: a fabric the point-to-point schedule has never met), the watchdog
+    makes rank 0 print the line of the FIRST schedule, with the reason in `notes`, and every rank leaves with code 0."""
+    import json
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--workload", "c1", "--tile", "128", "--steps", "2", "--warmup", "1",
+                        "--test-shared-gpu", "--no-extras"], {"GPN_BENCH_TEST_HANG_SCHEDULE": "mesh", "GPN_BENCH_WATCHDOG_S": "20"}, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    case = [c for c in LML if c["name"] == "C1_rbf_512_2"][0]
+    assert d["exchange_schedule"] == "bcast" and set(d["exchange_schedules"]) == {"bcast"}
+    assert abs(d["lml"] - case["lml"]) < 1e-8 and d["value"] > 0
+    assert "watchdog" in d["notes"]["schedule_mesh_error"]
+
+
 def test_c_driver_single_rank_and_rccl_adapter(device):
     """gpn_dist_lml_forward (csrc/dist.hip), the block-cyclic evaluation behind the C ABI: (1) a 1x1 grid
     without a communicator on ragged multi-tile problems against the goldens; (2) the same call with
@@ -1299,6 +1316,14 @@ def test_refinement_removes_a_first_order_factor_error(device, kind, n, d, dy, a
         return out.cpu().numpy().copy()
     same = refine(f, terms.clone())
     assert abs(same[1] - true_quad) < 1e-11 * abs(true_quad) and same[0] == logdet
+    # the C-level call with the mean function passed separately (Y, M as gpn_lml_forward takes them) instead of the residual
+    Mm = torch.tensor(rng.normal(12, (n, dy)), device=device)
+    Yp = (Y + Mm).contiguous()
+    out_m = terms.clone()
+    st = lib.gpn_lml_refine(_ops._stream(device), _ops.KINDS[kind], _ops._ptr(X), n, d, _ops._ptr(Yp), _ops._ptr(Mm), dy, _ops._ptr(tv),
+                            _ops._ptr(tl), tl.numel(), _ops._ptr(tn), _ops._ptr(f.A), f.ld, _ops._ptr(f.winv), _ops._ptr(work), _ops._ptr(out_m))
+    _native.check(st, "gpn_lml_refine")
+    assert abs(out_m[1].item() - same[1]) < 1e-11 * abs(same[1])
     assert abs(same[2] - (-0.5 * same[1] - dy * logdet - 0.5 * dy * n * np.log(2 * np.pi))) < 1e-9 * abs(same[2])
     f2, terms2 = _ops.lml_forward(kind, X, Y, t(var), t(ls), t(nz * 1.00001), refine=False)
     wrong = terms2[1].item()
