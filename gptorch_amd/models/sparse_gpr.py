@@ -48,6 +48,16 @@ from ..util import as_tensor
 from .base import GPModel
 
 CHUNK_ROWS = 65536   # rows of x per streamed chunk (scratch: 2 x CHUNK_ROWS x ld(M) x 8 B)
+# Measured alternative, OFF by default (round 3): from INVERSE_MIN_M inducing points on (and N >= 4 M) form W = L^-1 once per
+# evaluation (M^3/3 flops) and compute every chunk's A_c = L^-1 Kuf_c as W Kuf_c -- already in the [M, rows] layout the A A^T
+# accumulation reads, so the right-solve recursion AND the transpose go.  Same bound to 8e-12 relative at config 5, gradients
+# equal to the solve path's wherever Kuu is not numerically singular (tests: test_vfe_inverse_path_vs_oracle) -- but not
+# faster: as ONE K-clipped launch per chunk 0.610 s (uneven tiles, dealt round-robin over the XCDs), as block rows of
+# INVERSE_BLOCK rows with plain launches 0.561-0.564 s, against 0.549-0.552 s for the right-solve (same box, interleaved;
+# profiles/r3_vfe_inverse_ab.txt): with two chunk pipelines in flight the bound is throughput-bound at ~62 TFLOP/s and the
+# inverse form carries 6 % more flops.
+INVERSE_MIN_M = int(__import__('os').environ.get('GPN_VFE_INVERSE_MIN_M', 1 << 62))
+INVERSE_BLOCK = int(__import__('os').environ.get('GPN_VFE_INVERSE_BLOCK', 512))
 # N-sharding over the GPUs of a node: when set to a torch.distributed process group
 # (or True for the default group) every rank holds a ROW SHARD of (x, y) and the same Z and
 # hyper-parameters; the M-sized sums A A^T, A err and the scalars N, |y|^2 are all-reduced in the
@@ -236,6 +246,7 @@ def _vfe_forward(asm, x, err, Z, s2):
     parts = torch.zeros(split, AAT.shape[0], AAT.shape[1], dtype=torch.float64, device=dev) if split > 1 else None
     aerr_parts = torch.zeros(split, mp, dy, dtype=torch.float64, device=dev) if split > 1 else None
     acc_done = None                                                        # event: AAT/Aerr updated through chunk c-1
+    W_uu = _ops.lower_inverse(f_uu) if (m >= INVERSE_MIN_M and n >= 4 * m) else None
     for stq in streams[1:]:
         stq.wait_stream(cur)
     for ci, (c0, r) in enumerate(_chunks(n, nc)):
@@ -246,9 +257,16 @@ def _vfe_forward(asm, x, err, Z, s2):
             if r < nc:                                                     # ragged tail: stale entries -> 0
                 At.zero_(), A.zero_(), errT.zero_()
             asm.kuf(x[c0:c0 + r], Z, At, f_uu.ld)
-            f_uu.solve_right_lt(At, r)                                     # A_c^T = Kuf_c^T L^-T
-            _ops._native.check(lib.gpn_transpose(stream, _ops._ptr(At), r, m, At.stride(0), _ops._ptr(A), nc),
-                               "gpn_transpose")
+            if W_uu is not None:
+                # A_c = W Kuf_c, W = L^-1 lower triangular: block rows of INVERSE_BLOCK rows, each with the K range it
+                # needs (k < its last row) as a plain contraction
+                for b0 in range(0, m, INVERSE_BLOCK):
+                    rows = min(INVERSE_BLOCK, m - b0)
+                    _ops.gemm_nt(W_uu[b0:], At, rows, r, _ops.round_up(b0 + rows, 16), C=A[b0:])
+            else:
+                f_uu.solve_right_lt(At, r)                                 # A_c^T = Kuf_c^T L^-T
+                _ops._native.check(lib.gpn_transpose(stream, _ops._ptr(At), r, m, At.stride(0), _ops._ptr(A), nc),
+                                   "gpn_transpose")
             errT[:dy, :r] = err[c0:c0 + r].t()
             kp = _ops.round_up(r, 16)
             first = 0.0 if c0 == 0 else 1.0
