@@ -751,7 +751,7 @@ def run_multi(args, rank, local_rank, world, device):
     # the remaining schedule(s), under a watchdog: if one does not come back, rank 0 prints the line it has and every
     # rank leaves (a blocked collective cannot be cancelled from Python)
     for sched in schedules[1:]:
-        deadline = float(os.environ.get("GPN_BENCH_WATCHDOG_S", 10.0 * t_first + 120.0))
+        deadline = float(os.environ.get("GPN_BENCH_WATCHDOG_S", 3.0 * t_first + 45.0))    # (the same work took t_first)
         done = threading.Event()
 
         def watchdog(sched=sched, deadline=deadline):
