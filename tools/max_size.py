@@ -41,3 +41,13 @@ for i in map(int, rows):
         wk = max(wk, abs(got - want))
 print("max |(L L^T - K)_ij| over %d sampled entries: %.2e; max |(L a - y)_i|: %.2e; peak HBM %.1f GB" % (
     5 * len(rows), wk, ws, torch.cuda.max_memory_allocated() / 1e9))
+# round 3: the refinement step of the quadratic form at this size (back-substitution over N/128 blocks + symmetric residual pass)
+f2, terms2 = _ops.lml_forward("Rbf", x, R, t(var), t(ls), t(noise), factor=f, refine=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+f2, terms2 = _ops.lml_forward("Rbf", x, R, t(var), t(ls), t(noise), factor=f, refine=True)
+torch.cuda.synchronize()
+sec2 = time.perf_counter() - t0
+tr = terms2.cpu().numpy()
+print("with gpn_lml_refine: %.2f s, LML %.6f (plain %.6f, difference %.2e), quadratic form %.9e vs %.9e" % (
+    sec2, tr[2], terms[2], tr[2] - terms[2], tr[1], terms[1]), flush=True)
