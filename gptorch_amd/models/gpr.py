@@ -156,7 +156,9 @@ def batched_log_likelihood(models, streams=None):
     with torch.no_grad():
         for m, st in zip(models, streams):
             k = m._stationary()
-            if k is None:                       # dense-K kernels: sequential path
+            if k is None or m.X.shape[0] >= _ops.refine_min_n():
+                # dense-K / composite kernels, and sizes at which log_likelihood() refines the quadratic form
+                # (the value must not depend on which entry point computed it): sequential path
                 pending.append(None)
                 continue
             with torch.cuda.stream(st):
