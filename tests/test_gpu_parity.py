@@ -1509,7 +1509,7 @@ def test_c_dist_consumer_runs(device, tmp_path):
     # RCCL's own bootstrap (ncclGetUniqueId / ncclCommInitRank pick a socket interface by themselves) was seen to hang
     # once on one box of the pool (a normal run takes 3 s; tools/rccl_consumer_soak.sh: 12 of 12 fine on another): one
     # retry over the loopback interface, and a bootstrap that never completes is reported as such, not as a parity error
-    for attempt, extra in enumerate(({}, {"NCCL_SOCKET_IFNAME": "lo", "NCCL_DEBUG": "WARN"})):
+    for attempt, extra in enumerate(({"NCCL_SOCKET_IFNAME": "lo"}, {"NCCL_DEBUG": "WARN"})):        # loopback first: it always exists
         try:
             r = subprocess.run([exe, "2048", "8", "512"], capture_output=True, text=True, timeout=120, env=dict(os.environ, **extra))
             break
