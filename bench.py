@@ -681,19 +681,6 @@ def run_multi(args, rank, local_rank, world, device):
             extra["single_gpu_same_run"] = single
             extra["lml_abs_diff_vs_single_gpu"] = abs(lml - single["lml_without_refinement"])
             extra["lml_abs_diff_vs_single_gpu_refined"] = abs(lml - single["lml"])
-        if args.dist_backward:
-            # opt-in: one distributed loss + closed-form backward (U = L^-T carried on the grid, Kyy^-1 = U U^T,
-            # per-rank sweeps) of the same model -- 2x the local matrix and ~3x the evaluation's time
-            try:
-                barrier()
-                t0 = time.perf_counter()
-                lml_b, grad = g.log_likelihood_and_grad(var, ls, nz, Y)
-                barrier()
-                tb = max_over_ranks(time.perf_counter() - t0)
-                extra["dist_loss_backward"] = {"config": w["name"].replace("LML eval", "LML + closed-form gradients") + ", block-cyclic over %d GPUs" % world,
-                                               "ms_per_step": tb * 1e3, "lml": float(lml_b.item()), "grads_constrained": [float(v) for v in grad.tolist()]}
-            except Exception as exc:
-                notes["dist_backward_error"] = repr(exc)
         # labelled extra: independent C2 replicas, one model per GPU, no collective (GP-fits/s at small N)
         try:
             mr, _, _ = build_model(WORKLOADS["c2"], seed=rank, device=device)
@@ -748,28 +735,54 @@ def run_multi(args, rank, local_rank, world, device):
             line["notes"] = dict(notes)
         return json.dumps(line)
 
-    # the remaining schedule(s), under a watchdog: if one does not come back, rank 0 prints the line it has and every
-    # rank leaves (a blocked collective cannot be cancelled from Python)
-    for sched in schedules[1:]:
-        deadline = float(os.environ.get("GPN_BENCH_WATCHDOG_S", 3.0 * t_first + 45.0))    # (the same work took t_first)
+    # Everything below runs under a watchdog: if a leg does not come back, rank 0 prints the line it has and every rank
+    # leaves (a blocked collective cannot be cancelled from Python).  (An exception on one rank only would leave the others
+    # in a collective: the watchdog covers that case too.)
+    def guarded(label, deadline, fn):
         done = threading.Event()
 
-        def watchdog(sched=sched, deadline=deadline):
+        def watchdog():
             if not done.wait(deadline):
-                notes["schedule_%s_error" % sched] = "no result within %.0f s (watchdog): schedule abandoned" % deadline
+                notes[label + "_error"] = "no result within %.0f s (watchdog): leg abandoned" % deadline
                 if rank == 0:
                     print(line_text(), flush=True)
                 os._exit(0)
-        th = threading.Thread(target=watchdog, daemon=True)
-        th.start()
+        threading.Thread(target=watchdog, daemon=True).start()
         try:
-            measure(sched)
+            fn()
         except Exception as exc:
-            notes["schedule_%s_error" % sched] = repr(exc)
-            per_schedule.pop(sched, None)
+            notes[label + "_error"] = repr(exc)
         done.set()
-        # every rank must agree on whether the schedule produced a result (an exception on one rank only would leave
-        # the others in a collective: the watchdog covers that case)
+
+    wd = os.environ.get("GPN_BENCH_WATCHDOG_S")
+    # (1) the remaining exchange schedule(s): the same work took t_first
+    for sched in schedules[1:]:
+        def second(sched=sched):
+            try:
+                measure(sched)
+            except Exception:
+                per_schedule.pop(sched, None)
+                raise
+        guarded("schedule_%s" % sched, float(wd) if wd else 3.0 * t_first + 45.0, second)
+    # (2) GP fits / s at this GPU count (north_star): ONE distributed loss + closed-form backward of the same model (U = L^-T
+    # carried on the grid, Kyy^-1 = U U^T with panels of U travelling like factorisation panels, per-rank sweeps, D + 2
+    # scalars all-reduced) -- the step of GPModel.optimize's Adam loop (base.py:260-269); a fit of BASELINE configs[2]'s
+    # length is 50 of them.  3x the local matrix and about 3x the evaluation's time; --no-dist-backward skips it.
+    if not args.no_extras and not args.no_dist_backward:
+        def dist_backward():
+            best_engine = engines[min(per_schedule, key=lambda k: per_schedule[k]["ms_per_step"])]
+            barrier()
+            t0 = time.perf_counter()
+            lml_b, grad = best_engine.log_likelihood_and_grad(var, ls, nz, Y)
+            barrier()
+            tb = max_over_ranks(time.perf_counter() - t0)
+            extra["dist_loss_backward"] = {
+                "config": w["name"].replace("LML eval", "LML + closed-form gradients") + ", block-cyclic over %d GPUs, exchange schedule '%s'" % (world, best_engine.schedule),
+                "ms_per_step": tb * 1e3, "lml": float(lml_b.item()), "grads_constrained": [float(v) for v in grad.tolist()],
+                "note": "first call: includes the allocation of the identity rows and of the Kyy^-1 accumulator"}
+            extra["fits_per_s_estimate"] = 1.0 / (50.0 * tb)
+            extra["fits_per_s_estimate_note"] = "1 / (50 x one distributed loss+backward): a fit = 50 Adam steps (BASELINE configs[2]); measured end to end only at N = 1 (c3_adam50)"
+        guarded("dist_backward", float(wd) if wd else 12.0 * sec * (args.steps + args.warmup + 1) + 60.0, dist_backward)
     if rank == 0:
         print(line_text(), flush=True)
 
@@ -835,7 +848,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: c3 on one GPU; c4 (block-cyclic) on several")
     ap.add_argument("--tile", type=int, default=2048, help="block-cyclic tile size (N > 1 GPUs)")
-    ap.add_argument("--dist-backward", action="store_true", help="(N > 1 GPUs) also time one distributed loss + backward")
+    ap.add_argument("--dist-backward", action="store_true", help=argparse.SUPPRESS)      # (now the default; kept for old command lines)
+    ap.add_argument("--no-dist-backward", action="store_true", help="(N > 1 GPUs) skip the distributed loss + backward leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fit", action="store_true", help="skip the 50-Adam-step fit leg (c3_adam50: about 30 s)")
     ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline from the 8192-row sample only (extrapolated), "
