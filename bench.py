@@ -747,12 +747,17 @@ def run_multi(args, rank, local_rank, world, device):
                 if rank == 0:
                     print(line_text(), flush=True)
                 os._exit(0)
-        threading.Thread(target=watchdog, daemon=True).start()
+        th = threading.Thread(target=watchdog, daemon=True)
+        th.start()
         try:
             fn()
         except Exception as exc:
             notes[label + "_error"] = repr(exc)
         done.set()
+        # wait for the watchdog thread to END before going on: its closure references this run's engines and process
+        # groups, and if run_multi returned first the thread would drop the last references -- tearing the groups down
+        # from a daemon thread that the interpreter kills at exit (SIGABRT seen at 8 ranks; tools/dbg/abort_trace.c)
+        th.join()
 
     wd = os.environ.get("GPN_BENCH_WATCHDOG_S")
     # (1) the remaining exchange schedule(s): the same work took t_first
