@@ -302,6 +302,14 @@ class BlockCyclicGP:
                 g = dist.new_group(ranks) if self.xcol else None
                 if c == self.my_c:
                     self.col_group = g
+            if dist.get_backend(group) == "nccl":
+                # RCCL builds a sub-communicator at its first collective, with EVERY member in the call.  The mesh
+                # schedule's grouped point-to-point stages do not involve every member every time, so make the
+                # communicators exist first (row groups are disjoint, so are column groups: no ordering hazard)
+                tok = torch.zeros(1, device=X.device)
+                for g in (self.row_group, self.col_group):
+                    if g is not None:
+                        dist.all_reduce(tok, group=g)
         # -- local geometry -------------------------------------------------------
         T, nt, r, c = self.T, self.nt, self.my_r, self.my_c
         self.nrow_t = len(range(r, nt, self.pr))
