@@ -19,6 +19,7 @@
 // refine_resid_sym_kernel<KIND> (the 64 x 64 tiles of Kyy on / below the diagonal times a_hat, each used for its rows and for its
 // mirror columns; error-free products and sums: Ogita-Rump-Oishi Dot2) + refine_gather_kernel (per-row sums of the tile partials),
 // refine_finish_kernel (r, the two dot products and the LML, one workgroup, double-double throughout).
+#include <algorithm>
 #include "gpn_common.h"
 #include "kernel_fn.h"
 
@@ -170,6 +171,7 @@ struct RefineSymArgs {
   double* pcol;          // [ntri][dy][64][2]
   int64_t lds;
   int n, d, nls, dy;
+  int q_off;             // first tile of this launch in the enumeration of the lower tiles (a rank's share: gpn_refine_resid_part)
 };
 
 template <int KIND, int NRHS>
@@ -179,11 +181,12 @@ __global__ __launch_bounds__(256) void refine_resid_sym_kernel(RefineSymArgs p) 
   __shared__ double inv_ell[RDC];
   __shared__ double arow[NRHS][RT], acol[NRHS][RT];
   __shared__ double red[2][RT][17];
-  const int q = blockIdx.x;
-  int ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-  while (ti * (ti + 1) / 2 > q) --ti;
-  while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
-  const int tj = q - ti * (ti + 1) / 2;
+  const int q = blockIdx.x;                  // slot of the partials
+  const int qg = q + p.q_off;                // the tile
+  int ti = (int)((sqrt(8.0 * (double)qg + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > qg) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= qg) ++ti;
+  const int tj = qg - ti * (ti + 1) / 2;
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
   const int i0 = ti * RT, j0 = tj * RT;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void refine_resid_sym_kernel(RefineSymArgs p) 
 // ka[c][i] = sum_{J <= T} prow[(T, J)][c][r] + sum_{I > T} pcol[(I, T)][c][r]   (T = i / 64, r = i % 64), double-double,
 // fixed order; 4 lanes per row take every 4th partial and are combined through LDS
 __global__ __launch_bounds__(256) void refine_gather_kernel(const double* prow, const double* pcol, int nt, int dy, int64_t lds,
-                                                            int64_t n, double* ka) {
+                                                            int64_t n, double* ka, int64_t q0 = 0, int64_t q1 = (int64_t)1 << 62) {
   __shared__ double sh[2][4][RT];
   const int T = blockIdx.x, c = blockIdx.y;
   const int r = threadIdx.x & (RT - 1), lane4 = threadIdx.x >> 6;
@@ -313,8 +316,10 @@ __global__ __launch_bounds__(256) void refine_gather_kernel(const double* prow, 
   const int total = nt;                       // T + 1 row partials + (nt - 1 - T) column partials
   for (int k = lane4; k < total; k += 4) {
     const double* src;
-    if (k <= T) src = prow + ((((int64_t)T * (T + 1) / 2 + k) * dy + c) * RT + r) * 2;
-    else src = pcol + ((((int64_t)k * (k + 1) / 2 + T) * dy + c) * RT + r) * 2;
+    const int64_t qq = k <= T ? (int64_t)T * (T + 1) / 2 + k : (int64_t)k * (k + 1) / 2 + T;
+    if (qq < q0 || qq >= q1) continue;       // not in this launch's share of the tiles
+    if (k <= T) src = prow + (((qq - q0) * dy + c) * RT + r) * 2;
+    else src = pcol + (((qq - q0) * dy + c) * RT + r) * 2;
     dd_add(acc, dd{src[0], src[1]});
   }
   sh[0][lane4][r] = acc.hi;
@@ -377,6 +382,55 @@ __global__ __launch_bounds__(1024) void refine_finish_kernel(const double* Y, co
     out3[2] = -0.5 * quad - (double)dy * logdet - 0.5 * (double)dy * (double)n * 1.8378770664093454836;
     if (resid_norm) resid_norm[0] = rn[0];
   }
+}
+
+// ---- pieces for a factor that is spread over several GPUs (gptorch_amd/dist.py BlockCyclicGP._refine) ----------------------
+// c[cc][col] += sum_r L[r][col] a[cc][r] for a rows x cols block of a row-major matrix (a tile row of the local factor times
+// the back-substituted block it belongs to): one thread per column, the rows dealt over blockIdx.y chunks whose partial sums
+// a second kernel adds in a fixed order (no atomics: the result does not depend on the schedule).
+template <int NRHS>
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* __restrict__ L, int64_t ld, int rows, int cols,
+                                                             const double* __restrict__ a, int64_t lda, int nc, int rows_per_chunk,
+                                                             double* __restrict__ part) {
+  __shared__ double as[NRHS][256];
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  double acc[NRHS];
+#pragma unroll
+  for (int c = 0; c < NRHS; ++c) acc[c] = 0.0;
+  for (int rb = r0; rb < r1; rb += 256) {
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) as[c][threadIdx.x] = rb + (int)threadIdx.x < r1 ? a[(int64_t)c * lda + rb + threadIdx.x] : 0.0;
+    __syncthreads();
+    if (col < cols) {
+      const int rn = min(256, r1 - rb);
+      const double* Lp = L + (int64_t)rb * ld + col;
+      for (int r = 0; r < rn; ++r) {
+        const double l = Lp[(int64_t)r * ld];
+#pragma unroll
+        for (int c = 0; c < NRHS; ++c) acc[c] = fma(l, as[c][r], acc[c]);
+      }
+    }
+  }
+  if (col < cols)
+    for (int c = 0; c < nc; ++c) part[((int64_t)blockIdx.y * nc + c) * cols + col] = acc[c];
+}
+
+__global__ __launch_bounds__(256) void gemv_t_reduce_kernel(const double* part, int nchunk, int nc, int cols, double* c, int64_t ldc) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  for (int cc = 0; cc < nc; ++cc) {
+    double sum = 0.0;
+    for (int k = 0; k < nchunk; ++k) sum += part[((int64_t)k * nc + cc) * cols + col];
+    c[(int64_t)cc * ldc + col] += sum;
+  }
+}
+
+static int gemv_t_chunks(int64_t rows, int64_t cols) {
+  const int64_t col_wgs = (cols + 255) / 256;
+  int64_t nchunk = (1024 + col_wgs - 1) / col_wgs;
+  nchunk = std::max<int64_t>(1, std::min<int64_t>(nchunk, (rows + 31) / 32));
+  return (int)nchunk;
 }
 
 struct RefineLayout { int64_t lds, s, a, partial, norm, prow, pcol, total; int nseg, tiles_per_seg; };
@@ -443,7 +497,7 @@ extern "C" int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n
   RefineSymArgs p;
   p.X = X; p.variance = variance; p.ls = length_scales; p.noise = noise; p.a = av;
   p.prow = work + L.prow; p.pcol = work + L.pcol; p.lds = L.lds;
-  p.n = (int)n; p.d = d; p.nls = nls; p.dy = dy;
+  p.n = (int)n; p.d = d; p.nls = nls; p.dy = dy; p.q_off = 0;
   const dim3 grid((unsigned)(ntile * (ntile + 1) / 2));
 #define GPN_RESID(KIND)                                                                                 \
   do {                                                                                                  \
@@ -464,6 +518,134 @@ extern "C" int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n
                      L.lds, n, work + L.partial);
   GPN_LAUNCH_CHECK();
   hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(1024), 0, s, Y, M, av, work + L.partial, n, dy, 1, L.lds, out3, work + L.norm);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// ---- the same step in pieces, for a factor spread over several GPUs (include/gpnative.h) -----------------------------------
+extern "C" int64_t gpn_gemv_t_work_bytes(int64_t rows, int64_t cols, int dy) {
+  if (rows <= 0 || cols <= 0 || dy <= 0) return 0;
+  return (int64_t)gemv_t_chunks(rows, cols) * std::min(dy, RDY) * cols * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_gemv_t_acc(void* stream, const double* L, int64_t ld, int64_t rows, int64_t cols, const double* a, int64_t lda,
+                              int dy, double* c, int64_t ldc, double* work) {
+  if (!L) return -2;
+  if (ld < cols) return -3;
+  if (rows < 0) return -4;
+  if (cols < 0) return -5;
+  if (!a) return -6;
+  if (lda < rows) return -7;
+  if (dy <= 0) return -8;
+  if (!c) return -9;
+  if (ldc < cols) return -10;
+  if (!work) return -11;
+  if (rows == 0 || cols == 0) return GPN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nchunk = gemv_t_chunks(rows, cols);
+  const int rpc = (int)((rows + nchunk - 1) / nchunk);
+  const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)nchunk);
+  for (int c0 = 0; c0 < dy; c0 += RDY) {
+    const int nc = std::min(RDY, dy - c0);
+    if (nc == 1) hipLaunchKernelGGL(gemv_t_partial_kernel<1>, grid, dim3(256), 0, s, L, ld, (int)rows, (int)cols, a + (int64_t)c0 * lda, lda, nc, rpc, work);
+    else hipLaunchKernelGGL(gemv_t_partial_kernel<RDY>, grid, dim3(256), 0, s, L, ld, (int)rows, (int)cols, a + (int64_t)c0 * lda, lda, nc, rpc, work);
+    hipLaunchKernelGGL(gemv_t_reduce_kernel, dim3(grid.x), dim3(256), 0, s, work, nchunk, nc, (int)cols, c + (int64_t)c0 * ldc, ldc);
+  }
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+extern "C" int gpn_backsolve_lt(void* stream, const double* L, int64_t n, int64_t ldl, int dy, double* sv, double* av, int64_t lds,
+                                double* winv, int32_t* info) {
+  if (!L) return -2;
+  if (n < 0) return -3;
+  if (ldl < round_up(n, LEAF) || (ldl % 2) != 0) return -4;
+  if (dy <= 0) return -5;
+  if (!sv) return -6;
+  if (!av) return -7;
+  if (lds < round_up(n, LEAF)) return -8;
+  if (!winv) return -9;
+  if (reinterpret_cast<uintptr_t>(L) & 15) return GPN_E_ALIGN;
+  if (n == 0) return GPN_OK;
+  int rc = gpn_trtri_diag(stream, L, n, ldl, winv, info);       // the leaf blocks' inverses (one workgroup per block)
+  if (rc != GPN_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nb = (int)((n + LEAF - 1) / LEAF);
+  for (int c0 = 0; c0 < dy; c0 += (dy == 1 ? 1 : RDY))
+    for (int k = nb; k >= 1; --k) {
+      if (dy == 1) hipLaunchKernelGGL(backsub_step_kernel<1>, dim3((unsigned)k), dim3(256), 0, s, L, ldl, winv, k, nb, n, dy, c0, sv, av, lds);
+      else hipLaunchKernelGGL(backsub_step_kernel<RDY>, dim3((unsigned)k), dim3(256), 0, s, L, ldl, winv, k, nb, n, dy, c0, sv, av, lds);
+    }
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+extern "C" int64_t gpn_refine_resid_part_work_bytes(int dy, int64_t ntiles) {
+  if (dy <= 0 || ntiles <= 0) return 0;
+  return 2 * ntiles * dy * RT * 2 * (int64_t)sizeof(double);
+}
+
+extern "C" int64_t gpn_refine_tile_count(int64_t n) {
+  const int64_t ntile = (n + RT - 1) / RT;
+  return ntile * (ntile + 1) / 2;
+}
+
+extern "C" int gpn_refine_resid_part(void* stream, int kind, const double* X, int64_t n, int d,
+                                     const double* variance, const double* length_scales, int nls, const double* noise,
+                                     const double* a, int dy, int64_t q0, int64_t q1, double* work, double* ka) {
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
+  if (!X) return -3;
+  if (n <= 0) return -4;
+  if (d <= 0) return -5;
+  if (!variance || !length_scales) return -6;
+  if (nls != 1 && nls != d) return -8;
+  if (!noise) return -9;
+  if (!a) return -10;
+  if (dy <= 0) return -11;
+  const int64_t ntile = (n + RT - 1) / RT, ntri = ntile * (ntile + 1) / 2;
+  if (q0 < 0 || q1 < q0 || q1 > ntri) return -12;
+  if (!work) return -14;
+  if (!ka) return -15;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t lds = round_up(n, LEAF);
+  const int64_t cnt = q1 - q0;
+  RefineSymArgs p;
+  p.X = X; p.variance = variance; p.ls = length_scales; p.noise = noise; p.a = a;
+  p.prow = work; p.pcol = work + cnt * dy * RT * 2; p.lds = lds;
+  p.n = (int)n; p.d = d; p.nls = nls; p.dy = dy; p.q_off = (int)q0;
+  if (cnt > 0) {
+    const dim3 grid((unsigned)cnt);
+#define GPN_RESID(KIND)                                                                                 \
+  do {                                                                                                  \
+    if (dy == 1) hipLaunchKernelGGL((refine_resid_sym_kernel<KIND, 1>), grid, dim3(256), 0, s, p);      \
+    else hipLaunchKernelGGL((refine_resid_sym_kernel<KIND, RDY>), grid, dim3(256), 0, s, p);            \
+  } while (0)
+    switch (kind) {
+      case GPN_RBF: GPN_RESID(GPN_RBF); break;
+      case GPN_MATERN52: GPN_RESID(GPN_MATERN52); break;
+      case GPN_MATERN32: GPN_RESID(GPN_MATERN32); break;
+      case GPN_EXP: GPN_RESID(GPN_EXP); break;
+      default: GPN_RESID(GPN_PERIODIC); break;
+    }
+#undef GPN_RESID
+    GPN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(refine_gather_kernel, dim3((unsigned)ntile, (unsigned)dy), dim3(256), 0, s, p.prow, p.pcol, (int)ntile, dy, lds, n, ka,
+                     q0, q1);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+extern "C" int gpn_refine_finish(void* stream, const double* Y, const double* M, const double* a, const double* ka, int64_t n, int dy,
+                                 double* out3) {
+  if (!Y) return -2;
+  if (!a) return -4;
+  if (!ka) return -5;
+  if (n < 0) return -6;
+  if (dy <= 0) return -7;
+  if (!out3) return -8;
+  hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), Y, M, a, ka, n, dy, 1, round_up(n, LEAF), out3,
+                     static_cast<double*>(nullptr));
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

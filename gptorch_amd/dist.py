@@ -243,6 +243,55 @@ class NativeTileOps:
         """-> [m]: sum_c A[r, c]^2 over the first n columns."""
         return _ops.row_sumsq(A, m, n)
 
+    # -- the refinement step of the quadratic form, in pieces (BlockCyclicGP._refine; csrc/refine.hip) ------------
+    def backsolve_t(self, L, n, S):
+        """-> [dy, ld]: row c = L[:n,:n]^-T S[c, :n]  (S: [dy, ld] contiguous, ld >= round_up(n, 128); consumed)."""
+        lib = _ops._native.lib()
+        dy, lds = S.shape
+        a = torch.zeros_like(S)
+        winv = torch.empty(max(1, self.winv_numel(n)), dtype=torch.float64, device=S.device)
+        info = torch.zeros(1, dtype=torch.int32, device=S.device)
+        st = lib.gpn_backsolve_lt(_ops._stream(S.device), _ops._ptr(L), n, L.stride(0), dy, _ops._ptr(S), _ops._ptr(a), lds,
+                                  _ops._ptr(winv), _ops._ptr(info))
+        _ops._native.check(st, "gpn_backsolve_lt")
+        return a
+
+    def gemv_t_acc(self, L, rows, cols, a, c):
+        """c[:, :cols] += a[:, :rows] @ L[:rows, :cols]  (a, c: [dy, ld] row-major, fixed summation order)."""
+        lib = _ops._native.lib()
+        dy = a.shape[0]
+        work = torch.empty(max(1, int(lib.gpn_gemv_t_work_bytes(rows, cols, dy)) // 8), dtype=torch.float64, device=a.device)
+        st = lib.gpn_gemv_t_acc(_ops._stream(a.device), _ops._ptr(L), L.stride(0), rows, cols, _ops._ptr(a), a.stride(0), dy,
+                                _ops._ptr(c), c.stride(0), _ops._ptr(work))
+        _ops._native.check(st, "gpn_gemv_t_acc")
+
+    def refine_tile_count(self, n):
+        return int(_ops._native.lib().gpn_refine_tile_count(n))
+
+    def resid_part(self, kind, X, variance, ls, noise, a, q0, q1):
+        """-> ka [dy, round_up(n, 128), 2]: (hi, lo) of the rows of Kyy a restricted to the lower 64 x 64 tiles q0 <= q < q1
+        (and their mirror entries), Kyy re-computed from X; a: [dy, round_up(n, 128)] contiguous."""
+        lib = _ops._native.lib()
+        n, d = X.shape
+        dy, lds = a.shape
+        ka = torch.empty(dy, lds, 2, dtype=torch.float64, device=X.device)
+        work = torch.empty(max(1, int(lib.gpn_refine_resid_part_work_bytes(dy, q1 - q0)) // 8), dtype=torch.float64, device=X.device)
+        var, l, nz = _ops._c(variance.detach()), _ops._c(ls.detach()), _ops._c(noise.detach())
+        st = lib.gpn_refine_resid_part(_ops._stream(X.device), _ops.KINDS[kind], _ops._ptr(_ops._c(X)), n, d, _ops._ptr(var), _ops._ptr(l),
+                                       l.numel(), _ops._ptr(nz), _ops._ptr(a), dy, q0, q1, _ops._ptr(work), _ops._ptr(ka))
+        _ops._native.check(st, "gpn_refine_resid_part")
+        ka[:, n:].zero_()
+        return ka
+
+    def refine_finish(self, R, a, ka):
+        """-> tensor []: y^T a + a^T (y - Kyy a) with y = R [n, dy], a [dy, lds], ka from resid_part (all shares summed)."""
+        n, dy = R.shape
+        out = torch.zeros(3, dtype=torch.float64, device=R.device)
+        st = _ops._native.lib().gpn_refine_finish(_ops._stream(R.device), _ops._ptr(_ops._c(R)), None, _ops._ptr(a), _ops._ptr(ka), n, dy,
+                                                  _ops._ptr(out))
+        _ops._native.check(st, "gpn_refine_finish")
+        return out[1]
+
 
 class BlockCyclicGP:
     """Distributed LML for a stationary kernel.  All ranks call every method collectively."""
@@ -261,6 +310,8 @@ class BlockCyclicGP:
             raise ValueError("schedule must be 'bcast' or 'mesh'")
         self.mesh_stages = int(os.environ.get("GPN_DIST_MESH_STAGES", MESH_STAGES))
         self.comm_timing = False       # record an event pair around every wait on a collective (exposed_comm_ms)
+        self.refine = None             # refinement step of the quadratic form after the factorisation: None = from refine_min_n() rows on
+        self.refined = False
         self._wait_events = []
         self.sent_bytes = {}           # global peer rank -> payload bytes this rank sent it ("mesh"; reset_comm_stats)
         self.bcast_root_bytes = 0      # payload bytes this rank was the root of ("bcast": the route is the backend's)
@@ -794,16 +845,79 @@ class BlockCyclicGP:
     def log_likelihood(self, variance, length_scales, noise, resid, max_tries=10):
         """assemble + factor with the jitter ladder of functions.py:20-43 (decided on the
         all-reduced info, so every rank takes the same branch)."""
+        refine = self.refine if self.refine is not None else self.n >= _ops.refine_min_n()
+        refine = refine and (self.comm or self.world == 1)        # (a phantom rank of tools/dist_phantom_profile.py has no peers to ask)
+        self.refined = False
         self.assemble(variance, length_scales, noise, resid)
         self.jitter_rung = -1
         if self.factor() == 0:
+            if refine:
+                self._refine(variance, length_scales, noise, resid)
             return self.lml()
         for i in range(max_tries):
-            self.assemble(variance, length_scales, noise + 10.0 ** (-max_tries + i), resid)
+            nz = noise + 10.0 ** (-max_tries + i)
+            self.assemble(variance, length_scales, nz, resid)
             self.jitter_rung = i
             if self.factor() == 0:
+                if refine:
+                    self._refine(variance, length_scales, nz, resid)
                 return self.lml()
         raise RuntimeError("Max tries exceeded.")
+
+    def _refine(self, variance, length_scales, noise, resid):
+        """One refinement step of y^T Kyy^-1 y on the grid (the single-GPU step of csrc/refine.hip / DESIGN 3.5, so that the
+        value does not depend on how many GPUs computed it: at N = 65536 the plain value is 6e-8 from the CPU reference on
+        1 x 2 GPUs and 9e-9 on 2 x 4, the refined one 4e-9 everywhere).
+          1. alpha^T from the residual segment, replicated (one all-reduce of N x dy);
+          2. a = L^-T alpha, tile row by tile row from the bottom: the owner of (J, J) back-substitutes its diagonal tile, a_J
+             is broadcast, and process row J mod Pr adds L[J, j]^T a_J to what it owes the tile columns j < J (summed over
+             the process column when their turn comes: one small all-reduce + one small broadcast per tile row);
+          3. Kyy a from the points in double-double: the 64 x 64 tiles of the lower triangle are dealt evenly over the
+             ranks regardless of where the factor's tiles live; one all-reduce of N x dy x 2;
+          4. quad = y^T a + a^T (y - Kyy a)  ->  self._sumsq."""
+        ops, T, nt, n, p = self.ops, self.T, self.nt, self.n, self.lml_rows
+        lv = nt * T
+        alpha = ops.zeros(p, lv)
+        if self.has_res:
+            for lj, J in enumerate(range(self.my_c, nt, self.pc)):
+                nJ = self.rows_of(J)
+                alpha[:, J * T:J * T + nJ] = self.A[self.res_off:self.res_off + p, lj * T:lj * T + nJ]
+        if self.comm:
+            dist.all_reduce(alpha, group=self.group)
+        a = ops.zeros(p, lv)
+        owed = ops.zeros(p, max(self.ncol_t, 1) * T)       # sum over MY tile rows I of L[I, j]^T a_I, per local column
+        for J in range(nt - 1, -1, -1):
+            nJ, cj, rj = self.rows_of(J), J % self.pc, J % self.pr
+            owner = rj * self.pc + cj
+            buf = ops.zeros(p, T)
+            if self.my_c == cj:
+                lj = (J - self.my_c) // self.pc
+                buf[:, :nJ] = owed[:, lj * T:lj * T + nJ]
+                if self.xcol:
+                    dist.all_reduce(buf, group=self.col_group)
+            aJ = ops.zeros(p, T)
+            if self.rank == owner:
+                li = (J - self.my_r) // self.pr
+                s = (alpha[:, J * T:(J + 1) * T] - buf).contiguous()
+                aJ = ops.backsolve_t(self.A[li * T:, lj * T:], nJ, s)
+            if self.comm:
+                dist.broadcast(aJ, src=owner if self.group is None else dist.get_global_rank(self.group, owner), group=self.group)
+            a[:, J * T:J * T + nJ] = aJ[:, :nJ]
+            if self.my_r == rj and J > 0:
+                ncl = self._cols_le(J - 1)
+                if ncl:
+                    li = (J - self.my_r) // self.pr
+                    ops.gemv_t_acc(self.A[li * T:, :], nJ, ncl * T, aJ, owed)
+        lds = _ops.round_up(n, LEAF)
+        ar = a[:, :lds].contiguous()
+        ntri = ops.refine_tile_count(n)
+        q0, q1 = ntri * self.rank // self.world, ntri * (self.rank + 1) // self.world
+        ka = ops.resid_part(self.kind, self.X, variance, length_scales, noise, ar, q0, q1)
+        if self.comm:
+            dist.all_reduce(ka, group=self.group)
+        self._sumsq_plain = self._sumsq
+        self._sumsq = float(ops.refine_finish(resid[:, :p].contiguous(), ar, ka))
+        self.refined = True
 
 
 class NativeDistLML:

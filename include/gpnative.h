@@ -282,6 +282,34 @@ int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n, int d,
                    const double* variance, const double* length_scales, int nls, const double* noise,
                    const double* A, int64_t lda, const double* winv, double* work, double* out3);
 
+/* The same refinement step in pieces, for a factor that is spread over several GPUs (gptorch_amd/dist.py
+ * BlockCyclicGP._refine: 2-D block-cyclic tiles; the exchange between the pieces is the caller's).  Vectors are
+ * [dy][ld] row-major, one right-hand side per row.
+ *   gpn_backsolve_lt   a = L^-T s for ONE diagonal tile L (n x n lower, e.g. 2048): leaf inverses into `winv`
+ *                      (gpn_winv_bytes(n)), then n/128 dependent launches; s is consumed; lds >= round_up(n, 128)
+ *   gpn_gemv_t_acc     c[cc][col] += sum_r L[r][col] a[cc][r] for a rows x cols block of the local factor: what the tile
+ *                      row of a back-substituted block owes the blocks left of it (fixed summation order);
+ *                      work: gpn_gemv_t_work_bytes(rows, cols, dy)
+ *   gpn_refine_resid_part   Kyy a_hat restricted to the lower 64 x 64 tiles q0 <= q < q1 of gpn_refine_tile_count(n)
+ *                      (row-major enumeration of the lower triangle; each tile also feeds its mirror entries), Kyy
+ *                      re-computed from the points, double-double: ka[dy][round_up(n,128)][2] = (hi, lo) per row.  The
+ *                      shares of all ranks add up to Kyy a_hat; a rank's share does not depend on where the factor's
+ *                      tiles live.  work: gpn_refine_resid_part_work_bytes(dy, q1 - q0)
+ *   gpn_refine_finish  out3[1] = y^T a_hat + a_hat^T r, out3[2] = the LML with it, r = (y - m) - ka in double-double;
+ *                      out3[0] = sum log L_ii on entry. */
+int gpn_backsolve_lt(void* stream, const double* L, int64_t n, int64_t ldl, int dy, double* s, double* a, int64_t lds,
+                     double* winv, int32_t* info);
+int64_t gpn_gemv_t_work_bytes(int64_t rows, int64_t cols, int dy);
+int gpn_gemv_t_acc(void* stream, const double* L, int64_t ld, int64_t rows, int64_t cols, const double* a, int64_t lda,
+                   int dy, double* c, int64_t ldc, double* work);
+int64_t gpn_refine_tile_count(int64_t n);
+int64_t gpn_refine_resid_part_work_bytes(int dy, int64_t ntiles);
+int gpn_refine_resid_part(void* stream, int kind, const double* X, int64_t n, int d,
+                          const double* variance, const double* length_scales, int nls, const double* noise,
+                          const double* a, int dy, int64_t q0, int64_t q1, double* work, double* ka);
+int gpn_refine_finish(void* stream, const double* Y, const double* M, const double* a, const double* ka, int64_t n, int dy,
+                      double* out3);
+
 /* gpn_lml_backward = the autograd backward of gpr.py:47-67 in closed form (what PyTorch's
  * CholeskyBackward0 + TriangularSolveBackward0 + elementwise chain compute for the reference):
  * U = L^-T, Kyy^-1 = U U^T, a = U alpha, one sweep.  grads[0] = dLML/d variance,
