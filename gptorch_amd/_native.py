@@ -62,7 +62,6 @@ SIGNATURES = {
     "gpn_copy_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "gpn_row_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "gpn_fill_zero": (c_int, [c_void_p, c_void_p, c_int64]),
-    "gpn_backsolve_lt": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "gpn_gemv_t_work_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "gpn_gemv_t_acc": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "gpn_refine_tile_count": (c_int64, [c_int64]),

@@ -555,31 +555,6 @@ extern "C" int gpn_gemv_t_acc(void* stream, const double* L, int64_t ld, int64_t
   return GPN_OK;
 }
 
-extern "C" int gpn_backsolve_lt(void* stream, const double* L, int64_t n, int64_t ldl, int dy, double* sv, double* av, int64_t lds,
-                                double* winv, int32_t* info) {
-  if (!L) return -2;
-  if (n < 0) return -3;
-  if (ldl < round_up(n, LEAF) || (ldl % 2) != 0) return -4;
-  if (dy <= 0) return -5;
-  if (!sv) return -6;
-  if (!av) return -7;
-  if (lds < round_up(n, LEAF)) return -8;
-  if (!winv) return -9;
-  if (reinterpret_cast<uintptr_t>(L) & 15) return GPN_E_ALIGN;
-  if (n == 0) return GPN_OK;
-  int rc = gpn_trtri_diag(stream, L, n, ldl, winv, info);       // the leaf blocks' inverses (one workgroup per block)
-  if (rc != GPN_OK) return rc;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int nb = (int)((n + LEAF - 1) / LEAF);
-  for (int c0 = 0; c0 < dy; c0 += (dy == 1 ? 1 : RDY))
-    for (int k = nb; k >= 1; --k) {
-      if (dy == 1) hipLaunchKernelGGL(backsub_step_kernel<1>, dim3((unsigned)k), dim3(256), 0, s, L, ldl, winv, k, nb, n, dy, c0, sv, av, lds);
-      else hipLaunchKernelGGL(backsub_step_kernel<RDY>, dim3((unsigned)k), dim3(256), 0, s, L, ldl, winv, k, nb, n, dy, c0, sv, av, lds);
-    }
-  GPN_LAUNCH_CHECK();
-  return GPN_OK;
-}
-
 extern "C" int64_t gpn_refine_resid_part_work_bytes(int dy, int64_t ntiles) {
   if (dy <= 0 || ntiles <= 0) return 0;
   return 2 * ntiles * dy * RT * 2 * (int64_t)sizeof(double);

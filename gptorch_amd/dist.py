@@ -244,17 +244,35 @@ class NativeTileOps:
         return _ops.row_sumsq(A, m, n)
 
     # -- the refinement step of the quadratic form, in pieces (BlockCyclicGP._refine; csrc/refine.hip) ------------
-    def backsolve_t(self, L, n, S):
-        """-> [dy, ld]: row c = L[:n,:n]^-T S[c, :n]  (S: [dy, ld] contiguous, ld >= round_up(n, 128); consumed)."""
+    def tile_inverse_t(self, L, n):
+        """-> U = L[:n,:n]^-T (upper triangular) in a zero-padded [round_up(n,128)]^2 buffer: leaf inverses + the level-parallel
+        triangular inversion of _backward._upper_inverse, for ONE diagonal tile."""
         lib = _ops._native.lib()
-        dy, lds = S.shape
-        a = torch.zeros_like(S)
-        winv = torch.empty(max(1, self.winv_numel(n)), dtype=torch.float64, device=S.device)
-        info = torch.zeros(1, dtype=torch.int32, device=S.device)
-        st = lib.gpn_backsolve_lt(_ops._stream(S.device), _ops._ptr(L), n, L.stride(0), dy, _ops._ptr(S), _ops._ptr(a), lds,
-                                  _ops._ptr(winv), _ops._ptr(info))
-        _ops._native.check(st, "gpn_backsolve_lt")
-        return a
+        npad = _ops.round_up(max(n, 1), LEAF)
+        U = _ops.zeros(npad, npad, L.device)
+        S = _ops.zeros(npad, npad, L.device)
+        winv = torch.empty(max(1, self.winv_numel(n)), dtype=torch.float64, device=L.device)
+        info = torch.zeros(1, dtype=torch.int32, device=L.device)
+        st = lib.gpn_trtri_diag(_ops._stream(L.device), _ops._ptr(L), n, L.stride(0), _ops._ptr(winv), _ops._ptr(info))
+        _ops._native.check(st, "gpn_trtri_diag")
+        if n > 2 * LEAF:
+            st = lib.gpn_trtri_upper_ws(_ops._stream(L.device), _ops._ptr(L), n, L.stride(0), _ops._ptr(winv), _ops._ptr(U), npad,
+                                        _ops._ptr(S), npad)
+        else:
+            st = lib.gpn_trtri_upper(_ops._stream(L.device), _ops._ptr(L), n, L.stride(0), _ops._ptr(winv), _ops._ptr(U), npad)
+        _ops._native.check(st, "gpn_trtri_upper")
+        S.record_stream(torch.cuda.current_stream(L.device))
+        return U
+
+    def apply_u(self, U, n, S):
+        """-> [dy, ld]: row c = U[:n,:n] S[c, :n] = L^-T s  (S: [dy, ld] zero beyond n).  (The contraction reads its left
+        operand in whole 16-row groups: the right-hand sides go through a padded copy.)"""
+        dy, ld = S.shape
+        Sp = torch.zeros(_ops.round_up(dy, 16), ld, dtype=torch.float64, device=S.device)
+        Sp[:dy] = S
+        out = torch.zeros_like(Sp)
+        _ops.gemm_nt(Sp, U, dy, n, _ops.round_up(n, 16), C=out, tri=_ops.TRI_B_UPPER)
+        return out[:dy].contiguous()
 
     def gemv_t_acc(self, L, rows, cols, a, c):
         """c[:, :cols] += a[:, :rows] @ L[:rows, :cols]  (a, c: [dy, ld] row-major, fixed summation order)."""
@@ -869,7 +887,7 @@ class BlockCyclicGP:
         value does not depend on how many GPUs computed it: at N = 65536 the plain value is 6e-8 from the CPU reference on
         1 x 2 GPUs and 9e-9 on 2 x 4, the refined one 4e-9 everywhere).
           1. alpha^T from the residual segment, replicated (one all-reduce of N x dy);
-          2. a = L^-T alpha, tile row by tile row from the bottom: the owner of (J, J) back-substitutes its diagonal tile, a_J
+          2. a = L^-T alpha, tile row by tile row from the bottom: the owner of (J, J) applies its (pre-inverted) diagonal tile, a_J
              is broadcast, and process row J mod Pr adds L[J, j]^T a_J to what it owes the tile columns j < J (summed over
              the process column when their turn comes: one small all-reduce + one small broadcast per tile row);
           3. Kyy a from the points in double-double: the 64 x 64 tiles of the lower triangle are dealt evenly over the
@@ -886,20 +904,26 @@ class BlockCyclicGP:
             dist.all_reduce(alpha, group=self.group)
         a = ops.zeros(p, lv)
         owed = ops.zeros(p, max(self.ncol_t, 1) * T)       # sum over MY tile rows I of L[I, j]^T a_I, per local column
+        # the inverses of MY diagonal tiles, all ranks at once and before the serial sweep: a_J is then ONE skinny product
+        # per step (the step tolerates any approximate a: the corrected value is exact to second order in y - Kyy a)
+        buf, recv = ops.zeros(p, T), ops.zeros(p, T)
+        Uinv = {}
+        for J in range(nt):
+            if self.mine(J, J):
+                Uinv[J] = ops.tile_inverse_t(self.A[((J - self.my_r) // self.pr) * T:, ((J - self.my_c) // self.pc) * T:], self.rows_of(J))
         for J in range(nt - 1, -1, -1):
             nJ, cj, rj = self.rows_of(J), J % self.pc, J % self.pr
             owner = rj * self.pc + cj
-            buf = ops.zeros(p, T)
             if self.my_c == cj:
                 lj = (J - self.my_c) // self.pc
+                buf.zero_()
                 buf[:, :nJ] = owed[:, lj * T:lj * T + nJ]
                 if self.xcol:
                     dist.all_reduce(buf, group=self.col_group)
-            aJ = ops.zeros(p, T)
+            aJ = recv                                      # (overwritten by the broadcast on every rank but the owner)
             if self.rank == owner:
-                li = (J - self.my_r) // self.pr
                 s = (alpha[:, J * T:(J + 1) * T] - buf).contiguous()
-                aJ = ops.backsolve_t(self.A[li * T:, lj * T:], nJ, s)
+                aJ = ops.apply_u(Uinv.pop(J), nJ, s)
             if self.comm:
                 dist.broadcast(aJ, src=owner if self.group is None else dist.get_global_rank(self.group, owner), group=self.group)
             a[:, J * T:J * T + nJ] = aJ[:, :nJ]

@@ -285,8 +285,7 @@ int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n, int d,
 /* The same refinement step in pieces, for a factor that is spread over several GPUs (gptorch_amd/dist.py
  * BlockCyclicGP._refine: 2-D block-cyclic tiles; the exchange between the pieces is the caller's).  Vectors are
  * [dy][ld] row-major, one right-hand side per row.
- *   gpn_backsolve_lt   a = L^-T s for ONE diagonal tile L (n x n lower, e.g. 2048): leaf inverses into `winv`
- *                      (gpn_winv_bytes(n)), then n/128 dependent launches; s is consumed; lds >= round_up(n, 128)
+ *   (a diagonal tile's own solve a_J = L_JJ^-T s_J is gpn_trtri_diag + gpn_trtri_upper once + one gpn_gemm_nt per use)
  *   gpn_gemv_t_acc     c[cc][col] += sum_r L[r][col] a[cc][r] for a rows x cols block of the local factor: what the tile
  *                      row of a back-substituted block owes the blocks left of it (fixed summation order);
  *                      work: gpn_gemv_t_work_bytes(rows, cols, dy)
@@ -297,8 +296,6 @@ int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n, int d,
  *                      tiles live.  work: gpn_refine_resid_part_work_bytes(dy, q1 - q0)
  *   gpn_refine_finish  out3[1] = y^T a_hat + a_hat^T r, out3[2] = the LML with it, r = (y - m) - ka in double-double;
  *                      out3[0] = sum log L_ii on entry. */
-int gpn_backsolve_lt(void* stream, const double* L, int64_t n, int64_t ldl, int dy, double* s, double* a, int64_t lds,
-                     double* winv, int32_t* info);
 int64_t gpn_gemv_t_work_bytes(int64_t rows, int64_t cols, int dy);
 int gpn_gemv_t_acc(void* stream, const double* L, int64_t ld, int64_t rows, int64_t cols, const double* a, int64_t lda,
                    int dy, double* c, int64_t ldc, double* work);
@@ -369,6 +366,9 @@ int64_t gpn_dist_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, 
  * info of the WHOLE matrix as a double (0 = ok, j > 0 = first failing pivot: replay with
  * noise + 10^(-10+i) as functions.py:20-43 does; GPN_INFO_INTERNAL = internal failure), identical on
  * every rank.  comm may be NULL for a 1 x 1 grid.  No host synchronisation.
+ * out4[1] is the PLAIN |alpha|^2: from about 10^4 rows on the caller that wants north_star's 1e-8 absolute refines it with the
+ * pieces declared next to gpn_lml_refine (gptorch_amd/dist.py BlockCyclicGP._refine is that sequence over torch.distributed; at
+ * N = 65536 the plain value is 6e-8 from the CPU reference on a 1 x 2 grid, 9e-9 on 2 x 4, the refined one 2-4e-9 on every grid).
  * Errors on a multi-rank grid: a non-zero status (bad argument aside) means this rank stopped issuing the evaluation's
  * collectives part-way; its peers may be blocked inside the transport.  Nothing is drained (a collective whose peers never
  * arrive cannot complete): abort the communicators on every rank (ncclCommAbort) before reusing them. */

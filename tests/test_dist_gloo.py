@@ -73,9 +73,12 @@ class CpuTileOps:
         return A[:m, :n].pow(2).sum(1)
 
     # the refinement step's pieces (BlockCyclicGP._refine)
-    def backsolve_t(self, L, n, S):
+    def tile_inverse_t(self, L, n):
+        return torch.linalg.inv(L[:n, :n]).t().contiguous()
+
+    def apply_u(self, U, n, S):
         a = torch.zeros_like(S)
-        a[:, :n] = torch.linalg.solve_triangular(L[:n, :n].t(), S[:, :n].t(), upper=True).t()
+        a[:, :n] = S[:, :n] @ U[:n, :n].t()
         return a
 
     def gemv_t_acc(self, L, rows, cols, a, c):
