@@ -373,6 +373,24 @@ def test_c2_gradient_golden(device):
         assert err < 1e-8, (name, g, ref)
 
 
+def test_c3_full_size_predict_golden(device):
+    """GPR._predict (gpr.py:88-117) at BASELINE config 3's size: 1024 test points (seed 7), diag, and a 64 x 64 full covariance,
+    against the CPU oracle evaluated once at full size on a GPU box's host (tests/golden/predict_c3_cpu_oracle.npz,
+    tests/sweeps/c3_predict_cpu_parity.py: 95 s on 64 threads).  Measured: mean 2.2e-11 (|mean| <= 1.8), variance 1.2e-14,
+    covariance 1.4e-14."""
+    case = load_json("lml_c3.json")
+    m, x, y = _model(case, device)
+    gold = load_npz("predict_c3_cpu_oracle.npz")
+    xs = rng.normal(7, (1024, case["d"]))
+    with torch.no_grad():
+        mean, var = m.predict_f(xs, diag=True)
+        _, cov = m.predict_f(xs[:64], diag=False)
+    tonp = lambda t: t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+    assert np.abs(tonp(mean) - gold["mean"]).max() < 1e-9
+    assert np.abs(tonp(var) - gold["var"]).max() < 1e-11
+    assert np.abs(tonp(cov) - gold["cov"]).max() < 1e-11
+
+
 def test_c3_full_size_backward_properties(device):
     """BASELINE config 3's backward at FULL size (N = 32768, D = 16, Matern52: the 2048-wide panels,
     the left-looking in-panel update, 128x128 K-clipped tiles in the triangular inversion and in
