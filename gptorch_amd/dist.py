@@ -244,9 +244,10 @@ class NativeTileOps:
         return _ops.row_sumsq(A, m, n)
 
     # -- the refinement step of the quadratic form, in pieces (BlockCyclicGP._refine; csrc/refine.hip) ------------
-    def tile_inverse_t(self, L, n):
-        """-> U = L[:n,:n]^-T (upper triangular) in a zero-padded [round_up(n,128)]^2 buffer: leaf inverses + the level-parallel
-        triangular inversion of _backward._upper_inverse, for ONE diagonal tile."""
+    def tile_inverse(self, L, n):
+        """-> W = L[:n,:n]^-1 (lower triangular, row-major) in a zero-padded [round_up(n,128)]^2 buffer: leaf inverses + the
+        level-parallel triangular inversion of _backward._upper_inverse + one transpose, for ONE diagonal tile.  (Row-major W
+        makes a = L^-T s a column-sum product: gemv_t_acc(W, n, n, s, a).)"""
         lib = _ops._native.lib()
         npad = _ops.round_up(max(n, 1), LEAF)
         U = _ops.zeros(npad, npad, L.device)
@@ -261,24 +262,19 @@ class NativeTileOps:
         else:
             st = lib.gpn_trtri_upper(_ops._stream(L.device), _ops._ptr(L), n, L.stride(0), _ops._ptr(winv), _ops._ptr(U), npad)
         _ops._native.check(st, "gpn_trtri_upper")
-        S.record_stream(torch.cuda.current_stream(L.device))
-        return U
-
-    def apply_u(self, U, n, S):
-        """-> [dy, ld]: row c = U[:n,:n] S[c, :n] = L^-T s  (S: [dy, ld] zero beyond n).  (The contraction reads its left
-        operand in whole 16-row groups: the right-hand sides go through a padded copy.)"""
-        dy, ld = S.shape
-        Sp = torch.zeros(_ops.round_up(dy, 16), ld, dtype=torch.float64, device=S.device)
-        Sp[:dy] = S
-        out = torch.zeros_like(Sp)
-        _ops.gemm_nt(Sp, U, dy, n, _ops.round_up(n, 16), C=out, tri=_ops.TRI_B_UPPER)
-        return out[:dy].contiguous()
+        st = lib.gpn_transpose(_ops._stream(L.device), _ops._ptr(U), npad, npad, npad, _ops._ptr(S), npad)      # S <- U^T = L^-1
+        _ops._native.check(st, "gpn_transpose")
+        U.record_stream(torch.cuda.current_stream(L.device))
+        return S
 
     def gemv_t_acc(self, L, rows, cols, a, c):
         """c[:, :cols] += a[:, :rows] @ L[:rows, :cols]  (a, c: [dy, ld] row-major, fixed summation order)."""
         lib = _ops._native.lib()
         dy = a.shape[0]
-        work = torch.empty(max(1, int(lib.gpn_gemv_t_work_bytes(rows, cols, dy)) // 8), dtype=torch.float64, device=a.device)
+        need = max(1, int(lib.gpn_gemv_t_work_bytes(rows, cols, dy)) // 8)
+        work = getattr(self, "_gemv_work", None)
+        if work is None or work.numel() < need or work.device != a.device:
+            work = self._gemv_work = torch.empty(need, dtype=torch.float64, device=a.device)
         st = lib.gpn_gemv_t_acc(_ops._stream(a.device), _ops._ptr(L), L.stride(0), rows, cols, _ops._ptr(a), a.stride(0), dy,
                                 _ops._ptr(c), c.stride(0), _ops._ptr(work))
         _ops._native.check(st, "gpn_gemv_t_acc")
@@ -906,11 +902,11 @@ class BlockCyclicGP:
         owed = ops.zeros(p, max(self.ncol_t, 1) * T)       # sum over MY tile rows I of L[I, j]^T a_I, per local column
         # the inverses of MY diagonal tiles, all ranks at once and before the serial sweep: a_J is then ONE skinny product
         # per step (the step tolerates any approximate a: the corrected value is exact to second order in y - Kyy a)
-        buf, recv = ops.zeros(p, T), ops.zeros(p, T)
+        buf, recv, sJ, mine_a = ops.zeros(p, T), ops.zeros(p, T), ops.zeros(p, T), ops.zeros(p, T)
         Uinv = {}
         for J in range(nt):
             if self.mine(J, J):
-                Uinv[J] = ops.tile_inverse_t(self.A[((J - self.my_r) // self.pr) * T:, ((J - self.my_c) // self.pc) * T:], self.rows_of(J))
+                Uinv[J] = ops.tile_inverse(self.A[((J - self.my_r) // self.pr) * T:, ((J - self.my_c) // self.pc) * T:], self.rows_of(J))
         for J in range(nt - 1, -1, -1):
             nJ, cj, rj = self.rows_of(J), J % self.pc, J % self.pr
             owner = rj * self.pc + cj
@@ -922,8 +918,10 @@ class BlockCyclicGP:
                     dist.all_reduce(buf, group=self.col_group)
             aJ = recv                                      # (overwritten by the broadcast on every rank but the owner)
             if self.rank == owner:
-                s = (alpha[:, J * T:(J + 1) * T] - buf).contiguous()
-                aJ = ops.apply_u(Uinv.pop(J), nJ, s)
+                torch.sub(alpha[:, J * T:(J + 1) * T], buf, out=sJ)
+                aJ = mine_a
+                aJ.zero_()
+                ops.gemv_t_acc(Uinv.pop(J), nJ, nJ, sJ, aJ)               # a_J = W^T s_J = L_JJ^-T s_J
             if self.comm:
                 dist.broadcast(aJ, src=owner if self.group is None else dist.get_global_rank(self.group, owner), group=self.group)
             a[:, J * T:J * T + nJ] = aJ[:, :nJ]

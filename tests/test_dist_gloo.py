@@ -73,13 +73,8 @@ class CpuTileOps:
         return A[:m, :n].pow(2).sum(1)
 
     # the refinement step's pieces (BlockCyclicGP._refine)
-    def tile_inverse_t(self, L, n):
-        return torch.linalg.inv(L[:n, :n]).t().contiguous()
-
-    def apply_u(self, U, n, S):
-        a = torch.zeros_like(S)
-        a[:, :n] = S[:, :n] @ U[:n, :n].t()
-        return a
+    def tile_inverse(self, L, n):
+        return torch.linalg.inv(L[:n, :n]).contiguous()
 
     def gemv_t_acc(self, L, rows, cols, a, c):
         c[:, :cols] += a[:, :rows] @ L[:rows, :cols]
