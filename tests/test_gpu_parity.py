@@ -1832,6 +1832,28 @@ def test_bench_two_ranks_refine_on_the_grid(device):
     assert line["exchange_schedules"]["bcast"]["lml"] == line["exchange_schedules"]["mesh"]["lml"]
 
 
+def test_c3_full_size_block_cyclic_2x2_grid(device):
+    """BASELINE config 3's matrix (N = 32768: the largest size the REFERENCE itself evaluated, tests/golden/lml_c3.json) block-cyclic
+    over a 2 x 2 grid -- four ranks sharing this box's GPU over gloo -- with the refinement step on the grid: the LML within
+    north_star's 1e-8 of the reference's value, and the distributed closed-form gradients against autograd through the CPU oracle
+    at full size (tests/golden/lml_c3_grad_cpu_oracle.json)."""
+    import json
+    out = _torchrun(4, ["bench.py", "--gpus", "4", "--workload", "c3", "--steps", "1", "--warmup", "0", "--test-shared-gpu",
+                        "--schedule", "bcast"], {}, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    case = load_json("lml_c3.json")
+    assert line["n_gpus"] == 4 and "block-cyclic 2x2" in line["config"]["parallelism"] and line["info"] == 0 and line["lml_refined"] is True
+    assert abs(line["lml"] - case["lml"]) < 1e-8, (line["lml"], case["lml"])
+    assert abs(line["lml"] - line["single_gpu_same_run"]["lml"]) < 1e-9, (line["lml"], line["single_gpu_same_run"]["lml"])
+    gref = load_json("lml_c3_grad_cpu_oracle.json")
+    db = line["dist_loss_backward"]
+    assert abs(db["lml"] - case["lml"]) < 1e-8
+    want = [-gref["grad_loss"]["kernel.variance"][0] / case["variance"], -gref["grad_loss"]["kernel.length_scales"][0] / case["length_scales"],
+            -gref["grad_loss"]["likelihood.variance"][0] / case["noise"]]      # golden: d loss / d log(theta)
+    assert np.abs(np.asarray(db["grads_constrained"]) - np.asarray(want)).max() < 1e-9 * np.abs(want).max(), (db, want)
+
+
 def test_c4_full_size_block_cyclic_2x4_grid(device):
     """BASELINE config 4 at FULL size (N = 65536, D = 32) through the driver's own command line for 8 GPUs --
     `bench.py --gpus 8` under torch.distributed.run, grid 2x4, 32 x 32 tiles of 2048 -- with the eight ranks
