@@ -97,6 +97,7 @@ class DistComm(ctypes.Structure):
 
 SIGNATURES.update({
     "gpn_dist_work_bytes": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int64]),
+    "gpn_dist_lml_refine_work_bytes": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int64]),
     "gpn_dist_grad_work_bytes": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int64]),
     "gpn_dist_lml_grad": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
@@ -107,6 +108,8 @@ SIGNATURES.update({
                                  c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_dist_lml_forward": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                      c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "gpn_dist_lml_refine": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
+                                    c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
 })
 # libgpnative_rccl.so: the RCCL adapter of that table (declared in the same header)
 RCCL_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpnative_rccl.so")

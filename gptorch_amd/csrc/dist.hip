@@ -711,3 +711,149 @@ extern "C" int gpn_dist_lml_grad(void* stream, const gpn_dist_comm* comm, int ra
   return dist_evaluate(stream, comm, rank, pr, pc, kind, X, n, d, Y, dy, variance, length_scales, nls, noise, tile, work, work_bytes,
                        out4, true, grads, grad_resid);
 }
+
+// ---- gpn_dist_lml_refine: the refinement step of the quadratic form (refine.hip) on the grid ------------------------
+// The sequence of gptorch_amd/dist.py BlockCyclicGP._refine over the callback table (world all-reduces only: a sum in which all
+// ranks but one contribute zeros is the broadcast).  `work` is the forward call's workspace, untouched since: it holds L and alpha.
+struct DistRefineLayout { int64_t alpha, a, owed, buf, sj, aj, ar, ka, U, S, W, winv, gwork, rwork, total; int64_t lv, lds, q0, q1; int ndiag; };
+static DistRefineLayout refine_layout_dist(const DistGeom& g) {
+  DistRefineLayout R;
+  const int64_t T = g.T;
+  R.lv = g.nt * T;
+  R.lds = round_up(g.n, LEAF);
+  R.ndiag = 0;
+  for (int64_t J = g.my_c; J < g.nt; J += g.pc) if (J % g.pr == g.my_r) ++R.ndiag;
+  const int64_t ntri = gpn_refine_tile_count(g.n);
+  const int64_t world = (int64_t)g.pr * g.pc;
+  R.q0 = ntri * g.rank / world;
+  R.q1 = ntri * (g.rank + 1) / world;
+  int64_t o = 0;
+  auto take = [&](int64_t cnt) { const int64_t at = o; o += round_up(std::max<int64_t>(cnt, 1), 32); return at; };
+  R.alpha = take((int64_t)g.dy * R.lv);
+  R.a = take((int64_t)g.dy * R.lv);
+  R.owed = take((int64_t)g.dy * std::max<int64_t>(g.ncol_t, 1) * T);
+  R.buf = take((int64_t)g.dy * T);
+  R.sj = take((int64_t)g.dy * T);
+  R.aj = take((int64_t)g.dy * T);
+  R.ar = take((int64_t)g.dy * R.lds);
+  R.ka = take((int64_t)g.dy * R.lds * 2);
+  R.U = take(T * T);
+  R.S = take(T * T);
+  R.W = take((int64_t)std::max(R.ndiag, 1) * T * T);
+  R.winv = take(gpn_winv_bytes(T) / 8);
+  R.gwork = take(gpn_gemv_t_work_bytes(T, std::max<int64_t>(g.ncol_t, 1) * T, g.dy) / 8);
+  R.rwork = take(gpn_refine_resid_part_work_bytes(g.dy, R.q1 - R.q0) / 8);
+  R.total = o;
+  return R;
+}
+
+extern "C" int64_t gpn_dist_lml_refine_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile) {
+  (void)d;
+  DistGeom g;
+  if (n <= 0 || dy <= 0 || make_geom(g, rank, pr, pc, n, dy, tile) != GPN_OK) return -1;
+  return refine_layout_dist(g).total * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_dist_lml_refine(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                                   const double* X, int64_t n, int d, const double* Y, int dy,
+                                   const double* variance, const double* length_scales, int nls, const double* noise,
+                                   int64_t tile, const double* work, double* rwork, int64_t rwork_bytes, double* out4) {
+  DistGeom g;
+  int rc = make_geom(g, rank, pr, pc, n, dy, tile);
+  if (rc != GPN_OK) return rc;
+  if (pr * pc > 1 && (!comm || !comm->allreduce)) return -2;
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -6;
+  if (!X) return -7;
+  if (n <= 0) return -8;
+  if (d <= 0) return -9;
+  if (!Y) return -10;
+  if (dy <= 0) return -11;
+  if (!variance || !length_scales || !noise) return -12;
+  if (nls != 1 && nls != d) return -14;
+  if (!work) return -16;
+  if (!rwork) return -17;
+  if (!out4) return -19;
+  const DistLayout L = make_layout(g, d);
+  const DistRefineLayout R = refine_layout_dist(g);
+  if (rwork_bytes < R.total * (int64_t)sizeof(double)) return -18;
+  if (reinterpret_cast<uintptr_t>(rwork) & 255) return GPN_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const gpn_dist_comm* cm = (pr * pc > 1 || (comm && (comm->flags & GPN_DIST_FORCE_COLLECTIVES))) ? comm : nullptr;
+  const int64_t T = g.T, nt = g.nt, lv = R.lv;
+  const double* A = work + L.A;
+  double* alpha = rwork + R.alpha;
+  double* a = rwork + R.a;
+  double* owed = rwork + R.owed;
+  double* buf = rwork + R.buf;
+  double* sj = rwork + R.sj;
+  double* aj = rwork + R.aj;
+  const int64_t ldo = std::max<int64_t>(g.ncol_t, 1) * T;
+  auto zero = [&](double* ptr, int64_t cnt) { return hipMemsetAsync(ptr, 0, (size_t)cnt * sizeof(double), s); };
+#define GPN_RC(expr) do { rc = (expr); if (rc != GPN_OK) return rc; } while (0)
+  // 1. alpha^T from the residual segment of the factor, replicated
+  GPN_HIP_CHECK(zero(alpha, (int64_t)dy * lv));
+  GPN_HIP_CHECK(zero(a, (int64_t)dy * lv));
+  GPN_HIP_CHECK(zero(owed, (int64_t)dy * ldo));
+  if (g.has_res)
+    for (int64_t lj = 0, J = g.my_c; J < nt; J += g.pc, ++lj)
+      GPN_RC(gpn_copy_matrix(stream, A + g.res_off * g.ld + lj * T, dy, g.rows_of(J), g.ld, alpha + J * T, lv, 0));
+  if (cm) GPN_RC(cm->allreduce(cm->ctx, alpha, (int64_t)dy * lv, stream));
+  // 2. my diagonal tiles' inverses (row-major L^-1), before the serial sweep
+  {
+    int slot = 0;
+    for (int64_t lj = 0, J = g.my_c; J < nt; J += g.pc, ++lj) {
+      if (J % g.pr != g.my_r) continue;
+      const int64_t li = (J - g.my_r) / g.pr, nJ = g.rows_of(J);
+      const double* Lt = A + li * T * g.ld + lj * T;
+      double* U = rwork + R.U;
+      double* S = rwork + R.S;
+      double* W = rwork + R.W + (int64_t)slot * T * T;
+      GPN_HIP_CHECK(zero(U, T * T));
+      GPN_HIP_CHECK(zero(S, T * T));
+      GPN_RC(gpn_trtri_diag(stream, Lt, nJ, g.ld, rwork + R.winv, nullptr));
+      if (nJ > 2 * LEAF) GPN_RC(gpn_trtri_upper_ws(stream, Lt, nJ, g.ld, rwork + R.winv, U, T, S, T));
+      else GPN_RC(gpn_trtri_upper(stream, Lt, nJ, g.ld, rwork + R.winv, U, T));
+      GPN_RC(gpn_transpose(stream, U, T, T, T, W, T));
+      ++slot;
+    }
+  }
+  // 3. a = L^-T alpha, tile row by tile row from the bottom
+  {
+    int slot = R.ndiag;                                   // my diagonal tiles are met in descending order
+    for (int64_t J = nt - 1; J >= 0; --J) {
+      const int64_t nJ = g.rows_of(J);
+      const int cj = (int)(J % g.pc), rj = (int)(J % g.pr);
+      const bool owner = g.my_r == rj && g.my_c == cj;
+      GPN_HIP_CHECK(zero(buf, (int64_t)dy * T));
+      if (g.my_c == cj) {
+        const int64_t lj = (J - g.my_c) / g.pc;
+        GPN_RC(gpn_copy_matrix(stream, owed + lj * T, dy, nJ, ldo, buf, T, 0));
+      }
+      if (cm) GPN_RC(cm->allreduce(cm->ctx, buf, (int64_t)dy * T, stream));      // (only process column cj contributes)
+      GPN_HIP_CHECK(zero(aj, (int64_t)dy * T));
+      if (owner) {
+        --slot;
+        GPN_RC(gpn_copy_matrix(stream, alpha + J * T, dy, T, lv, sj, T, 0));
+        hipLaunchKernelGGL(dist_axpy_kernel, dim3(1), dim3(1024), 0, s, sj, buf, -1.0, (int)(dy * T));
+        GPN_LAUNCH_CHECK();
+        GPN_RC(gpn_gemv_t_acc(stream, rwork + R.W + (int64_t)slot * T * T, T, nJ, nJ, sj, T, dy, aj, T, rwork + R.gwork));
+      }
+      if (cm) GPN_RC(cm->allreduce(cm->ctx, aj, (int64_t)dy * T, stream));        // = broadcast from the owner
+      GPN_RC(gpn_copy_matrix(stream, aj, dy, nJ, T, a + J * T, lv, 0));
+      if (g.my_r == rj && J > 0) {
+        const int64_t ncl = g.cols_le(J - 1), li = (J - g.my_r) / g.pr;
+        if (ncl > 0) GPN_RC(gpn_gemv_t_acc(stream, A + li * T * g.ld, g.ld, nJ, ncl * T, aj, T, dy, owed, ldo, rwork + R.gwork));
+      }
+    }
+  }
+  // 4. my share of Kyy a (double-double), summed over the ranks; 5. finish
+  double* ar = rwork + R.ar;
+  double* ka = rwork + R.ka;
+  GPN_RC(gpn_copy_matrix(stream, a, dy, R.lds, lv, ar, R.lds, 0));
+  GPN_HIP_CHECK(zero(ka, (int64_t)dy * R.lds * 2));
+  GPN_RC(gpn_refine_resid_part(stream, kind, X, n, d, variance, length_scales, nls, noise, ar, dy, R.q0, R.q1, rwork + R.rwork, ka));
+  if (cm) GPN_RC(cm->allreduce(cm->ctx, ka, (int64_t)dy * R.lds * 2, stream));
+  GPN_RC(gpn_refine_finish(stream, Y, nullptr, ar, ka, n, dy, out4));
+#undef GPN_RC
+  return GPN_OK;
+}

@@ -974,6 +974,9 @@ class NativeDistLML:
             raise ValueError("bad grid / tile for gpn_dist_lml_forward")
         self.work = torch.empty(nbytes // 8, dtype=torch.float64, device=X.device)
         self.work_is_grad_sized = False
+        self.rwork = None                        # workspace of gpn_dist_lml_refine (first use)
+        self.refine = None                       # None = from refine_min_n() rows on (as the single-GPU path)
+        self.refined = False
         self.out = torch.zeros(4, dtype=torch.float64, device=X.device)
         self.info = 0
         self.table = None
@@ -1032,10 +1035,13 @@ class NativeDistLML:
             if c == my_c:
                 col_group = g
         def view(ptr, count):
-            work = self.work                       # looked up per call: the workspace may have been re-allocated
-            off = (ptr - work.data_ptr()) // 8
-            assert 0 <= off and off + count <= work.numel()
-            return work[off:off + count]
+            for work in (self.work, self.rwork):   # looked up per call: the workspaces may have been re-allocated
+                if work is None:
+                    continue
+                off = (ptr - work.data_ptr()) // 8
+                if 0 <= off and off + count <= work.numel():
+                    return work[off:off + count]
+            raise AssertionError("collective on a buffer outside the workspaces")
 
         def bcast(ctx, which, buf, count, root, stream):
             try:
@@ -1169,4 +1175,23 @@ class NativeDistLML:
             host = self._evaluate(variance, length_scales, noise + 10.0 ** (-max_tries + i))
         if self.info != 0:
             raise RuntimeError("Max tries exceeded.")
+        self.refined = False
+        if self.refine if self.refine is not None else self.n >= _ops.refine_min_n():
+            nz = noise if self.jitter_rung < 0 else noise + 10.0 ** (-max_tries + self.jitter_rung)
+            host = self._refine(variance, length_scales, nz)
         return host[2].to(self.X.device)
+
+    def _refine(self, variance, length_scales, noise):
+        """gpn_dist_lml_refine on the factor the forward call left in self.work."""
+        ct, lib = self._ct, self._native.lib()
+        if self.rwork is None:
+            nbytes = int(lib.gpn_dist_lml_refine_work_bytes(self.rank, self.pr, self.pc, self.n, self.d, self.dy, self.T))
+            self.rwork = torch.empty(nbytes // 8, dtype=torch.float64, device=self.X.device)
+        var, ls, nz = (_ops._c(t.detach()) for t in (variance, length_scales, noise))
+        st = lib.gpn_dist_lml_refine(_ops._stream(self.X.device), ct.byref(self.table) if self.table is not None else None,
+                                     self.rank, self.pr, self.pc, _ops.KINDS[self.kind], _ops._ptr(self.X), self.n, self.d,
+                                     _ops._ptr(self.Y), self.dy, _ops._ptr(var), _ops._ptr(ls), ls.numel(), _ops._ptr(nz),
+                                     self.T, _ops._ptr(self.work), _ops._ptr(self.rwork), self.rwork.numel() * 8, _ops._ptr(self.out))
+        self._native.check(st, "gpn_dist_lml_refine")
+        self.refined = True
+        return self.out.cpu()

