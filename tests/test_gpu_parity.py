@@ -913,6 +913,31 @@ def test_vfe_gradients_golden(device, idx):
     assert m.Z.requires_grad          # unlike sparse_gpr.py:165 predicting does not freeze Z
 
 
+def test_vfe_streamed_backward_at_scale(device):
+    """The streamed closed-form backward with every mechanism of the large case in play -- N = 262144 (four chunks of 65536 rows,
+    two pipelines, split-K accumulation), M = 2048, ARD Rbf -- against AUTOGRAD through the CPU oracle's op chain, evaluated once on
+    a GPU box's host (tests/sweeps/vfe_grad_cpu_parity.py: 82 s on 64 threads; tests/golden/vfe_grad_262144_2048_cpu_oracle.npz).
+    cond(K(Z)) = 6.5e6 here: three fp64 evaluations (native, the CPU closed form, CPU autograd) differ from each other by
+    4e-9 ... 4e-8 relative in the kernel and inducing-point gradients (profiles/r3_vfe_grad_cpu_parity.json); the bound itself and
+    the noise gradient agree to 7e-15."""
+    from gptorch_amd.models import VFE
+    n, mm, d = 262144, 2048, 8
+    ls = np.array([1.2, 1.4, 1.6, 1.8, 2.0, 2.2, 2.4, 2.6])
+    x, y = rng.make_regression(n, d, 1, seed=0)
+    z = rng.normal(99, (mm, d))
+    m = VFE(x, y, kernels.Rbf(d, variance=1.3, length_scales=ls, ARD=True), inducing_points=z,
+            likelihood=likelihoods.Gaussian(variance=0.05), mean_function=mean_functions.Zero(1))
+    m.cuda()
+    loss, got = _vfe_grads(m)
+    ref = load_npz("vfe_grad_262144_2048_cpu_oracle.npz")
+    assert abs(-loss - float(ref["elbo"])) < 1e-12 * abs(float(ref["elbo"]))
+    # the oracle differentiates the bound w.r.t. the CONSTRAINED values; .grad is d loss / d raw = -value * that
+    want = [-1.3 * ref["g_variance"].ravel(), -ls * ref["g_length_scales"].ravel(), -0.05 * ref["g_noise"].ravel(), -ref["g_Z"]]
+    tol = [2e-7, 2e-7, 1e-12, 2e-7]
+    for g, r, t in zip(got, want, tol):
+        assert np.abs(g.reshape(r.shape) - r).max() < t * np.abs(r).max(), (np.abs(g.reshape(r.shape) - r).max() / np.abs(r).max(), t)
+
+
 def test_vfe_streamed_chunks_match(device, monkeypatch):
     """the N-sized work is streamed in row chunks: 5 ragged chunks == one chunk."""
     from gptorch_amd.models import sparse_gpr
