@@ -415,6 +415,29 @@ def gen_composite(out):
     print("composite:", [(c["name"], c["loss"], sorted(c["grads"])) for c in cases])
 
 
+def gen_composite_big(out):
+    """the reference's own example model (examples/regression_1d.py:34-53: Linear + Rbf + Constant) at BASELINE configs[1]'s size
+    (N = 8192, D = 8): loss, raw-parameter gradients and predictions from the reference -- the fused expression path at a size
+    where its tiling and the 1536-column panels are in play (composite_cases.json stops at N = 400)."""
+    n, d = 8192, 8
+    x, y = rng.make_regression(n, d, 1, seed=0)
+    xs = rng.normal(71, (16, d))
+    t0 = time.time()
+    m = RefGPR(x, y, rk.Linear(d, variance=0.3) + rk.Rbf(d, variance=1.2, length_scales=float(np.sqrt(d))) + rk.Constant(d, variance=0.4),
+               likelihood=rl.Gaussian(variance=0.01))
+    m.zero_grad()
+    loss = m.loss()
+    loss.backward()
+    grads = {nm: p.grad.tolist() for nm, p in m.named_parameters() if p.grad is not None}
+    with torch.no_grad():
+        mu, var = m._predict(torch.tensor(xs))
+    case = dict(name="linear_plus_rbf_plus_constant_8192_8", n=n, d=d, dy=1, noise=0.01, seed_xs=71, loss=float(loss.item()), grads=grads,
+                mean=mu.tolist(), var=var.tolist(), ref_seconds=time.time() - t0)
+    with open(os.path.join(out, "composite_big_case.json"), "w") as f:
+        json.dump(case, f, indent=1)
+    print("composite big:", case["loss"], {k: v for k, v in grads.items()}, "%.1f s" % case["ref_seconds"])
+
+
 def gen_sparse_composite(out):
     """VFE over kernels without a single native kind (sparse_gpr.py:126-129 takes any kernel object):
     bound, raw-parameter / inducing-point gradients and predictions from the reference."""
@@ -525,7 +548,7 @@ if __name__ == "__main__":
     steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
                  lml=lambda: gen_lml(HERE, args.big), adam=lambda: gen_adam(HERE),
                  func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE),
-                 comp=lambda: gen_composite(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), lbfgs=lambda: gen_lbfgs(HERE))
+                 comp=lambda: gen_composite(HERE), compbig=lambda: gen_composite_big(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), lbfgs=lambda: gen_lbfgs(HERE))
     for k, fn in steps.items():
         if not args.only or k in args.only.split(","):
             fn()

@@ -1099,6 +1099,32 @@ def _composite_kernel(name):
     return kernels.Matern52(3, variance=1.0, length_scales=1.3) + kernels.White(3, variance=0.05)
 
 
+def test_gpr_example_model_at_c2_size(device):
+    """the reference's own example model (examples/regression_1d.py:34-53: Linear + Rbf + Constant) at BASELINE configs[1]'s size,
+    N = 8192, D = 8, on the FUSED expression path (one N x N write, 1536-column panels, one sweep per leaf in the backward): loss
+    within north_star's 1e-8, every raw-parameter gradient and the predictions against the reference
+    (tests/golden/composite_big_case.json, make_golden.py --only compbig)."""
+    case = load_json("composite_big_case.json")
+    d = case["d"]
+    x, y = rng.make_regression(case["n"], d, case["dy"], seed=0)
+    k = kernels.Linear(d, variance=0.3) + kernels.Rbf(d, variance=1.2, length_scales=float(np.sqrt(d))) + kernels.Constant(d, variance=0.4)
+    m = GPR(x, y, k, likelihood=likelihoods.Gaussian(variance=case["noise"]))
+    m.cuda()
+    assert m._expression(m.X) is not None and type(m.log_likelihood().grad_fn).__name__.startswith("ExprLogLik")
+    loss = m.loss()
+    assert abs(loss.item() - case["loss"]) < 1e-8, (loss.item(), case["loss"])
+    loss.backward()
+    got = {n: p.grad.cpu().numpy() for n, p in m.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(case["grads"])
+    for n, r in case["grads"].items():
+        r = np.asarray(r)
+        assert np.abs(got[n].reshape(r.shape) - r).max() < 1e-8 * max(1.0, np.abs(r).max()), (n, got[n], r)
+    xs = rng.normal(case["seed_xs"], (16, d))
+    mu, var = m.predict_f(xs)
+    assert np.max(np.abs(mu - np.asarray(case["mean"]))) < 1e-8
+    assert np.max(np.abs(var - np.asarray(case["var"]))) < 1e-8
+
+
 def _composed(k, X, X2=None):
     """a Sum / Product tree evaluated the reference's way: the children's matrices combined by elementwise ops."""
     if isinstance(k, kernels.Sum):
