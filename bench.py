@@ -635,14 +635,18 @@ def run_multi(args, rank, local_rank, world, device):
         st = g.comm_stats()
         mine = torch.tensor([st["exposed_comm_ms"], sum(cls[c][1] for c in (P_GEMM, P_SYRK, P_SOLVE, P_TRI)),
                              float(sum(st["sent_bytes_per_peer"].values())), float(max(list(st["sent_bytes_per_peer"].values()) or [0])),
-                             float(st["bcast_root_bytes"]), float(st["recv_bytes"])], dtype=torch.float64,
+                             float(st["bcast_root_bytes"]), float(st["recv_bytes"]),
+                             float(getattr(g, "last_refine_ms", 0.0)) if g.refined else 0.0], dtype=torch.float64,
                             device=cpu if shared else device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         allr = torch.stack(allr).cpu()
         res.update({"exposed_comm_ms_per_rank": [float(v) for v in allr[:, 0]], "exposed_comm_ms_max": float(allr[:, 0].max()),
                     "contraction_ms_per_rank": [float(v) for v in allr[:, 1]],
-                    "recv_gb_per_rank": [float(v) / 1e9 for v in allr[:, 5]]})
+                    "recv_gb_per_rank": [float(v) / 1e9 for v in allr[:, 5]],
+                    # the refinement step of the quadratic form on the grid (part of every timed evaluation from 12288
+                    # rows on): this rank's stream time in it, incl. its 2 small collectives per tile row
+                    "refine_ms_per_rank": [float(v) for v in allr[:, 6]]})
         if sched == "mesh":
             res["p2p_sent_gb_per_rank"] = [float(v) / 1e9 for v in allr[:, 2]]
             res["p2p_sent_gb_busiest_link_per_rank"] = [float(v) / 1e9 for v in allr[:, 3]]

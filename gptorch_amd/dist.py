@@ -891,6 +891,10 @@ class BlockCyclicGP:
           4. quad = y^T a + a^T (y - Kyy a)  ->  self._sumsq."""
         ops, T, nt, n, p = self.ops, self.T, self.nt, self.n, self.lml_rows
         lv = nt * T
+        ev0 = ev1 = None
+        if self.comm_timing and self.X.is_cuda:       # how long this rank's stream spends in the step (bench.py refine_ms_per_rank)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         alpha = ops.zeros(p, lv)
         if self.has_res:
             for lj, J in enumerate(range(self.my_c, nt, self.pc)):
@@ -940,6 +944,10 @@ class BlockCyclicGP:
         self._sumsq_plain = self._sumsq
         self._sumsq = float(ops.refine_finish(resid[:, :p].contiguous(), ar, ka))
         self.refined = True
+        if ev0 is not None:
+            ev1.record()
+            ev1.synchronize()
+            self.last_refine_ms = ev0.elapsed_time(ev1)
 
 
 class NativeDistLML:
