@@ -62,6 +62,30 @@ if n_large:
     bad += soak(ml, n_large, "N=16384 D=8 Matern52 (8-wave tile)", grads_every=10)
     del ml
     torch.cuda.empty_cache()
+if n_large:
+    # the block-cyclic engine (one rank) with the refinement step on the grid: tile inversions, the serial sweep's chunked
+    # column sums, a share of the double-double residual pass -- and the same step inside the library (gpn_dist_lml_refine)
+    from gptorch_amd import dist as gdist
+    w = dict(n=16384, d=8)
+    xg, yg = rng.make_regression(w["n"], w["d"], 1, seed=3)
+    X, Y = torch.tensor(xg, device=dev), torch.tensor(yg, device=dev)
+    tt = lambda v: torch.tensor([v], dtype=torch.float64, device=dev)
+    for label, eng in (("block-cyclic engine + _refine", gdist.BlockCyclicGP(X, Y, "Matern52", tile=2048)),
+                       ("C driver + gpn_dist_lml_refine", gdist.NativeDistLML(X, Y, "Matern52", tile=2048))):
+        eng.refine = True
+        ref, nb, t0 = None, 0, time.perf_counter()
+        reps = max(1, n_large // 3)
+        for i in range(reps):
+            args = (tt(1.0), tt(8.0 ** 0.5), tt(1e-2)) + ((Y,) if isinstance(eng, gdist.BlockCyclicGP) else ())
+            cur = eng.log_likelihood(*args).reshape(1).cpu().numpy().tobytes()
+            if ref is None:
+                ref = cur
+            elif cur != ref:
+                nb += 1
+        print("N=16384 %s: %d evaluations, %d differ from the first, %.1f s" % (label, reps, nb, time.perf_counter() - t0), flush=True)
+        bad += nb
+        del eng
+        torch.cuda.empty_cache()
 # two evaluations in flight on two streams
 models = [bench.build_model(bench.WORKLOADS["c2"], 50 + r, dev)[0] for r in range(4)]
 ref = None
