@@ -11,7 +11,7 @@ read-back (jitter ladder).  Inputs are resident in HBM before the timed region.
     configuration and the north-star target size: GPR + Matern52, N=32768, D=16, fp64 (synthetic
     X~N(0,1), y=sin(sum x)+0.1 eps from gptorch_amd.rng seed 0; sigma^2=1, ell=4, sigma_n^2=1e-2),
     through the gptorch-compatible shell (`model.log_likelihood()`).  Keyed extras carry the other
-    single-GPU configs, each with its own config string: `c2` (N=8192, D=8, Rbf), `c4_1gpu`
+    single-GPU configs, each with its own config string: `c1` (N=512, with its CPU timing), `c2` (N=8192, D=8, Rbf; + `cpu_baseline`), `c4_1gpu`
     (N=65536, D=32: the 34 GB factor fits one GPU's HBM), `c5_vfe` (sparse VFE, N=1e6, M=4096) and
     `loss_backward` (one Adam step's loss()+backward()) at C2 and C3.
 --gpus N>1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of
@@ -559,6 +559,30 @@ def run_single(args, device):
             line["cpu_baseline"] = cpu_baseline(w, x, y, full=not args.cpu_sample_only)
         except Exception as exc:
             notes["cpu_baseline_error"] = repr(exc)
+        # the CPU path is timed for C1, C2 and C3-forward.  The smaller two beside their GPU legs: median of 3
+        # evaluations after one warm-up on the thread count the sweep above found fastest.
+        if args.workload == "c3" and not args.no_extras and "cpu_baseline" in line:
+            th = int(line["cpu_baseline"].get("cores") or 8)
+            for key in ("c1", "c2"):
+                try:
+                    ww = WORKLOADS[key]
+                    r = cpu_child(ww, ww["n"], th, 1, 3, 300.0)
+                    rec = {"seconds_per_eval": float(np.median(r["times"])), "cores": th, "kind": "port", "lml": r["lml"],
+                           "sample": "the whole workload, median of 3 after 1 warm-up"}
+                    if key == "c2" and "c2" in line:
+                        line["c2"]["cpu_baseline"] = rec
+                    else:
+                        # C1 (BASELINE configs[0], "CPU parity"): the GPU evaluation of the same model beside it
+                        mm, _, _ = build_model(ww, 0, device)
+                        with torch.no_grad():
+                            tg, og = timed(lambda: mm.log_likelihood(), 50, 5)
+                        gl1 = golden_lml(dict(ww, golden=("lml_cases.json", "C1_rbf_512_2")))
+                        line["c1"] = {"config": ww["name"], "ms_per_step": tg * 1e3, "value": 1.0 / tg, "unit": "LML evals/s", "lml": og.item(),
+                                      "lml_abs_err_vs_reference_golden": None if gl1 is None else abs(og.item() - gl1),
+                                      "lml_abs_diff_vs_cpu_oracle_this_box": abs(og.item() - r["lml"]), "cpu_baseline": rec}
+                        del mm
+                except Exception as exc:
+                    notes["cpu_%s_error" % key] = repr(exc)
     if notes:
         line["notes"] = notes
     print(json.dumps(line), flush=True)
