@@ -81,6 +81,17 @@ def test_argument_validation_without_launch():
     w1, w8 = lib.gpn_dist_work_bytes(0, 1, 1, 65536, 32, 1, 2048), lib.gpn_dist_work_bytes(3, 2, 4, 65536, 32, 1, 2048)
     assert w1 > 65536 * 65536 * 8 and w8 < w1 / 5 and w8 % 256 == 0
     assert lib.gpn_dist_lml_forward(null, null, 0, 2, 4, 0, null, 100, 2, null, 1, null, null, 1, null, 128, null, 0, null) == -2   # no comm table
+    # the refinement step in pieces and on the grid: sizing and validation are host code as well
+    assert lib.gpn_refine_tile_count(65536) == 1024 * 1025 // 2 and lib.gpn_refine_tile_count(65) == 3
+    assert lib.gpn_refine_resid_part_work_bytes(1, 10) == 2 * 10 * 64 * 2 * 8 and lib.gpn_refine_resid_part_work_bytes(0, 10) == 0
+    assert lib.gpn_gemv_t_work_bytes(2048, 16384, 1) > 0 and lib.gpn_gemv_t_work_bytes(0, 16384, 1) == 0
+    assert lib.gpn_gemv_t_acc(null, null, 16, 4, 4, null, 4, 1, null, 4, null) == -2
+    assert lib.gpn_refine_resid_part(null, 0, null, 4, 2, null, null, 1, null, null, 1, 0, 1, null, null) == -3
+    assert lib.gpn_refine_finish(null, null, null, null, null, 4, 1, null) == -2
+    assert lib.gpn_dist_lml_refine_work_bytes(0, 2, 3, 1000, 2, 1, 128) == -1                       # Pr must divide Pc
+    r1, r8 = lib.gpn_dist_lml_refine_work_bytes(0, 1, 1, 65536, 32, 1, 2048), lib.gpn_dist_lml_refine_work_bytes(3, 2, 4, 65536, 32, 1, 2048)
+    assert r8 % 256 == 0 and 0 < r8 < r1 / 3          # (the tile inverses and the residual share divide by the ranks)
+    assert lib.gpn_dist_lml_refine(null, null, 0, 2, 4, 0, null, 100, 2, null, 1, null, null, 1, null, 128, null, null, 0, null) == -2   # no comm table
     # zero-size problems are no-ops that succeed
     one = ctypes.c_double(0.0)
     p = ctypes.cast(ctypes.pointer(one), ctypes.c_void_p)
