@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
+#include <cstdlib>
 #include "gpn_common.h"
 
 namespace gpn {
@@ -47,6 +48,7 @@ struct GemmArgs {
   // lower-tile launch with q_mt tile rows (its partial last round: gemm_nt_impl); block b = quarter (b & 3) of tile q_off + b/4
   int q_off, q_cnt, q_mt;
   int lds_pad_kb;   // extra dynamic LDS per workgroup: caps the workgroups per CU of a launch that shares the chip (look-ahead)
+  int group_h;      // tile rows per group of the grouped tile order (8; A/B of the L2 reuse: tools' build)
   // staircase: C is M x (nb * st_blk); column block b (st_blk columns) only has the rows from b * st_step on, and with
   // st_diag its first st_blk x st_blk square is lower-only -- the local tile columns of one block-cyclic trailing update
   int st_blk, st_step, st_diag;
@@ -67,12 +69,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // `spread`: K-clipped (triangular-operand) launches have very unequal work per tile row, so
 // their tiles are dealt round-robin over the XCDs (plain blockIdx order) instead of in
 // contiguous per-XCD chunks: balance beats L2 locality there.
-__device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, bool spread, int& ti, int& tj) {
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, bool spread, int& ti, int& tj, int GH = 8) {
   const int logical = spread ? bid : xcd_remap(bid, nwg);
-  const int group = 8 * nt;
+  const int group = GH * nt;
   const int g = logical / group;
-  const int first = g * 8;
-  const int gm = min(8, mt - first);
+  const int first = g * GH;
+  const int gm = min(GH, mt - first);
   const int rem = logical - g * group;
   ti = first + rem % gm;
   tj = rem / gm;
@@ -82,35 +84,41 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int mt, int nt, 
 // number of real tiles): groups of 8 tile rows; group g holds the 8g full columns
 // left of the diagonal super-tile (column-major, 8 per column) followed by the
 // 36 tiles of the diagonal super-tile.  Tiles before group g: 32 g^2 + 4 g.
-__device__ __forceinline__ void lower_tile_of_index(int q, int mt, int& ti, int& tj);
-__device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bool spread, int& ti, int& tj) {
-  lower_tile_of_index(spread ? bid : xcd_remap(bid, nwg), mt, ti, tj);
+__device__ __forceinline__ void lower_tile_of_index(int q, int mt, int& ti, int& tj, int GH = 8);
+__device__ __forceinline__ void tile_of_block_lower(int bid, int nwg, int mt, bool spread, int& ti, int& tj, int GH = 8) {
+  lower_tile_of_index(spread ? bid : xcd_remap(bid, nwg), mt, ti, tj, GH);
 }
-// logical index q of the grouped lower enumeration -> tile
-__device__ __forceinline__ void lower_tile_of_index(int q, int mt, int& ti, int& tj) {
-  const int G = mt >> 3;
-  const int full_total = 32 * G * G + 4 * G;
+// logical index q of the grouped lower enumeration -> tile.  Group height GH (8 in the product): group g holds the GH g
+// full columns left of its diagonal super-tile (column-major, GH per column) followed by the GH (GH + 1) / 2 tiles of the
+// super-tile; tiles before group g: GH^2 g (g - 1) / 2 + g GH (GH + 1) / 2  (GH = 8: 32 g^2 + 4 g).
+__device__ __forceinline__ void lower_tile_of_index(int q, int mt, int& ti, int& tj, int GH) {
+  const int G = mt / GH;
+  const int tri = GH * (GH + 1) / 2, sq = GH * GH;
+  auto before = [&](int g) { return sq * (g * (g - 1) / 2) + g * tri; };
+  const int full_total = before(G);
   int g, h;
   if (q < full_total) {
-    g = (int)((sqrt(16.0 + 128.0 * (double)q) - 4.0) * (1.0 / 64.0));
-    while (32 * g * g + 4 * g > q) --g;
-    while (32 * (g + 1) * (g + 1) + 4 * (g + 1) <= q) ++g;
-    h = 8;
+    // sq/2 g^2 + (tri - sq/2) g - q = 0
+    const double a = 0.5 * sq, b = (double)tri - 0.5 * sq;
+    g = (int)((sqrt(b * b + 4.0 * a * (double)q) - b) / (2.0 * a));
+    while (g > 0 && before(g) > q) --g;
+    while (before(g + 1) <= q) ++g;
+    h = GH;
   } else {
     g = G;
-    h = mt & 7;
+    h = mt - G * GH;
   }
-  int r = q - (32 * g * g + 4 * g);
-  const int left = h * 8 * g;
+  int r = q - before(g);
+  const int left = h * GH * g;
   if (r < left) {
     tj = r / h;
-    ti = 8 * g + r - tj * h;
+    ti = GH * g + r - tj * h;
   } else {
     r -= left;
     int c = 0;
     while (r >= h - c) { r -= h - c; ++c; }
-    ti = 8 * g + c + r;
-    tj = 8 * g + c;
+    ti = GH * g + c + r;
+    tj = GH * g + c;
   }
 }
 
@@ -151,15 +159,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(
     if (p.st_diag && rows_t >= bt) {
       const int rect = (rows_t - bt) * bt;
       if (q < rect) {
-        tile_of_block(q, rect, rows_t - bt, bt, true, ti, tj);
+        tile_of_block(q, rect, rows_t - bt, bt, true, ti, tj, p.group_h);
         ti += sbt + bt;
       } else {
-        tile_of_block_lower(q - rect, bt * (bt + 1) / 2, bt, true, ti, tj);
+        tile_of_block_lower(q - rect, bt * (bt + 1) / 2, bt, true, ti, tj, p.group_h);
         stair_diag_tile = ti == tj;
         ti += sbt;
       }
     } else {
-      tile_of_block(q, cnt, rows_t, bt, true, ti, tj);
+      tile_of_block(q, cnt, rows_t, bt, true, ti, tj, p.group_h);
       ti += sbt;
     }
     tj += b * bt;
@@ -171,22 +179,22 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(
     const int rect = (p.mt - p.nt) * p.nt;
     const int q = xcd_remap(bid, nwg);
     if (q < rect) {
-      tile_of_block(q, rect, p.mt - p.nt, p.nt, true, ti, tj);
+      tile_of_block(q, rect, p.mt - p.nt, p.nt, true, ti, tj, p.group_h);
       ti += p.nt;
     } else {
-      tile_of_block_lower(q - rect, nwg - rect, p.nt, true, ti, tj);
+      tile_of_block_lower(q - rect, nwg - rect, p.nt, true, ti, tj, p.group_h);
     }
   } else if (p.lower == 4) {
     // quarters of the big tiles of a partial last round: the four quarters of one parent are consecutive logical ids,
     // i.e. on one XCD (they share the parent's operand panels)
     const int idx = xcd_remap(bid, nwg);
     int pi, pj;
-    lower_tile_of_index(p.q_off + (idx >> 2), p.q_mt, pi, pj);
+    lower_tile_of_index(p.q_off + (idx >> 2), p.q_mt, pi, pj, p.group_h);
     ti = 2 * pi + ((idx >> 1) & 1);
     tj = 2 * pj + (idx & 1);
     if (tj > ti || ti >= p.mt) return;        // the upper-right quarter of a diagonal parent; a ragged parent's empty half
-  } else if (p.lower) tile_of_block_lower(bid, nwg, p.mt, spread, ti, tj);
-  else tile_of_block(bid, nwg, p.mt, p.nt, spread, ti, tj);
+  } else if (p.lower) tile_of_block_lower(bid, nwg, p.mt, spread, ti, tj, p.group_h);
+  else tile_of_block(bid, nwg, p.mt, p.nt, spread, ti, tj, p.group_h);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -518,9 +526,11 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
 
 #ifdef GPN_DEBUG_SWITCHES
 static thread_local int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
+static thread_local int g_group_h = 0;       // 0 = from GPN_GEMM_GROUP_H at first use (default 8): A/B of the grouped tile order's L2 reuse
 static thread_local int g_split_tail = 0;    // 1 = the partial last round of a big lower-tile launch as quarter tiles (measured neutral: off)
 #else
 static constexpr int g_gemm_variant = 0;
+static constexpr int g_group_h = 8;
 static constexpr int g_split_tail = 0;
 #endif
 
@@ -565,6 +575,10 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   a.st_blk = st.blk; a.st_step = st.step; a.st_diag = st.diag;
   a.q_off = a.q_cnt = a.q_mt = 0;
   a.lds_pad_kb = lds_pad_kb;
+#ifdef GPN_DEBUG_SWITCHES
+  if (g_group_h == 0) { const char* e = getenv("GPN_GEMM_GROUP_H"); g_group_h = e ? atoi(e) : 8; if (g_group_h < 1 || g_group_h > 64) g_group_h = 8; }
+#endif
+  a.group_h = g_group_h;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
   // Tile choice (same-box sweeps, tools/gemm_ab.py).  The big tile is 128x128 as EIGHT waves of 32x64 (2 workgroups
