@@ -1133,6 +1133,12 @@ class NativeDistLML:
             host = attempt(noise + 10.0 ** (-max_tries + i))
         if self.info != 0:
             raise RuntimeError("Max tries exceeded.")
+        self.refined = False
+        if self.refine if self.refine is not None else self.n >= _ops.refine_min_n():
+            # the value by the same rule as log_likelihood (the factor and alpha^T are where the forward part left them: the
+            # backward writes its inverse elsewhere in the workspace)
+            nz = noise if self.jitter_rung < 0 else noise + 10.0 ** (-max_tries + self.jitter_rung)
+            host = self._refine(variance, length_scales, nz)
         return host[2].to(self.X.device), grads, g_resid
 
     def predict(self, variance, length_scales, noise, x_new, mean_new=None, diag=True, max_tries=10):

@@ -1872,6 +1872,11 @@ def test_block_cyclic_refinement_native_pieces(device):
         assert c.refined and c.info == 0
         assert abs(c.out[1].item() - quad) < tol * abs(quad), (c.out[1].item(), quad, plain[1].item())
         assert abs(lc.item() - lml.item()) < 10 * tol * abs(lml.item())
+        lg, gg, _ = c.log_likelihood_and_grad(var, ls, nz)          # (gpn_dist_lml_grad + the same step on what it leaves in the workspace)
+        assert c.refined and abs(lg.item() - lc.item()) < 10 * tol * abs(lc.item()), (lg.item(), lc.item())
+        lg2, gg2 = g.log_likelihood_and_grad(var, ls, nz, Y)
+        assert abs(lg2.item() - lml.item()) < 10 * tol * abs(lml.item())
+        assert torch.allclose(gg.cpu(), gg2.cpu(), rtol=1e-8 if noise > 1e-3 else 1e-5, atol=0.0), (gg, gg2)
         if noise < 1e-3:      # here the step has something to remove: the plain values of the three factorisations are further apart
             c.refine = False
             c.log_likelihood(var, ls, nz)
