@@ -224,7 +224,21 @@ class ExprLogLik(torch.autograd.Function):
         f.jitter_rung = _ops._ladder(attempt)
         ctx.prog, ctx.factor, ctx.generation = prog, f, f.generation
         ctx.save_for_backward(X, R, noise, theta, *params)
-        return f.lml_terms()[2:3].clone()
+        terms = f.lml_terms()
+        f.refined = False
+        if n >= _ops.refine_min_n():
+            # the refinement step of the quadratic form, with the residual pass over the expression program
+            lib = _native.lib()
+            nz = nz0 if f.jitter_rung < 0 else nz0 + 10.0 ** (-_ops.JITTER_TRIES + f.jitter_rung)
+            if f._refine_work is None:
+                f._refine_work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=X.device)
+            Xc, Rc = _c(X.detach()), _c(R.detach())
+            st = lib.gpn_lml_refine_expr(_stream(X.device), prog.terms, len(prog.instances), prog.gstart, prog.ngroups, _ptr(theta),
+                                         _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e, _ptr(nz), _ptr(f.A), f.ld, _ptr(f.winv),
+                                         _ptr(f._refine_work), _ptr(terms))
+            _native.check(st, "gpn_lml_refine_expr")
+            f.refined = True
+        return terms[2:3].clone()
 
     @staticmethod
     def backward(ctx, grad_out):

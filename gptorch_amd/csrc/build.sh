@@ -11,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 pids=()
 for f in "$HERE"/*.hip; do
   o="$OBJ/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/refine_tail.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi

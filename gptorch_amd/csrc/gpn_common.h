@@ -61,6 +61,12 @@ enum { PROF_GEMM = 0,         // rectangular contraction (in-panel updates, pred
 // release the exchange streams/events gpn_dist_lml_forward keeps for a caller stream (dist.hip)
 void dist_release(hipStream_t s);
 
+// the residual pass of the refinement step for a covariance expression (kexpr.hip; refine.hip gpn_lml_refine_expr): tiles
+// q0 <= q < q0 + cnt of the lower 64 x 64 tiles times a [dy][lds] into prow / pcol (slot q - q0), double-double
+int expr_resid(hipStream_t s, const gpn_expr_term* terms, int nterms, const int* gstart, int ngroups, const double* theta,
+               const double* X, int64_t n, int d, const double* noise, const double* a, int dy, int64_t lds, int64_t q0, int64_t cnt,
+               double* prow, double* pcol);
+
 bool profile_on();
 int profile_begin(hipStream_t s, double work, int cls);
 void profile_end(hipStream_t s, int idx);

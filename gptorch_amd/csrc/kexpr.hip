@@ -14,6 +14,7 @@
 // the product of the other terms of its group and with d term / d theta, re-computing everything from the points, so
 // each launch reads G once and nothing N x N is written.  A Sum of T leaves costs T such sweeps.
 #include "gpn_common.h"
+#include "refine_tail.h"
 #include "kernel_fn.h"
 
 namespace gpn {
@@ -221,6 +222,66 @@ __global__ __launch_bounds__(256) void kexpr_kernel(ExprArgs p, ExprProgram prog
       krow[col] = v;
     }
   }
+}
+
+// The residual pass of the refinement step (refine.hip) for an expression: tile q0 + blockIdx.x of the lower 64 x 64
+// tiles of Kyy = expression(X, X) + noise I, evaluated exactly as kexpr_kernel assembled it, times a_hat in double-double -- row
+// partial and (off-diagonal tiles) mirror column partial, the layout and reduction of refine.hip's stationary kernel.
+struct ExprResidArgs {
+  const double* X;
+  const double* theta;
+  const double* noise;
+  RefineTailArgs tail;
+  int n, d, q_off;
+};
+
+template <int NRHS>
+__global__ __launch_bounds__(256) void kexpr_resid_kernel(ExprResidArgs p, ExprProgram prog) {
+  static_assert(ET == RT, "the expression tile and the residual tile are the same 64 x 64 tile");
+  __shared__ __attribute__((aligned(16))) double xs[EDC][ET];
+  __shared__ __attribute__((aligned(16))) double ys[EDC][ET];
+  __shared__ double scale[EDC];
+  __shared__ double arow[NRHS][RT], acol[NRHS][RT];
+  __shared__ double red[2][RT][17];
+  TileCtx c;
+  c.X = p.X; c.X2 = p.X; c.theta = p.theta; c.n = p.n; c.m = p.n; c.d = p.d; c.symmetric = 1;
+  c.tid = threadIdx.x; c.tx = c.tid & 15; c.ty = c.tid >> 4;
+  int ti, tj;
+  tile_of_block((int)blockIdx.x + p.q_off, true, 0, ti, tj);
+  c.i0 = ti * ET; c.j0 = tj * ET;
+  double total[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) total[a][b] = 0.0;
+  for (int g = 0; g < prog.ngroups; ++g) {
+    double prod[4][4], val[4][4];
+    for (int t = prog.gstart[g]; t < prog.gstart[g + 1]; ++t) {
+      term_value(c, prog.terms[t], xs, ys, scale, val);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) prod[a][b] = t == prog.gstart[g] ? val[a][b] : prod[a][b] * val[a][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) total[a][b] += prod[a][b];
+  }
+  const double noise = p.noise[0];
+  double v[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = c.i0 + c.ty * 4 + a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = c.j0 + (b >> 1) * 32 + c.tx * 2 + (b & 1);
+      double e = total[a][b];
+      if (row == col) e += noise;
+      v[a][b] = (row < p.n && col < p.n) ? e : 0.0;
+    }
+  }
+  refine_tile_tail<NRHS>(p.tail, v, ti != tj, (int)blockIdx.x, c.i0, c.j0, arow, acol, red);
 }
 
 struct ExprGradArgs {
@@ -495,6 +556,24 @@ static void fill_program(ExprProgram& P, const gpn_expr_term* terms, int nterms,
     if (t < nterms) P.terms[t] = terms[t];
     else P.terms[t] = gpn_expr_term{GPN_TERM_CONSTANT, 0, 0, 0, 1, 1};
   }
+}
+
+int expr_resid(hipStream_t s, const gpn_expr_term* terms, int nterms, const int* gstart, int ngroups, const double* theta,
+               const double* X, int64_t n, int d, const double* noise, const double* a, int dy, int64_t lds, int64_t q0, int64_t cnt,
+               double* prow, double* pcol) {
+  int rc = check_program(terms, nterms, gstart, ngroups, d, false);
+  if (rc != GPN_OK) return rc;
+  if (cnt <= 0) return GPN_OK;
+  ExprResidArgs p;
+  p.X = X; p.theta = theta; p.noise = noise;
+  p.tail.a = a; p.tail.prow = prow; p.tail.pcol = pcol; p.tail.lds = lds; p.tail.n = (int)n; p.tail.dy = dy;
+  p.n = (int)n; p.d = d; p.q_off = (int)q0;
+  ExprProgram P;
+  fill_program(P, terms, nterms, gstart, ngroups);
+  if (dy == 1) hipLaunchKernelGGL(kexpr_resid_kernel<1>, dim3((unsigned)cnt), dim3(256), 0, s, p, P);
+  else hipLaunchKernelGGL(kexpr_resid_kernel<RDY>, dim3((unsigned)cnt), dim3(256), 0, s, p, P);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
 }
 
 }  // namespace gpn

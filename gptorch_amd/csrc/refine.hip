@@ -22,36 +22,13 @@
 #include <algorithm>
 #include "gpn_common.h"
 #include "kernel_fn.h"
+#include "refine_tail.h"
 
 namespace gpn {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-// ---- double-double accumulation (explicitly rounded intrinsics: never contracted into FMAs by the compiler) ----
-struct dd { double hi, lo; };
-__device__ __forceinline__ void two_sum(double a, double b, double& s, double& e) {
-  s = __dadd_rn(a, b);
-  const double bb = __dsub_rn(s, a);
-  e = __dadd_rn(__dsub_rn(a, __dsub_rn(s, bb)), __dsub_rn(b, bb));
-}
-__device__ __forceinline__ void dd_fma(dd& acc, double a, double b) {        // acc += a * b, error-free product and sum
-  const double p = __dmul_rn(a, b);
-  const double ep = __fma_rn(a, b, -p);
-  double s, es;
-  two_sum(acc.hi, p, s, es);
-  acc.hi = s;
-  acc.lo = __dadd_rn(acc.lo, __dadd_rn(es, ep));
-}
-__device__ __forceinline__ void dd_add(dd& acc, const dd x) {
-  double s, e;
-  two_sum(acc.hi, x.hi, s, e);
-  acc.hi = s;
-  acc.lo = __dadd_rn(acc.lo, __dadd_rn(e, x.lo));
-}
-
-constexpr int RT = 64;        // tile edge of the residual kernel (= kmat.hip's KT)
 constexpr int RDC = 16;       // coordinates staged per pass (= kmat.hip's DC: the same summation order over d)
-constexpr int RDY = 2;        // right-hand sides per pass when dy > 1
 constexpr int BS_COLS = 128;  // columns per workgroup of the back-substitution update = one leaf block
 
 // s <- alpha^T (the first n entries of the factor buffer's extra rows; what is right of them is the corner that
@@ -251,58 +228,9 @@ __global__ __launch_bounds__(256) void refine_resid_sym_kernel(RefineSymArgs p) 
       v[a][b] = (row < p.n && col < p.n) ? e : 0.0;
     }
   }
-  for (int c0 = 0; c0 < p.dy; c0 += NRHS) {
-    const int nc = min(NRHS, p.dy - c0);
-    __syncthreads();
-    if (tid < 2 * RT) {
-      const int pt = tid & (RT - 1);
-      const int idx = (tid < RT ? i0 : j0) + pt;
-      for (int c = 0; c < nc; ++c) (tid < RT ? arow : acol)[c][pt] = idx < p.n ? p.a[(int64_t)(c0 + c) * p.lds + idx] : 0.0;
-    }
-    __syncthreads();
-    for (int c = 0; c < nc; ++c) {
-      // rows of I: sum over my 4 columns of v * a_J[col], then over the 16 tx lanes (fixed order)
-      dd r[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        r[a] = dd{0.0, 0.0};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dd_fma(r[a], v[a][b], acol[c][(b >> 1) * 32 + tx * 2 + (b & 1)]);
-        red[0][ty * 4 + a][tx] = r[a].hi;
-        red[1][ty * 4 + a][tx] = r[a].lo;
-      }
-      __syncthreads();
-      if (tid < RT) {
-        dd sum{red[0][tid][0], red[1][tid][0]};
-        for (int k = 1; k < 16; ++k) dd_add(sum, dd{red[0][tid][k], red[1][tid][k]});
-        double* out = p.prow + (((int64_t)q * p.dy + (c0 + c)) * RT + tid) * 2;
-        out[0] = sum.hi;
-        out[1] = sum.lo;
-      }
-      __syncthreads();
-      if (offdiag) {
-        // columns of J (the mirror entries): sum over my 4 rows of v * a_I[row], then over the 16 ty lanes
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          dd cc{0.0, 0.0};
-#pragma unroll
-          for (int a = 0; a < 4; ++a) dd_fma(cc, v[a][b], arow[c][ty * 4 + a]);
-          const int cl = (b >> 1) * 32 + tx * 2 + (b & 1);
-          red[0][cl][ty] = cc.hi;
-          red[1][cl][ty] = cc.lo;
-        }
-        __syncthreads();
-        if (tid < RT) {
-          dd sum{red[0][tid][0], red[1][tid][0]};
-          for (int k = 1; k < 16; ++k) dd_add(sum, dd{red[0][tid][k], red[1][tid][k]});
-          double* out = p.pcol + (((int64_t)q * p.dy + (c0 + c)) * RT + tid) * 2;
-          out[0] = sum.hi;
-          out[1] = sum.lo;
-        }
-        __syncthreads();
-      }
-    }
-  }
+  RefineTailArgs tp;
+  tp.a = p.a; tp.prow = p.prow; tp.pcol = p.pcol; tp.lds = p.lds; tp.n = p.n; tp.dy = p.dy;
+  refine_tile_tail<NRHS>(tp, v, offdiag, q, i0, j0, arow, acol, red);
 }
 
 // ka[c][i] = sum_{J <= T} prow[(T, J)][c][r] + sum_{I > T} pcol[(I, T)][c][r]   (T = i / 64, r = i % 64), double-double,
@@ -461,6 +389,33 @@ extern "C" int64_t gpn_lml_refine_work_bytes(int64_t n, int dy) {
   return refine_layout(n, dy).total * (int64_t)sizeof(double);
 }
 
+// a_hat = L^-T alpha into work (s, a), from the factor's extra rows
+static int refine_backsub(hipStream_t s, const double* A, int64_t lda, const double* winv, int64_t n, int dy, double* work, const RefineLayout& L) {
+  double* sv = work + L.s;
+  double* av = work + L.a;
+  hipLaunchKernelGGL(refine_init_kernel, dim3((unsigned)((L.lds + 255) / 256)), dim3(256), 0, s, A, lda, n, dy, sv, L.lds);
+  GPN_LAUNCH_CHECK();
+  const int nb = (int)((n + LEAF - 1) / LEAF);
+  for (int c0 = 0; c0 < dy; c0 += (dy == 1 ? 1 : RDY))
+    for (int k = nb; k >= 1; --k) {                 // launch k: update blocks < k by a_k (k < nb), then a_{k-1}
+      if (dy == 1) hipLaunchKernelGGL(backsub_step_kernel<1>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
+      else hipLaunchKernelGGL(backsub_step_kernel<RDY>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
+    }
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// Kyy a per row from the tile partials (double-double), then r, the dot products and the LML
+static int refine_gather_finish(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* work, const RefineLayout& L, double* out3) {
+  const int64_t ntile = (n + RT - 1) / RT;
+  hipLaunchKernelGGL(refine_gather_kernel, dim3((unsigned)ntile, (unsigned)dy), dim3(256), 0, s, work + L.prow, work + L.pcol, (int)ntile, dy,
+                     L.lds, n, work + L.partial);
+  GPN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(1024), 0, s, Y, M, work + L.a, work + L.partial, n, dy, 1, L.lds, out3, work + L.norm);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
 extern "C" int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n, int d,
                               const double* Y, const double* M, int dy,
                               const double* variance, const double* length_scales, int nls, const double* noise,
@@ -482,20 +437,11 @@ extern "C" int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n
   if (n == 0) return GPN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const RefineLayout L = refine_layout(n, dy);
-  double* sv = work + L.s;
-  double* av = work + L.a;
-  hipLaunchKernelGGL(refine_init_kernel, dim3((unsigned)((L.lds + 255) / 256)), dim3(256), 0, s, A, lda, n, dy, sv, L.lds);
-  GPN_LAUNCH_CHECK();
-  const int nb = (int)((n + LEAF - 1) / LEAF);
-  for (int c0 = 0; c0 < dy; c0 += (dy == 1 ? 1 : RDY))
-    for (int k = nb; k >= 1; --k) {                 // launch k: update blocks < k by a_k (k < nb), then a_{k-1}
-      if (dy == 1) hipLaunchKernelGGL(backsub_step_kernel<1>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
-      else hipLaunchKernelGGL(backsub_step_kernel<RDY>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
-    }
-  GPN_LAUNCH_CHECK();
+  int rc = refine_backsub(s, A, lda, winv, n, dy, work, L);
+  if (rc != GPN_OK) return rc;
   const int64_t ntile = (n + RT - 1) / RT;
   RefineSymArgs p;
-  p.X = X; p.variance = variance; p.ls = length_scales; p.noise = noise; p.a = av;
+  p.X = X; p.variance = variance; p.ls = length_scales; p.noise = noise; p.a = work + L.a;
   p.prow = work + L.prow; p.pcol = work + L.pcol; p.lds = L.lds;
   p.n = (int)n; p.d = d; p.nls = nls; p.dy = dy; p.q_off = 0;
   const dim3 grid((unsigned)(ntile * (ntile + 1) / 2));
@@ -513,13 +459,37 @@ extern "C" int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n
   }
 #undef GPN_RESID
   GPN_LAUNCH_CHECK();
-  // Kyy a per row, double-double, into the slot the finish kernel reads as its single segment
-  hipLaunchKernelGGL(refine_gather_kernel, dim3((unsigned)ntile, (unsigned)dy), dim3(256), 0, s, work + L.prow, work + L.pcol, (int)ntile, dy,
-                     L.lds, n, work + L.partial);
-  GPN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(refine_finish_kernel, dim3(1), dim3(1024), 0, s, Y, M, av, work + L.partial, n, dy, 1, L.lds, out3, work + L.norm);
-  GPN_LAUNCH_CHECK();
-  return GPN_OK;
+  return refine_gather_finish(s, Y, M, n, dy, work, L, out3);
+}
+
+// the same step for a covariance EXPRESSION (kexpr.hip: sums of products of native leaves -- the composite kernels of
+// kernels.py:286-306): the residual pass evaluates the expression per tile exactly as the fused assembly did
+extern "C" int gpn_lml_refine_expr(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                                   const double* theta, const double* X, int64_t n, int d, const double* Y, const double* M, int dy,
+                                   const double* noise, const double* A, int64_t lda, const double* winv, double* work, double* out3) {
+  if (!terms || !group_start) return -2;
+  if (!theta) return -6;
+  if (!X) return -7;
+  if (n < 0) return -8;
+  if (d <= 0) return -9;
+  if (!Y) return -10;
+  if (dy <= 0) return -12;
+  if (!noise) return -13;
+  if (!A) return -14;
+  if (lda != gpn_factor_ld(n, dy)) return -15;
+  if (!winv) return -16;
+  if (!work) return -17;
+  if (!out3) return -18;
+  if (n == 0) return GPN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const RefineLayout L = refine_layout(n, dy);
+  int rc = refine_backsub(s, A, lda, winv, n, dy, work, L);
+  if (rc != GPN_OK) return rc;
+  const int64_t ntile = (n + RT - 1) / RT;
+  rc = expr_resid(s, terms, nterms, group_start, ngroups, theta, X, n, d, noise, work + L.a, dy, L.lds, 0, ntile * (ntile + 1) / 2,
+                  work + L.prow, work + L.pcol);
+  if (rc != GPN_OK) return rc;
+  return refine_gather_finish(s, Y, M, n, dy, work, L, out3);
 }
 
 // ---- the same step in pieces, for a factor spread over several GPUs (include/gpnative.h) -----------------------------------

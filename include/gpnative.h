@@ -282,6 +282,13 @@ int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n, int d,
                    const double* variance, const double* length_scales, int nls, const double* noise,
                    const double* A, int64_t lda, const double* winv, double* work, double* out3);
 
+/* gpn_lml_refine for a covariance EXPRESSION (gpn_kernel_matrix_expr's program: the composite kernels of kernels.py:286-306),
+ * after a factorisation of that expression's Kyy that carried the residual as extra rows: same step, the residual pass evaluates
+ * the expression per tile exactly as the fused assembly did.  out3[0] = sum log L_ii on entry; work: gpn_lml_refine_work_bytes. */
+int gpn_lml_refine_expr(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                        const double* theta, const double* X, int64_t n, int d, const double* Y, const double* M, int dy,
+                        const double* noise, const double* A, int64_t lda, const double* winv, double* work, double* out3);
+
 /* The same refinement step in pieces, for a factor that is spread over several GPUs (gptorch_amd/dist.py
  * BlockCyclicGP._refine: 2-D block-cyclic tiles; the exchange between the pieces is the caller's).  Vectors are
  * [dy][ld] row-major, one right-hand side per row.

@@ -1099,6 +1099,36 @@ def _composite_kernel(name):
     return kernels.Matern52(3, variance=1.0, length_scales=1.3) + kernels.White(3, variance=0.05)
 
 
+def test_refinement_on_the_fused_expression_path(device, monkeypatch):
+    """gpn_lml_refine_expr: the refinement step of the quadratic form with the residual pass over the expression program.  Rbf + Rbf
+    with one length scale IS an Rbf with the summed variance: the composite model (fused expression path) and the stationary
+    model (gpn_lml_refine) are refined by two different residual kernels and must agree far below either's distance to its
+    plain value; a deliberately ill-conditioned case makes that distance visible."""
+    monkeypatch.setenv("GPN_REFINE_MIN_N", "2048")
+    n, d = 4160, 6                      # (ragged: 65 tiles of 64)
+    x, y = rng.make_regression(n, d, 2, seed=11)
+    for lsv, noise in ((1.7, 0.02), (3.5, 1e-5)):
+        mc = GPR(x, y, kernels.Rbf(d, variance=0.7, length_scales=lsv) + kernels.Rbf(d, variance=0.5, length_scales=lsv),
+                 likelihood=likelihoods.Gaussian(variance=noise))
+        ms = GPR(x, y, kernels.Rbf(d, variance=1.2, length_scales=lsv), likelihood=likelihoods.Gaussian(variance=noise))
+        mc.cuda(), ms.cuda()
+        with torch.no_grad():
+            lc, ls_ = mc.log_likelihood().item(), ms.log_likelihood().item()
+        assert mc._holder["factor"].refined and mc._expression(mc.X) is not None
+        monkeypatch.setenv("GPN_REFINE_MIN_N", "0")
+        with torch.no_grad():
+            pc, ps = mc.log_likelihood().item(), ms.log_likelihood().item()
+        monkeypatch.setenv("GPN_REFINE_MIN_N", "2048")
+        tol = 1e-12 if noise > 1e-3 else 1e-9
+        assert abs(lc - ls_) < tol * abs(ls_), (lc, ls_, pc, ps)
+        if noise < 1e-3:
+            assert abs(lc - ls_) < 0.1 * max(abs(pc - lc), abs(ps - ls_)), (lc - ls_, pc - lc, ps - ls_)
+        else:
+            o = orc.GPROracle(x, y, kind="Rbf", variance=1.2, length_scales=lsv, noise=noise)
+            with torch.no_grad():
+                assert abs(lc - o.log_likelihood().item()) < 1e-9 * abs(lc)
+
+
 def test_gpr_example_model_at_c2_size(device):
     """the reference's own example model (examples/regression_1d.py:34-53: Linear + Rbf + Constant) at BASELINE configs[1]'s size,
     N = 8192, D = 8, on the FUSED expression path (one N x N write, 1536-column panels, one sweep per leaf in the backward): loss
