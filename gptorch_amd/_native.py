@@ -78,6 +78,7 @@ class ExprTerm(ctypes.Structure):
 TERM_STATIONARY, TERM_LINEAR, TERM_CONSTANT, TERM_WHITE = 0, 1, 2, 3
 EXPR_MAX_TERMS, EXPR_MAX_GROUPS = 16, 8
 SIGNATURES.update({
+    "gpn_lml_refine_dense": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_lml_refine_expr": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p, c_int64, c_int,
                                     c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_kernel_matrix_expr": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p,

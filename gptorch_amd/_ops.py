@@ -513,7 +513,20 @@ class DenseLogLik(torch.autograd.Function):
         Kyy.diagonal().add_(noise.detach()[0])
         f = cholesky_factor(Kyy, rhs=R)
         ctx.factor = f
-        return f.lml_terms()[2:3].clone()
+        terms = f.lml_terms()
+        f.refined = False
+        if n >= refine_min_n():
+            # the refinement step of the quadratic form; the residual pass reads the dense Kyy it was factorised from
+            lib = _native.lib()
+            e = R.shape[1]
+            jitter = 0.0 if f.jitter_rung < 0 else 10.0 ** (-JITTER_TRIES + f.jitter_rung)
+            work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=K.device)
+            Rc = _c(R.detach())
+            st = lib.gpn_lml_refine_dense(_stream(K.device), _ptr(Kyy), Kyy.stride(0), jitter, n, _ptr(Rc), None, e, _ptr(f.A), f.ld,
+                                          _ptr(f.winv), _ptr(work), _ptr(terms))
+            _native.check(st, "gpn_lml_refine_dense")
+            f.refined = True
+        return terms[2:3].clone()
 
     @staticmethod
     def backward(ctx, grad_out):

@@ -233,6 +233,46 @@ __global__ __launch_bounds__(256) void refine_resid_sym_kernel(RefineSymArgs p) 
   refine_tile_tail<NRHS>(tp, v, offdiag, q, i0, j0, arow, acol, red);
 }
 
+// The same pass for a Kyy that exists as a dense matrix (the dense-K fall-back of GPR: kernels the expression builder cannot take):
+// the tile's entries are READ (lower tiles of the symmetric matrix; diag_add = the jitter the ladder settled on) instead of computed.
+struct DenseResidArgs {
+  const double* K;
+  int64_t ldk;
+  double diag_add;
+  RefineTailArgs tail;
+  int n;
+};
+
+template <int NRHS>
+__global__ __launch_bounds__(256) void refine_resid_dense_kernel(DenseResidArgs p) {
+  __shared__ double arow[NRHS][RT], acol[NRHS][RT];
+  __shared__ double red[2][RT][17];
+  const int q = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > q) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+  const int tj = q - ti * (ti + 1) / 2;
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int i0 = ti * RT, j0 = tj * RT;
+  double v[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int row = i0 + ty * 4 + a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int col = j0 + (b >> 1) * 32 + tx * 2 + (b & 1);
+      double e = 0.0;
+      if (row < p.n && col < p.n) {
+        e = p.K[(int64_t)row * p.ldk + col];
+        if (row == col) e += p.diag_add;
+      }
+      v[a][b] = e;
+    }
+  }
+  refine_tile_tail<NRHS>(p.tail, v, ti != tj, q, i0, j0, arow, acol, red);
+}
+
 // ka[c][i] = sum_{J <= T} prow[(T, J)][c][r] + sum_{I > T} pcol[(I, T)][c][r]   (T = i / 64, r = i % 64), double-double,
 // fixed order; 4 lanes per row take every 4th partial and are combined through LDS
 __global__ __launch_bounds__(256) void refine_gather_kernel(const double* prow, const double* pcol, int nt, int dy, int64_t lds,
@@ -489,6 +529,36 @@ extern "C" int gpn_lml_refine_expr(void* stream, const gpn_expr_term* terms, int
   rc = expr_resid(s, terms, nterms, group_start, ngroups, theta, X, n, d, noise, work + L.a, dy, L.lds, 0, ntile * (ntile + 1) / 2,
                   work + L.prow, work + L.pcol);
   if (rc != GPN_OK) return rc;
+  return refine_gather_finish(s, Y, M, n, dy, work, L, out3);
+}
+
+// the same step for a Kyy given as a dense symmetric matrix (K [n, n], leading dimension ldk, as it was factorised up to
+// diag_add on the diagonal): gptorch_amd/_ops.py DenseLogLik
+extern "C" int gpn_lml_refine_dense(void* stream, const double* K, int64_t ldk, double diag_add, int64_t n, const double* Y, const double* M, int dy,
+                                    const double* A, int64_t lda, const double* winv, double* work, double* out3) {
+  if (!K) return -2;
+  if (ldk < n) return -3;
+  if (n < 0) return -5;
+  if (!Y) return -6;
+  if (dy <= 0) return -8;
+  if (!A) return -9;
+  if (lda != gpn_factor_ld(n, dy)) return -10;
+  if (!winv) return -11;
+  if (!work) return -12;
+  if (!out3) return -13;
+  if (n == 0) return GPN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const RefineLayout L = refine_layout(n, dy);
+  int rc = refine_backsub(s, A, lda, winv, n, dy, work, L);
+  if (rc != GPN_OK) return rc;
+  const int64_t ntile = (n + RT - 1) / RT;
+  DenseResidArgs p;
+  p.K = K; p.ldk = ldk; p.diag_add = diag_add; p.n = (int)n;
+  p.tail.a = work + L.a; p.tail.prow = work + L.prow; p.tail.pcol = work + L.pcol; p.tail.lds = L.lds; p.tail.n = (int)n; p.tail.dy = dy;
+  const dim3 grid((unsigned)(ntile * (ntile + 1) / 2));
+  if (dy == 1) hipLaunchKernelGGL(refine_resid_dense_kernel<1>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(refine_resid_dense_kernel<RDY>, grid, dim3(256), 0, s, p);
+  GPN_LAUNCH_CHECK();
   return refine_gather_finish(s, Y, M, n, dy, work, L, out3);
 }
 

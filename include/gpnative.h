@@ -289,6 +289,10 @@ int gpn_lml_refine_expr(void* stream, const gpn_expr_term* terms, int nterms, co
                         const double* theta, const double* X, int64_t n, int d, const double* Y, const double* M, int dy,
                         const double* noise, const double* A, int64_t lda, const double* winv, double* work, double* out3);
 
+/* ... and for a Kyy that exists as a dense symmetric matrix K [n, n] (factorised as K + diag_add I; the dense-K fall-back of GPR). */
+int gpn_lml_refine_dense(void* stream, const double* K, int64_t ldk, double diag_add, int64_t n, const double* Y, const double* M, int dy,
+                         const double* A, int64_t lda, const double* winv, double* work, double* out3);
+
 /* The same refinement step in pieces, for a factor that is spread over several GPUs (gptorch_amd/dist.py
  * BlockCyclicGP._refine: 2-D block-cyclic tiles; the exchange between the pieces is the caller's).  Vectors are
  * [dy][ld] row-major, one right-hand side per row.

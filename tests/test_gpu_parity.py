@@ -1121,6 +1121,12 @@ def test_refinement_on_the_fused_expression_path(device, monkeypatch):
         monkeypatch.setenv("GPN_REFINE_MIN_N", "2048")
         tol = 1e-12 if noise > 1e-3 else 1e-9
         assert abs(lc - ls_) < tol * abs(ls_), (lc, ls_, pc, ps)
+        # ... and the dense-K fall-back (gpn_lml_refine_dense: the residual pass READS the matrix it was factorised from)
+        from gptorch_amd import _ops
+        with torch.no_grad():
+            Kd = ms.kernel.K(ms.X)
+            ld = _ops.DenseLogLik.apply(Kd, ms.Y - ms.mean_function(ms.X), ms.likelihood.variance.transform()).item()
+        assert abs(ld - ls_) < tol * abs(ls_), (ld, ls_, ps)
         if noise < 1e-3:
             assert abs(lc - ls_) < 0.1 * max(abs(pc - lc), abs(ps - ls_)), (lc - ls_, pc - lc, ps - ls_)
         else:
