@@ -438,6 +438,25 @@ def gen_composite_big(out):
     print("composite big:", case["loss"], {k: v for k, v in grads.items()}, "%.1f s" % case["ref_seconds"])
 
 
+def gen_composite_16k(out):
+    """the example model once more at N = 16384 -- above the size from which the native paths refine the quadratic form:
+    loss and raw-parameter gradients from the reference (about 30 GB of host memory for its autograd)."""
+    n, d = 16384, 8
+    x, y = rng.make_regression(n, d, 1, seed=0)
+    t0 = time.time()
+    m = RefGPR(x, y, rk.Linear(d, variance=0.3) + rk.Rbf(d, variance=1.2, length_scales=float(np.sqrt(d))) + rk.Constant(d, variance=0.4),
+               likelihood=rl.Gaussian(variance=0.01))
+    m.zero_grad()
+    loss = m.loss()
+    loss.backward()
+    grads = {nm: p.grad.tolist() for nm, p in m.named_parameters() if p.grad is not None}
+    case = dict(name="linear_plus_rbf_plus_constant_16384_8", n=n, d=d, dy=1, noise=0.01, loss=float(loss.item()), grads=grads,
+                ref_seconds=time.time() - t0)
+    with open(os.path.join(out, "composite_16k_case.json"), "w") as f:
+        json.dump(case, f, indent=1)
+    print("composite 16k:", case["loss"], "%.1f s" % case["ref_seconds"])
+
+
 def gen_sparse_composite(out):
     """VFE over kernels without a single native kind (sparse_gpr.py:126-129 takes any kernel object):
     bound, raw-parameter / inducing-point gradients and predictions from the reference."""
@@ -548,7 +567,7 @@ if __name__ == "__main__":
     steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
                  lml=lambda: gen_lml(HERE, args.big), adam=lambda: gen_adam(HERE),
                  func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE),
-                 comp=lambda: gen_composite(HERE), compbig=lambda: gen_composite_big(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), lbfgs=lambda: gen_lbfgs(HERE))
+                 comp=lambda: gen_composite(HERE), compbig=lambda: gen_composite_big(HERE), comp16k=lambda: gen_composite_16k(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), lbfgs=lambda: gen_lbfgs(HERE))
     for k, fn in steps.items():
         if not args.only or k in args.only.split(","):
             fn()

@@ -1161,6 +1161,34 @@ def test_gpr_example_model_at_c2_size(device):
     assert np.max(np.abs(var - np.asarray(case["var"]))) < 1e-8
 
 
+def test_gpr_example_model_at_16k(device):
+    """the same model at N = 16384: above the size from which every native path refines the quadratic form -- here through
+    gpn_lml_refine_expr (residual pass over the expression program).  Loss within north_star's 1e-8 of the EXTENDED-PRECISION value
+    (see below), gradients to 1e-8 relative of the reference's (tests/golden/composite_16k_case.json, make_golden.py --only comp16k)."""
+    case = load_json("composite_16k_case.json")
+    d = case["d"]
+    x, y = rng.make_regression(case["n"], d, case["dy"], seed=0)
+    k = kernels.Linear(d, variance=0.3) + kernels.Rbf(d, variance=1.2, length_scales=float(np.sqrt(d))) + kernels.Constant(d, variance=0.4)
+    m = GPR(x, y, k, likelihood=likelihoods.Gaussian(variance=case["noise"]))
+    m.cuda()
+    loss = m.loss()
+    assert m._holder["factor"].refined
+    # this Kyy (0.4 * 1 1^T and a rank-8 linear part on top of the Rbf) has a condition number of a few 1e6: the reference's own fp64
+    # value is 2.5e-8 ABOVE the extended-precision one (tests/golden/make_comp16k_extended.py: iterative refinement with an 80-bit
+    # residual, composite_16k_extended.json), i.e. further from it than north_star's tolerance.  The refined native value is held to
+    # 1e-8 against the extended-precision value (measured 3.3e-9) and to the reference's within the reference's own error.
+    ext = load_json("composite_16k_extended.json")
+    assert abs(loss.item() - ext["loss_extended"]) < 1e-8, (loss.item(), ext["loss_extended"])
+    assert abs(loss.item() - case["loss"]) < 1e-8 + ext["reference_abs_err_vs_extended"], (loss.item(), case["loss"])
+    loss.backward()
+    got = {n: p.grad.cpu().numpy() for n, p in m.named_parameters() if p.grad is not None}
+    # (the eight Linear variances' gradients are O(0.1) sums of cancelling O(1e5) terms: held to 1e-12 of the gradient's scale)
+    gscale = max(np.abs(np.asarray(r)).max() for r in case["grads"].values())
+    for n, r in case["grads"].items():
+        r = np.asarray(r)
+        assert np.abs(got[n].reshape(r.shape) - r).max() < max(1e-8 * max(1.0, np.abs(r).max()), 1e-12 * gscale), (n, got[n], r)
+
+
 def _composed(k, X, X2=None):
     """a Sum / Product tree evaluated the reference's way: the children's matrices combined by elementwise ops."""
     if isinstance(k, kernels.Sum):
