@@ -1910,7 +1910,7 @@ def test_dist_gpr_model_native_shared_gpu(device, world):
 
 
 def test_block_cyclic_refinement_native_pieces(device):
-    """BlockCyclicGP._refine on the native pieces (gpn_backsolve_lt, gpn_gemv_t_acc, gpn_refine_resid_part, gpn_refine_finish) against
+    """BlockCyclicGP._refine on the native pieces (tile inverses, gpn_gemv_t_acc, gpn_refine_resid_part, gpn_refine_finish) against
     the single-GPU step (gpn_lml_refine) on the same matrix: both are exact to second order in their own factor's error, so they
     agree far below either's distance to the plain value.  Ragged sizes: last tile of 440 rows, last leaf block of 56."""
     from gptorch_amd import _ops, dist as gdist
