@@ -1988,6 +1988,30 @@ def test_c3_full_size_block_cyclic_2x2_grid(device):
     assert np.abs(np.asarray(db["grads_constrained"]) - np.asarray(want)).max() < 1e-9 * np.abs(want).max(), (db, want)
 
 
+def test_c4_full_size_grid_gradients_match_single_gpu(device):
+    """BASELINE config 4's gradients: the distributed closed-form backward on a 2 x 2 grid (four ranks sharing this box's GPU:
+    U = L^-T carried as identity rows, Kyy^-1 = U U^T with panels of U travelling like factorisation panels, per-rank sweeps)
+    against the single-GPU backward (gpn_lml_backward) of the same model -- two different code paths at N = 65536; the single-GPU
+    path itself is pinned against autograd through the CPU oracle at C3's size (lml_c3_grad_cpu_oracle.json)."""
+    import json
+    import bench
+    w = bench.WORKLOADS["c4"]
+    m, _, _ = bench.build_model(w, 0, device)
+    loss = m.loss()
+    loss.backward()
+    want = [-m.kernel.variance.grad.item() / w["variance"], -m.kernel.length_scales.grad.item() / w["length_scales"],
+            -m.likelihood.variance.grad.item() / w["noise"]]                 # d LML / d (constrained value)
+    lml1 = -loss.item()
+    del m, loss
+    torch.cuda.empty_cache()
+    out = _torchrun(4, ["bench.py", "--gpus", "4", "--steps", "1", "--warmup", "0", "--test-shared-gpu", "--schedule", "bcast"], {}, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    db = line["dist_loss_backward"]
+    assert line["config"]["N"] == 65536 and abs(db["lml"] - lml1) < 1e-8, (db["lml"], lml1)
+    assert np.abs(np.asarray(db["grads_constrained"]) - np.asarray(want)).max() < 1e-9 * np.abs(want).max(), (db, want)
+
+
 def test_c4_full_size_block_cyclic_2x4_grid(device):
     """BASELINE config 4 at FULL size (N = 65536, D = 32) through the driver's own command line for 8 GPUs --
     `bench.py --gpus 8` under torch.distributed.run, grid 2x4, 32 x 32 tiles of 2048 -- with the eight ranks
