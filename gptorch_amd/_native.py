@@ -152,6 +152,7 @@ DEBUG_SIGNATURES = {
     "gpn_debug_set_potrf_variant": (c_int, [c_int]),
     "gpn_debug_masked_stream": (c_int, [ctypes.POINTER(ctypes.c_uint32), c_int, ctypes.POINTER(c_void_p)]),
     "gpn_debug_leaf_timing": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "gpn_debug_leaf16_timing": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
 }
 DEBUG_LIB_PATH = os.path.join(_HERE, "lib", "libgpnative_dbg.so")
 

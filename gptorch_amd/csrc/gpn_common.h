@@ -40,6 +40,12 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
 int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B, int64_t ldb,
              double* C, int64_t ldc);
 
+// the 128 x 128 factor leaf, second generation (leaf16.hip): `batch` independent leaves in one launch, problem b at
+// A + b sA, winv + b sW, info + b sInfo
+int leaf16(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* winv, int32_t* info, int batch, int64_t sA,
+           int64_t sW, int64_t sInfo);
+int leaf16_timing(hipStream_t s, double* A, int64_t lda, double* winv, int32_t* info, unsigned long long* diag72);
+
 // `batch` problems of identical shape at constant strides (elements) in one launch
 int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                     const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,

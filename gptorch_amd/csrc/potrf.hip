@@ -513,6 +513,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
 #define GPN_SWITCH static constexpr int
 #endif
 GPN_SWITCH g_leaf_pipe = 1;          // 1 = two-phase leaf (pivot wave advances its own block); 0 = three-phase
+GPN_SWITCH g_leaf_gen = 2;           // 2 = 16-pivot-block leaf (leaf16.hip, round 4); 1 = the first-generation leaf above
 // bit 0: every in-place solve against an inverted leaf block (the chain's and the right-solve recursion's) through
 // colpanel.hip; bit 1: the chain's next-column update too (measured slower: DESIGN 8-1f); 0 = the generic contraction
 GPN_SWITCH g_chain_kernel = 1;
@@ -529,6 +530,23 @@ struct Ctx {
   // touched -- the extra rows get a rectangular update of their own.
   bool corner = true;
 };
+
+// one factor leaf (or `batch` of them at constant strides) on stream s
+static int launch_leaf(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* W, int32_t* info, int batch = 1,
+                       int64_t sA = 0, int64_t sW = 0, int64_t sInfo = 0) {
+  if (g_leaf_gen == 2) return leaf16(s, A, lda, kb, col0, W, info, batch, sA, sW, sInfo);
+  for (int b = 0; b < batch; ++b) {
+    double* Ab = A + b * sA;
+    double* Wb = W + b * sW;
+    int32_t* ib = info + b * sInfo;
+    if (g_leaf_pipe)
+      hipLaunchKernelGGL((potrf_leaf_kernel<true, false, true>), dim3(1), dim3(LEAF_THREADS), 0, s, Ab, lda, kb, col0, Wb, ib, 0, nullptr);
+    else
+      hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, s, Ab, lda, kb, col0, Wb, ib, 0, nullptr);
+  }
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
 
 static inline int64_t split_point(int64_t n) {
   // largest power-of-two multiple of LEAF strictly below n
@@ -558,13 +576,8 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
 static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   if (c.rc != GPN_OK || n <= 0) return;
   if (n <= LEAF) {
-    if (g_leaf_pipe)
-      hipLaunchKernelGGL((potrf_leaf_kernel<true, false, true>), dim3(1), dim3(LEAF_THREADS), 0, c.s, A, c.lda, (int)n,
-                         (int)col0, c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0, nullptr);
-    else
-      hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, A, c.lda, (int)n, (int)col0,
-                         c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, 0, nullptr);
-    if (hipGetLastError() != hipSuccess) { c.rc = GPN_E_HIP; return; }
+    c.rc = launch_leaf(c.s, A, c.lda, (int)n, (int)col0, c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info);
+    if (c.rc != GPN_OK) return;
     if (e > 0) trsm_rec(c, A + n * c.lda, e, c.lda, A, c.lda, n, col0, c.winv);
     return;
   }
@@ -663,14 +676,8 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       double* Akk = A + k0 * lda + k0;
       const double* Wk = c.winv + (k0 / LEAF) * (LEAF * LEAF);
       const int rec = profile_on() ? profile_begin(c.s, 2.0 * LEAF * LEAF * LEAF / 3.0, PROF_LEAF) : -1;
-      if (g_leaf_pipe)
-        hipLaunchKernelGGL((potrf_leaf_kernel<true, false, true>), dim3(1), dim3(LEAF_THREADS), 0, c.s, Akk, lda, (int)kb,
-                           (int)k0, const_cast<double*>(Wk), c.info, 0, nullptr);
-      else
-        hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, c.s, Akk, lda, (int)kb, (int)k0,
-                           const_cast<double*>(Wk), c.info, 0, nullptr);
+      { const int lrc = launch_leaf(c.s, Akk, lda, (int)kb, (int)k0, const_cast<double*>(Wk), c.info); if (c.rc == GPN_OK) c.rc = lrc; }
       if (rec >= 0) profile_end(c.s, rec);
-      hip_ok(hipGetLastError());
       const int64_t m = n + e - c1;                // rows below (incl. the extra rows)
       if (m <= 0 || c.rc != GPN_OK) continue;
       double* B = A + c1 * lda + k0;               // [m, kb] <- B W_k^T   (in place)
@@ -991,6 +998,7 @@ extern "C" int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t
 extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_potrf_variant = v & 1;           // bit 0: plain recursion; bit 2: three-phase leaf; bits 8..: panel width / 128
   g_leaf_pipe = ((v >> 2) & 1) ? 0 : 1;
+  g_leaf_gen = ((v >> 1) & 1) ? 1 : 2;                                   // bit 1: the first-generation leaf
   g_panel_width = ((v >> 8) & 0xff) * LEAF;
   g_aux_left_looking = ((v >> 3) & 1) ? 1 : (((v >> 5) & 1) ? 0 : -1);   // bit 3: force left-looking aux update, bit 5: force right-looking
   g_panel_lookahead = (v >> 4) & 1;                                      // bit 4: look-ahead over panels (bulk of the trailing update on a second stream)
@@ -1008,6 +1016,10 @@ extern "C" int gpn_debug_leaf_timing(void* stream, double* A, int64_t lda, doubl
                      A, lda, LEAF, 0, winv, info, 0, diag72);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
+}
+extern "C" int gpn_debug_leaf16_timing(void* stream, double* A, int64_t lda, double* winv, int32_t* info,
+                                       unsigned long long* diag72) {
+  return leaf16_timing(static_cast<hipStream_t>(stream), A, lda, winv, info, diag72);
 }
 #endif
 
