@@ -23,11 +23,25 @@
 // Deterministic (fixed summation order).  FACTOR=false (inverse of a given L) stays on the first kernel.
 #include "gpn_common.h"
 
+#ifndef L16_COALESCED_STORE
+#define L16_COALESCED_STORE 1
+#endif
+// Lanes of ONE wave exchange data through LDS without a barrier: the hardware executes a wave's LDS instructions in
+// order, but the COMPILER reasons per thread -- it may prove that a lane's own stores and loads never overlap and hoist
+// the loads above the stores (it did, in the prologue's layout change: lanes then read the previous tile).  This fence
+// pins the program order of memory instructions; it emits no code.
+#define L16_WAVE_FENCE() asm volatile("" ::: "memory")
+
 namespace gpn {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int L16_THREADS = 576;      // 8 tile waves + the pivot wave
+// 12 waves: the hardware deals a workgroup's waves round-robin over the CU's 4 SIMDs, so waves {0,4,8} share one.  Wave 0 is
+// the PIVOT wave and waves 4 and 8 stay idle (barriers only): fp64 MFMAs and fp64 vector instructions of one SIMD share
+// the DP pipe, and a tile wave's 64-cycle MFMAs next to the pivot wave stretched its dependent chain from ~100 to ~370
+// cycles per pivot (measured: tools/lat_bench.hip alone vs the s_memtime stamps of the 9-wave version).  The 8 tile rows
+// go to the other three SIMDs by cost: {0,7} | {1,3,5} | {2,4,6} (56 tile updates each).
+constexpr int L16_THREADS = 768;
 constexpr int RS = 18;                // row stride (doubles) of the row-major 16 x 16 blocks in LDS (144 B: 16-B aligned rows)
 
 struct Leaf16Args {
@@ -39,17 +53,23 @@ struct Leaf16Args {
   int64_t sA, sW, sInfo;              // per-workgroup strides (elements): blockIdx.x-th problem of a batch
 };
 
-#define L16_STAMP(k)                                                            \
-  if constexpr (DIAG) {                                                         \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                 \
-    acc_t[k] += t_ - last_t;                                                    \
-    last_t = t_;                                                                \
+// DIAG build: a timeline -- diag[(wave * 8 + k) * 8 + ev] = s_memtime at event ev of block k, pinned behind the value `tie`
+// (the stamp waits for every outstanding LDS operation of the wave: it perturbs what it measures a little)
+#define L16_TL(k, ev, tie)                                                                                   \
+  if constexpr (DIAG) {                                                                                      \
+    unsigned long long t_;                                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(tie) :: "memory");                  \
+    if (lane == 0) diag[(wave * 8 + (k)) * 8 + (ev)] = t_;                                                   \
   }
 
 template <bool DIAG>
 __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p, unsigned long long* diag) {
-  unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_t = 0;
-  if constexpr (DIAG) last_t = __builtin_amdgcn_s_memtime();
+  int tie0 = 0;
+  if constexpr (DIAG) {
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+    if ((threadIdx.x & 63) == 0) diag[((threadIdx.x >> 6) * 8 + 0) * 8 + 6] = t_;          // kernel entry
+  }
   double* A = p.A + (int64_t)blockIdx.x * p.sA;
   double* winv = p.winv + (int64_t)blockIdx.x * p.sW;
   int32_t* info = p.info ? p.info + (int64_t)blockIdx.x * p.sInfo : nullptr;
@@ -61,14 +81,20 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
   __shared__ double Wf[2][16 * RS];       // W_k, fragment-ready: Wf[RS * m + c] = W_k[c][m]
   __shared__ double Lrow[2][16 * RS];     // L_k, row-major
   __shared__ double Drow[32 * RS];        // rows 0..15: the pivot wave's next block (row-major); rows 16..31: identity
+  __shared__ double Tb[8][16 * 17];       // per tile wave: staging tile of the prologue's layout change
+  __shared__ double Lcol[64];              // the pivot wave's current column, for the broadcast reads
   __shared__ int tb_count;
   __shared__ int failflag;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool tilewave = wave < 8;
-  const int w = wave & 7;
+  // wave -> role: 0 pivot; 4, 8, 11 idle; tile row of the others
+  const int rowmap = (wave == 1) ? 1 : (wave == 5) ? 3 : (wave == 9) ? 5 : (wave == 2) ? 2 : (wave == 6) ? 4 : (wave == 10) ? 6 :
+                     (wave == 3) ? 0 : (wave == 7) ? 7 : -1;
+  const bool tilewave = rowmap >= 0;
+  const bool pivotwave = wave == 0;
+  const int w = rowmap & 7;
   const int g = lane >> 4, lc = lane & 15;
   if (tid == 0) { failflag = 0; tb_count = 0; }
   for (int idx = tid; idx < 16 * RS; idx += L16_THREADS) Drow[16 * RS + idx] = ((idx / RS) == (idx % RS)) ? 1.0 : 0.0;
@@ -83,23 +109,61 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
     // ======================================= tile waves =======================================
     // slot J (J <= w): A tile (w, J); slot J + 1 (J >= w): identity tile (8 + w, J).  Transposed storage.
     d4 acc[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const bool isA = q <= w;
-      const int J = isA ? q : q - 1;
+    L16_TL(1, 6, tie0)
+    {
+      // One memory round trip, COALESCED: the tiles are fetched row-major (lane (g, lc) reads T[g + 4 r][lc]: 16
+      // consecutive lanes = 128 consecutive bytes) with every load issued before the first use, then turned into the
+      // transposed storage through a per-wave 16 x 17 LDS tile.  (Fetching the transposed storage directly puts
+      // consecutive lanes on different rows: 64 transactions per load instruction, 13-21 k cycles of prologue.)
+      // Columns right of the diagonal are read too (finite garbage of the caller's buffer) and discarded.
+      double* tb = Tb[w];
+      double ld[8][4];
+      bool rok[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * w + lc, col = 16 * J + g + 4 * r;     // element T[lc][g + 4 r] of tile (w, J)
-        double v = (row == col) ? 1.0 : 0.0;
-        if (isA) {
-          const int rr = row > col ? row : col, cc = row > col ? col : row;   // diagonal tile: symmetric fill
-          if (q < w) v = 0.0;
-          if (rr < kb) v = A[(int64_t)rr * lda + cc];
-        } else if (J != w) {
-          v = 0.0;
-        }
-        acc[q][r] = v;
+        const int row = 16 * w + g + 4 * r;
+        rok[r] = row < kb;
+        const double* rowp = A + (int64_t)(rok[r] ? row : 0) * lda + lc;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ld[q][r] = rowp[16 * q];
       }
+      L16_TL(2, 6, tie0)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        if (q < 8 && q < w) {                                         // A tile left of the diagonal (uniform branch)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tb[(g + 4 * r) * 17 + lc] = rok[r] ? ld[q < 8 ? q : 0][r] : 0.0;
+          L16_WAVE_FENCE();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[q][r] = tb[lc * 17 + g + 4 * r];
+          L16_WAVE_FENCE();
+        } else if (q < 8 && q == w) {                                 // diagonal tile: symmetric fill from the lower triangle
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a_ = g + 4 * r, b_ = lc;
+            if (b_ <= a_) {
+              const double v = rok[r] ? ld[q < 8 ? q : 0][r] : (a_ == b_ ? 1.0 : 0.0);     // identity beyond kb
+              tb[a_ * 17 + b_] = v;
+              tb[b_ * 17 + a_] = v;
+            }
+          }
+          L16_WAVE_FENCE();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[q][r] = tb[lc * 17 + g + 4 * r];
+          L16_WAVE_FENCE();
+        } else {                                                      // identity tiles: (8 + w, w) = I, the others 0
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[q][r] = (q == w + 1 && lc == g + 4 * r) ? 1.0 : 0.0;
+        }
+      }
+    }
+    L16_TL(3, 6, acc[0])
+    if constexpr (DIAG) {                                             // debug: the tiles as loaded (after the 768 stamps)
+      double* dbg = reinterpret_cast<double*>(diag + 768);
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbg[((w * 9 + q) * 4 + r) * 64 + lane] = acc[q][r];
     }
     // the part of winv above the diagonal tiles is zero: W[16 k + ..][16 w + ..], k < w
 #pragma unroll
@@ -116,26 +180,24 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
     // raw tiles for the pivot wave's first steps: D(0,0) from wave 0, A(1,0) and D(1,1) from wave 1
     if (w == 0) dump(&Raw[0][1][0][0], acc[0]);
     if (w == 1) { dump(&Raw[1][0][0][0], acc[0]); dump(&Raw[1][1][0][0], acc[1]); }
+    L16_TL(4, 6, tie0)
     __syncthreads();                                                  // P
 
+    // software barrier of the 8 tile waves, split: ARRIVE right after the wave's X tile is in LDS, WAIT after its global
+    // stores -- the slowest wave's stores (the diagonal tile's masked rows) used to hold everybody for ~1.6 k cycles
     int epoch = 0;
-    auto tile_barrier = [&]() {
+    auto tb_arrive = [&]() {
       ++epoch;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(&tb_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto tb_wait = [&]() {
       int spins = 0;
       while (__hip_atomic_load(&tb_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * epoch) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1 << 22)) { failflag = LEAF + 1; break; }
       }
       asm volatile("" ::: "memory");
-    };
-    // X = T W_k^T in place (transposed storage both sides)
-    auto solve = [&](d4& t, const d4& wf) {
-      d4 x = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[r], t[r], x, 0, 0, 0);
-      t = x;
     };
     // T(i,j) -= X(i,k) X(j,k)^T:  xa = X(j,k) fragments, nx = -X(i,k) (own registers)
     auto update = [&](d4& t, const d4& xa, const d4& nx) {
@@ -149,35 +211,59 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       return f;
     };
 
+    // The panel loop is fully UNROLLED: the tile registers are reached through wave-uniform branches on static slots, and with
+    // k a run-time value those branches turn every accumulator update into MFMA-to-temporary + copy-back behind a pipeline
+    // drain (measured: the rolled loop ran the update phase at 58 % of the MFMA rate, the unrolled one at 78 %).  The code
+    // is 20+ KB of straight line, run once per wave: fine with a warm instruction cache.
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      L16_STAMP(0)
+      L16_TL(k, 0, tie0)
       __syncthreads();                                                // B(k): W_k and L_k are out
-      L16_STAMP(1)
+      L16_TL(k, 1, tie0)
       if (failflag) break;                                            // uniform
       d4 wf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) wf[r] = Wf[k & 1][RS * (g + 4 * r) + lc];
-      d4 nx;                                                          // -X of my tile in column k
-      if (w > k) {
-        solve(acc[k], wf);
-        const d4& x = acc[k];
-        if (k < 7) dump(&Xbuf[w][0][0], x);
-        const int row = 16 * w + lc;                                  // L tile (w, k)
+      const bool apart = w > k;                                       // my tile of column k: A tile (w, k) or identity tile (8 + w, k)
+      const int slot = apart ? k : k + 1;
+      // X = T W_k^T (transposed storage both sides); the tile's registers are dead afterwards
+      d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        if (q == slot) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[r], acc[q][r], x, 0, 0, 0);
+        }
+      }
+      L16_TL(k, 2, x)
+      if (apart && k < 7) dump(&Xbuf[w][0][0], x);
+      if (k < 7) tb_arrive();
+      if (apart) {
+        // L tile (w, k), stored row-major (coalesced): element X[g + 4 r][lc], read back from my register dump in Xbuf
+        // (or, for the last panel, straight from a dump made for the purpose)
+#if L16_COALESCED_STORE
+        if (k == 7) dump(&Xbuf[w][0][0], x);
+        L16_WAVE_FENCE();
+        const double* xd = &Xbuf[w][0][0] + (lc >> 2) * 64 + (lc & 3) * 16 + g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * w + g + 4 * r;
+          const double v = xd[4 * r];
+          if (row < kb) A[(int64_t)row * lda + 16 * k + lc] = v;
+        }
+#else
+        const int row = 16 * w + lc;
         if (row < kb) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) A[(int64_t)row * lda + 16 * k + g + 4 * r] = x[r];
         }
-        nx = d4{-x[0], -x[1], -x[2], -x[3]};
-      } else {
-        solve(acc[k + 1], wf);
-        const d4& x = acc[k + 1];                                     // W^T tile (w, k): X[a][b] = W[16 k + b][16 w + a]
+#endif
+      } else {                                                        // W^T tile (w, k): X[a][b] = W[16 k + b][16 w + a]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int wr = 16 * k + g + 4 * r, wc = 16 * w + lc;
           winv[(int64_t)wr * LEAF + wc] = (wr < kb && wc < kb) ? x[r] : 0.0;
         }
-        nx = d4{-x[0], -x[1], -x[2], -x[3]};
         if (w == k) {                                                 // the diagonal tile L_k comes from the pivot wave
           const double* Lr = Lrow[k & 1];
 #pragma unroll
@@ -187,41 +273,57 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
           }
         }
       }
-      L16_STAMP(2)
+      const d4 nx = d4{-x[0], -x[1], -x[2], -x[3]};
+      L16_TL(k, 3, tie0)
       if (k == 7) break;
-      tile_barrier();                                                 // T(k): the X tiles of this panel are in LDS
-      L16_STAMP(3)
-      if (w > k) {
-        // A tiles (w, j), j = k + 1 .. w
+      tb_wait();                                                      // T(k): the X tiles of this panel are in LDS
+      L16_TL(k, 4, tie0)
+      {
+        // A operand X(j,k) of the NEXT tile requested before the current tile's MFMAs (rolling prefetch)
+        d4 xa_n = load_frag(&Xbuf[k + 1][0][0]);
 #pragma unroll
-        for (int j = k + 1; j < 8; ++j) {
-          if (j < w) {
-            const d4 xa = load_frag(&Xbuf[j][0][0]);
-            update(acc[j], xa, nx);
-          } else if (j == w) {
-            const d4 xa = d4{-nx[0], -nx[1], -nx[2], -nx[3]};
-            update(acc[j], xa, nx);
+        for (int j = 1; j < 8; ++j) {
+          if (j > k) {                                                // uniform
+            const d4 xa = xa_n;
+            if (j < 7) xa_n = load_frag(&Xbuf[j + 1][0][0]);
+            if (apart) {                                              // A tiles (w, j), j = k + 1 .. w
+              if (j < w) {
+                update(acc[j], xa, nx);
+              } else if (j == w) {
+                update(acc[j], x, nx);
+              }
+              // the raw tiles the pivot wave needs after its NEXT block: A(k+2, k+1) and D(k+2, k+2), from wave k + 2
+              if (w == k + 2) {
+                if (j == k + 1) dump(&Raw[k & 1][0][0][0], acc[j]);
+                if (j == k + 2) dump(&Raw[k & 1][1][0][0], acc[j]);
+              }
+            } else {                                                  // identity tiles (8 + w, j), j = k + 1 .. 7
+              update(acc[j + 1], xa, nx);
+            }
           }
-          // the raw tiles the pivot wave needs after its NEXT block: A(k+2, k+1) and D(k+2, k+2), from wave k + 2
-          if (w == k + 2) {
-            if (j == k + 1) dump(&Raw[k & 1][0][0][0], acc[j]);
-            if (j == k + 2) dump(&Raw[k & 1][1][0][0], acc[j]);
-          }
-        }
-      } else {
-        // identity tiles (8 + w, j), j = k + 1 .. 7
-#pragma unroll
-        for (int j = k + 1; j < 8; ++j) {
-          const d4 xa = load_frag(&Xbuf[j][0][0]);
-          update(acc[j + 1], xa, nx);
         }
       }
-      L16_STAMP(4)
+      if constexpr (DIAG) {
+        double chk = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) chk += acc[q][0];
+        L16_TL(k, 5, chk)
+        if (chk == 1.2345e300) tie0 += 1;
+      }
+    }
+  } else if (!pivotwave) {
+    // idle waves (they share the pivot wave's SIMD): the barrier sequence only
+    __syncthreads();                                                  // P
+    for (int k = 0; k < 8; ++k) {
+      __syncthreads();                                                // B(k)
+      if (failflag) break;
     }
   } else {
     // ======================================= pivot wave =======================================
     __builtin_amdgcn_s_setprio(3);
+    L16_TL(4, 6, tie0)
     __syncthreads();                                                  // P
+    L16_TL(5, 6, tie0)
     double a[16];
     const int myrow = lane & 31;
     // block 0: D(0,0) as dumped by wave 0 (transposed storage of a symmetric tile) -> one row per lane
@@ -231,13 +333,20 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       for (int r = 0; r < 4; ++r) dacc[r] = Raw[0][1][r][lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) Drow[lc * RS + g + 4 * r] = dacc[r];
+      L16_WAVE_FENCE();
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = Drow[myrow * RS + c];
+      L16_WAVE_FENCE();
     }
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
-      L16_STAMP(0)
-      // ---- 16 pivots, one row per lane; lanes 16..31 carry the identity rows
+      L16_TL(k, 0, a[0])
+      // ---- 16 pivots, one row per lane; lanes 16..31 carry the identity rows.  Per pivot J only the NEXT column is updated
+      // at once (readlane broadcast: it feeds the next pivot); the columns after it take pivot J's rank-1 update one pivot
+      // LATER, from an LDS broadcast of the column (one ds_write_b64 + uniform ds_read_b128s issued here, consumed during
+      // pivot J + 1): two readlanes per column were what bound the first version (370 cycles per pivot, issue-bound).
+      // Every entry still receives its updates in pivot order, so the results are bit-identical to the eager form.
+      double sb[16], lprev = 0.0;
 #pragma unroll
       for (int J = 0; J < 16; ++J) {
         const double d = bcast(a[J], J);
@@ -249,10 +358,21 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
         const double pp = fma(e, 0.375, 0.5);
         const double l = fma(ay0 * e, pp, ay0);                       // column J: L[i][J] (lane J: sqrt(d))
         a[J] = l;
+        if (J >= 1) {                                                 // pivot J - 1's update of the columns J + 1 ..
 #pragma unroll
-        for (int c = J + 1; c < 16; ++c) a[c] = fma(-l, bcast(l, c), a[c]);
+          for (int c = J + 1; c < 16; ++c) a[c] = fma(-lprev, sb[c], a[c]);
+        }
+        if (J < 15) a[J + 1] = fma(-l, bcast(l, J + 1), a[J + 1]);
+        if (J < 14) {
+          L16_WAVE_FENCE();
+          Lcol[lane] = l;
+          L16_WAVE_FENCE();
+#pragma unroll
+          for (int c = J + 2; c < 16; ++c) sb[c] = Lcol[c];
+        }
+        lprev = l;
       }
-      L16_STAMP(1)
+      L16_TL(k, 1, a[15])
       // a failed pivot (d <= 0 or NaN) turns everything after it into NaN, a[15] of row 15 included
       {
         const double last = bcast(a[15], 15);
@@ -272,9 +392,9 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
 #pragma unroll
         for (int c = 0; c < 16; ++c) dst[c] = a[c];
       }
-      L16_STAMP(2)
+      L16_TL(k, 2, tie0)
       __syncthreads();                                                // B(k)
-      L16_STAMP(3)
+      L16_TL(k, 3, tie0)
       if (failflag || k == 7) break;
       // ---- next diagonal block from the raw tiles:  X = A(k+1,k) W_k^T,  D(k+1) -= X X^T
       {
@@ -291,17 +411,20 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
         for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[r], ar[r], x, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[r], x[r], dacc, 0, 0, 0);
+        L16_TL(k, 4, dacc)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Drow[lc * RS + g + 4 * r] = dacc[r];
+        L16_WAVE_FENCE();
 #pragma unroll
         for (int c = 0; c < 16; ++c) a[c] = Drow[myrow * RS + c];
+        L16_WAVE_FENCE();
       }
-      L16_STAMP(4)
+      L16_TL(k, 5, a[0])
     }
   }
   if constexpr (DIAG) {
-    L16_STAMP(7)
-    if (lane == 0) for (int q = 0; q < 8; ++q) diag[wave * 8 + q] = acc_t[q];
+    L16_TL(0, 7, tie0)                                                 // end of the wave's work
+    if (lane == 0) diag[(wave * 8 + 1) * 8 + 7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);   // HW_ID
   }
   __syncthreads();
   if (failflag) {
@@ -323,10 +446,10 @@ int leaf16(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* winv
   return GPN_OK;
 }
 
-int leaf16_timing(hipStream_t s, double* A, int64_t lda, double* winv, int32_t* info, unsigned long long* diag72) {
+int leaf16_timing(hipStream_t s, double* A, int64_t lda, double* winv, int32_t* info, unsigned long long* diag768) {
   Leaf16Args a;
   a.A = A; a.lda = lda; a.kb = LEAF; a.col0 = 0; a.winv = winv; a.info = info; a.sA = 0; a.sW = 0; a.sInfo = 0;
-  hipLaunchKernelGGL(potrf_leaf16_kernel<true>, dim3(1), dim3(L16_THREADS), 0, s, a, diag72);
+  hipLaunchKernelGGL(potrf_leaf16_kernel<true>, dim3(1), dim3(L16_THREADS), 0, s, a, diag768);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

@@ -97,19 +97,53 @@ with _native.debug_library() as lib:
         e1.record()
         torch.cuda.synchronize()
         print("gen %d leaf: %.2f us per launch back to back" % (gen, e0.elapsed_time(e1) * 1e3 / R))
-    # stamps
+    # timeline (DIAG build): diag[wave][k][ev]
     m = spd(128, 1e3)
     f = _ops.Factor(128, 0, dev)
-    diag = torch.zeros(72, dtype=torch.int64, device=dev)
-    for it in range(2):
+    diag = torch.zeros(12 * 8 * 8 + 8 * 9 * 4 * 64, dtype=torch.int64, device=dev)
+    for it in range(3):
         f.A[:128, :128] = m
         f.info.zero_()
+        diag.zero_()
         torch.cuda.synchronize()
         lib.gpn_debug_leaf16_timing(_stream(dev), _ptr(f.A), f.ld, _ptr(f.winv), _ptr(f.info), _ptr(diag))
         torch.cuda.synchronize()
-    d = diag.cpu().numpy().reshape(9, 8)
-    print("leaf16 cycles per 16-pivot block; rows = waves (8 = pivot wave)")
-    print("tile waves: [loop top | wait B(k) | solve+store | tile barrier | update];  pivot wave: [top | 16 pivots | publish | wait B(k) | catch-up]; last col = tail")
-    print(np.round(d[:, :5] / 8.0).astype(int), d[:, 7])
+    tiles = diag[768:].view(torch.float64).cpu().numpy().reshape(8, 9, 4, 64)
+    mm = m.cpu().numpy()
+    nbad = 0
+    for w_ in range(8):
+        for q in range(9):
+            for r in range(4):
+                for lane in range(64):
+                    g_, lc_ = lane >> 4, lane & 15
+                    a_, b_ = lc_, g_ + 4 * r            # element T[lc][g + 4 r]
+                    if q < w_:
+                        want = mm[16 * w_ + a_, 16 * q + b_]
+                    elif q == w_:
+                        i_, j_ = 16 * w_ + a_, 16 * w_ + b_
+                        want = mm[max(i_, j_), min(i_, j_)]
+                    else:
+                        want = 1.0 if (q == w_ + 1 and a_ == b_) else 0.0
+                    if tiles[w_, q, r, lane] != want:
+                        nbad += 1
+                        if nbad < 12:
+                            print("tile mismatch: row %d slot %d reg %d lane %d: got %r want %r" % (w_, q, r, lane, tiles[w_, q, r, lane], want))
+    print("prologue tiles: %d mismatches" % nbad)
+    d = diag[:768].cpu().numpy().reshape(12, 8, 8)
+    hwid = d[:, 1, 7].copy()
+    d[:, 1, 7] = 0
+    t0 = d[d > 0].min()
+    rel = np.where(d > 0, d - t0, -1)
+    print("kernel entry per wave:", [int(rel[w, 0, 6]) for w in range(12)])
+    print("prologue per wave [roles set, loads issued, tiles in registers, zero-fill + raw dumps issued]:")
+    print(rel[:, 1:5, 6])
+    print("pivot wave: at P / past P:", int(rel[0, 4, 6]), int(rel[0, 5, 6]))
+    print("HW_ID simd per wave:", [(int(hwid[w]) >> 4) & 3 for w in range(12)])
+    print("end of work per wave (cycles):", [int(rel[w, 0, 7]) for w in range(12)])
+    print("pivot wave (0): per block k: [top, pivots done, published, B(k) passed, catch-up MFMAs done, next block in registers]")
+    print(rel[0, :, :6])
+    for w in (3, 7, 1, 5, 9):
+        print("tile wave %d: per panel k: [at B(k), B(k) passed, solve done, stores/dump issued, T(k) passed, update done]" % w)
+        print(rel[w, :, :6])
 print("LEAF16 CHECK", "OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
