@@ -226,7 +226,7 @@ class ExprLogLik(torch.autograd.Function):
         ctx.save_for_backward(X, R, noise, theta, *params)
         terms = f.lml_terms()
         f.refined = False
-        if n >= _ops.refine_min_n():
+        if n >= _ops.refine_min_n(expression=True):
             # the refinement step of the quadratic form, with the residual pass over the expression program
             lib = _native.lib()
             nz = nz0 if f.jitter_rung < 0 else nz0 + 10.0 ** (-_ops.JITTER_TRIES + f.jitter_rung)

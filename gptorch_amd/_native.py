@@ -26,6 +26,10 @@ SIGNATURES = {
     "gpn_pack_rhs": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64]),
     "gpn_potrf_lower": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "gpn_potrf_lower_panel": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "gpn_potrf_lower_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int]),
+    "gpn_lml_reduce_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int]),
+    "gpn_lml_forward_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "gpn_potrf_panel_width": (c_int64, [c_int64]),
     "gpn_release_stream": (c_int, [c_void_p]),
     "gpn_trtri_diag": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),

@@ -160,6 +160,61 @@ class Factor:
         return B
 
 
+class FactorBatch:
+    """`batch` factor buffers of one shape in ONE allocation (problem b at stride sA / sW), for
+    gpn_lml_forward_batched / gpn_potrf_lower_batched; factor(b) is a Factor VIEW of problem b (same memory),
+    usable with every single-model entry point afterwards (predict, backward ...)."""
+
+    def __init__(self, batch, n, e, device):
+        lib = _native.lib()
+        self.batch, self.n, self.e = int(batch), int(n), int(e)
+        self.ld = int(lib.gpn_factor_ld(n, e))
+        self.rows = int(lib.gpn_factor_rows(n, e))
+        self.sA = self.rows * self.ld
+        self.sW = max(2, int(lib.gpn_winv_bytes(n)) // 8)
+        self.A = zeros(self.batch * self.rows, self.ld, device)
+        self.winv = torch.empty(self.batch * self.sW, dtype=torch.float64, device=device)
+        self.info = torch.zeros(self.batch, dtype=torch.int32, device=device)
+        self.out = torch.empty(self.batch, 3, dtype=torch.float64, device=device)
+
+    def factor(self, b):
+        f = Factor.__new__(Factor)
+        f.n, f.e, f.ld, f.rows = self.n, self.e, self.ld, self.rows
+        f.A = self.A[b * self.rows:(b + 1) * self.rows]
+        f.winv = self.winv[b * self.sW:(b + 1) * self.sW]
+        f.info = self.info[b:b + 1]
+        f.jitter_rung = -1
+        f.generation = 0
+        f._winv_full = None
+        f._refine_work = None
+        f.refined = False
+        return f
+
+
+def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None):
+    """GPR.log_likelihood (gpr.py:47-67) of `batch` models in lock step (gpn_lml_forward_batched): X [n, d] shared or
+    [batch, n, d]; R = Y - m(X) [n, dy] shared or [batch, n, dy]; variance [batch], length_scales [batch, nls],
+    noise [batch].  -> (FactorBatch, terms [batch, 3]); NO host synchronisation: the caller reads fb.info and
+    replays the models whose info != 0 through the sequential path (jitter ladder)."""
+    _req(X, R, variance, length_scales, noise)
+    batch = int(variance.numel())
+    shared_x, shared_r = X.dim() == 2, R.dim() == 2
+    n, d = X.shape[-2], X.shape[-1]
+    e = R.shape[-1]
+    if R.shape[-2] != n:
+        raise ValueError("X and Y must have same # data.")
+    if fb is None or fb.batch != batch or fb.n != n or fb.e != e or fb.A.device != X.device:
+        fb = FactorBatch(batch, n, e, X.device)
+    Xc, Rc = _c(X.detach()), _c(R.detach())
+    var, ls, nz = _c(variance.detach().reshape(batch)), _c(length_scales.detach().reshape(batch, -1)), _c(noise.detach().reshape(batch))
+    st = _native.lib().gpn_lml_forward_batched(
+        _stream(X.device), KINDS[kind], batch, _ptr(Xc), 0 if shared_x else n * d, n, d, _ptr(Rc), 0 if shared_r else n * e,
+        None, 0, e, _ptr(var), _ptr(ls), ls.shape[1], _ptr(nz), _ptr(fb.A), fb.ld, fb.sA, _ptr(fb.winv), fb.sW,
+        _ptr(fb.info), _ptr(fb.out))
+    _native.check(st, "gpn_lml_forward_batched")
+    return fb, fb.out
+
+
 REFINE_MIN_N = 12288
 JITTER_TRIES = 10  # functions.py:21 max_tries
 
@@ -252,14 +307,20 @@ def kernel_factor(kind, X, variance, length_scales, noise, R=None, factor=None):
     return f
 
 
-def refine_min_n():
+def refine_min_n(expression=False):
     """from this many rows on, lml_forward follows the factorisation with one refinement step of the quadratic form
     (gpn_lml_refine).  The plain value's distance to the exact one grows like N^1.85 (5.8e-10 at N = 8192, 7.6e-9 at
     32768, measured) and north_star's tolerance is 1e-8 ABSOLUTE against a reference that is itself 3.4e-9 off at
     32768: below about 10^4 rows the step buys nothing, above it costs about 3 %.  GPN_REFINE_MIN_N overrides
-    (0 = never)."""
+    (0 = never).
+    expression=True: covariance expressions (Linear / Constant terms grow the top eigenvalue like N |x|^2, so the
+    quadratic form's sensitivity to the factor's rounding is an order of magnitude above a stationary kernel's: the
+    reference's example model at N = 8192 sits 2e-8 from its golden unrefined, whichever leaf kernel factors it) refine
+    from half that size on."""
     import os
     v = int(os.environ.get("GPN_REFINE_MIN_N", REFINE_MIN_N))
+    if expression and v > 0:
+        v = v // 2
     return v if v > 0 else 1 << 62
 
 

@@ -36,6 +36,7 @@ struct ColPanelArgs {
   double* C;            // [m, nb]
   int64_t lda, ldb, ldc;
   int m, nb;
+  int64_t sA, sB, sC;   // per-problem strides (elements) of a batch: blockIdx.y-th problem
 };
 
 // MODE 0: C = A B^T with B lower triangular (C may alias A: every row tile is read completely before it is written)
@@ -48,6 +49,9 @@ __global__ __launch_bounds__(256, 2) void colpanel_kernel(ColPanelArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * CP_ROWS;
   const int lr = lane & 15, lq = lane >> 4;
+  p.A += (int64_t)blockIdx.y * p.sA;
+  p.B += (int64_t)blockIdx.y * p.sB;
+  p.C += (int64_t)blockIdx.y * p.sC;
 
   // ---- A tile: all loads of the workgroup in flight at once
   d2 areg[8];
@@ -128,16 +132,18 @@ __global__ __launch_bounds__(256, 2) void colpanel_kernel(ColPanelArgs p) {
     }
 }
 
-// C[m, nb] = A[m, 128] B[nb, 128]^T (mode 0, B lower triangular, C may be A) or C -= A B^T (mode 1); nb <= 128;
+// C[m, nb] = A[m, 128] B[nb, 128]^T (mode 0, B lower triangular, C may be A) or C -= A B^T (mode 1); nb <= 128; `batch`
+// problems at constant strides in one launch;
 // operands 16-byte aligned with even leading dimensions, K padding (columns past the block's end) zero.
 int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B, int64_t ldb,
-             double* C, int64_t ldc) {
-  if (m <= 0 || nb <= 0) return GPN_OK;
+             double* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC) {
+  if (m <= 0 || nb <= 0 || batch <= 0) return GPN_OK;
   ColPanelArgs a;
   a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.m = (int)m; a.nb = (int)nb;
-  const dim3 grid((unsigned)((m + CP_ROWS - 1) / CP_ROWS));
+  a.sA = sA; a.sB = sB; a.sC = sC;
+  const dim3 grid((unsigned)((m + CP_ROWS - 1) / CP_ROWS), (unsigned)batch);
   int rec = -1;
-  if (profile_on()) rec = profile_begin(s, 2.0 * (double)m * (double)nb * CP_K * (mode == 0 ? 0.5 : 1.0), mode == 0 ? PROF_GEMM_SOLVE : PROF_GEMM);
+  if (profile_on()) rec = profile_begin(s, 2.0 * batch * (double)m * (double)nb * CP_K * (mode == 0 ? 0.5 : 1.0), mode == 0 ? PROF_GEMM_SOLVE : PROF_GEMM);
   if (mode == 0) hipLaunchKernelGGL(colpanel_kernel<0>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(colpanel_kernel<1>, grid, dim3(256), 0, s, a);
   if (rec >= 0) profile_end(s, rec);

@@ -552,6 +552,13 @@ int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha
   return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, 0, tri, 0, batch, sA, sB, sC);
 }
 
+int gemm_nt_strided(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+                    const double* A, int64_t lda, const double* B, int64_t ldb,
+                    double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
+                    int batch, int64_t sA, int64_t sB, int64_t sC) {
+  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, batch, sA, sB, sC);
+}
+
 int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,
                   const double* A, int64_t lda, const double* B, int64_t ldb,
                   double beta, double* C, int64_t ldc, int64_t step, int diag) {

@@ -38,7 +38,7 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
 // the in-panel chain's column passes (colpanel.hip): C[m, nb] = A[m, 128] B[nb, 128]^T with B lower triangular (mode 0; C may
 // be A) or C -= A B^T (mode 1); nb <= 128
 int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B, int64_t ldb,
-             double* C, int64_t ldc);
+             double* C, int64_t ldc, int batch = 1, int64_t sA = 0, int64_t sB = 0, int64_t sC = 0);
 
 // the 128 x 128 factor leaf, second generation (leaf16.hip): `batch` independent leaves in one launch, problem b at
 // A + b sA, winv + b sW, info + b sInfo
@@ -51,9 +51,20 @@ int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha
                     const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
                     double beta, double* C, int64_t ldc, int64_t sC, int tri, int batch);
 
+// gemm_nt for `batch` problems at constant strides, with the lower-tile forms (the batched factorisation's updates)
+int gemm_nt_strided(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+                    const double* A, int64_t lda, const double* B, int64_t ldb,
+                    double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
+                    int batch, int64_t sA, int64_t sB, int64_t sC);
+
 // extra rows <- (Y - M)^T, corner right of them <- 0, *info <- 0 (kmat.hip; used by gpn_lml_forward)
 int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
                   int32_t* info);
+
+// K(X_b) + noise_b I (lower tiles) + right-hand sides + info words of `batch` models (kmat.hip; gpn_lml_forward_batched)
+int assemble_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d, const double* Y, int64_t sY,
+                     const double* M, int64_t sM, int dy, const double* variance, const double* length_scales, int nls,
+                     const double* noise, double* A, int64_t lda, int64_t sA, int32_t* info);
 
 // launch classes of the optional HIP-event profiler (profile.hip; bench.py's roofline legs)
 enum { PROF_GEMM = 0,         // rectangular contraction (in-panel updates, predict, VFE ...)

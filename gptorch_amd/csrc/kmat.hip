@@ -31,6 +31,7 @@ struct KmatArgs {
   int64_t ldk;
   int n, m, d, nls;
   int symmetric, lower, vec_ok;
+  int64_t sX, sK;     // strided batch (gridDim.z problems): points and output at these strides, hyper-parameters consecutive
 };
 
 template <int KIND>
@@ -39,6 +40,12 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   __shared__ __attribute__((aligned(16))) double ys[DC][KT];   // column points
 
   __shared__ double inv_ell[DC];
+  if (gridDim.z > 1) {                       // problem z of a strided batch (gpn_lml_forward_batched)
+    const int z = blockIdx.z;
+    p.X += z * p.sX; p.X2 += z * p.sX; p.K += z * p.sK;
+    p.variance += z; p.ls += z * p.nls;
+    if (p.noise) p.noise += z;
+  }
   int tj, ti;
   if (p.lower) {
     // only the tiles on/below the diagonal are launched (row-major over the triangle): no
@@ -137,7 +144,13 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
 // accumulates -alpha alpha^T during the factorisation) and the info word -- one launch instead of
 // this one plus two fills in gpn_lml_forward
 __global__ void pack_rhs_kernel(const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
-                                int corner, int32_t* info) {
+                                int corner, int32_t* info, int64_t sY = 0, int64_t sM = 0, int64_t sE = 0) {
+  if (gridDim.y > 1) {                       // problem y of a strided batch
+    Y += blockIdx.y * sY;
+    if (M) M += blockIdx.y * sM;
+    E += blockIdx.y * sE;
+    if (info) info += blockIdx.y;
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (corner) {
     if (i == 0 && info) *info = 0;
@@ -155,6 +168,38 @@ __global__ void pack_rhs_kernel(const double* Y, const double* M, int64_t n, int
 int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
                   int32_t* info) {
   hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((lde + 255) / 256)), dim3(256), 0, s, Y, M, n, dy, E, lde, 1, info);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// symmetric K(X_b) + noise_b I, lower tiles, for `batch` models in one launch (+ their right-hand sides and info words)
+int assemble_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d, const double* Y, int64_t sY,
+                     const double* M, int64_t sM, int dy, const double* variance, const double* length_scales, int nls,
+                     const double* noise, double* A, int64_t lda, int64_t sA, int32_t* info) {
+  KmatArgs a;
+  a.X = X; a.X2 = X;
+  a.variance = variance; a.ls = length_scales; a.noise = noise;
+  a.K = A; a.ldk = lda;
+  a.n = (int)n; a.m = (int)n; a.d = d; a.nls = nls;
+  a.symmetric = 1; a.lower = 1;
+  a.vec_ok = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((sA & 1) == 0);
+  a.sX = sX; a.sK = sA;
+  const unsigned tm = (unsigned)((n + KT - 1) / KT);
+  const dim3 grid(tm * (tm + 1) / 2, 1, (unsigned)batch);
+  int rec = -1;
+  if (profile_on()) rec = profile_begin(s, batch * 8.0 * (0.5 * n * (n + 1.0) + (double)n * d), PROF_KMAT);
+  switch (kind) {
+    case GPN_RBF: hipLaunchKernelGGL(kmat_kernel<GPN_RBF>, grid, dim3(256), 0, s, a); break;
+    case GPN_MATERN52: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN52>, grid, dim3(256), 0, s, a); break;
+    case GPN_MATERN32: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN32>, grid, dim3(256), 0, s, a); break;
+    case GPN_EXP: hipLaunchKernelGGL(kmat_kernel<GPN_EXP>, grid, dim3(256), 0, s, a); break;
+    case GPN_PERIODIC: hipLaunchKernelGGL(kmat_kernel<GPN_PERIODIC>, grid, dim3(256), 0, s, a); break;
+    default: return -2;
+  }
+  if (rec >= 0) profile_end(s, rec);
+  GPN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((lda + 255) / 256), (unsigned)batch), dim3(256), 0, s, Y, M, n, dy,
+                     A + n * lda, lda, 1, info, sY, sM, sA);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
@@ -187,6 +232,7 @@ extern "C" int gpn_kernel_matrix(void* stream, int kind, const double* X, int64_
   a.n = (int)n; a.m = (int)m; a.d = d; a.nls = nls;
   a.symmetric = symmetric; a.lower = (uplo == GPN_LOWER);
   a.vec_ok = ((ldk & 1) == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0);
+  a.sX = 0; a.sK = 0;
   const unsigned tn = (unsigned)((m + KT - 1) / KT), tm = (unsigned)((n + KT - 1) / KT);
   dim3 grid = a.lower ? dim3(tm * (tm + 1) / 2) : dim3(tn, tm);
   hipStream_t s = static_cast<hipStream_t>(stream);

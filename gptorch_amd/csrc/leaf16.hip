@@ -35,6 +35,7 @@
 namespace gpn {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 // 12 waves: the hardware deals a workgroup's waves round-robin over the CU's 4 SIMDs, so waves {0,4,8} share one.  Wave 0 is
 // the PIVOT wave and waves 4 and 8 stay idle (barriers only): fp64 MFMAs and fp64 vector instructions of one SIMD share
@@ -42,6 +43,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // cycles per pivot (measured: tools/lat_bench.hip alone vs the s_memtime stamps of the 9-wave version).  The 8 tile rows
 // go to the other three SIMDs by cost: {0,7} | {1,3,5} | {2,4,6} (56 tile updates each).
 constexpr int L16_THREADS = 768;
+constexpr int TS = 18;                // row stride of the prologue's staging tiles (16-B aligned rows, conflict-free transposed reads)
 constexpr int RS = 18;                // row stride (doubles) of the row-major 16 x 16 blocks in LDS (144 B: 16-B aligned rows)
 
 struct Leaf16Args {
@@ -55,6 +57,12 @@ struct Leaf16Args {
 
 // DIAG build: a timeline -- diag[(wave * 8 + k) * 8 + ev] = s_memtime at event ev of block k, pinned behind the value `tie`
 // (the stamp waits for every outstanding LDS operation of the wave: it perturbs what it measures a little)
+#define L16_TU(k, j, tie)                                                                                    \
+  if constexpr (DIAG) {                                                                                      \
+    unsigned long long t_;                                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(tie) :: "memory");                  \
+    if (lane == 0) diag[768 + 18432 + (wave * 8 + (k)) * 8 + (j)] = t_;                                      \
+  }
 #define L16_TL(k, ev, tie)                                                                                   \
   if constexpr (DIAG) {                                                                                      \
     unsigned long long t_;                                                                                   \
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
   __shared__ double Wf[2][16 * RS];       // W_k, fragment-ready: Wf[RS * m + c] = W_k[c][m]
   __shared__ double Lrow[2][16 * RS];     // L_k, row-major
   __shared__ double Drow[32 * RS];        // rows 0..15: the pivot wave's next block (row-major); rows 16..31: identity
-  __shared__ double Tb[8][16 * 17];       // per tile wave: staging tile of the prologue's layout change
+  __shared__ __attribute__((aligned(16))) double Tb[8][16 * TS];   // per tile wave: staging tile of the prologue's layout change
   __shared__ double Lcol[64];              // the pivot wave's current column, for the broadcast reads
   __shared__ int tb_count;
   __shared__ int failflag;
@@ -111,45 +119,59 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
     d4 acc[9];
     L16_TL(1, 6, tie0)
     {
-      // One memory round trip, COALESCED: the tiles are fetched row-major (lane (g, lc) reads T[g + 4 r][lc]: 16
-      // consecutive lanes = 128 consecutive bytes) with every load issued before the first use, then turned into the
-      // transposed storage through a per-wave 16 x 17 LDS tile.  (Fetching the transposed storage directly puts
-      // consecutive lanes on different rows: 64 transactions per load instruction, 13-21 k cycles of prologue.)
-      // Columns right of the diagonal are read too (finite garbage of the caller's buffer) and discarded.
+      // One memory round trip, COALESCED and 16 bytes per lane: a tile is fetched row-major by two instructions (lane l:
+      // row (l >> 3) + 8 i, columns 2 (l & 7), + 1 -- 8 consecutive lanes = 128 consecutive bytes), only the tiles on and left
+      // of the diagonal, every load issued before the first use; then turned into the transposed storage through a per-wave
+      // 16 x 18 LDS tile.  (Fetching the transposed storage directly puts consecutive lanes on different rows: 64
+      // transactions per load instruction, 13-21 k cycles of prologue; the memory pipe takes 16 cycles per wave
+      // instruction whatever its width, so 8-byte loads of all 8 tile columns still cost 4 k cycles CU-wide.)
       double* tb = Tb[w];
-      double ld[8][4];
-      bool rok[4];
+      const int pr = lane & 7;
+      d2 ld[8][2];
+      bool rok[2];
+      int rl[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * w + g + 4 * r;
-        rok[r] = row < kb;
-        const double* rowp = A + (int64_t)(rok[r] ? row : 0) * lda + lc;
+      for (int i2 = 0; i2 < 2; ++i2) {
+        rl[i2] = (lane >> 3) + 8 * i2;
+        const int row = 16 * w + rl[i2];
+        rok[i2] = row < kb;
+        const double* rowp = A + (int64_t)(rok[i2] ? row : 0) * lda + 2 * pr;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ld[q][r] = rowp[16 * q];
+        for (int q = 0; q < 8; ++q) {
+          if (q <= w) ld[q][i2] = *reinterpret_cast<const d2*>(rowp + 16 * q);      // (uniform branch, no use inside)
+        }
       }
       L16_TL(2, 6, tie0)
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
         if (q < 8 && q < w) {                                         // A tile left of the diagonal (uniform branch)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tb[(g + 4 * r) * 17 + lc] = rok[r] ? ld[q < 8 ? q : 0][r] : 0.0;
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const d2 v = rok[i2] ? ld[q < 8 ? q : 0][i2] : d2{0.0, 0.0};
+            *reinterpret_cast<d2*>(&tb[rl[i2] * TS + 2 * pr]) = v;
+          }
           L16_WAVE_FENCE();
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[q][r] = tb[lc * 17 + g + 4 * r];
+          for (int r = 0; r < 4; ++r) acc[q][r] = tb[lc * TS + g + 4 * r];
           L16_WAVE_FENCE();
         } else if (q < 8 && q == w) {                                 // diagonal tile: symmetric fill from the lower triangle
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int a_ = g + 4 * r, b_ = lc;
-            if (b_ <= a_) {
-              const double v = rok[r] ? ld[q < 8 ? q : 0][r] : (a_ == b_ ? 1.0 : 0.0);     // identity beyond kb
-              tb[a_ * 17 + b_] = v;
-              tb[b_ * 17 + a_] = v;
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const d2 vv = ld[q < 8 ? q : 0][i2];
+            const int a_ = rl[i2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int b_ = 2 * pr + h;
+              if (b_ <= a_) {
+                const double v = rok[i2] ? vv[h] : (a_ == b_ ? 1.0 : 0.0);                   // identity beyond kb
+                tb[a_ * TS + b_] = v;
+                tb[b_ * TS + a_] = v;
+              }
             }
           }
           L16_WAVE_FENCE();
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[q][r] = tb[lc * 17 + g + 4 * r];
+          for (int r = 0; r < 4; ++r) acc[q][r] = tb[lc * TS + g + 4 * r];
           L16_WAVE_FENCE();
         } else {                                                      // identity tiles: (8 + w, w) = I, the others 0
 #pragma unroll
@@ -164,14 +186,6 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       for (int q = 0; q < 9; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dbg[((w * 9 + q) * 4 + r) * 64 + lane] = acc[q][r];
-    }
-    // the part of winv above the diagonal tiles is zero: W[16 k + ..][16 w + ..], k < w
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      if (k < w) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) winv[(int64_t)(16 * k + g + 4 * r) * LEAF + 16 * w + lc] = 0.0;
-      }
     }
     auto dump = [&](double* dst, const d4& t) {
 #pragma unroll
@@ -289,8 +303,10 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
             if (apart) {                                              // A tiles (w, j), j = k + 1 .. w
               if (j < w) {
                 update(acc[j], xa, nx);
+                L16_TU(k, j, acc[j])
               } else if (j == w) {
                 update(acc[j], x, nx);
+                L16_TU(k, j, acc[j])
               }
               // the raw tiles the pivot wave needs after its NEXT block: A(k+2, k+1) and D(k+2, k+2), from wave k + 2
               if (w == k + 2) {
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
               }
             } else {                                                  // identity tiles (8 + w, j), j = k + 1 .. 7
               update(acc[j + 1], xa, nx);
+              L16_TU(k, j, acc[j + 1])
             }
           }
         }
@@ -312,8 +329,20 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       }
     }
   } else if (!pivotwave) {
-    // idle waves (they share the pivot wave's SIMD): the barrier sequence only
+    // idle waves (they share the pivot wave's SIMD): the barrier sequence, and -- off everybody's critical path -- the zero
+    // fill of winv above the diagonal tiles (28 tiles W[16 k + ..][16 j + ..], k < j; 16 bytes per lane)
     __syncthreads();                                                  // P
+    {
+      const int me = (wave == 4) ? 0 : (wave == 8) ? 1 : 2;
+      int t = 0;
+      for (int k = 0; k < 7; ++k)
+        for (int j2 = k + 1; j2 < 8; ++j2, ++t) {
+          if (t % 3 != me) continue;
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2)
+            *reinterpret_cast<d2*>(&winv[(int64_t)(16 * k + (lane >> 3) + 8 * i2) * LEAF + 16 * j2 + 2 * (lane & 7)]) = d2{0.0, 0.0};
+        }
+    }
     for (int k = 0; k < 8; ++k) {
       __syncthreads();                                                // B(k)
       if (failflag) break;

@@ -71,6 +71,45 @@ extern "C" int gpn_lml_forward(void* stream, int kind, const double* X, int64_t 
   return gpn_lml_reduce(stream, A, n, dy, lda, out3);
 }
 
+// `batch` evaluations of GPR.log_likelihood in lock step (hyper-parameter restarts, one model per entry): the reference
+// can only evaluate them one after the other (gptorch/models/base.py:260-269).  Model b: points X + b sX (sX = 0: shared),
+// targets Y + b sY, mean values M + b sM (or NULL), hyper-parameters variance[b], length_scales[b nls ..], noise[b];
+// factor buffer A + b sA, leaf inverses winv + b sW, info[b], out3[3 b ..].  Every model's numbers are bit-identical to
+// gpn_lml_forward on that model alone.
+extern "C" int gpn_lml_forward_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
+                                       const double* Y, int64_t sY, const double* M, int64_t sM, int dy,
+                                       const double* variance, const double* length_scales, int nls, const double* noise,
+                                       double* A, int64_t lda, int64_t sA, double* winv, int64_t sW, int32_t* info, double* out3) {
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
+  if (batch < 1) return -3;
+  if (!X) return -4;
+  if (n < 0) return -6;
+  if (d <= 0) return -7;
+  if (!Y) return -8;
+  if (dy <= 0) return -12;
+  if (!variance) return -13;
+  if (!length_scales) return -14;
+  if (nls != 1 && nls != d) return -15;
+  if (!noise) return -16;
+  if (!A) return -17;
+  if (lda != gpn_factor_ld(n, dy)) return -18;
+  if (batch > 1 && (sA < gpn_factor_rows(n, dy) * lda || (sA & 1))) return -19;
+  if (!winv) return -20;
+  if (batch > 1 && sW < gpn_winv_bytes(n) / (int64_t)sizeof(double)) return -21;
+  if (!info) return -22;
+  if (!out3) return -23;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    GPN_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * batch, s));
+    return gpn_lml_reduce_batched(stream, A, n, dy, lda, sA, out3, batch);
+  }
+  int rc = assemble_batched(s, kind, batch, X, sX, n, d, Y, sY, M, sM, dy, variance, length_scales, nls, noise, A, lda, sA, info);
+  if (rc != GPN_OK) return rc;
+  rc = gpn_potrf_lower_batched(stream, A, n, dy, lda, sA, winv, sW, info, batch);
+  if (rc != GPN_OK) return rc;
+  return gpn_lml_reduce_batched(stream, A, n, dy, lda, sA, out3, batch);
+}
+
 extern "C" int64_t gpn_lml_backward_work_bytes(int64_t n, int dy, int nls) {
   if (n < 0 || dy <= 0 || nls <= 0) return 0;
   return backward_layout(n, dy, nls).total * (int64_t)sizeof(double);

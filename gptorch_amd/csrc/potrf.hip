@@ -529,7 +529,24 @@ struct Ctx {
   // corner = false (a tile column of a larger matrix, gpn_potrf_lower_panel): nothing right of column n is
   // touched -- the extra rows get a rectangular update of their own.
   bool corner = true;
+  // `batch` independent factorisations of identical shape in lock step (gpn_potrf_lower_batched): problem b lives at
+  // A + b sA, winv + b sW, info + b; every launch of the drivers below covers all of them
+  int batch = 1;
+  int64_t sA = 0, sW = 0;
 };
+
+// the drivers' contraction / column-pass launches, batched when the context is
+static inline int cgemm(const Ctx& c, hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0,
+                        int lds_pad_kb = 0) {
+  if (c.batch == 1) return gemm_nt(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, lds_pad_kb);
+  return gemm_nt_strided(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, c.batch, c.sA, c.sA, c.sA);
+}
+// mode 0: B = an inverted leaf block of winv; mode 1: everything inside the factor buffers
+static inline int ccolpanel(const Ctx& c, hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B,
+                            int64_t ldb, double* C, int64_t ldc) {
+  return colpanel(s, mode, m, nb, A, lda, B, ldb, C, ldc, c.batch, c.sA, mode == 0 ? c.sW : c.sA, c.sA);
+}
 
 // one factor leaf (or `batch` of them at constant strides) on stream s
 static int launch_leaf(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* W, int32_t* info, int batch = 1,
@@ -562,21 +579,22 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
   if (kb <= LEAF) {
     const double* W = winv + (diag0 / LEAF) * (LEAF * LEAF);
     // in place: one LEAF-wide column tile per row block (see file header)
-    if (g_chain_kernel & 1) c.rc = colpanel(c.s, 0, m, kb, B, ldb, W, LEAF, B, ldb);
-    else c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
+    if (g_chain_kernel & 1) c.rc = ccolpanel(c, c.s, 0, m, kb, B, ldb, W, LEAF, B, ldb);
+    else if (c.batch == 1) c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
+    else c.rc = gemm_nt_strided(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, GPN_TRI_B_LOWER, 1, c.batch, c.sA, c.sW, c.sA);
     return;
   }
   const int64_t h = split_point(kb);
   trsm_rec(c, B, m, ldb, L, ldl, h, diag0, winv);
   if (c.rc != GPN_OK) return;
-  c.rc = gemm_nt(c.s, m, kb - h, h, -1.0, B, ldb, L + h * ldl, ldl, 1.0, B + h, ldb, 0);
+  c.rc = cgemm(c, c.s, m, kb - h, h, -1.0, B, ldb, L + h * ldl, ldl, 1.0, B + h, ldb, 0);
   trsm_rec(c, B + h, m, ldb, L + h * ldl + h, ldl, kb - h, diag0 + h, winv);
 }
 
 static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   if (c.rc != GPN_OK || n <= 0) return;
   if (n <= LEAF) {
-    c.rc = launch_leaf(c.s, A, c.lda, (int)n, (int)col0, c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info);
+    c.rc = launch_leaf(c.s, A, c.lda, (int)n, (int)col0, c.winv + (col0 / LEAF) * (LEAF * LEAF), c.info, c.batch, c.sA, c.sW, 1);
     if (c.rc != GPN_OK) return;
     if (e > 0) trsm_rec(c, A + n * c.lda, e, c.lda, A, c.lda, n, col0, c.winv);
     return;
@@ -588,12 +606,12 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
   trsm_rec(c, A21, m, c.lda, A, c.lda, h, col0, c.winv);
   if (c.rc != GPN_OK) return;
   if (c.corner || e == 0) {
-    c.rc = gemm_nt(c.s, m, m, h, -1.0, A21, c.lda, A21, c.lda, 1.0, A21 + h, c.lda, 1);
+    c.rc = cgemm(c, c.s, m, m, h, -1.0, A21, c.lda, A21, c.lda, 1.0, A21 + h, c.lda, 1);
   } else {
     const int64_t ms = n - h;
-    c.rc = gemm_nt(c.s, ms, ms, h, -1.0, A21, c.lda, A21, c.lda, 1.0, A21 + h, c.lda, 1);
+    c.rc = cgemm(c, c.s, ms, ms, h, -1.0, A21, c.lda, A21, c.lda, 1.0, A21 + h, c.lda, 1);
     if (c.rc == GPN_OK)
-      c.rc = gemm_nt(c.s, e, ms, h, -1.0, A21 + ms * c.lda, c.lda, A21, c.lda, 1.0, A21 + ms * c.lda + h, c.lda, 0);
+      c.rc = cgemm(c, c.s, e, ms, h, -1.0, A21 + ms * c.lda, c.lda, A21, c.lda, 1.0, A21 + ms * c.lda + h, c.lda, 0);
   }
   potrf_rec(c, A21 + h, n - h, e, col0 + h);
 }
@@ -675,14 +693,15 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       const int64_t c1 = k0 + kb;                 // first row/column after this block
       double* Akk = A + k0 * lda + k0;
       const double* Wk = c.winv + (k0 / LEAF) * (LEAF * LEAF);
-      const int rec = profile_on() ? profile_begin(c.s, 2.0 * LEAF * LEAF * LEAF / 3.0, PROF_LEAF) : -1;
-      { const int lrc = launch_leaf(c.s, Akk, lda, (int)kb, (int)k0, const_cast<double*>(Wk), c.info); if (c.rc == GPN_OK) c.rc = lrc; }
+      const int rec = profile_on() ? profile_begin(c.s, c.batch * 2.0 * LEAF * LEAF * LEAF / 3.0, PROF_LEAF) : -1;
+      { const int lrc = launch_leaf(c.s, Akk, lda, (int)kb, (int)k0, const_cast<double*>(Wk), c.info, c.batch, c.sA, c.sW, 1); if (c.rc == GPN_OK) c.rc = lrc; }
       if (rec >= 0) profile_end(c.s, rec);
       const int64_t m = n + e - c1;                // rows below (incl. the extra rows)
       if (m <= 0 || c.rc != GPN_OK) continue;
       double* B = A + c1 * lda + k0;               // [m, kb] <- B W_k^T   (in place)
-      if (g_chain_kernel & 1) c.rc = colpanel(c.s, 0, m, kb, B, lda, Wk, LEAF, B, lda);
-      else c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
+      if (g_chain_kernel & 1) c.rc = ccolpanel(c, c.s, 0, m, kb, B, lda, Wk, LEAF, B, lda);
+      else if (c.batch == 1) c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
+      else c.rc = gemm_nt_strided(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, 1, c.batch, c.sA, c.sW, c.sA);
       if (c.rc != GPN_OK || c1 >= pend) continue;  // last block of the panel: nothing left inside it
       const int64_t nb1 = std::min<int64_t>(LEAF, pend - c1);
       const int64_t c2 = c1 + nb1;
@@ -696,8 +715,8 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       // update crowd this small launch out (16 us instead of 7); behind it they overlap with
       // the next leaf + solve instead.
       if (c.rc == GPN_OK) {
-        if ((g_chain_kernel & 2) && kb == LEAF) c.rc = colpanel(c.s, 1, m, nb1, B, lda, B, lda, A + c1 * lda + c1, lda);
-        else c.rc = gemm_nt(c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
+        if ((g_chain_kernel & 2) && kb == LEAF) c.rc = ccolpanel(c, c.s, 1, m, nb1, B, lda, B, lda, A + c1 * lda + c1, lda);
+        else c.rc = cgemm(c, c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
       }
       if (fork) hip_ok(hipEventRecord(ax->solve[step & 3], c.s));
       if (fork && c.rc == GPN_OK) {                // the rest of the panel on the aux stream
@@ -705,7 +724,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
         const int64_t m2 = n + e - c2;
         if (!left_looking) {
           // right-looking: all remaining columns of the panel by block k (K = LEAF)
-          c.rc = gemm_nt(ax->s1, m2, pend - c2, kb, -1.0, A + c2 * lda + k0, lda, A + c2 * lda + k0, lda, 1.0,
+          c.rc = cgemm(c, ax->s1, m2, pend - c2, kb, -1.0, A + c2 * lda + k0, lda, A + c2 * lda + k0, lda, 1.0,
                          A + c2 * lda + c2, lda, 0);
         } else {
           // left-looking: only the column block AFTER the next one, by every solved column of the
@@ -714,7 +733,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
           // updates of 250+ tile rows outlast the leaf (C3 200.6 -> 198.9 ms, C4 1473 -> 1463 ms);
           // costs 2 % at C2, where the long-K launches of one tile column are latency-bound
           const int64_t nb2 = std::min<int64_t>(LEAF, pend - c2);
-          c.rc = gemm_nt(ax->s1, m2, nb2, c1 - p0, -1.0, A + c2 * lda + p0, lda, A + c2 * lda + p0, lda, 1.0,
+          c.rc = cgemm(c, ax->s1, m2, nb2, c1 - p0, -1.0, A + c2 * lda + p0, lda, A + c2 * lda + p0, lda, 1.0,
                          A + c2 * lda + c2, lda, 0);
         }
         rest_idx = step & 3;
@@ -736,19 +755,19 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }   // it wrote these columns
       hip_ok(hipEventRecord(ax->chain_done, c.s));                                  // panel p is solved
       // strip: rows >= pend x the next panel's columns (lower-only inside its top square)
-      c.rc = gemm_nt(c.s, m, pw2, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
+      c.rc = cgemm(c, c.s, m, pw2, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
       if (c.rc != GPN_OK) break;
       hip_ok(hipStreamWaitEvent(ax->s2, ax->chain_done, 0));
       double* P2 = P + pw2 * lda;                  // rows >= pend + pw2 of the solved panel
       double* C2 = A + (pend + pw2) * lda + pend + pw2;
       const int64_t m2 = m - pw2;
       if (c.corner || e == 0) {
-        c.rc = gemm_nt(ax->s2, m2, m2, kp, -1.0, P2, lda, P2, lda, 1.0, C2, lda, 1, 0, 0, g_bulk_pad);
+        c.rc = cgemm(c, ax->s2, m2, m2, kp, -1.0, P2, lda, P2, lda, 1.0, C2, lda, 1, 0, 0, g_bulk_pad);
       } else {
         const int64_t ms = m2 - e;
-        c.rc = gemm_nt(ax->s2, ms, ms, kp, -1.0, P2, lda, P2, lda, 1.0, C2, lda, 1, 0, 0, g_bulk_pad);
+        c.rc = cgemm(c, ax->s2, ms, ms, kp, -1.0, P2, lda, P2, lda, 1.0, C2, lda, 1, 0, 0, g_bulk_pad);
         if (c.rc == GPN_OK)
-          c.rc = gemm_nt(ax->s2, e, ms, kp, -1.0, P2 + ms * lda, lda, P2, lda, 1.0, C2 + ms * lda, lda, 0, 0, 0, g_bulk_pad);
+          c.rc = cgemm(c, ax->s2, e, ms, kp, -1.0, P2 + ms * lda, lda, P2, lda, 1.0, C2 + ms * lda, lda, 0, 0, 0, g_bulk_pad);
       }
       hip_ok(hipEventRecord(ax->bulk_done, ax->s2));
       bulk_pending = true;
@@ -758,12 +777,12 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
     if (pend < n) {
       double* P = A + pend * lda + p0;             // [m, pw] solved panel below the diagonal square
       if (c.corner || e == 0) {
-        c.rc = gemm_nt(c.s, m, m, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+        c.rc = cgemm(c, c.s, m, m, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
       } else {
         const int64_t ms = n - pend;               // matrix rows / columns left; the e extra rows: rectangular
-        c.rc = gemm_nt(c.s, ms, ms, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+        c.rc = cgemm(c, c.s, ms, ms, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
         if (c.rc == GPN_OK)
-          c.rc = gemm_nt(c.s, e, ms, round_up(pw, 16), -1.0, P + ms * lda, lda, P, lda, 1.0, A + n * lda + pend, lda, 0);
+          c.rc = cgemm(c, c.s, e, ms, round_up(pw, 16), -1.0, P + ms * lda, lda, P, lda, 1.0, A + n * lda + pend, lda, 0);
       }
     }
   }
@@ -802,7 +821,9 @@ static void trtri_rec(Ctx& c, const double* L, int64_t ldl, double* U, int64_t l
 
 // ---- reductions / utilities -------------------------------------------------
 __global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* A, int64_t n, int64_t e, int64_t lda,
-                                                          double* out3) {
+                                                          double* out3, int64_t sA) {
+  A += (int64_t)blockIdx.x * sA;                 // `gridDim.x` problems at stride sA, results 3 apart
+  out3 += 3 * blockIdx.x;
   // single workgroup: sums are O(N) work.  The diagonal is one cache line per element, so the
   // loads go out in batches of 8 per thread before the first log() needs one (issued one by
   // one behind a log() each they cost a full memory round trip per element: 30 us at N = 8192)
@@ -1173,7 +1194,46 @@ extern "C" int gpn_lml_reduce(void* stream, const double* A, int64_t n, int64_t 
   if (e < 0) return -4;
   if (lda < n) return -5;
   if (!out3) return -6;
-  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), A, n, e, lda, out3);
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), A, n, e, lda, out3, (int64_t)0);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// ---- `batch` factorisations in lock step -----------------------------------------------------------------------------
+// The reference evaluates one model per optimiser step (gptorch/models/base.py:260-269); a hyper-parameter search runs
+// many independent models of one shape.  Below N ~ 10^4 one factorisation cannot fill the chip -- its chain of N / 128
+// leaf steps runs on ONE compute unit for a third of the time -- so B of them share every launch: the leaf runs as a grid
+// of B workgroups, the column passes and every contraction as one strided-batch launch.  Same drivers, same kernels,
+// same per-entry summation order as gpn_potrf_lower: every factor is bit-identical to its sequential factorisation.
+extern "C" int gpn_potrf_lower_batched(void* stream, double* A, int64_t n, int64_t e, int64_t lda, int64_t sA,
+                                       double* winv, int64_t sW, int32_t* info, int batch) {
+  if (!A) return -2;
+  if (n < 0) return -3;
+  if (e < 0) return -4;
+  if (lda < round_up(n + e, LEAF) || (lda % LEAF) != 0) return -5;
+  if (batch < 1) return -10;
+  if (batch > 1 && (sA < gpn_factor_rows(n, e) * lda || (sA & 1))) return -6;
+  if (!winv) return -7;
+  if (batch > 1 && sW < gpn_winv_bytes(n) / (int64_t)sizeof(double)) return -8;
+  if (!info) return -9;
+  if (reinterpret_cast<uintptr_t>(A) & 15) return GPN_E_ALIGN;
+  if (n == 0) return GPN_OK;
+  Ctx c{static_cast<hipStream_t>(stream), lda, winv, info, GPN_OK};
+  c.batch = batch; c.sA = sA; c.sW = sW;
+  if (g_potrf_variant == 1 || n <= 2 * LEAF) potrf_rec(c, A, n, e, 0);
+  else potrf_lookahead(c, A, n, e);
+  return c.rc;
+}
+
+extern "C" int gpn_lml_reduce_batched(void* stream, const double* A, int64_t n, int64_t e, int64_t lda, int64_t sA, double* out3,
+                                      int batch) {
+  if (!A) return -2;
+  if (n < 0) return -3;
+  if (e < 0) return -4;
+  if (lda < n) return -5;
+  if (!out3) return -7;
+  if (batch < 1) return -8;
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3((unsigned)batch), dim3(1024), 0, static_cast<hipStream_t>(stream), A, n, e, lda, out3, sA);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

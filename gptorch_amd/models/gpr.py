@@ -9,7 +9,7 @@ the inputs changed (the reference re-factorises on every call, gpr.py:104).
 """
 import torch
 
-from .. import _ops
+from .. import _ops, mean_functions
 from .. import kernels
 from .base import GPModel
 
@@ -120,32 +120,89 @@ class GPR(GPModel):
         return mean_f, var_f
 
 
-_LANES = {}          # device -> two HIP streams shared by every batched call
+_LANES = {}          # device -> two HIP streams shared by every batched call (streams= placement only)
+_BATCH_BUFFERS = {}  # (device, batch, n, dy) -> _ops.FactorBatch reused by batched_log_likelihood
+
+
+def _stacked_values(params):
+    """constrained values of same-shaped Params as one [B, ...] tensor: one stack + ONE transform when they share it."""
+    t0 = params[0]._transform
+    if all(p._transform == t0 for p in params):
+        return t0(torch.stack([p.data for p in params]))
+    return torch.stack([p.transform() for p in params])
+
+
+def _lockstep_groups(models):
+    """indices of the models that can share one gpn_lml_forward_batched call, grouped by (kernel kind, n, d, dy, ARD, device):
+    stationary kernels below the size from which log_likelihood() refines the quadratic form."""
+    groups = {}
+    for i, m in enumerate(models):
+        k = m._stationary()
+        if k is None or m.X.shape[0] >= _ops.refine_min_n() or not m.X.is_cuda:
+            continue
+        key = (k._kind, tuple(m.X.shape), m.Y.shape[1], int(k.length_scales.numel()), m.X.device)
+        groups.setdefault(key, []).append(i)
+    return [g for g in groups.values() if len(g) >= 2]
 
 
 def batched_log_likelihood(models, streams=None):
-    """log_likelihood() of several INDEPENDENT GPR models (multi-start hyper-parameter
-    search: one model per restart) without a host round trip per model: every factorisation is
-    enqueued and the `info` words are read once at the end.  No gradients; returns a list of
-    (1,) tensors.  Any model whose factorisation reports info != 0 is re-evaluated through the
-    sequential path (jitter ladder of functions.py:20-43).
+    """log_likelihood() of several INDEPENDENT GPR models (multi-start hyper-parameter search: one model per restart; the
+    reference evaluates them one per optimiser step, gptorch/models/base.py:260-269).  No gradients; returns a list of
+    (1,) tensors, each BIT-IDENTICAL to that model's own log_likelihood().
 
-    streams=None (default): the models alternate between TWO internal HIP streams.  One
-    factorisation already overlaps its latency-bound chain with its own updates (look-ahead
-    driver), and two of them in flight fill what is left (180 vs 138 evals/s at N = 8192); more
-    concurrent streams than that lose again -- the runtime multiplexes streams onto 4 hardware
-    queues, and each factorisation uses an internal stream of its own.  A list of HIP streams
-    (one per model) overrides the placement; the current stream itself gives back-to-back
-    execution."""
+    streams=None (default): models of one shape (kernel kind, N, D, dy) run in LOCK STEP through ONE
+    gpn_lml_forward_batched call -- one assembly launch, the 128x128 leaf as a grid of B workgroups, every column pass and
+    contraction as a strided-batch launch -- and the `info` words are read once at the end; a model whose factorisation
+    reports info != 0 is re-evaluated through the sequential path (jitter ladder of functions.py:20-43).  Dense-K /
+    composite kernels, singletons and sizes at which log_likelihood() refines the quadratic form take the sequential path.
+
+    streams = a list of HIP streams (one per model): the round-3 placement instead -- whole evaluations alternating
+    over the given streams (the current stream itself gives back-to-back execution)."""
+    if streams is not None:
+        return _batched_on_streams(models, streams)
+    out = [None] * len(models)
+    with torch.no_grad():
+        pending = []
+        for g in _lockstep_groups(models):
+            ms = [models[i] for i in g]
+            m0 = ms[0]
+            k0 = m0._stationary()
+            dev = m0.X.device
+            # host side: a handful of launches per GROUP, none per model (a per-model exp / subtraction / comparison costs
+            # more than the model's share of the batch at N = 512)
+            same_x = all(m.X.data_ptr() == m0.X.data_ptr() for m in ms)
+            zero_mean = all(type(m.mean_function) is mean_functions.Zero for m in ms)
+            same_r = same_x and zero_mean and all(m.Y.data_ptr() == m0.Y.data_ptr() for m in ms)
+            X = m0.X if same_x else torch.stack([m.X for m in ms])
+            if same_r:
+                R = m0.Y
+            elif zero_mean:
+                R = torch.stack([m.Y for m in ms])
+            else:
+                R = torch.stack([m.Y - m.mean_function(m.X) for m in ms])
+            var = _stacked_values([m._stationary().variance for m in ms]).reshape(len(ms))
+            ls = _stacked_values([m._stationary().length_scales for m in ms]).reshape(len(ms), -1)
+            nz = _stacked_values([m.likelihood.variance for m in ms]).reshape(len(ms))
+            key = (dev, len(ms), m0.X.shape[0], m0.Y.shape[1])
+            fb, terms = _ops.lml_forward_batched(k0._kind, X, R, var, ls, nz, fb=_BATCH_BUFFERS.get(key))
+            _BATCH_BUFFERS[key] = fb
+            pending.append((g, fb, terms))
+        for g, fb, terms in pending:
+            info = fb.info.cpu()                   # one read-back per group (synchronises the stream)
+            for b, i in enumerate(g):
+                if int(info[b]) == 0:
+                    out[i] = terms[b, 2:3].clone()
+                    # (the per-model factor cache is NOT pointed at the shared buffer: the next batched call overwrites it)
+        for i, m in enumerate(models):
+            if out[i] is None:
+                out[i] = m.log_likelihood()
+    return out
+
+
+def _batched_on_streams(models, streams):
+    """whole evaluations placed on the caller's streams (see batched_log_likelihood)."""
     dev = models[0].X.device
     cur = torch.cuda.current_stream(dev)
-    if streams is None:
-        if len(models) < 2:
-            streams = [cur] * len(models)
-        else:
-            if dev not in _LANES:
-                _LANES[dev] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-            streams = [_LANES[dev][i % 2] for i in range(len(models))]
     side = any(st is not cur for st in streams)
     if side:
         # host-side fork/join: event waits between a created stream and the legacy default stream
@@ -176,3 +233,11 @@ def batched_log_likelihood(models, streams=None):
                     ok = int(p[0].info.item()) == 0        # synchronises that model's stream
             out.append(p[1][2:3] if ok else m.log_likelihood())
     return out
+
+
+def two_lane_streams(models):
+    """the round-3 default placement of batched_log_likelihood(streams=...): the models alternate between two internal streams."""
+    dev = models[0].X.device
+    if dev not in _LANES:
+        _LANES[dev] = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    return [_LANES[dev][i % 2] for i in range(len(models))]

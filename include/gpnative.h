@@ -105,6 +105,19 @@ int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
 int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
                           double* winv, int32_t* info);
 
+/* `batch` factorisations of identical shape in LOCK STEP: problem b at A + b*sA (a factor buffer each: sA >=
+ * gpn_factor_rows(n,e)*lda, even), winv + b*sW (sW >= gpn_winv_bytes(n)/8), info[b].  Same drivers and kernels as
+ * gpn_potrf_lower with every launch covering all problems -- the 128x128 leaf as a grid of `batch` workgroups, the
+ * column passes and contractions as strided-batch launches -- and the same summation order per entry: factor b is
+ * BIT-IDENTICAL to gpn_potrf_lower on problem b alone.  Replaces `batch` sequential torch.cholesky calls
+ * (functions.py:46-47) of models evaluated one per optimiser step (gptorch/models/base.py:260-269): below
+ * N ~ 10^4 one factorisation leaves most of the chip idle during its N/128 leaf steps. */
+int gpn_potrf_lower_batched(void* stream, double* A, int64_t n, int64_t e, int64_t lda, int64_t sA,
+                            double* winv, int64_t sW, int32_t* info, int batch);
+/* gpn_lml_reduce for `batch` factor buffers at stride sA: out3[3*b .. 3*b+2]. */
+int gpn_lml_reduce_batched(void* stream, const double* A, int64_t n, int64_t e, int64_t lda, int64_t sA,
+                           double* out3, int batch);
+
 /* Panel width the driver uses for an n x n factorisation (0 = the recursive driver): each panel ends
  * with one lower-tile K = width contraction -- the SYRK trailing update priced by bench.py. */
 int64_t gpn_potrf_panel_width(int64_t n);
@@ -266,6 +279,18 @@ int gpn_lml_forward(void* stream, int kind, const double* X, int64_t n, int d,
                     const double* variance, const double* length_scales, int nls,
                     const double* noise, double* A, int64_t lda, double* winv,
                     int32_t* info, double* out3);
+
+/* gpn_lml_forward for `batch` models of one shape (n, d, dy, nls) in lock step -- hyper-parameter restarts: the reference
+ * evaluates one model per optimiser step (gptorch/models/base.py:260-269).  Model b: points X + b*sX (sX = 0: shared),
+ * targets Y + b*sY (sY = 0: shared), mean values M + b*sM (M may be NULL), variance[b], length_scales[b*nls ..],
+ * noise[b]; factor buffer A + b*sA, leaf inverses winv + b*sW (see gpn_potrf_lower_batched), info[b], out3[3*b ..].
+ * One assembly launch, one right-hand-side launch, the batched factorisation, one reduction launch; every model's
+ * out3 / factor / info is bit-identical to gpn_lml_forward on that model alone.  info[b] > 0: replay THAT model through
+ * gpn_lml_forward with noise + 10^(-10+i) (functions.py:20-43). */
+int gpn_lml_forward_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
+                            const double* Y, int64_t sY, const double* M, int64_t sM, int dy,
+                            const double* variance, const double* length_scales, int nls, const double* noise,
+                            double* A, int64_t lda, int64_t sA, double* winv, int64_t sW, int32_t* info, double* out3);
 
 /* gpn_lml_refine: one step of iterative refinement of the quadratic form of gpr.py:61-67, to be called after a
  * gpn_lml_forward that returned info == 0 (same arguments; A / winv read only).  The factor satisfies

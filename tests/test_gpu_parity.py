@@ -1390,11 +1390,79 @@ def test_batched_restarts_match_sequential(device):
         m.cuda()
         ms.append(m)
     seq = [m.log_likelihood().item() for m in ms]
-    bat = [t.item() for t in batched_log_likelihood(ms)]
+    bat = [t.item() for t in batched_log_likelihood(ms)]          # lock step: one gpn_lml_forward_batched call
     assert seq == bat
     streams = [torch.cuda.Stream(device=device) for _ in ms]
     par = [t.item() for t in batched_log_likelihood(ms, streams)]
     assert seq == par
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,dy,batch,kind,ard,shared", [
+    (1500, 5, 1, 5, "Matern52", True, True),       # look-ahead driver, ragged last block, restarts over shared data
+    (1024, 8, 2, 3, "Rbf", False, False),          # each model its own data, two output columns
+    (200, 2, 1, 7, "Rbf", False, True),            # recursive driver (n <= 256)
+    (128, 3, 1, 4, "Matern32", False, False),      # one leaf
+    (2176, 4, 1, 2, "Rbf", False, True),           # two 1536-column panels: trailing SYRK as a strided-batch lower launch
+])
+def test_lockstep_batch_is_bit_identical_to_sequential(device, n, d, dy, batch, kind, ard, shared):
+    """gpn_lml_forward_batched (leaf grid = B, column passes and contractions as strided-batch launches): every model's
+    three terms, its factor, its alpha rows and its leaf inverses are BIT-IDENTICAL to gpn_lml_forward on that model alone
+    (gptorch/models/base.py:260-269 evaluates one model per step; functions.py:46-47)."""
+    from gptorch_amd import _ops
+    g = torch.Generator().manual_seed(n + batch)
+    xs, ys = [], []
+    for b in range(batch):
+        x, y = rng.make_regression(n, d, dy, seed=3 if shared else 3 + b)
+        xs.append(torch.as_tensor(x).to(device))
+        ys.append(torch.as_tensor(y).to(device))
+    var = (0.5 + torch.rand(batch, generator=g, dtype=torch.float64)).to(device)
+    ls = (0.7 + torch.rand(batch, d if ard else 1, generator=g, dtype=torch.float64)).to(device) * float(np.sqrt(d))
+    nz = (0.01 + 0.05 * torch.rand(batch, generator=g, dtype=torch.float64)).to(device)
+    X = xs[0] if shared else torch.stack(xs)
+    R = ys[0] if shared else torch.stack(ys)
+    fb, terms = _ops.lml_forward_batched(kind, X, R, var, ls, nz)
+    info = fb.info.cpu()
+    assert int(info.abs().max()) == 0
+    for b in range(batch):
+        f, t = _ops.lml_forward(kind, xs[b], ys[b], var[b:b + 1], ls[b], nz[b:b + 1], refine=False)
+        assert torch.equal(t, terms[b]), (b, t, terms[b])
+        fbv = fb.factor(b)
+        assert torch.equal(torch.tril(f.A[:n, :n]), torch.tril(fbv.A[:n, :n])), b
+        assert torch.equal(f.A[n:n + dy, :n], fbv.A[n:n + dy, :n]), b
+        assert torch.equal(f.winv, fbv.winv), b
+
+
+@pytest.mark.gpu
+def test_lockstep_batch_replays_the_ladder_per_failing_model(device):
+    """one model of the batch is singular at its own noise level (duplicated points, noise 0): its info word is set, the
+    others are untouched by it, and batched_log_likelihood replays THAT model through the jitter ladder of functions.py:20-43
+    -- same value as its sequential log_likelihood()."""
+    from gptorch_amd.models import batched_log_likelihood
+    from gptorch_amd import _ops
+    n, d = 600, 2
+    x, y = rng.make_regression(n, d, 1, seed=21)
+    xdup = np.array(x)
+    xdup[300:] = xdup[:300]                          # rank-deficient K
+    ms = []
+    for b in range(4):
+        xb = xdup if b == 2 else x
+        m = GPR(xb, y, kernels.Rbf(d, variance=1.0 + 0.1 * b, length_scales=1.3), likelihood=likelihoods.Gaussian(variance=0.03))
+        m.cuda()
+        if b == 2:
+            m.likelihood.variance.data.fill_(-80.0)   # exp(-80): numerically zero noise
+        ms.append(m)
+    seq = [m.log_likelihood().item() for m in ms]
+    assert ms[2]._holder["factor"].jitter_rung >= 0   # the sequential path needed the ladder
+    bat = [t.item() for t in batched_log_likelihood(ms)]
+    assert seq == bat
+    # and the raw batched call flags exactly that model
+    var = torch.stack([m.kernel.variance.transform().reshape(()) for m in ms])
+    ls = torch.stack([m.kernel.length_scales.transform().reshape(-1) for m in ms])
+    nz = torch.stack([m.likelihood.variance.transform().reshape(()) for m in ms])
+    fb, terms = _ops.lml_forward_batched("Rbf", torch.stack([m.X for m in ms]), torch.stack([m.Y for m in ms]), var, ls, nz)
+    info = fb.info.cpu().tolist()
+    assert info[2] > 0 and info[0] == info[1] == info[3] == 0, info
 
 
 def test_c3_full_size_lml_golden(device):

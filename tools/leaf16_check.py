@@ -100,7 +100,7 @@ with _native.debug_library() as lib:
     # timeline (DIAG build): diag[wave][k][ev]
     m = spd(128, 1e3)
     f = _ops.Factor(128, 0, dev)
-    diag = torch.zeros(12 * 8 * 8 + 8 * 9 * 4 * 64, dtype=torch.int64, device=dev)
+    diag = torch.zeros(12 * 8 * 8 + 8 * 9 * 4 * 64 + 12 * 8 * 8, dtype=torch.int64, device=dev)
     for it in range(3):
         f.A[:128, :128] = m
         f.info.zero_()
@@ -108,7 +108,8 @@ with _native.debug_library() as lib:
         torch.cuda.synchronize()
         lib.gpn_debug_leaf16_timing(_stream(dev), _ptr(f.A), f.ld, _ptr(f.winv), _ptr(f.info), _ptr(diag))
         torch.cuda.synchronize()
-    tiles = diag[768:].view(torch.float64).cpu().numpy().reshape(8, 9, 4, 64)
+    tu = diag[768 + 18432:].cpu().numpy().reshape(12, 8, 8)
+    tiles = diag[768:768 + 18432].view(torch.float64).cpu().numpy().reshape(8, 9, 4, 64)
     mm = m.cpu().numpy()
     nbad = 0
     for w_ in range(8):
@@ -142,6 +143,10 @@ with _native.debug_library() as lib:
     print("end of work per wave (cycles):", [int(rel[w, 0, 7]) for w in range(12)])
     print("pivot wave (0): per block k: [top, pivots done, published, B(k) passed, catch-up MFMAs done, next block in registers]")
     print(rel[0, :, :6])
+    print("update phase of panel 0 and 1, time each tile update (j = 1..7) completed, per wave (relative to T(k) passed):")
+    for w in (3, 7, 1, 5, 9, 2, 6, 10):
+        for k_ in (0, 1):
+            print("  wave %2d k %d:" % (w, k_), [int(tu[w, k_, j] - d[w, k_, 4]) if tu[w, k_, j] > 0 else -1 for j in range(1, 8)], " T(k) passed at", int(rel[w, k_, 4]))
     for w in (3, 7, 1, 5, 9):
         print("tile wave %d: per panel k: [at B(k), B(k) passed, solve done, stores/dump issued, T(k) passed, update done]" % w)
         print(rel[w, :, :6])
