@@ -92,6 +92,17 @@ def algorithmic_syrk_flops(n, dy, pw):
     return total
 
 
+def golden_source(w):
+    """who computed the golden LML of this workload: "reference" (the imported gptorch, tests/golden/make_golden.py) or
+    "cpu_oracle" (oracle/ at full size on a GPU box's host, where the reference does not fit: C4)."""
+    g = w.get("golden")
+    return None if not g else ("cpu_oracle" if "cpu_oracle" in g[0] else "reference")
+
+
+def golden_err_key(w):
+    return "lml_abs_err_vs_%s_golden" % golden_source(w)
+
+
 def golden_lml(w):
     """the reference's LML for this workload from the committed fixtures (tests/golden/, generated
     by importing the reference: tests/golden/make_golden.py), or None.  C4 (N = 65536) does not fit the container the
@@ -356,7 +367,10 @@ def backward_leg(lib, model, w, steps):
             "bound": "mfma", "kernel": "gemm_nt_kernel, K-clipped launches (U = L^-T by level-parallel inversion, Kyy^-1 = U U^T)",
             "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
             "algorithmic_flops_per_step": 2.0 * n ** 3 / 3.0, "kernel_ms_per_step": tri_ms,
-            "launches_per_step": cls[P_TRI][0] / steps, "executed_tflops": cls[P_TRI][2] / steps / (tri_ms * 1e-3) / 1e12}
+            "launches_per_step": cls[P_TRI][0] / steps,
+            # tiles launched x 2 BM BN K with the UNCLIPPED K: these launches skip the zero half of their triangular operands, so
+            # this is an upper bound on what ran (it can exceed the peak), not an executed rate -- `achieved` is the figure
+            "launched_tile_tflops_unclipped_k": cls[P_TRI][2] / steps / (tri_ms * 1e-3) / 1e12}
     if cls[P_GRAD][0]:
         gms, gb = cls[P_GRAD][1], cls[P_GRAD][2]
         gbs = gb / (gms * 1e-3) / 1e9
@@ -430,7 +444,8 @@ def run_single(args, device):
                            "cholesky_frac_of_fp64_peak": (ww["n"] ** 3 / 3.0) / t / 1e12 / PEAK_FP64_MFMA_TFLOPS}
                     gl = golden_lml(ww)
                     if gl is not None:
-                        res["lml_abs_err_vs_reference_golden"] = abs(res["lml"] - gl)
+                        res[golden_err_key(ww)] = abs(res["lml"] - gl)
+                        res["lml_golden_provenance"] = golden_source(ww)
                     r2 = rooflines(lib, ww, steps, st)
                     if "roofline_syrk" in r2:
                         r2["roofline_all_contractions"], r2["roofline"] = r2["roofline"], dict(r2["roofline_syrk"])
@@ -439,12 +454,13 @@ def run_single(args, device):
                             res[k2] = r2[k2]
                 if with_backward:
                     res["loss_backward"] = backward_leg(lib, m, ww, max(2, steps // 4) if ww["n"] <= 8192 else 2)
-                if key == "c2":
-                    # configs[1] reads "kernel build + Cholesky + predict": GPR.predict_f at 1024 test points
-                    # (gpr.py:88-117) -- with the factor cached between calls, and re-factorising every call as
-                    # the reference does (gpr.py:104)
+                if key in ("c2", "c3"):
+                    # configs[1] reads "kernel build + Cholesky + predict": GPR._predict at 1024 test points (gpr.py:88-117) with
+                    # the factor cached between calls (steady state: the right-solve through the inverted 1024 x 1024 diagonal
+                    # blocks), and re-factorising every call as the reference does (gpr.py:104)
                     from gptorch_amd import rng
-                    xs = torch.tensor(rng.normal(7, (1024, ww["d"])), device=device)
+                    ns_ = 1024
+                    xs = torch.tensor(rng.normal(7, (ns_, ww["d"])), device=device)
 
                     def pred():
                         with torch.no_grad():
@@ -453,10 +469,19 @@ def run_single(args, device):
                     def pred_refactor():
                         m._predict_cache = None
                         return pred()
-                    tp, _ = timed(pred, 10, 3)
-                    tr, _ = timed(pred_refactor, 5, 1)
-                    res["predict"] = {"config": "C2: GPR._predict at 1024 test points, diag variance", "ms_cached_factor": tp * 1e3,
-                                      "ms_with_refactorisation": tr * 1e3}
+                    tp, _ = timed(pred, 10, 4)
+                    nn = float(ww["n"])
+                    pflops = nn * nn * ns_                       # the TRSM of predict, N^2 N*
+                    res["predict"] = {"config": "%s: GPR._predict at %d test points, diag variance" % (ww["name"][:2], ns_), "ms_cached_factor": tp * 1e3}
+                    res["roofline_predict"] = {
+                        "bound": "mfma", "kernel": "gemm_nt_kernel launches of gpn_predict_blocked (X_k = B_k W_k^T, B_rest -= X_k L^T; "
+                                                   "N / 1024 steps), whole call timed with the factor and its block inverses cached",
+                        "achieved": pflops / tp / 1e12, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": pflops / tp / 1e12 / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "algorithmic_flops_per_call": pflops,
+                        "hbm_bytes_K_star_write": 8.0 * nn * ns_, "ms_per_call": tp * 1e3}
+                    if key == "c2":
+                        tr, _ = timed(pred_refactor, 5, 1)
+                        res["predict"]["ms_with_refactorisation"] = tr * 1e3
                 return res
             return run
 
@@ -492,14 +517,42 @@ def run_single(args, device):
 
             def restarts():
                 from gptorch_amd.models import batched_log_likelihood
+                from gptorch_amd.models.gpr import two_lane_streams
                 R = 4
                 models = [build_model(WORKLOADS["c2"], seed=100 + r, device=device)[0] for r in range(R)]
                 res = {}
-                for label, streams in (("two_lanes", None), ("back_to_back", [torch.cuda.current_stream(device)] * R)):
+                for label, streams in (("two_lanes", two_lane_streams(models)), ("back_to_back", [torch.cuda.current_stream(device)] * R)):
                     t, _ = timed(lambda: batched_log_likelihood(models, streams), 5, 2)
                     res[label] = R / t
-                return {"config": "C2 x %d independent restarts alternating between two HIP streams (batched_log_likelihood)" % R,
+                return {"config": "C2 x %d independent restarts as WHOLE evaluations alternating between two HIP streams (round 3's placement; "
+                                  "c2_batched is the lock-step form)" % R,
                         "evals_per_s": res["two_lanes"], "evals_per_s_back_to_back": res["back_to_back"]}
+
+            def lockstep(key, B):
+                # hyper-parameter restarts in LOCK STEP (gpn_lml_forward_batched: leaf grid = B, strided-batch column passes and
+                # contractions): B models of one shape over shared data, each value bit-identical to its own log_likelihood()
+                def run():
+                    from gptorch_amd.models import batched_log_likelihood
+                    ww = WORKLOADS[key]
+                    models = []
+                    for b in range(B):
+                        mb = build_model(dict(ww, variance=ww["variance"] * (1.0 + 0.01 * b), length_scales=ww["length_scales"] * (1.0 + 0.02 * b)),
+                                         0, device)[0]
+                        if models:
+                            mb.X, mb.Y = models[0].X, models[0].Y
+                        models.append(mb)
+                    with torch.no_grad():
+                        t, out = timed(lambda: batched_log_likelihood(models), 5, 2)
+                        t1, _ = timed(lambda: [m.log_likelihood() for m in models], 2, 1)
+                        same = [o.item() for o in out] == [m.log_likelihood().item() for m in models]
+                    n = ww["n"]
+                    return {"config": "%s x %d restarts in lock step (batched_log_likelihood -> gpn_lml_forward_batched)" % (ww["name"], B),
+                            "batch": B, "evals_per_s": B / t, "ms_per_batch": t * 1e3, "evals_per_s_one_after_the_other": B / t1,
+                            "bit_identical_to_sequential": bool(same),
+                            "cholesky_frac_of_fp64_peak": B * (n ** 3 / 3.0) / t / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+                return run
+            leg("c2_batched", lockstep("c2", 8))
+            leg("c1_batched", lockstep("c1", 64))
             leg("c2_concurrent_restarts", restarts)
             held.clear()
             torch.cuda.empty_cache()
@@ -542,8 +595,9 @@ def run_single(args, device):
     }
     gl = golden_lml(w)
     if gl is not None:
-        line["lml_reference_golden"] = gl
-        line["lml_abs_err_vs_reference_golden"] = abs(lml - gl)
+        line["lml_%s_golden" % golden_source(w)] = gl
+        line[golden_err_key(w)] = abs(lml - gl)
+        line["lml_golden_provenance"] = golden_source(w)
     if args.workload == "c3":
         try:     # extended-precision value of the same expression (tests/golden/make_c3_extended.py)
             ext = json.load(open(os.path.join(ROOT, "tests", "golden", "lml_c3_extended.json")))
@@ -665,12 +719,25 @@ def run_multi(args, rank, local_rank, world, device):
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         allr = torch.stack(allr).cpu()
+        # the modelled latency-bound tail: in the last third of the panels the updates are too short to cover the
+        # three dependent exchanges per panel -- per-panel exposed waits of every rank there, as a histogram
+        pp = torch.tensor(st["exposed_ms_per_panel"], dtype=torch.float64, device=cpu if shared else device)
+        allp = [torch.zeros_like(pp) for _ in range(world)]
+        dist.all_gather(allp, pp)
+        allp = torch.stack(allp).cpu()
+        third = allp[:, (2 * allp.shape[1]) // 3:]
+        edges = [0.0, 0.05, 0.2, 1.0, 5.0, 1e30]
+        hist = [int(((third >= lo) & (third < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
         res.update({"exposed_comm_ms_per_rank": [float(v) for v in allr[:, 0]], "exposed_comm_ms_max": float(allr[:, 0].max()),
                     "contraction_ms_per_rank": [float(v) for v in allr[:, 1]],
                     "recv_gb_per_rank": [float(v) / 1e9 for v in allr[:, 5]],
                     # the refinement step of the quadratic form on the grid (part of every timed evaluation from 12288
                     # rows on): this rank's stream time in it, incl. its 2 small collectives per tile row
-                    "refine_ms_per_rank": [float(v) for v in allr[:, 6]]})
+                    "refine_ms_per_rank": [float(v) for v in allr[:, 6]],
+                    "last_third_wait_histogram_ms": {"panels": [int((2 * allp.shape[1]) // 3), int(allp.shape[1]) - 1],
+                                                     "bucket_edges_ms": edges[:-1] + ["inf"], "counts_over_ranks_x_panels": hist,
+                                                     "sum_ms_per_rank": [float(v) for v in third.sum(dim=1)],
+                                                     "rank0_ms_per_panel": [round(float(v), 4) for v in third[0]]}})
         if sched == "mesh":
             res["p2p_sent_gb_per_rank"] = [float(v) / 1e9 for v in allr[:, 2]]
             res["p2p_sent_gb_busiest_link_per_rank"] = [float(v) / 1e9 for v in allr[:, 3]]
@@ -772,7 +839,8 @@ def run_multi(args, rank, local_rank, world, device):
         }
         gl = golden_lml(w)
         if gl is not None:                         # C2: the reference's value; C4: the CPU oracle's, measured at full size on a GPU box's host
-            line["lml_abs_err_vs_reference_golden"] = abs(r["lml"] - gl)
+            line[golden_err_key(w)] = abs(r["lml"] - gl)
+            line["lml_golden_provenance"] = golden_source(w)
         line.update(extra)
         if "single_gpu_same_run" in extra:         # the strong-scaling number of THIS run: same matrix, same box, same binary
             t1 = extra["single_gpu_same_run"]["ms_per_step"] * 1e-3
@@ -791,9 +859,21 @@ def run_multi(args, rank, local_rank, world, device):
         def watchdog():
             if not done.wait(deadline):
                 notes[label + "_error"] = "no result within %.0f s (watchdog): leg abandoned" % deadline
+                # A blocked collective cannot be cancelled from Python: every rank leaves.  Rank 0 first prints (and saves) the
+                # line it has; the others wait for that, so the launcher's SIGTERM on the first exit cannot pre-empt the print.
+                # The exit code is NON-ZERO (3): a run that gave up on a GPU process is not a success, whatever the line holds.
                 if rank == 0:
-                    print(line_text(), flush=True)
-                os._exit(0)
+                    txt = line_text()
+                    print(txt, flush=True)
+                    if args.partial_line_path:
+                        try:
+                            with open(args.partial_line_path, "w") as fh:
+                                fh.write(txt)
+                        except OSError:
+                            pass
+                else:
+                    time.sleep(3.0)
+                os._exit(3)
         th = threading.Thread(target=watchdog, daemon=True)
         th.start()
         try:

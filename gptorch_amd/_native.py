@@ -62,6 +62,11 @@ SIGNATURES = {
     "gpn_predict_work_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "gpn_predict": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                             c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gpn_block_inverse_bytes": (c_int64, [c_int64]),
+    "gpn_block_inverse": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "gpn_trsm_right_lt_blocked": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64]),
+    "gpn_predict_blocked": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gpn_transpose": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64]),
     "gpn_copy_matrix": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "gpn_row_sumsq": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),

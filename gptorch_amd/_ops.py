@@ -486,12 +486,42 @@ def lower_inverse(f):
     return W
 
 
-def gpr_predict(kind, X, x_new, variance, length_scales, f, diag=True, use_inverse=False, mean_new=None):
+BLOCKED_PREDICT_MIN_N = 4096      # from here on a repeated prediction pays for the inverted 1024 x 1024 diagonal blocks
+
+
+def block_inverses(f):
+    """inverses of the 1024 x 1024 diagonal blocks of a factor (gpn_block_inverse), cached on it for one generation."""
+    wb = getattr(f, "_wblock", None)
+    if wb is None or wb[0] != f.generation:
+        lib = _native.lib()
+        buf = torch.empty(max(1, int(lib.gpn_block_inverse_bytes(f.n)) // 8), dtype=torch.float64, device=f.device)
+        _native.check(lib.gpn_block_inverse(_stream(f.device), _ptr(f.A), f.n, f.ld, _ptr(f.winv), _ptr(buf)), "gpn_block_inverse")
+        f._wblock = wb = (f.generation, buf)
+    return wb[1]
+
+
+def gpr_predict(kind, X, x_new, variance, length_scales, f, diag=True, use_inverse=False, mean_new=None, blocked=False):
     """Returns (m(x*) + A^T V  [n*, dy],  var) with A = L^-1 K(X, x*), V = L^-1 (Y - m) held
     in f.extra(); var = rowsumsq-reduced diag [n*] or full K(x*) - A^T A [n*, n*].  mean_new [n*, dy]: the mean
-    function at the test points (gpr.py:107-108), None = zero."""
+    function at the test points (gpr.py:107-108), None = zero.  blocked: the right-solve through the inverted 1024 x 1024
+    diagonal blocks (built on first use, cached on the factor)."""
     ns = x_new.shape[0]
     n, dy = f.n, f.e
+    if blocked and not use_inverse and dy > 0 and n >= BLOCKED_PREDICT_MIN_N:
+        _req(X, x_new, variance, length_scales)
+        lib = _native.lib()
+        wb = block_inverses(f)
+        Xc, Xs = _c(X.detach()), _c(x_new.detach())
+        var, ls = _c(variance.detach()), _c(length_scales.detach())
+        work = torch.empty(max(1, 2 * int(lib.gpn_predict_work_bytes(n, ns, dy)) // 8), dtype=torch.float64, device=f.device)
+        mean = torch.empty(ns, dy, dtype=torch.float64, device=f.device)
+        out = torch.empty((ns,) if diag else (ns, ns), dtype=torch.float64, device=f.device)
+        ms = None if mean_new is None else _c(mean_new.detach().expand(ns, dy))
+        st = lib.gpn_predict_blocked(_stream(f.device), KINDS[kind], _ptr(Xc), n, Xc.shape[1], _ptr(Xs), ns, _ptr(ms), _ptr(var), _ptr(ls),
+                                     ls.numel(), _ptr(f.A), f.ld, _ptr(f.winv), _ptr(wb), dy, 0 if diag else 1, _ptr(work), _ptr(mean),
+                                     _ptr(out))
+        _native.check(st, "gpn_predict_blocked")
+        return mean, out
     if not use_inverse and dy > 0:
         # one library call: K(x*, X) -> right-solve chain -> mean / variance (gpn_predict)
         _req(X, x_new, variance, length_scales)

@@ -157,11 +157,11 @@ extern "C" int64_t gpn_predict_work_bytes(int64_t n, int64_t ns, int dy) {
   return round_up(ns > 0 ? ns : 1, 128) * gpn_factor_ld(n, dy) * (int64_t)sizeof(double);
 }
 
-extern "C" int gpn_predict(void* stream, int kind, const double* X, int64_t n, int d,
-                           const double* Xs, int64_t ns, const double* Ms,
-                           const double* variance, const double* length_scales, int nls,
-                           const double* A, int64_t lda, const double* winv, int dy, int full_cov,
-                           double* work, double* mean, double* var) {
+static int predict_impl(void* stream, int kind, const double* X, int64_t n, int d,
+                        const double* Xs, int64_t ns, const double* Ms,
+                        const double* variance, const double* length_scales, int nls,
+                        const double* A, int64_t lda, const double* winv, const double* wb, int dy, int full_cov,
+                        double* work, double* mean, double* var) {
   if (n < 0) return -4;
   if (!Xs) return -6;
   if (ns < 0) return -7;
@@ -174,13 +174,20 @@ extern "C" int gpn_predict(void* stream, int kind, const double* X, int64_t n, i
   if (!var) return -18;
   if (ns == 0) return GPN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t one = gpn_predict_work_bytes(n, ns, dy);
   double* Bt = work;                                // [round_up(ns,128), lda], zero padded
-  GPN_HIP_CHECK(hipMemsetAsync(Bt, 0, (size_t)gpn_predict_work_bytes(n, ns, dy), s));
+  GPN_HIP_CHECK(hipMemsetAsync(Bt, 0, (size_t)((wb && (n % 16)) ? 2 * one : one), s));    // (the second buffer: only its K padding must be zero)
   int rc = GPN_OK;
   if (n > 0) {
     rc = gpn_kernel_matrix(stream, kind, Xs, ns, X, n, d, variance, length_scales, nls, nullptr, GPN_FULL, Bt, lda);  // K(x*, X)
     if (rc != GPN_OK) return rc;
-    rc = gpn_trsm_right_lt(stream, A, n, lda, winv, Bt, ns, lda);                      // A^T = K(x*, X) L^-T
+    if (wb) {                                       // A^T = K(x*, X) L^-T through the big inverted blocks, into the second buffer
+      double* At = work + one / (int64_t)sizeof(double);
+      rc = gpn_trsm_right_lt_blocked(stream, A, n, lda, wb, Bt, ns, lda, At, lda);
+      Bt = At;
+    } else {
+      rc = gpn_trsm_right_lt(stream, A, n, lda, winv, Bt, ns, lda);                    // A^T = K(x*, X) L^-T
+    }
     if (rc != GPN_OK) return rc;
   }
   const int64_t kp = round_up(n, 16);
@@ -198,4 +205,23 @@ extern "C" int gpn_predict(void* stream, int kind, const double* X, int64_t n, i
   rc = gpn_kernel_matrix(stream, kind, Xs, ns, nullptr, ns, d, variance, length_scales, nls, nullptr, GPN_FULL, var, ns);
   if (rc != GPN_OK) return rc;
   return gpn_gemm_nt(stream, ns, ns, kp, -1.0, Bt, lda, Bt, lda, 1.0, var, ns, 0, 0);  // K(x*) - A^T A
+}
+
+extern "C" int gpn_predict(void* stream, int kind, const double* X, int64_t n, int d,
+                           const double* Xs, int64_t ns, const double* Ms,
+                           const double* variance, const double* length_scales, int nls,
+                           const double* A, int64_t lda, const double* winv, int dy, int full_cov,
+                           double* work, double* mean, double* var) {
+  return predict_impl(stream, kind, X, n, d, Xs, ns, Ms, variance, length_scales, nls, A, lda, winv, nullptr, dy, full_cov, work, mean, var);
+}
+
+// gpn_predict with the right-solve through the inverted 1024 x 1024 diagonal blocks (gpn_block_inverse: formed ONCE per
+// factor by a caller that predicts more than once with it).  work: 2 * gpn_predict_work_bytes(n, ns, dy).
+extern "C" int gpn_predict_blocked(void* stream, int kind, const double* X, int64_t n, int d,
+                                   const double* Xs, int64_t ns, const double* Ms,
+                                   const double* variance, const double* length_scales, int nls,
+                                   const double* A, int64_t lda, const double* winv, const double* wb, int dy, int full_cov,
+                                   double* work, double* mean, double* var) {
+  if (!wb) return -15;
+  return predict_impl(stream, kind, X, n, d, Xs, ns, Ms, variance, length_scales, nls, A, lda, winv, wb, dy, full_cov, work, mean, var);
 }

@@ -20,6 +20,7 @@
 // trailing update of the right spine of the recursion; on exit they hold
 // (L^-1 R)^T -- alpha^T of gpr.py:62 -- for free.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -1071,6 +1072,75 @@ extern "C" int gpn_trsm_right_lt(void* stream, const double* L, int64_t n, int64
   Ctx c{static_cast<hipStream_t>(stream), ldl, const_cast<double*>(winv), nullptr, GPN_OK};
   trsm_rec(c, B, m, ldb, L, ldl, n, 0, winv);
   return c.rc;
+}
+
+// ---- right-solves against BIG inverted diagonal blocks -----------------------------------------------------------------
+// gpn_trsm_right_lt walks the recursion down to the 128-wide leaf inverses: at m = 1024 right-hand sides (GPR._predict,
+// gpr.py:104-106) its <= 512-wide levels are ~190 latency-bound launches -- 2.3 ms at N = 8192 for 6.9e10 flops (33
+// TFLOP/s).  With the inverses of the BIGB x BIGB diagonal blocks formed once per factor (n BIGB^2 / 3 flops), the same
+// solve is n / BIGB steps of two large contractions:  X_k = B_k W_k^T  (K-clipped),  B_rest -= X_k L(rest, k)^T.
+static int64_t bigb_env() { const char* e = getenv("GPN_BIGB"); const int64_t v = e ? atoll(e) : 0; return (v >= 256 && v % 128 == 0) ? v : 1024; }
+static const int64_t BIGB = bigb_env();      // (GPN_BIGB: A/B of the block size, tools only)
+
+extern "C" int64_t gpn_block_inverse_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  const int64_t nb = (n + BIGB - 1) / BIGB;
+  return (nb * BIGB * BIGB + (BIGB + 16) * BIGB) * (int64_t)sizeof(double);       // the blocks + one scratch U
+}
+
+// wb[b] (BIGB x BIGB, ld BIGB, row-major lower, zero above the diagonal and beyond a ragged last block) = L_bb^-1
+extern "C" int gpn_block_inverse(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv, double* wb) {
+  if (!L) return -2;
+  if (n < 0) return -3;
+  if (ldl < round_up(n, LEAF) || (ldl % LEAF) != 0) return -4;
+  if (!winv) return -5;
+  if (!wb) return -6;
+  if ((reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(wb) & 15)) return GPN_E_ALIGN;
+  if (n == 0) return GPN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t nb = (n + BIGB - 1) / BIGB;
+  double* U = wb + nb * BIGB * BIGB;
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t nk = std::min(BIGB, n - b * BIGB);
+    GPN_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)((BIGB + 16) * BIGB) * sizeof(double), s));
+    GPN_HIP_CHECK(hipMemsetAsync(wb + b * BIGB * BIGB, 0, (size_t)(BIGB * BIGB) * sizeof(double), s));
+    int rc = gpn_trtri_upper(stream, L + b * BIGB * (ldl + 1), nk, ldl, winv + b * (BIGB / LEAF) * LEAF * LEAF, U, BIGB);
+    if (rc != GPN_OK) return rc;
+    rc = gpn_transpose(stream, U, nk, nk, BIGB, wb + b * BIGB * BIGB, BIGB);       // W = U^T
+    if (rc != GPN_OK) return rc;
+  }
+  return GPN_OK;
+}
+
+// X[m, n] = B L^-T with the block inverses of gpn_block_inverse; B [m, n] (ldb) is CONSUMED (it receives the updates);
+// B and X padded like factor buffers (rows to a multiple of 16, zero K padding), X != B.
+extern "C" int gpn_trsm_right_lt_blocked(void* stream, const double* L, int64_t n, int64_t ldl, const double* wb,
+                                         double* B, int64_t m, int64_t ldb, double* X, int64_t ldx) {
+  if (!L) return -2;
+  if (n < 0) return -3;
+  if (ldl < round_up(n, LEAF) || (ldl % LEAF) != 0) return -4;
+  if (!wb) return -5;
+  if (!B) return -6;
+  if (m < 0) return -7;
+  if (ldb < round_up(n, 16) || (ldb & 1)) return -8;
+  if (!X || X == B) return -9;
+  if (ldx < round_up(n, 16) || (ldx & 1)) return -10;
+  if ((reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(X) & 15) ||
+      (reinterpret_cast<uintptr_t>(wb) & 15)) return GPN_E_ALIGN;
+  if (n == 0 || m == 0) return GPN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t nb = (n + BIGB - 1) / BIGB;
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t c0 = b * BIGB, nk = std::min(BIGB, n - c0), kp = round_up(nk, 16);
+    int rc = gemm_nt(s, m, nk, kp, 1.0, B + c0, ldb, wb + b * BIGB * BIGB, BIGB, 0.0, X + c0, ldx, 0, GPN_TRI_B_LOWER);
+    if (rc != GPN_OK) return rc;
+    const int64_t rest = n - (c0 + nk);
+    if (rest > 0) {
+      rc = gemm_nt(s, m, rest, kp, -1.0, X + c0, ldx, L + (c0 + nk) * ldl + c0, ldl, 1.0, B + c0 + nk, ldb, 0);
+      if (rc != GPN_OK) return rc;
+    }
+  }
+  return GPN_OK;
 }
 
 // Level-parallel variant with a scratch matrix S (same shape as U, zero-initialised):

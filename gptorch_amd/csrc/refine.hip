@@ -438,8 +438,9 @@ static int refine_backsub(hipStream_t s, const double* A, int64_t lda, const dou
   const int nb = (int)((n + LEAF - 1) / LEAF);
   for (int c0 = 0; c0 < dy; c0 += (dy == 1 ? 1 : RDY))
     for (int k = nb; k >= 1; --k) {                 // launch k: update blocks < k by a_k (k < nb), then a_{k-1}
-      if (dy == 1) hipLaunchKernelGGL(backsub_step_kernel<1>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
-      else hipLaunchKernelGGL(backsub_step_kernel<RDY>, dim3((unsigned)k), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
+      const unsigned wgs = (unsigned)(k == nb ? 1 : k);             // the first launch only forms a_{nb-1}: one workgroup
+      if (dy == 1) hipLaunchKernelGGL(backsub_step_kernel<1>, dim3(wgs), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
+      else hipLaunchKernelGGL(backsub_step_kernel<RDY>, dim3(wgs), dim3(256), 0, s, A, lda, winv, k, nb, n, dy, c0, sv, av, L.lds);
     }
   GPN_LAUNCH_CHECK();
   return GPN_OK;
@@ -565,7 +566,12 @@ extern "C" int gpn_lml_refine_dense(void* stream, const double* K, int64_t ldk, 
 // ---- the same step in pieces, for a factor spread over several GPUs (include/gpnative.h) -----------------------------------
 extern "C" int64_t gpn_gemv_t_work_bytes(int64_t rows, int64_t cols, int dy) {
   if (rows <= 0 || cols <= 0 || dy <= 0) return 0;
-  return (int64_t)gemv_t_chunks(rows, cols) * std::min(dy, RDY) * cols * (int64_t)sizeof(double);
+  // MONOTONE in cols: a caller may size the scratch once for its widest call and reuse it for narrower ones
+  // (gpn_dist_lml_refine does).  chunks(c) * c itself is not monotone (chunks = ceil(1024 / ceil(c / 256))); both bounds
+  // below are, and each dominates chunks(c') * c' for every c' <= cols.
+  const int64_t by_width = 262144 + round_up(cols, 256);            // (1024 / wgs + 1) * 256 wgs
+  const int64_t by_rows = ((rows + 31) / 32) * cols;                // chunks <= ceil(rows / 32)
+  return std::min(by_width, by_rows) * std::min(dy, RDY) * (int64_t)sizeof(double);
 }
 
 extern "C" int gpn_gemv_t_acc(void* stream, const double* L, int64_t ld, int64_t rows, int64_t cols, const double* a, int64_t lda,

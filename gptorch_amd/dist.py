@@ -498,7 +498,7 @@ class BlockCyclicGP:
             for w in works:
                 w.wait()
             e1.record()
-            self._wait_events.append((e0, e1))
+            self._wait_events.append((e0, e1, getattr(self, "_panel_tag", -1)))
         else:
             for w in works:
                 w.wait()
@@ -509,11 +509,18 @@ class BlockCyclicGP:
     def comm_stats(self):
         """-> dict: exposed_comm_ms (sum over the recorded waits; synchronises), bytes sent per peer, bytes received."""
         ms = 0.0
+        per_panel = {}
         if self._wait_events:
             torch.cuda.synchronize()
-            ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+            for a, b, tag in self._wait_events:
+                dt = a.elapsed_time(b)
+                ms += dt
+                per_panel[tag] = per_panel.get(tag, 0.0) + dt
+        # exposed_ms_per_panel[k]: how long this rank's compute stream stood still for the exchanges of panel k of the
+        # factorisation (its diagonal tile's broadcast, its rows, its columns); -1 = waits outside the factorisation
         return {"exposed_comm_ms": ms, "waits": len(self._wait_events), "sent_bytes_per_peer": dict(self.sent_bytes),
-                "bcast_root_bytes": self.bcast_root_bytes, "recv_bytes": self.recv_bytes}
+                "bcast_root_bytes": self.bcast_root_bytes, "recv_bytes": self.recv_bytes,
+                "exposed_ms_per_panel": [per_panel.get(k, 0.0) for k in range(self.nt)], "exposed_ms_outside_panels": per_panel.get(-1, 0.0)}
 
     # -- assembly ---------------------------------------------------------------
     def assemble(self, variance, length_scales, noise, resid):
@@ -651,6 +658,7 @@ class BlockCyclicGP:
         Returns the global LAPACK-style info (0 = ok)."""
         nt = self.nt
         self.info_t.zero_()
+        self._panel_tag = 0                                       # (comm_timing: which panel's exchange a wait belongs to)
         self._panel_phase(0)
         left = right = None
         works = []
@@ -659,8 +667,10 @@ class BlockCyclicGP:
             self._wait(works)
             right, works = self._start_cols(0, left)
         for k in range(nt - 1):
+            self._panel_tag = k
             self._wait(works)                                     # panel k is everywhere it is needed
             works = []
+            self._panel_tag = k + 1
             nxt = self._cols_le(k + 1) - 1 if (k + 1) % self.pc == self.my_c else -1
             if nxt >= 0:
                 self._update(k, left, right, nxt, nxt + 1)        # tile column k+1 first ...
@@ -674,6 +684,7 @@ class BlockCyclicGP:
                 nright, works = self._start_cols(k + 1, nleft)    # ... and under the second half
                 self._update(k, left, right, half, self.ncol_t)
                 left, right = nleft, nright
+        self._panel_tag = -1
         return self._finish()
 
     def _finish(self):

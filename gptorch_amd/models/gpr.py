@@ -14,7 +14,8 @@ from .. import kernels
 from .base import GPModel
 
 
-INVERSE_AFTER_CALLS = 3      # predictions with one cached factor before L^-1 is formed (see _predict)
+INVERSE_AFTER_CALLS = 3      # predictions with one cached factor before L^-1 is formed (see _predict); N < 4096 only
+BLOCKED_AFTER_CALLS = 1      # ... and before the 1024 x 1024 diagonal blocks are inverted (N >= 4096)
 
 
 class GPR(GPModel):
@@ -112,10 +113,14 @@ class GPR(GPModel):
             return self._predict_dense(x_new, diag, x)
         f, var, ls = self._factor_for_predict(x)
         with torch.no_grad():
-            # from the third prediction with the same factor on, the right-solve chain is replaced
-            # by one contraction with the explicit inverse (built once, n^3/3 flops)
+            # The first prediction with a factor walks the right-solve recursion down to the 128-wide leaf inverses (~2 n / 128
+            # small launches).  From the second on (N >= 4096): the inverses of the 1024 x 1024 diagonal blocks are formed once
+            # (n 1024^2 / 3 flops) and the solve is n / 1024 steps of two large contractions (2.3 -> 1.3 ms at N = 8192, 1024
+            # test points).  Below 4096 rows: from the third prediction on, one contraction with the explicit inverse.
+            big = x.shape[0] >= _ops.BLOCKED_PREDICT_MIN_N
             mean_f, v = _ops.gpr_predict(k._kind, x, x_new, var, ls, f, diag=diag,
-                                         use_inverse=self._predict_calls >= INVERSE_AFTER_CALLS, mean_new=self.mean_function(x_new))
+                                         use_inverse=(not big) and self._predict_calls >= INVERSE_AFTER_CALLS,
+                                         mean_new=self.mean_function(x_new), blocked=big and self._predict_calls > BLOCKED_AFTER_CALLS)
             var_f = v[:, None].expand_as(mean_f) if diag else v
         return mean_f, var_f
 

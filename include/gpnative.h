@@ -368,6 +368,22 @@ int gpn_predict(void* stream, int kind, const double* X, int64_t n, int d,
                 const double* A, int64_t lda, const double* winv, int dy, int full_cov,
                 double* work, double* mean, double* var);
 
+/* The right-solve of gpn_predict against BIG inverted diagonal blocks (GPR._predict, gpr.py:104-106, for a model that
+ * predicts more than once with one factor).  gpn_block_inverse: wb (gpn_block_inverse_bytes(n) bytes) <- the inverses of
+ * the 1024 x 1024 diagonal blocks of L (n * 1024^2 / 3 flops, once per factor).  gpn_trsm_right_lt_blocked: X = B L^-T as
+ * n / 1024 steps of two large contractions (B [m, n] is CONSUMED; X != B; both padded like factor buffers) instead of the
+ * ~2 n / 128 small launches of gpn_trsm_right_lt -- 1024 right-hand sides at n = 8192: 2.3 -> 1.3 ms.
+ * gpn_predict_blocked = gpn_predict with that right-solve; work: 2 * gpn_predict_work_bytes(n, ns, dy). */
+int64_t gpn_block_inverse_bytes(int64_t n);
+int gpn_block_inverse(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv, double* wb);
+int gpn_trsm_right_lt_blocked(void* stream, const double* L, int64_t n, int64_t ldl, const double* wb,
+                              double* B, int64_t m, int64_t ldb, double* X, int64_t ldx);
+int gpn_predict_blocked(void* stream, int kind, const double* X, int64_t n, int d,
+                        const double* Xs, int64_t ns, const double* Ms,
+                        const double* variance, const double* length_scales, int nls,
+                        const double* A, int64_t lda, const double* winv, const double* wb, int dy, int full_cov,
+                        double* work, double* mean, double* var);
+
 /* ---- several GPUs: 2-D block-cyclic log marginal likelihood --------------------
  * The reference is single-GPU (gptorch/models/base.py:33 "Assume single GPU"); this is
  * GPR.log_likelihood (gpr.py:47-67) for a Gram matrix that is partitioned over a Pr x Pc process

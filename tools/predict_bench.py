@@ -28,10 +28,20 @@ def cold():
 
 
 import gptorch_amd.models.gpr as gpr_mod
-gpr_mod.INVERSE_AFTER_CALLS = 10 ** 9
-print("%s N*=%d: predict_y diag, factor cached   %.3f ms (right-solve chain)" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+from gptorch_amd import _ops  # noqa: E402
+gpr_mod.INVERSE_AFTER_CALLS = gpr_mod.BLOCKED_AFTER_CALLS = 10 ** 9
+print("%s N*=%d: predict_y diag, factor cached   %.3f ms (right-solve chain down to the 128-wide leaf inverses)" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+gpr_mod.BLOCKED_AFTER_CALLS = 0
+print("%s N*=%d: predict_y diag, factor cached   %.3f ms (inverted 1024 x 1024 diagonal blocks, after their one-off construction)" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+f_ = m._predict_cache[1]
+f_._wblock = None
+torch.cuda.synchronize(); t0 = time.perf_counter(); _ops.block_inverses(f_); torch.cuda.synchronize()
+print("%s: forming the block inverses once: %.3f ms" % (w["name"][:2], (time.perf_counter() - t0) * 1e3))
+gpr_mod.BLOCKED_AFTER_CALLS = 10 ** 9
+_ops.BLOCKED_PREDICT_MIN_N, keep = 10 ** 9, _ops.BLOCKED_PREDICT_MIN_N
 gpr_mod.INVERSE_AFTER_CALLS = 0
-print("%s N*=%d: predict_y diag, factor cached   %.3f ms (explicit inverse, after its one-off construction)" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+print("%s N*=%d: predict_y diag, factor cached   %.3f ms (explicit full inverse, after its one-off construction)" % (w["name"][:2], ns, t(lambda: m.predict_y(xs))))
+_ops.BLOCKED_PREDICT_MIN_N = keep
 gpr_mod.INVERSE_AFTER_CALLS = 10 ** 9
 print("%s N*=%d: predict_y full cov, cached      %.3f ms" % (w["name"][:2], ns, t(lambda: m.predict_y(xs, diag=False))))
 print("%s N*=%d: predict_y diag, incl. re-factor %.3f ms (the reference re-factorises every call)" % (w["name"][:2], ns, t(cold)))
