@@ -36,6 +36,8 @@ struct ColPanelArgs {
   double* C;            // [m, nb]
   int64_t lda, ldb, ldc;
   int m, nb;
+  int kvalid;           // K columns of A that hold data: the rest of the 128-wide K range is read as zero (a ragged last block's
+                        // padding columns may hold anything, NaN included: 0 * NaN inside an MFMA would poison the row)
   int64_t sA, sB, sC;   // per-problem strides (elements) of a batch: blockIdx.y-th problem
 };
 
@@ -60,7 +62,13 @@ __global__ __launch_bounds__(256, 2) void colpanel_kernel(ColPanelArgs p) {
     const bool ok = r0 + row < p.m;
     const double* src = p.A + (int64_t)(r0 + row) * p.lda + seg0 * 2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) areg[i] = ok ? *reinterpret_cast<const d2*>(src + i * 16) : d2{0.0, 0.0};
+    for (int i = 0; i < 8; ++i) {
+      d2 v = ok ? *reinterpret_cast<const d2*>(src + i * 16) : d2{0.0, 0.0};
+      const int k0 = seg0 * 2 + i * 16;
+      if (k0 >= p.kvalid) v.x = 0.0;
+      if (k0 + 1 >= p.kvalid) v.y = 0.0;
+      areg[i] = v;
+    }
   }
   // ---- old C tile into the accumulators (update), or zeros (solve)
   const int ct[2] = {MODE == 0 ? wave : 2 * wave, MODE == 0 ? 7 - wave : 2 * wave + 1};   // my two 16-column tiles
@@ -134,13 +142,15 @@ __global__ __launch_bounds__(256, 2) void colpanel_kernel(ColPanelArgs p) {
 
 // C[m, nb] = A[m, 128] B[nb, 128]^T (mode 0, B lower triangular, C may be A) or C -= A B^T (mode 1); nb <= 128; `batch`
 // problems at constant strides in one launch;
-// operands 16-byte aligned with even leading dimensions, K padding (columns past the block's end) zero.
+// operands 16-byte aligned with even leading dimensions; mode 0 reads only the first nb of A's 128 K columns (the padding
+// columns of a ragged last block may hold anything).
 int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B, int64_t ldb,
              double* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC) {
   if (m <= 0 || nb <= 0 || batch <= 0) return GPN_OK;
   ColPanelArgs a;
   a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.m = (int)m; a.nb = (int)nb;
   a.sA = sA; a.sB = sB; a.sC = sC;
+  a.kvalid = mode == 0 ? (int)nb : CP_K;
   const dim3 grid((unsigned)((m + CP_ROWS - 1) / CP_ROWS), (unsigned)batch);
   int rec = -1;
   if (profile_on()) rec = profile_begin(s, 2.0 * batch * (double)m * (double)nb * CP_K * (mode == 0 ? 0.5 : 1.0), mode == 0 ? PROF_GEMM_SOLVE : PROF_GEMM);

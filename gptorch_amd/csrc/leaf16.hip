@@ -19,8 +19,16 @@
 //   * the pivot wave runs ahead by itself: after block k it forms the next diagonal block from two RAW tiles the tile
 //     waves published one panel earlier,  X = A(k+1,k) W_k^T,  D(k+1) -= X X^T  (8 MFMAs),  so it never waits for the
 //     tile waves' update;
-//   * ONE hardware barrier per 16 pivots (W_k out, raw tiles in) + one software barrier of the 8 tile waves.
+//   * NO barrier inside the panel loop: the kernel is a dataflow over LDS flags.  Every tile that crosses waves is kept
+//     for the whole kernel (28 X tiles, 8 W blocks, 8 L blocks: nothing is ever overwritten, so a lagging wave cannot
+//     lose its input) and announced by a flag its readers poll: wready (W_k, L_k out), xready[j] (X(j,k) of tile row j
+//     out), rawflag[k] (the two raw tiles for block k out).  A wave waits for exactly the tiles it reads: the pivot wave
+//     only for the light rows next to the diagonal, never for the heavy rows far below it or for the identity part.
+//     (The first version had one hardware barrier per 16 pivots + a barrier of the 8 tile waves: the pivot wave stood
+//     still for 2.8 / 2.7 / 2.2 / 1.7 k cycles in panels 1-4 waiting for the SLOWEST tile wave -- profiles/r4_leaf16_timeline.txt.)
 // Deterministic (fixed summation order).  FACTOR=false (inverse of a given L) stays on the first kernel.
+#include <atomic>
+#include <type_traits>
 #include "gpn_common.h"
 
 #ifndef L16_COALESCED_STORE
@@ -44,6 +52,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // go to the other three SIMDs by cost: {0,7} | {1,3,5} | {2,4,6} (56 tile updates each).
 constexpr int L16_THREADS = 768;
 constexpr int TS = 18;                // row stride of the prologue's staging tiles (16-B aligned rows, conflict-free transposed reads)
+constexpr int L16_LDS_DOUBLES = 28 * 256 + 2 * 2 * 256 + 2 * 8 * 16 * 18 + 32 * 18 + 64;
+constexpr int L16_LDS_BYTES = L16_LDS_DOUBLES * 8;
 constexpr int RS = 18;                // row stride (doubles) of the row-major 16 x 16 blocks in LDS (144 B: 16-B aligned rows)
 
 struct Leaf16Args {
@@ -55,28 +65,25 @@ struct Leaf16Args {
   int64_t sA, sW, sInfo;              // per-workgroup strides (elements): blockIdx.x-th problem of a batch
 };
 
-// DIAG build: a timeline -- diag[(wave * 8 + k) * 8 + ev] = s_memtime at event ev of block k, pinned behind the value `tie`
-// (the stamp waits for every outstanding LDS operation of the wave: it perturbs what it measures a little)
-#define L16_TU(k, j, tie)                                                                                    \
-  if constexpr (DIAG) {                                                                                      \
-    unsigned long long t_;                                                                                   \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(tie) :: "memory");                  \
-    if (lane == 0) diag[768 + 18432 + (wave * 8 + (k)) * 8 + (j)] = t_;                                      \
-  }
+// DIAG build: a timeline -- stamp[(wave * 8 + k) * 8 + ev] = s_memtime when the wave ISSUED past event ev of block k.  The
+// stamps go to LDS (one ds_write by lane 0; copied to `diag` at the end of the kernel) and tie nothing: a stamp that waits
+// for the value it brackets, or stores to global memory, perturbs the tile waves' loop by hundreds of cycles per tile.
 #define L16_TL(k, ev, tie)                                                                                   \
   if constexpr (DIAG) {                                                                                      \
-    unsigned long long t_;                                                                                   \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(tie) :: "memory");                  \
-    if (lane == 0) diag[(wave * 8 + (k)) * 8 + (ev)] = t_;                                                   \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
+    if (lane == 0) stampbuf[(wave * 8 + (k)) * 8 + (ev)] = t_;                                               \
   }
+#define L16_TU(k, j, tie)
 
 template <bool DIAG>
 __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p, unsigned long long* diag) {
   int tie0 = 0;
+  __shared__ unsigned long long stampbuf[DIAG ? 12 * 8 * 8 : 1];
   if constexpr (DIAG) {
-    unsigned long long t_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
-    if ((threadIdx.x & 63) == 0) diag[((threadIdx.x >> 6) * 8 + 0) * 8 + 6] = t_;          // kernel entry
+    for (int idx = threadIdx.x; idx < 12 * 8 * 8; idx += L16_THREADS) stampbuf[idx] = 0;
+    __syncthreads();
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) stampbuf[((threadIdx.x >> 6) * 8 + 0) * 8 + 6] = t_;      // kernel entry
   }
   double* A = p.A + (int64_t)blockIdx.x * p.sA;
   double* winv = p.winv + (int64_t)blockIdx.x * p.sW;
@@ -84,27 +91,39 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
   const int64_t lda = p.lda;
   const int kb = p.kb;
 
-  __shared__ double Xbuf[8][4][64];       // solved panel tiles X(j,k), j > k (A part): register dumps, read as A operands
-  __shared__ double Raw[2][2][4][64];     // [parity][0: A(k+1,k), 1: D(k+1,k+1)][reg][lane]: raw tiles for the pivot wave
-  __shared__ double Wf[2][16 * RS];       // W_k, fragment-ready: Wf[RS * m + c] = W_k[c][m]
-  __shared__ double Lrow[2][16 * RS];     // L_k, row-major
-  __shared__ double Drow[32 * RS];        // rows 0..15: the pivot wave's next block (row-major); rows 16..31: identity
-  __shared__ __attribute__((aligned(16))) double Tb[8][16 * TS];   // per tile wave: staging tile of the prologue's layout change
-  __shared__ double Lcol[64];              // the pivot wave's current column, for the broadcast reads
-  __shared__ int tb_count;
+  // LDS (dynamic: L16_LDS_BYTES = 105 KB): everything that crosses waves lives for the whole kernel
+  extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+  double* const Xall = lds_dyn;                         // [28][4][64]: X(j,k), j > k, at slot j (j - 1) / 2 + k: register dumps, read as A operands
+  double* const Raw = Xall + 28 * 256;                  // [2 parity][2: A(k+1,k), D(k+1,k+1)][4][64]: raw tiles for the pivot wave
+  double* const Wf = Raw + 2 * 2 * 256;                 // [8 blocks][16 * RS]: W_k, fragment-ready: Wf[RS * m + c] = W_k[c][m]
+  double* const Lrow = Wf + 8 * 16 * RS;                // [8 blocks][16 * RS]: L_k, row-major
+  double* const Drow = Lrow + 8 * 16 * RS;              // [32 * RS]: rows 0..15 the pivot wave's next block; rows 16..31 identity
+  double* const Lcol = Drow + 32 * RS;                  // [64]: the pivot wave's current column, for the broadcast reads
+  double* const Tb0 = Xall;                             // prologue only: per tile wave a 16 x TS staging tile (aliases Xall)
+  __shared__ int wready;                                // number of diagonal blocks whose W / L are out
+  __shared__ int xready[8];                             // xready[j]: number of panels whose X(j, .) is out
+  __shared__ int rawflag[8];                            // rawflag[k] != 0: the raw tiles for diagonal block k are out
   __shared__ int failflag;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // wave -> role: 0 pivot; 4, 8, 11 idle; tile row of the others
-  const int rowmap = (wave == 1) ? 1 : (wave == 5) ? 3 : (wave == 9) ? 5 : (wave == 2) ? 2 : (wave == 6) ? 4 : (wave == 10) ? 6 :
-                     (wave == 3) ? 0 : (wave == 7) ? 7 : -1;
+  // wave -> role: 0 pivot; 4, 8, 11 idle; tile row of the others.  Waves {1,5,9}, {2,6,10}, {3,7,11} share a SIMD each, and
+  // on one SIMD the OLDER wave wins the matrix pipe whenever both are ready -- s_setprio does not reorder fp64 MFMAs, and a
+  // dependent MFMA chain holds the pipe (tools/prio_bench.hip: two waves with 64 dependent MFMAs each run one after the
+  // other, the older first, whatever their priorities).  Age is therefore the only priority there is: the oldest wave of a
+  // SIMD gets the HIGHEST tile row, which stays in the factor's own (critical) part longest, and the rows that turn to the
+  // identity part (-> W, needed by nobody inside the kernel) first sit on the youngest waves and fill what is left.
+  const int rowmap = (wave == 1) ? 5 : (wave == 5) ? 3 : (wave == 9) ? 1 : (wave == 2) ? 6 : (wave == 6) ? 4 : (wave == 10) ? 2 :
+                     (wave == 3) ? 7 : (wave == 7) ? 0 : -1;
   const bool tilewave = rowmap >= 0;
   const bool pivotwave = wave == 0;
-  const int w = rowmap & 7;
+  const int wrow = rowmap & 7;
   const int g = lane >> 4, lc = lane & 15;
-  if (tid == 0) { failflag = 0; tb_count = 0; }
+  if (tid == 0) failflag = 0;
+  if (tid < 8) { xready[tid] = 0; rawflag[tid] = 0; }
+  if (tid == 8) wready = 0;
+  // (Drow's identity rows are written AFTER the prologue's staging tiles are dead: they do not alias, but keep the order simple)
   for (int idx = tid; idx < 16 * RS; idx += L16_THREADS) Drow[16 * RS + idx] = ((idx / RS) == (idx % RS)) ? 1.0 : 0.0;
 
   auto bcast = [](double v, int src) -> double {
@@ -113,8 +132,31 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
     return __hiloint2double(hi, lo);
   };
 
-  if (tilewave) {
-    // ======================================= tile waves =======================================
+  // flags: the writer's LDS stores are issued before its flag store and a wave's LDS operations execute in order; the
+  // reader polls, then reads.  Spins are bounded: on a lost flag the leaf reports an internal failure instead of hanging.
+  auto publish_flag = [&](int* flag, int value) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wait_flag = [&](int* flag, int above) -> bool {               // until *flag > above; false: give up (failure somewhere)
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= above) {
+      if (__hip_atomic_load(&failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) { failflag = LEAF + 1; return false; }
+    }
+    asm volatile("" ::: "memory");
+    return true;
+  };
+  auto xslot = [&](int j, int k) -> double* { return Xall + (j * (j - 1) / 2 + k) * 256; };
+
+  // ======================================= tile waves =======================================
+  // The code of a tile wave is instantiated once per tile ROW (w a compile-time constant, selected by a switch): with w a
+  // run-time value every "is this tile mine" test is a wave-uniform branch around MFMAs, and at each join the register
+  // allocator copied whole accumulators behind a pipeline drain (s_nop 14 + 8 v_mov per tile, out-of-place MFMAs): the
+  // update phase ran at 40-50 % of the matrix pipe.  Per-row code is straight line; only the flag spins branch.
+  auto tile_wave = [&](auto wconst) {
+    constexpr int w = decltype(wconst)::value;
     // slot J (J <= w): A tile (w, J); slot J + 1 (J >= w): identity tile (8 + w, J).  Transposed storage.
     d4 acc[9];
     L16_TL(1, 6, tie0)
@@ -125,7 +167,7 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       // 16 x 18 LDS tile.  (Fetching the transposed storage directly puts consecutive lanes on different rows: 64
       // transactions per load instruction, 13-21 k cycles of prologue; the memory pipe takes 16 cycles per wave
       // instruction whatever its width, so 8-byte loads of all 8 tile columns still cost 4 k cycles CU-wide.)
-      double* tb = Tb[w];
+      double* tb = Tb0 + w * (16 * TS);
       const int pr = lane & 7;
       d2 ld[8][2];
       bool rok[2];
@@ -180,39 +222,17 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       }
     }
     L16_TL(3, 6, acc[0])
-    if constexpr (DIAG) {                                             // debug: the tiles as loaded (after the 768 stamps)
-      double* dbg = reinterpret_cast<double*>(diag + 768);
-#pragma unroll
-      for (int q = 0; q < 9; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dbg[((w * 9 + q) * 4 + r) * 64 + lane] = acc[q][r];
-    }
     auto dump = [&](double* dst, const d4& t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) dst[r * 64 + lane] = t[r];
     };
+    // (the staging tiles alias Xall: its first write is panel 0's solve, behind the barrier P below)
     // raw tiles for the pivot wave's first steps: D(0,0) from wave 0, A(1,0) and D(1,1) from wave 1
-    if (w == 0) dump(&Raw[0][1][0][0], acc[0]);
-    if (w == 1) { dump(&Raw[1][0][0][0], acc[0]); dump(&Raw[1][1][0][0], acc[1]); }
+    if (w == 0) dump(Raw + (0 * 2 + 1) * 256, acc[0]);
+    if (w == 1) { dump(Raw + (1 * 2 + 0) * 256, acc[0]); dump(Raw + (1 * 2 + 1) * 256, acc[1]); publish_flag(&rawflag[1], 1); }
     L16_TL(4, 6, tie0)
     __syncthreads();                                                  // P
 
-    // software barrier of the 8 tile waves, split: ARRIVE right after the wave's X tile is in LDS, WAIT after its global
-    // stores -- the slowest wave's stores (the diagonal tile's masked rows) used to hold everybody for ~1.6 k cycles
-    int epoch = 0;
-    auto tb_arrive = [&]() {
-      ++epoch;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(&tb_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto tb_wait = [&]() {
-      int spins = 0;
-      while (__hip_atomic_load(&tb_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * epoch) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) { failflag = LEAF + 1; break; }
-      }
-      asm volatile("" ::: "memory");
-    };
     // T(i,j) -= X(i,k) X(j,k)^T:  xa = X(j,k) fragments, nx = -X(i,k) (own registers)
     auto update = [&](d4& t, const d4& xa, const d4& nx) {
 #pragma unroll
@@ -227,17 +247,17 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
 
     // The panel loop is fully UNROLLED: the tile registers are reached through wave-uniform branches on static slots, and with
     // k a run-time value those branches turn every accumulator update into MFMA-to-temporary + copy-back behind a pipeline
-    // drain (measured: the rolled loop ran the update phase at 58 % of the MFMA rate, the unrolled one at 78 %).  The code
-    // is 20+ KB of straight line, run once per wave: fine with a warm instruction cache.
+    // drain (measured: the rolled loop ran the update phase at 58 % of the MFMA rate, the unrolled one at 78 %).
+    bool ok = true;                                                   // false: a failure somewhere -- no more global stores
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       L16_TL(k, 0, tie0)
-      __syncthreads();                                                // B(k): W_k and L_k are out
+      ok = ok && wait_flag(&wready, k);                               // W_k and L_k are out
       L16_TL(k, 1, tie0)
-      if (failflag) break;                                            // uniform
+      if (!ok) break;                                                 // uniform
       d4 wf;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) wf[r] = Wf[k & 1][RS * (g + 4 * r) + lc];
+      for (int r = 0; r < 4; ++r) wf[r] = Wf[k * (16 * RS) + RS * (g + 4 * r) + lc];
       const bool apart = w > k;                                       // my tile of column k: A tile (w, k) or identity tile (8 + w, k)
       const int slot = apart ? k : k + 1;
       // X = T W_k^T (transposed storage both sides); the tile's registers are dead afterwards
@@ -250,28 +270,69 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
         }
       }
       L16_TL(k, 2, x)
-      if (apart && k < 7) dump(&Xbuf[w][0][0], x);
-      if (k < 7) tb_arrive();
+      double* myx = xslot(w > 0 ? w : 1, k < w ? k : 0);              // (only used when apart)
       if (apart) {
-        // L tile (w, k), stored row-major (coalesced): element X[g + 4 r][lc], read back from my register dump in Xbuf
-        // (or, for the last panel, straight from a dump made for the purpose)
-#if L16_COALESCED_STORE
-        if (k == 7) dump(&Xbuf[w][0][0], x);
+        dump(myx, x);
+        publish_flag(&xready[w], k + 1);                              // X(w, k) is out
+      }
+      const d4 nx = d4{-x[0], -x[1], -x[2], -x[3]};
+      L16_TL(k, 3, tie0)
+      if (k < 7) {
+        // ---- updates with panel k, BEFORE this panel's global stores (the stores are fire-and-forget, the next blocks wait
+        // for these tiles).  The A operand X(j, k) of the NEXT tile is requested between the first and the second MFMA of
+        // the current one (a non-blocking look at its flag: by now nearly every X(., k) is out), so a tile costs its four
+        // dependent MFMAs and not flag poll + LDS round trip + MFMAs in a row.
+        const int jlast = apart ? w - 1 : 7;                          // last tile column whose operand comes from another wave
+        d4 xa = d4{0.0, 0.0, 0.0, 0.0};
+        if (k + 1 <= jlast) {
+          ok = ok && wait_flag(&xready[k + 1], k);
+          xa = load_frag(xslot(k + 1, k));
+        }
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+          if (j > k) {                                                // (static)
+            if (j <= jlast) {                                         // (uniform) operand from tile row j
+              auto op = [&](d4& t) {
+                const d4 cur = xa;
+                bool got = true;
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0], nx[0], t, 0, 0, 0);
+                if (j + 1 <= jlast && j + 1 < 8) {
+                  got = __hip_atomic_load(&xready[j + 1 < 8 ? j + 1 : 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > k;
+                  if (got) xa = load_frag(xslot(j + 1 < 8 ? j + 1 : 7, k));
+                }
+#pragma unroll
+                for (int r = 1; r < 4; ++r) t = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[r], nx[r], t, 0, 0, 0);
+                if (!got) {
+                  ok = ok && wait_flag(&xready[j + 1 < 8 ? j + 1 : 7], k);
+                  xa = load_frag(xslot(j + 1 < 8 ? j + 1 : 7, k));
+                }
+              };
+              if (apart) op(acc[j]);                                  // A tile (w, j)
+              else op(acc[j + 1]);                                    // identity tile (8 + w, j)
+            } else if (apart && j == w) {                             // my diagonal tile: the operand is my own X
+              update(acc[j], x, nx);
+            }
+            // the raw tiles the pivot wave needs for diagonal block k + 2: A(k+2, k+1) and D(k+2, k+2), from tile row k + 2
+            if (apart && w == k + 2) {
+              if (j == k + 1) dump(Raw + ((k & 1) * 2 + 0) * 256, acc[j]);
+              if (j == k + 2) { dump(Raw + ((k & 1) * 2 + 1) * 256, acc[j]); publish_flag(&rawflag[k + 2], 1); }
+            }
+          }
+        }
+      }
+      L16_TL(k, 4, tie0)
+      // ---- this panel's final tiles to global memory
+      if (!ok) break;
+      if (apart) {
+        // L tile (w, k), stored row-major (coalesced): element X[g + 4 r][lc], read back from my register dump
         L16_WAVE_FENCE();
-        const double* xd = &Xbuf[w][0][0] + (lc >> 2) * 64 + (lc & 3) * 16 + g;
+        const double* xd = myx + (lc >> 2) * 64 + (lc & 3) * 16 + g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * w + g + 4 * r;
           const double v = xd[4 * r];
           if (row < kb) A[(int64_t)row * lda + 16 * k + lc] = v;
         }
-#else
-        const int row = 16 * w + lc;
-        if (row < kb) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) A[(int64_t)row * lda + 16 * k + g + 4 * r] = x[r];
-        }
-#endif
       } else {                                                        // W^T tile (w, k): X[a][b] = W[16 k + b][16 w + a]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -279,7 +340,7 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
           winv[(int64_t)wr * LEAF + wc] = (wr < kb && wc < kb) ? x[r] : 0.0;
         }
         if (w == k) {                                                 // the diagonal tile L_k comes from the pivot wave
-          const double* Lr = Lrow[k & 1];
+          const double* Lr = Lrow + k * (16 * RS);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = g + 4 * r, col = lc;
@@ -287,49 +348,22 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
           }
         }
       }
-      const d4 nx = d4{-x[0], -x[1], -x[2], -x[3]};
-      L16_TL(k, 3, tie0)
-      if (k == 7) break;
-      tb_wait();                                                      // T(k): the X tiles of this panel are in LDS
-      L16_TL(k, 4, tie0)
-      {
-        // A operand X(j,k) of the NEXT tile requested before the current tile's MFMAs (rolling prefetch)
-        d4 xa_n = load_frag(&Xbuf[k + 1][0][0]);
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-          if (j > k) {                                                // uniform
-            const d4 xa = xa_n;
-            if (j < 7) xa_n = load_frag(&Xbuf[j + 1][0][0]);
-            if (apart) {                                              // A tiles (w, j), j = k + 1 .. w
-              if (j < w) {
-                update(acc[j], xa, nx);
-                L16_TU(k, j, acc[j])
-              } else if (j == w) {
-                update(acc[j], x, nx);
-                L16_TU(k, j, acc[j])
-              }
-              // the raw tiles the pivot wave needs after its NEXT block: A(k+2, k+1) and D(k+2, k+2), from wave k + 2
-              if (w == k + 2) {
-                if (j == k + 1) dump(&Raw[k & 1][0][0][0], acc[j]);
-                if (j == k + 2) dump(&Raw[k & 1][1][0][0], acc[j]);
-              }
-            } else {                                                  // identity tiles (8 + w, j), j = k + 1 .. 7
-              update(acc[j + 1], xa, nx);
-              L16_TU(k, j, acc[j + 1])
-            }
-          }
-        }
-      }
-      if constexpr (DIAG) {
-        double chk = 0.0;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) chk += acc[q][0];
-        L16_TL(k, 5, chk)
-        if (chk == 1.2345e300) tie0 += 1;
-      }
+      L16_TL(k, 5, tie0)
+    }
+  };
+  if (tilewave) {
+    switch (wrow) {
+      case 0: tile_wave(std::integral_constant<int, 0>{}); break;
+      case 1: tile_wave(std::integral_constant<int, 1>{}); break;
+      case 2: tile_wave(std::integral_constant<int, 2>{}); break;
+      case 3: tile_wave(std::integral_constant<int, 3>{}); break;
+      case 4: tile_wave(std::integral_constant<int, 4>{}); break;
+      case 5: tile_wave(std::integral_constant<int, 5>{}); break;
+      case 6: tile_wave(std::integral_constant<int, 6>{}); break;
+      default: tile_wave(std::integral_constant<int, 7>{}); break;
     }
   } else if (!pivotwave) {
-    // idle waves (they share the pivot wave's SIMD): the barrier sequence, and -- off everybody's critical path -- the zero
+    // idle waves (they share the pivot wave's SIMD): the prologue barrier, and -- off everybody's critical path -- the zero
     // fill of winv above the diagonal tiles (28 tiles W[16 k + ..][16 j + ..], k < j; 16 bytes per lane)
     __syncthreads();                                                  // P
     {
@@ -343,10 +377,6 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
             *reinterpret_cast<d2*>(&winv[(int64_t)(16 * k + (lane >> 3) + 8 * i2) * LEAF + 16 * j2 + 2 * (lane & 7)]) = d2{0.0, 0.0};
         }
     }
-    for (int k = 0; k < 8; ++k) {
-      __syncthreads();                                                // B(k)
-      if (failflag) break;
-    }
   } else {
     // ======================================= pivot wave =======================================
     __builtin_amdgcn_s_setprio(3);
@@ -359,7 +389,7 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
     {
       d4 dacc;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dacc[r] = Raw[0][1][r][lane];
+      for (int r = 0; r < 4; ++r) dacc[r] = Raw[(0 * 2 + 1) * 256 + r * 64 + lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) Drow[lc * RS + g + 4 * r] = dacc[r];
       L16_WAVE_FENCE();
@@ -417,23 +447,26 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       }
       // ---- publish L_k (rows, lanes 0..15) and W_k (lanes 16..31 hold the rows of W_k^T)
       if (lane < 32) {
-        double* dst = lane < 16 ? &Lrow[k & 1][lane * RS] : &Wf[k & 1][(lane - 16) * RS];
+        double* dst = lane < 16 ? Lrow + k * (16 * RS) + lane * RS : Wf + k * (16 * RS) + (lane - 16) * RS;
 #pragma unroll
         for (int c = 0; c < 16; ++c) dst[c] = a[c];
       }
       L16_TL(k, 2, tie0)
-      __syncthreads();                                                // B(k)
+      // (after a failed pivot nothing is announced: the waiters see failflag in their spin and leave without storing)
+      if (__hip_atomic_load(&failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+      publish_flag(&wready, k + 1);                                   // W_k and L_k are out
+      if (k == 7) break;
+      if (!wait_flag(&rawflag[k + 1], 0)) break;                      // the raw tiles for block k + 1 (published one panel earlier)
       L16_TL(k, 3, tie0)
-      if (failflag || k == 7) break;
       // ---- next diagonal block from the raw tiles:  X = A(k+1,k) W_k^T,  D(k+1) -= X X^T
       {
         const int par = (k + 1) & 1;
         d4 wf, ar, dacc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          wf[r] = Wf[k & 1][RS * (g + 4 * r) + lc];
-          ar[r] = Raw[par][0][r][lane];
-          dacc[r] = Raw[par][1][r][lane];
+          wf[r] = Wf[k * (16 * RS) + RS * (g + 4 * r) + lc];
+          ar[r] = Raw[(par * 2 + 0) * 256 + r * 64 + lane];
+          dacc[r] = Raw[(par * 2 + 1) * 256 + r * 64 + lane];
         }
         d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -453,9 +486,12 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
   }
   if constexpr (DIAG) {
     L16_TL(0, 7, tie0)                                                 // end of the wave's work
-    if (lane == 0) diag[(wave * 8 + 1) * 8 + 7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);   // HW_ID
+    if (lane == 0) stampbuf[(wave * 8 + 1) * 8 + 7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);   // HW_ID
   }
   __syncthreads();
+  if constexpr (DIAG) {
+    for (int idx = tid; idx < 12 * 8 * 8; idx += L16_THREADS) diag[idx] = stampbuf[idx];
+  }
   if (failflag) {
     if (tid == 0 && info) {
       if (failflag > LEAF) *info = GPN_INFO_INTERNAL;
@@ -470,7 +506,12 @@ int leaf16(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* winv
            int64_t sW, int64_t sInfo) {
   Leaf16Args a;
   a.A = A; a.lda = lda; a.kb = kb; a.col0 = col0; a.winv = winv; a.info = info; a.sA = sA; a.sW = sW; a.sInfo = sInfo;
-  hipLaunchKernelGGL(potrf_leaf16_kernel<false>, dim3((unsigned)batch), dim3(L16_THREADS), 0, s, a, nullptr);
+  static std::atomic<int> attr_done{0};
+  if (!attr_done.load(std::memory_order_acquire)) {
+    GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS_BYTES));
+    attr_done.store(1, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(potrf_leaf16_kernel<false>, dim3((unsigned)batch), dim3(L16_THREADS), L16_LDS_BYTES, s, a, nullptr);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
@@ -478,7 +519,8 @@ int leaf16(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* winv
 int leaf16_timing(hipStream_t s, double* A, int64_t lda, double* winv, int32_t* info, unsigned long long* diag768) {
   Leaf16Args a;
   a.A = A; a.lda = lda; a.kb = LEAF; a.col0 = 0; a.winv = winv; a.info = info; a.sA = 0; a.sW = 0; a.sInfo = 0;
-  hipLaunchKernelGGL(potrf_leaf16_kernel<true>, dim3(1), dim3(L16_THREADS), 0, s, a, diag768);
+  GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_leaf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS_BYTES));
+  hipLaunchKernelGGL(potrf_leaf16_kernel<true>, dim3(1), dim3(L16_THREADS), L16_LDS_BYTES, s, a, diag768);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

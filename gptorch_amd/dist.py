@@ -829,6 +829,7 @@ class BlockCyclicGP:
                             schedule=self.schedule)
         eng.comm, eng.xrow, eng.xcol = self.comm, self.xrow, self.xcol
         eng.lml_rows = dy
+        eng.refine = False        # the LML of this engine is discarded: no back-substitution sweep / residual pass for it
         eng.log_likelihood(variance, length_scales, noise, R, max_tries)
         self.info, self.jitter_rung = eng.info, eng.jitter_rung
         ncr = eng.cidx.numel()

@@ -245,6 +245,33 @@ def gen_lml(out, big):
         json.dump(res, f, indent=1)
 
 
+MID_CASE = dict(name="mid_rbf_12000_8", kind="Rbf", n=12000, d=8, dy=1, variance=1.0, length_scales=float(np.sqrt(8.0)), ARD=False, noise=1e-2)
+
+
+def gen_mid(out):
+    """one golden on the UNREFINED side of the refinement threshold (12288 rows): the reference's LML at N = 12000
+    (round-3 review: 8193 <= N < 12288 was neither refined nor covered by any golden), plus predictions at 16 points."""
+    case = MID_CASE
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    t0 = time.time()
+    with torch.no_grad():
+        m = ref_model(case, x, y)
+        loss = m.loss()
+        xs = rng.normal(4242, (16, case["d"]))
+        mf, vf = m.predict_f(xs)
+    entry = dict(case)
+    entry["x_checksum"], entry["y_checksum"] = rng.checksum(x), rng.checksum(y)
+    entry["lml"] = float(-loss.item())
+    entry["predict"] = dict(seed_xs=4242, mean_f=mf.tolist(), var_f=vf.tolist())
+    entry["ref_seconds"] = time.time() - t0
+    with torch.no_grad():
+        ol = oracle_model(case, x, y).loss()
+    entry["oracle_abs_diff"] = float(abs(ol.item() - loss.item()))
+    print(f"lml {case['name']}: lml={entry['lml']:.10f} ref_time={entry['ref_seconds']:.1f}s oracle diff {entry['oracle_abs_diff']:.2e}")
+    with open(os.path.join(out, "lml_mid_12000.json"), "w") as f:
+        json.dump(entry, f, indent=1)
+
+
 def gen_adam(out):
     """50-step Adam trajectories (base.py:149-151, 260-269)."""
     res = []
@@ -565,7 +592,7 @@ if __name__ == "__main__":
     args = ap.parse_args()
     torch.manual_seed(0)
     steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
-                 lml=lambda: gen_lml(HERE, args.big), adam=lambda: gen_adam(HERE),
+                 lml=lambda: gen_lml(HERE, args.big), mid=lambda: gen_mid(HERE), adam=lambda: gen_adam(HERE),
                  func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE),
                  comp=lambda: gen_composite(HERE), compbig=lambda: gen_composite_big(HERE), comp16k=lambda: gen_composite_16k(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), lbfgs=lambda: gen_lbfgs(HERE))
     for k, fn in steps.items():

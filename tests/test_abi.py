@@ -175,3 +175,27 @@ def test_product_library_has_no_debug_switches():
         assert hasattr(dbg, n), "libgpnative_dbg.so lacks %s" % n
     for n in _native.SIGNATURES:
         assert hasattr(dbg, n)
+
+
+def test_gemv_scratch_size_is_monotone_in_the_width():
+    """gpn_gemv_t_work_bytes must not shrink when the width grows: gpn_dist_lml_refine sizes its scratch once for the widest
+    call and reuses it for every narrower one (round-3 advice: chunks(c) * c alone is not monotone -- T = 2048: 31 tile
+    columns needed 317440 doubles, 32 only 262144)."""
+    from gptorch_amd import _native
+    lib = _native.lib()
+    for rows in (128, 2048, 4096):
+        for dy in (1, 3):
+            prev = 0
+            for cols in list(range(1, 600, 7)) + [k * 2048 for k in range(1, 40)]:
+                b = lib.gpn_gemv_t_work_bytes(rows, cols, dy)
+                assert b > 0
+            widths = sorted(set(list(range(1, 600, 7)) + [k * 2048 for k in range(1, 40)]))
+            for cols in widths:
+                b = lib.gpn_gemv_t_work_bytes(rows, cols, dy)
+                assert b >= prev, (rows, cols, dy, b, prev)
+                prev = b
+            # and it still covers what one call uses: chunks * min(dy, 2) * cols doubles with chunks = ceil(1024 / ceil(cols / 256))
+            for cols in widths:
+                wgs = (cols + 255) // 256
+                chunks = max(1, min((1024 + wgs - 1) // wgs, (rows + 31) // 32))
+                assert lib.gpn_gemv_t_work_bytes(rows, cols, dy) >= chunks * min(dy, 2) * cols * 8

@@ -2181,3 +2181,46 @@ def test_c4_full_size_block_cyclic_2x4_grid(device):
     assert abs(line["lml"] - gold) < 1e-8, (line["lml"], gold)
     assert line["lml_abs_err_vs_cpu_oracle_golden"] == abs(line["lml"] - gold) and line["lml_golden_provenance"] == "cpu_oracle"
     assert "lml_abs_err_vs_reference_golden" not in line
+
+
+@pytest.mark.gpu
+def test_right_solve_ignores_the_padding_of_a_ragged_last_block(device):
+    """gpn_trsm_right_lt on a factor whose size is not a multiple of 128: the padding columns of B beyond n may hold
+    anything (NaN here) -- the dedicated column kernel reads a full 128-wide K range of its A tile and masks what lies
+    beyond the block's width (round-3 advice: 0 * NaN inside the MFMA)."""
+    from gptorch_amd import _ops
+    n, m = 300, 70
+    a = torch.randn(n, n, dtype=torch.float64, device=device)
+    spd = a @ a.t() / n + torch.eye(n, dtype=torch.float64, device=device)
+    f = _ops.cholesky_factor(spd)
+    B = _ops.padded_like_factor(f, m)
+    B[:m, :n] = torch.randn(m, n, dtype=torch.float64, device=device)
+    ref = torch.linalg.solve_triangular(torch.linalg.cholesky(spd), B[:m, :n].t().contiguous(), upper=False).t()
+    B[:, n:] = float("nan")                          # poison the padding columns
+    f.solve_right_lt(B, m)
+    got = B[:m, :n]
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 1e-10 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_mid_size_golden_on_the_unrefined_side_of_the_threshold(device):
+    """N = 12000 (Rbf, D = 8, noise 1e-2): just below the 12288 rows from which log_likelihood() refines the quadratic form --
+    the reference's own LML (tests/golden/lml_mid_12000.json, make_golden.py --only mid) within north_star's 1e-8 ABSOLUTE
+    with the refinement step OFF, and its predictions at 16 points (round-3 review: 8193 <= N < 12288 had no golden)."""
+    from gptorch_amd import _ops
+    case = load_json("lml_mid_12000.json")
+    assert case["n"] < _ops.refine_min_n()
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    assert rng.checksum(x) == case["x_checksum"] and rng.checksum(y) == case["y_checksum"]
+    m = GPR(x, y, kernels.Rbf(case["d"], variance=case["variance"], length_scales=case["length_scales"]),
+            likelihood=likelihoods.Gaussian(variance=case["noise"]))
+    m.cuda()
+    with torch.no_grad():
+        lml = m.log_likelihood().item()
+    assert m._holder["factor"].refined is False
+    assert abs(lml - case["lml"]) < 1e-8, (lml, case["lml"])
+    xs = rng.normal(case["predict"]["seed_xs"], (16, case["d"]))
+    mf, vf = m.predict_f(xs)
+    assert np.abs(mf - np.asarray(case["predict"]["mean_f"])).max() < 1e-8
+    assert np.abs(vf - np.asarray(case["predict"]["var_f"])).max() < 1e-8

@@ -108,28 +108,6 @@ with _native.debug_library() as lib:
         torch.cuda.synchronize()
         lib.gpn_debug_leaf16_timing(_stream(dev), _ptr(f.A), f.ld, _ptr(f.winv), _ptr(f.info), _ptr(diag))
         torch.cuda.synchronize()
-    tu = diag[768 + 18432:].cpu().numpy().reshape(12, 8, 8)
-    tiles = diag[768:768 + 18432].view(torch.float64).cpu().numpy().reshape(8, 9, 4, 64)
-    mm = m.cpu().numpy()
-    nbad = 0
-    for w_ in range(8):
-        for q in range(9):
-            for r in range(4):
-                for lane in range(64):
-                    g_, lc_ = lane >> 4, lane & 15
-                    a_, b_ = lc_, g_ + 4 * r            # element T[lc][g + 4 r]
-                    if q < w_:
-                        want = mm[16 * w_ + a_, 16 * q + b_]
-                    elif q == w_:
-                        i_, j_ = 16 * w_ + a_, 16 * w_ + b_
-                        want = mm[max(i_, j_), min(i_, j_)]
-                    else:
-                        want = 1.0 if (q == w_ + 1 and a_ == b_) else 0.0
-                    if tiles[w_, q, r, lane] != want:
-                        nbad += 1
-                        if nbad < 12:
-                            print("tile mismatch: row %d slot %d reg %d lane %d: got %r want %r" % (w_, q, r, lane, tiles[w_, q, r, lane], want))
-    print("prologue tiles: %d mismatches" % nbad)
     d = diag[:768].cpu().numpy().reshape(12, 8, 8)
     hwid = d[:, 1, 7].copy()
     d[:, 1, 7] = 0
@@ -143,10 +121,10 @@ with _native.debug_library() as lib:
     print("end of work per wave (cycles):", [int(rel[w, 0, 7]) for w in range(12)])
     print("pivot wave (0): per block k: [top, pivots done, published, B(k) passed, catch-up MFMAs done, next block in registers]")
     print(rel[0, :, :6])
-    print("update phase of panel 0 and 1, time each tile update (j = 1..7) completed, per wave (relative to T(k) passed):")
-    for w in (3, 7, 1, 5, 9, 2, 6, 10):
-        for k_ in (0, 1):
-            print("  wave %2d k %d:" % (w, k_), [int(tu[w, k_, j] - d[w, k_, 4]) if tu[w, k_, j] > 0 else -1 for j in range(1, 8)], " T(k) passed at", int(rel[w, k_, 4]))
+    rowof = {3: 7, 7: 0, 1: 5, 5: 3, 9: 1, 2: 6, 6: 4, 10: 2}
+    print("compact: per tile ROW (wave), per panel: [W_k seen | solve done | updates done]")
+    for w in sorted(rowof, key=lambda q: rowof[q]):
+        print("  row %d (wave %2d, simd %d):" % (rowof[w], w, (int(hwid[w]) >> 4) & 3), " ".join("[%5d %5d %5d]" % (rel[w, k, 1], rel[w, k, 2], rel[w, k, 5]) for k in range(8)))
     for w in (3, 7, 1, 5, 9):
         print("tile wave %d: per panel k: [at B(k), B(k) passed, solve done, stores/dump issued, T(k) passed, update done]" % w)
         print(rel[w, :, :6])
