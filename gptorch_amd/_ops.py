@@ -307,7 +307,7 @@ def kernel_factor(kind, X, variance, length_scales, noise, R=None, factor=None):
     return f
 
 
-def refine_min_n(expression=False):
+def refine_min_n(expression=False, grid=False):
     """from this many rows on, lml_forward follows the factorisation with one refinement step of the quadratic form
     (gpn_lml_refine).  The plain value's distance to the exact one grows like N^1.85 (5.8e-10 at N = 8192, 7.6e-9 at
     32768, measured) and north_star's tolerance is 1e-8 ABSOLUTE against a reference that is itself 3.4e-9 off at
@@ -316,11 +316,16 @@ def refine_min_n(expression=False):
     expression=True: covariance expressions (Linear / Constant terms grow the top eigenvalue like N |x|^2, so the
     quadratic form's sensitivity to the factor's rounding is an order of magnitude above a stationary kernel's: the
     reference's example model at N = 8192 sits 2e-8 from its golden unrefined, whichever leaf kernel factors it) refine
-    from half that size on."""
+    from half that size on.
+    grid=True: the block-cyclic drivers (their tile-wide trailing updates accumulate over K = 1024..2048 per launch, a
+    different rounding profile from the single-GPU panels: C2's matrix on a 1 x 1 grid of 2048-wide tiles sits 0.9-1.1e-8
+    from the golden unrefined) refine from two thirds of that size on (8192 rows)."""
     import os
     v = int(os.environ.get("GPN_REFINE_MIN_N", REFINE_MIN_N))
     if expression and v > 0:
         v = v // 2
+    elif grid and v > 0:
+        v = (2 * v) // 3
     return v if v > 0 else 1 << 62
 
 

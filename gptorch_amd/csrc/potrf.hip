@@ -677,7 +677,17 @@ GPN_SWITCH g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
 // N = 16384 31.9 (1536) vs 32.2 (2048), C3 201.5 / 200.0 / 201.1, C4 1492 / 1473 / 1472; with the
 // left-looking aux update (below) the large sizes prefer 2048: C3 198.1, C4 1454 ms.
 static inline bool large_problem(int64_t n) { return n >= 24576; }
-static inline int64_t panel_width(int64_t n) { return g_panel_width ? g_panel_width : (large_problem(n) ? 2048 : 1536); }
+// Panel width by size.  Round 4 (16-pivot-block leaf, 18.7 us instead of 39): the in-panel chain got cheaper, so what a
+// wide panel saves in trailing-update launches no longer pays for its K = 128 in-panel updates below N ~ 16 k.  Same-box
+// sweep, ms per evaluation (tools/potrf_ab.py n=<N>, VARIANTS=0x200..0xc00 = 256 .. 1536):
+//   N = 2048: 256 0.68 | 512 0.77 | 1536 0.81      N = 4096: 256 1.61 | 512 1.76 | 1536 1.89
+//   N = 8192: 256 5.68 | 512 5.74 | 1024 5.85 | 1536 6.03 (| 2048 6.19)
+//   N = 12288: 256 16.2 | 512 15.4 | 1024 15.5 | 1536 15.8      N = 16384: 512 31.2 | 1024 30.9 | 1536 31.4
+//   C3 (N = 32768): 1536 188.4 | 2048 188.6-188.9 | 2560 189.9 ms
+static inline int64_t panel_width(int64_t n) {
+  if (g_panel_width) return g_panel_width;
+  return n <= 10240 ? 256 : n < 16384 ? 512 : n < 24576 ? 1024 : 2048;
+}
 
 static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   Aux* ax = aux_for(c.s);

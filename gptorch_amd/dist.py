@@ -871,7 +871,7 @@ class BlockCyclicGP:
     def log_likelihood(self, variance, length_scales, noise, resid, max_tries=10):
         """assemble + factor with the jitter ladder of functions.py:20-43 (decided on the
         all-reduced info, so every rank takes the same branch)."""
-        refine = self.refine if self.refine is not None else self.n >= _ops.refine_min_n()
+        refine = self.refine if self.refine is not None else self.n >= _ops.refine_min_n(grid=True)
         refine = refine and (self.comm or self.world == 1)        # (a phantom rank of tools/dist_phantom_profile.py has no peers to ask)
         self.refined = False
         self.assemble(variance, length_scales, noise, resid)
@@ -1146,7 +1146,7 @@ class NativeDistLML:
         if self.info != 0:
             raise RuntimeError("Max tries exceeded.")
         self.refined = False
-        if self.refine if self.refine is not None else self.n >= _ops.refine_min_n():
+        if self.refine if self.refine is not None else self.n >= _ops.refine_min_n(grid=True):
             # the value by the same rule as log_likelihood (the factor and alpha^T are where the forward part left them: the
             # backward writes its inverse elsewhere in the workspace)
             nz = noise if self.jitter_rung < 0 else noise + 10.0 ** (-max_tries + self.jitter_rung)
@@ -1202,7 +1202,7 @@ class NativeDistLML:
         if self.info != 0:
             raise RuntimeError("Max tries exceeded.")
         self.refined = False
-        if self.refine if self.refine is not None else self.n >= _ops.refine_min_n():
+        if self.refine if self.refine is not None else self.n >= _ops.refine_min_n(grid=True):
             nz = noise if self.jitter_rung < 0 else noise + 10.0 ** (-max_tries + self.jitter_rung)
             host = self._refine(variance, length_scales, nz)
         return host[2].to(self.X.device)
