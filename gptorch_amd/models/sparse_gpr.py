@@ -64,6 +64,7 @@ INVERSE_BLOCK = int(__import__('os').environ.get('GPN_VFE_INVERSE_BLOCK', 512))
 # forward and the gradients in the backward, so every rank sees the bound and the gradients of the
 # WHOLE data set (optimisers on all ranks stay in step).
 SHARD_GROUP = None
+BLOCKED_SOLVE_MIN_M = 2048   # from this many inducing points on, chunk right-solves go through the inverted 1024 x 1024 blocks
 LANES = 2                # chunk pipelines in flight (1: strictly one chunk after the other)
 SPLIT_K = 8              # partial accumulators of the A A^T accumulation (1: none)
 SYRK_K_SLICE = 8192      # columns of a chunk per accumulation launch (0: the whole chunk at once)
@@ -240,6 +241,12 @@ def _vfe_forward(asm, x, err, Z, s2):
     bufs = [(_zeros(nc + 16, f_uu.ld, dev), _zeros(mp, nc, dev), _zeros(_ops.round_up(dy, 16), nc, dev))
             for _ in range(lanes)]
     lib = _ops._native.lib()
+    # round 4: the chunk's right-solve through the inverted 1024 x 1024 diagonal blocks of L_uu (gpn_trsm_right_lt_blocked:
+    # M / 1024 steps of two large contractions) instead of the recursion down to the 128-wide leaf inverses, whose K <= 256
+    # levels ran at ~12 TFLOP/s (round-3 review: colpanel_kernel 19 % of C5's kernel time); one more chunk-sized buffer per lane
+    blocked = m >= BLOCKED_SOLVE_MIN_M and n >= 4 * m
+    wb_uu = _ops.block_inverses(f_uu) if blocked else None
+    xbufs = [_zeros(nc + 16, f_uu.ld, dev) for _ in range(lanes)] if blocked else None
     # split-K partial accumulators (see below): only when M^2/2 has too few 128x128 tiles to fill the GPU
     mt128 = (m + 127) // 128
     split = SPLIT_K if (mt128 * (mt128 + 1) // 2 < 4096 and nc >= 4096 * SPLIT_K) else 1
@@ -263,6 +270,11 @@ def _vfe_forward(asm, x, err, Z, s2):
                 for b0 in range(0, m, INVERSE_BLOCK):
                     rows = min(INVERSE_BLOCK, m - b0)
                     _ops.gemm_nt(W_uu[b0:], At, rows, r, _ops.round_up(b0 + rows, 16), C=A[b0:])
+            elif blocked:
+                Xo = xbufs[ci % lanes]
+                _ops._native.check(lib.gpn_trsm_right_lt_blocked(stream, _ops._ptr(f_uu.A), m, f_uu.ld, _ops._ptr(wb_uu), _ops._ptr(At), r,
+                                                                 At.stride(0), _ops._ptr(Xo), Xo.stride(0)), "gpn_trsm_right_lt_blocked")
+                _ops._native.check(lib.gpn_transpose(stream, _ops._ptr(Xo), r, m, Xo.stride(0), _ops._ptr(A), nc), "gpn_transpose")
             else:
                 f_uu.solve_right_lt(At, r)                                 # A_c^T = Kuf_c^T L^-T
                 _ops._native.check(lib.gpn_transpose(stream, _ops._ptr(At), r, m, At.stride(0), _ops._ptr(A), nc),

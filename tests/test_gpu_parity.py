@@ -2224,3 +2224,33 @@ def test_mid_size_golden_on_the_unrefined_side_of_the_threshold(device):
     mf, vf = m.predict_f(xs)
     assert np.abs(mf - np.asarray(case["predict"]["mean_f"])).max() < 1e-8
     assert np.abs(vf - np.asarray(case["predict"]["var_f"])).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_vfe_blocked_right_solve_matches_the_leaf_chain(device, monkeypatch):
+    """M >= 2048 inducing points: the chunk right-solves of the streamed VFE bound go through the inverted 1024 x 1024 diagonal
+    blocks of L_uu (gpn_trsm_right_lt_blocked; ragged last block: M = 2304).  Same bound, same gradients as the recursion down
+    to the 128-wide leaf inverses (sparse_gpr.py:108-195), and the bound against the CPU oracle."""
+    from gptorch_amd.models import VFE, sparse_gpr
+    from gptorch_amd import mean_functions
+    n, m, d = 9000, 2304, 3
+    x, y = rng.make_regression(n, d, 1, seed=31)
+    z = rng.normal(32, (m, d)) * 2.0
+    res = {}
+    for name, thr in (("blocked", 2048), ("chain", 10 ** 9)):
+        monkeypatch.setattr(sparse_gpr, "BLOCKED_SOLVE_MIN_M", thr)
+        monkeypatch.setattr(sparse_gpr, "CHUNK_ROWS", 4096)
+        mod = VFE(x, y, kernels.Matern52(d, variance=1.2, length_scales=0.6), inducing_points=z, likelihood=likelihoods.Gaussian(variance=0.1),
+                  mean_function=mean_functions.Zero(1))
+        mod.cuda()
+        loss = mod.loss()
+        loss.backward()
+        res[name] = (loss.item(), {k: p.grad.clone() for k, p in mod.named_parameters() if p.grad is not None})
+    (lb, gb), (lc, gc) = res["blocked"], res["chain"]
+    assert abs(lb - lc) < 1e-10 * abs(lc), (lb, lc)
+    for k in gc:
+        assert (gb[k] - gc[k]).abs().max().item() < 1e-7 * max(1.0, gc[k].abs().max().item()), k
+    o = orc.VFEOracle(x, y, z, "Matern52", 1.2, 0.6, 0.1)
+    with torch.no_grad():
+        ref = o.log_likelihood().item()
+    assert abs(-lb - ref) < 1e-9 * abs(ref), (lb, ref)

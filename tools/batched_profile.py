@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 from gptorch_amd import _ops, rng  # noqa: E402
 what, B = sys.argv[1], int(sys.argv[2])
 n, d = (8192, 8) if what == "c2" else (512, 2)
+reps = 6 if what == "c2" else 50
 dev = torch.device("cuda:0")
 x, y = rng.make_regression(n, d, 1, seed=0)
 X, Y = torch.as_tensor(x).to(dev), torch.as_tensor(y).to(dev)
@@ -15,7 +16,7 @@ var = torch.linspace(1.0, 1.1, B, dtype=torch.float64, device=dev)
 ls = (float(np.sqrt(d)) * torch.linspace(1.0, 1.2, B, dtype=torch.float64, device=dev))[:, None]
 nz = torch.full((B,), 1e-2, dtype=torch.float64, device=dev)
 fb = None
-for it in range(6):
+for it in range(reps):
     fb, terms = _ops.lml_forward_batched("Rbf", X, Y, var, ls, nz, fb=fb)
     torch.cuda.synchronize()
 print(terms[:, 2].cpu().numpy(), fb.info.cpu().numpy())
