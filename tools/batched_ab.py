@@ -10,7 +10,7 @@ var = torch.linspace(1.0, 1.1, B, dtype=torch.float64, device=dev)
 ls = (float(np.sqrt(d)) * torch.linspace(1.0, 1.2, B, dtype=torch.float64, device=dev))[:, None]
 nz = torch.full((B,), 1e-2, dtype=torch.float64, device=dev)
 with _native.debug_library() as lib:
-    for name, v in (("shipped", 0), ("left-looking aux", 8), ("PW 1024", 8 << 8), ("PW 2048", 16 << 8), ("left + PW2048", 8 | (16 << 8)), ("shipped", 0)):
+    for name, v in (("shipped", 0), ("PW 384", 3 << 8), ("PW 512", 4 << 8), ("PW 512 left", 8 | (4 << 8)), ("PW 768", 6 << 8), ("PW 768 left", 8 | (6 << 8)), ("PW 1024", 8 << 8), ("PW 1024 left", 8 | (8 << 8)), ("PW 1536 left", 8 | (12 << 8)), ("shipped", 0)):
         lib.gpn_debug_set_potrf_variant(v)
         fb = None
         for it in range(2):
