@@ -52,7 +52,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // go to the other three SIMDs by cost: {0,7} | {1,3,5} | {2,4,6} (56 tile updates each).
 constexpr int L16_THREADS = 768;
 constexpr int TS = 18;                // row stride of the prologue's staging tiles (16-B aligned rows, conflict-free transposed reads)
-constexpr int L16_LDS_DOUBLES = 28 * 256 + 2 * 2 * 256 + 2 * 8 * 16 * 18 + 32 * 18 + 64;
+constexpr int L16_LDS_DOUBLES = 28 * 256 + 2 * 2 * 256 + 2 * 8 * 16 * 18 + 32 * 18 + 64 + 8 * 16 * 18;
 constexpr int L16_LDS_BYTES = L16_LDS_DOUBLES * 8;
 constexpr int RS = 18;                // row stride (doubles) of the row-major 16 x 16 blocks in LDS (144 B: 16-B aligned rows)
 
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
   const int64_t lda = p.lda;
   const int kb = p.kb;
 
-  // LDS (dynamic: L16_LDS_BYTES = 105 KB): everything that crosses waves lives for the whole kernel
+  // LDS (dynamic: L16_LDS_BYTES = 123 KB): everything that crosses waves lives for the whole kernel
   extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
   double* const Xall = lds_dyn;                         // [28][4][64]: X(j,k), j > k, at slot j (j - 1) / 2 + k: register dumps, read as A operands
   double* const Raw = Xall + 28 * 256;                  // [2 parity][2: A(k+1,k), D(k+1,k+1)][4][64]: raw tiles for the pivot wave
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
   double* const Lrow = Wf + 8 * 16 * RS;                // [8 blocks][16 * RS]: L_k, row-major
   double* const Drow = Lrow + 8 * 16 * RS;              // [32 * RS]: rows 0..15 the pivot wave's next block; rows 16..31 identity
   double* const Lcol = Drow + 32 * RS;                  // [64]: the pivot wave's current column, for the broadcast reads
-  double* const Tb0 = Xall;                             // prologue only: per tile wave a 16 x TS staging tile (aliases Xall)
+  double* const Tb0 = Lcol + 64;                        // prologue only: per tile wave a 16 x TS staging tile
   __shared__ int wready;                                // number of diagonal blocks whose W / L are out
   __shared__ int xready[8];                             // xready[j]: number of panels whose X(j, .) is out
   __shared__ int rawflag[8];                            // rawflag[k] != 0: the raw tiles for diagonal block k are out
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
   if (tid == 0) failflag = 0;
   if (tid < 8) { xready[tid] = 0; rawflag[tid] = 0; }
   if (tid == 8) wready = 0;
-  // (Drow's identity rows are written AFTER the prologue's staging tiles are dead: they do not alias, but keep the order simple)
   for (int idx = tid; idx < 16 * RS; idx += L16_THREADS) Drow[16 * RS + idx] = ((idx / RS) == (idx % RS)) ? 1.0 : 0.0;
+  __syncthreads();                                      // the flags and the identity rows are initialised: the ONLY barrier before the end
 
   auto bcast = [](double v, int src) -> double {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -226,12 +226,11 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
 #pragma unroll
       for (int r = 0; r < 4; ++r) dst[r * 64 + lane] = t[r];
     };
-    // (the staging tiles alias Xall: its first write is panel 0's solve, behind the barrier P below)
-    // raw tiles for the pivot wave's first steps: D(0,0) from wave 0, A(1,0) and D(1,1) from wave 1
-    if (w == 0) dump(Raw + (0 * 2 + 1) * 256, acc[0]);
+    // raw tiles for the pivot wave's first steps: D(0,0) from tile row 0, A(1,0) and D(1,1) from tile row 1 -- announced by
+    // flags, not by a barrier: the pivot wave starts when row 0's ONE tile is in, not when row 7's eight are
+    if (w == 0) { dump(Raw + (0 * 2 + 1) * 256, acc[0]); publish_flag(&rawflag[0], 1); }
     if (w == 1) { dump(Raw + (1 * 2 + 0) * 256, acc[0]); dump(Raw + (1 * 2 + 1) * 256, acc[1]); publish_flag(&rawflag[1], 1); }
     L16_TL(4, 6, tie0)
-    __syncthreads();                                                  // P
 
     // T(i,j) -= X(i,k) X(j,k)^T:  xa = X(j,k) fragments, nx = -X(i,k) (own registers)
     auto update = [&](d4& t, const d4& xa, const d4& nx) {
@@ -363,9 +362,8 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       default: tile_wave(std::integral_constant<int, 7>{}); break;
     }
   } else if (!pivotwave) {
-    // idle waves (they share the pivot wave's SIMD): the prologue barrier, and -- off everybody's critical path -- the zero
+    // idle waves (they share the pivot wave's SIMD): off everybody's critical path, the zero
     // fill of winv above the diagonal tiles (28 tiles W[16 k + ..][16 j + ..], k < j; 16 bytes per lane)
-    __syncthreads();                                                  // P
     {
       const int me = (wave == 4) ? 0 : (wave == 8) ? 1 : 2;
       int t = 0;
@@ -381,7 +379,7 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
     // ======================================= pivot wave =======================================
     __builtin_amdgcn_s_setprio(3);
     L16_TL(4, 6, tie0)
-    __syncthreads();                                                  // P
+    wait_flag(&rawflag[0], 0);                                        // D(0,0) is out (a failure leaves through the loop below)
     L16_TL(5, 6, tie0)
     double a[16];
     const int myrow = lane & 31;
@@ -454,20 +452,35 @@ __global__ __launch_bounds__(L16_THREADS) void potrf_leaf16_kernel(Leaf16Args p,
       L16_TL(k, 2, tie0)
       // (after a failed pivot nothing is announced: the waiters see failflag in their spin and leave without storing)
       if (__hip_atomic_load(&failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-      publish_flag(&wready, k + 1);                                   // W_k and L_k are out
-      if (k == 7) break;
-      if (!wait_flag(&rawflag[k + 1], 0)) break;                      // the raw tiles for block k + 1 (published one panel earlier)
-      L16_TL(k, 3, tie0)
-      // ---- next diagonal block from the raw tiles:  X = A(k+1,k) W_k^T,  D(k+1) -= X X^T
-      {
-        const int par = (k + 1) & 1;
-        d4 wf, ar, dacc;
+      // ONE LDS round trip between two blocks: the raw tiles for block k + 1 were published a panel ago, so they are read
+      // speculatively together with their flag and with my own W_k (in fragment order); the flag is checked afterwards
+      // and the reads repeated in the rare case it was not up yet.
+      const int par = (k + 1) & 1;
+      d4 wf, ar, dacc;
+      int rf = 1;
+      if (k < 7) {
+        L16_WAVE_FENCE();
+        rf = __hip_atomic_load(&rawflag[k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           wf[r] = Wf[k * (16 * RS) + RS * (g + 4 * r) + lc];
           ar[r] = Raw[(par * 2 + 0) * 256 + r * 64 + lane];
           dacc[r] = Raw[(par * 2 + 1) * 256 + r * 64 + lane];
         }
+      }
+      publish_flag(&wready, k + 1);                                   // W_k and L_k are out (waits for the LDS operations above)
+      if (k == 7) break;
+      if (rf == 0) {
+        if (!wait_flag(&rawflag[k + 1], 0)) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ar[r] = Raw[(par * 2 + 0) * 256 + r * 64 + lane];
+          dacc[r] = Raw[(par * 2 + 1) * 256 + r * 64 + lane];
+        }
+      }
+      L16_TL(k, 3, tie0)
+      // ---- next diagonal block from the raw tiles:  X = A(k+1,k) W_k^T,  D(k+1) -= X X^T
+      {
         d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[r], ar[r], x, 0, 0, 0);
