@@ -31,6 +31,7 @@ SIGNATURES = {
     "gpn_lml_forward_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                         c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "gpn_potrf_panel_width": (c_int64, [c_int64]),
+    "gpn_potrf_panel_levels": (c_int, [c_int64, c_void_p]),
     "gpn_release_stream": (c_int, [c_void_p]),
     "gpn_trtri_diag": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gpn_trsm_right_lt": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),

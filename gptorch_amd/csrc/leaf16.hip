@@ -53,7 +53,10 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr int L16_THREADS = 768;
 constexpr int TS = 18;                // row stride of the prologue's staging tiles (16-B aligned rows, conflict-free transposed reads)
 constexpr int L16_LDS_DOUBLES = 28 * 256 + 2 * 2 * 256 + 2 * 8 * 16 * 18 + 32 * 18 + 64 + 8 * 16 * 18;
-constexpr int L16_LDS_BYTES = L16_LDS_DOUBLES * 8;
+// The workgroup asks for 132 KB although it uses 123: with less than 32 KB of the CU's 160 KB left, no workgroup of the
+// contraction kernel (32 / 64 KB) or of the column kernel (33 KB) running on another stream can move in beside the leaf --
+// a co-resident wave on the pivot wave's SIMD would stall its fp64 chain (see the note on the 12 waves below).
+constexpr int L16_LDS_BYTES = (L16_LDS_DOUBLES * 8 > 132 * 1024) ? L16_LDS_DOUBLES * 8 : 132 * 1024;
 constexpr int RS = 18;                // row stride (doubles) of the row-major 16 x 16 blocks in LDS (144 B: 16-B aligned rows)
 
 struct Leaf16Args {

@@ -677,22 +677,48 @@ GPN_SWITCH g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
 // N = 16384 31.9 (1536) vs 32.2 (2048), C3 201.5 / 200.0 / 201.1, C4 1492 / 1473 / 1472; with the
 // left-looking aux update (below) the large sizes prefer 2048: C3 198.1, C4 1454 ms.
 static inline bool large_problem(int64_t n) { return n >= 24576; }
-// Panel width by size.  Round 4 (16-pivot-block leaf, 18.7 us instead of 39): the in-panel chain got cheaper, so what a
-// wide panel saves in trailing-update launches no longer pays for its K = 128 in-panel updates below N ~ 16 k.  Same-box
-// sweep, ms per evaluation (tools/potrf_ab.py n=<N>, VARIANTS=0x200..0xc00 = 256 .. 1536):
-//   N = 2048: 256 0.68 | 512 0.77 | 1536 0.81      N = 4096: 256 1.61 | 512 1.76 | 1536 1.89
-//   N = 8192: 256 5.68 | 512 5.74 | 1024 5.85 | 1536 6.03 (| 2048 6.19)
-//   N = 12288: 256 16.2 | 512 15.4 | 1024 15.5 | 1536 15.8      N = 16384: 512 31.2 | 1024 30.9 | 1536 31.4
-//   C3 (N = 32768): 1536 188.4 | 2048 188.6-188.9 | 2560 189.9 ms
-static inline int64_t panel_width(int64_t n) {
+// Nested panels (round 4).  The chain (leaf -> column solve -> K = 128 update of the next column block, plus the K = 128
+// updates of the rest of the panel on the aux stream when it is wider than 256) runs inside INNER panels of w[0]
+// columns; the update after an inner panel (K = w[0]) only reaches the end of the OUTER panel it sits in (a trapezoid:
+// all rows below, lower-only in its top square), and everything right of an outer panel is updated once, at its end,
+// with K = w[1] -- the lower-tile launch bench.py prices.  The inner width prices the chain's K = 128 work (HBM-bound
+// column passes), the outer width the C-tile traffic of the big updates: with one level C2 wanted 256-column panels
+// for the first and paid 11.5 GB of C traffic per evaluation for it (K = 256 updates of the whole trailing matrix).
+// Same-box sweeps, ms per evaluation (tools/outer_ab.py, Rbf D = 8, inner:outer):
+//   N = 2048:  256 0.606 | 256:512 0.615 | 256:1024 0.621
+//   N = 4096:  256 1.529 | 256:512 1.518 | 256:1024 1.535 | 256:2048 1.558      (x 8 in lock step: 4.89 | 4.68 | 4.65 | 4.69)
+//   N = 8192:  256 5.52 | 256:512 5.33 | 256:1024 5.34 | 256:2048 5.43 | 512:1024 5.58 | 128:1024 5.40
+//              (x 8 in lock step: 29.4 | 27.2 | 26.5 | 27.0 | 26.8 | 27.5 ms)
+//   N = 12288: 512 14.37 | 512:1024 14.3 | 512:2048 14.27 | 256:1024 13.97 | 256:2048 14.04 | 1024:2048 14.5
+//   N = 16384: 1024 29.7 | 1024:2048 29.97 | 512:1024 29.05 | 512:2048 29.3 | 256:1024 28.86 | 256:2048 29.05
+//   N = 24576: 2048 83.99 | 1024 83.9 | 512:2048 82.2 | 256:2048 81.7 | 256:1024 82.7
+//   N = 32768: 2048 184.6 | 512:2048 182.3 | 256:2048 182.7 | 256:1024 184.3 | 512:1024 184.4 | 1024:2048 184.2
+//              (a third level -- 256:1024:2048, 256:512:2048, 256:1024:4096, 512:2048:8192 -- is within 0.3 ms of 512:2048)
+// (Single level, round 4 after the leaf rewrite: N = 8192 256 5.68 | 512 5.74 | 1024 5.85 | 1536 6.03 | 2048 6.19;
+//  C3 1536 188.4 | 2048 188.6-188.9 | 2560 189.9.)
+struct PanelLevels { int n = 1; int64_t w[3] = {0, 0, 0}; };
+GPN_SWITCH g_outer_width = 0;        // 0 = by size, -1 = one level; > 0: debug overrides (tools' build)
+GPN_SWITCH g_outer_width2 = 0;
+static inline int64_t panel_width(int64_t n) {            // inner panels
   if (g_panel_width) return g_panel_width;
-  return n <= 10240 ? 256 : n < 16384 ? 512 : n < 24576 ? 1024 : 2048;
+  return n < 20480 ? 256 : 512;
+}
+static inline PanelLevels panel_levels(int64_t n) {
+  PanelLevels L;
+  L.w[0] = panel_width(n);
+  int64_t w1 = g_outer_width, w2 = g_outer_width2;
+  if (w1 == 0) w1 = n <= 2048 ? 0 : n < 20480 ? 1024 : 2048;
+  if (w1 == 2048 && w2 == 0 && n >= 49152) w2 = 4096;     // N = 65536: 512:2048 1344 | 512:2048:4096 1336 | one level of 2048: 1351 ms
+  if (w1 > L.w[0]) { L.w[L.n] = (w1 / L.w[L.n - 1]) * L.w[L.n - 1]; ++L.n; }
+  if (w2 > L.w[L.n - 1]) { L.w[L.n] = (w2 / L.w[L.n - 1]) * L.w[L.n - 1]; ++L.n; }
+  return L;
 }
 
 static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   Aux* ax = aux_for(c.s);
   if (!ax) { c.rc = GPN_E_HIP; return; }
-  const int64_t lda = c.lda, PW = panel_width(n);
+  const PanelLevels lev = panel_levels(n);
+  const int64_t lda = c.lda, PW = lev.w[0];
   const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
@@ -759,7 +785,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
     }
     const int64_t m = n + e - pend;
     const int64_t pw2 = std::min(PW, n - pend);    // width of the next panel
-    if (g_panel_lookahead && ax->s2 && pend + pw2 < n) {
+    if (g_panel_lookahead && lev.n == 1 && ax->s2 && pend + pw2 < n) {     // (A/B of the one-level schedule only)
       // ---- look-ahead: strip now, bulk on the second stream underneath the next panel's chain
       double* P = A + pend * lda + p0;
       const int64_t kp = round_up(pw, 16);
@@ -785,15 +811,26 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       continue;
     }
     if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }
-    if (pend < n) {
-      double* P = A + pend * lda + p0;             // [m, pw] solved panel below the diagonal square
+    if (pend >= n) break;
+    int l = 0;                                     // the widest level that ends here
+    while (l + 1 < lev.n && pend % lev.w[l + 1] == 0) ++l;
+    const int64_t o0 = l == 0 ? p0 : pend - lev.w[l];
+    if (l + 1 < lev.n) {
+      // below the top level: the columns up to the end of the panel one level up only (all rows below incl. the extra
+      // ones; lower-only in the top square)
+      const int64_t oend = std::min(n, (pend / lev.w[l + 1] + 1) * lev.w[l + 1]);
+      double* P = A + pend * lda + o0;
+      c.rc = cgemm(c, c.s, m, oend - pend, round_up(pend - o0, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
+    } else {
+      double* P = A + pend * lda + o0;             // [m, pend - o0] solved (outer) panel below the diagonal square
+      const int64_t kp = round_up(pend - o0, 16);
       if (c.corner || e == 0) {
-        c.rc = cgemm(c, c.s, m, m, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+        c.rc = cgemm(c, c.s, m, m, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
       } else {
         const int64_t ms = n - pend;               // matrix rows / columns left; the e extra rows: rectangular
-        c.rc = cgemm(c, c.s, ms, ms, round_up(pw, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+        c.rc = cgemm(c, c.s, ms, ms, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
         if (c.rc == GPN_OK)
-          c.rc = cgemm(c, c.s, e, ms, round_up(pw, 16), -1.0, P + ms * lda, lda, P, lda, 1.0, A + n * lda + pend, lda, 0);
+          c.rc = cgemm(c, c.s, e, ms, kp, -1.0, P + ms * lda, lda, P, lda, 1.0, A + n * lda + pend, lda, 0);
       }
     }
   }
@@ -976,7 +1013,19 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
 
 // panel width of the look-ahead driver for an n x n factorisation (what bench.py needs to count the
 // algorithmic flops of the SYRK trailing updates: one lower-tile K = width contraction per panel)
-extern "C" int64_t gpn_potrf_panel_width(int64_t n) { return (g_potrf_variant == 1 || n <= 2 * LEAF) ? 0 : panel_width(n); }
+extern "C" int64_t gpn_potrf_panel_width(int64_t n) {
+  if (g_potrf_variant == 1 || n <= 2 * LEAF) return 0;
+  const PanelLevels L = panel_levels(n);
+  return L.w[L.n - 1];
+}
+extern "C" int gpn_potrf_panel_levels(int64_t n, int64_t* widths3) {
+  if (!widths3) return -2;
+  widths3[0] = widths3[1] = widths3[2] = 0;
+  if (g_potrf_variant == 1 || n <= 2 * LEAF) return 0;
+  const PanelLevels L = panel_levels(n);
+  for (int i = 0; i < L.n; ++i) widths3[i] = L.w[i];
+  return L.n;
+}
 
 // The library keeps one low-priority helper stream + a few events per caller stream that has run a
 // factorisation (created on first use).  A caller that destroys a stream releases them here, so a
@@ -1038,6 +1087,7 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_chain_kernel = 1 ^ ((v >> 6) & 3);                                   // bit 6: the chain's solve through the generic contraction; bit 7: its next-column update through colpanel.hip
   return GPN_OK;
 }
+extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; }
 
 // diagnostic build of the leaf with s_memtime stamps (not part of the public header):
 // diag[wave*8 + k] = cycles summed over the pivot blocks in segment k

@@ -118,9 +118,12 @@ int gpn_potrf_lower_batched(void* stream, double* A, int64_t n, int64_t e, int64
 int gpn_lml_reduce_batched(void* stream, const double* A, int64_t n, int64_t e, int64_t lda, int64_t sA,
                            double* out3, int batch);
 
-/* Panel width the driver uses for an n x n factorisation (0 = the recursive driver): each panel ends
+/* (Outer) panel width the driver uses for an n x n factorisation (0 = the recursive driver): each such panel ends
  * with one lower-tile K = width contraction -- the SYRK trailing update priced by bench.py. */
 int64_t gpn_potrf_panel_width(int64_t n);
+/* All nesting levels of the driver's panels, innermost first (potrf.hip panel_levels): widths3[0] = the inner panels
+ * the leaf chain runs in, widths3[count-1] = gpn_potrf_panel_width(n); returns the count (0 = the recursive driver). */
+int gpn_potrf_panel_levels(int64_t n, int64_t* widths3);
 /* Release the helper streams/events the library keeps for `stream` (created by the first
  * factorisation / distributed evaluation enqueued on it); call before destroying the stream.
  * NULL = release all. */
