@@ -527,9 +527,11 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
 #ifdef GPN_DEBUG_SWITCHES
 static thread_local int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
 static thread_local int g_group_h = 0;       // 0 = from GPN_GEMM_GROUP_H at first use (default 8): A/B of the grouped tile order's L2 reuse
+static thread_local int g_big_tile_min_trapezoid = 4096;   // trapezoid launches (nested panels): 128x128 tiles from this many of them
 static thread_local int g_split_tail = 0;    // 1 = the partial last round of a big lower-tile launch as quarter tiles (measured neutral: off)
 #else
 static constexpr int g_gemm_variant = 0;
+static constexpr int g_big_tile_min_trapezoid = 4096;
 static constexpr int g_group_h = 8;
 static constexpr int g_split_tail = 0;
 #endif
@@ -606,7 +608,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   // N = 8192 3.02 (64) vs 3.12 ms (128), N = 12288 10.3 vs 9.8, N = 16384 25.3 vs 22.7; the
   // triangular inversion's rectangular products stay on 64x64 tiles up to N = 16384 (28.0 vs 29.2 ms).
   const bool small = tri ? !(K >= 8192 && t128 >= (lower ? 4096 : 8192) && M > 64 && N > 64)
-                         : !(K >= 512 && t128 >= 4096 && M > 64 && N > 64);
+                         : !(K >= 512 && t128 >= (lower == 2 ? g_big_tile_min_trapezoid : 4096) && M > 64 && N > 64);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
     // the whole N and K extent of its rows -- a workgroup only stores after its last load
@@ -681,6 +683,7 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
 }
 
 #ifdef GPN_DEBUG_SWITCHES
+extern "C" int gpn_debug_set_big_tile_min_trapezoid(int t) { gpn::g_big_tile_min_trapezoid = t; return GPN_OK; }
 extern "C" int gpn_debug_set_gemm_variant(int v) {     // (libgpnative_dbg.so only; the calling thread's launches)
   gpn::g_gemm_variant = v & 0x7f;
   gpn::g_split_tail = (v & 0x80) ? 1 : 0;   // bit 7: quarter-tile launch for the partial last round of big lower-tile launches

@@ -639,6 +639,7 @@ struct Aux {
   hipEvent_t chain_done = nullptr, bulk_done = nullptr;
   hipEvent_t solve[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t rest[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t extra_go = nullptr, extra_done = nullptr;   // the extra rows' share of an outer panel's trailing update (aux stream)
 };
 static std::mutex g_aux_mutex;
 static std::unordered_map<hipStream_t, Aux> g_aux;
@@ -657,6 +658,8 @@ static Aux* aux_for(hipStream_t s) {
   if (hipEventCreateWithFlags(&a.chain_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.bulk_done, hipEventDisableTiming) != hipSuccess) return nullptr;
 #endif
+  if (hipEventCreateWithFlags(&a.extra_go, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.extra_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   for (int i = 0; i < 4; ++i) {
     if (hipEventCreateWithFlags(&a.solve[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.rest[i], hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -666,7 +669,68 @@ static Aux* aux_for(hipStream_t s) {
   return &g_aux.emplace(s, a).first->second;
 }
 
+// The extra rows' share of an outer panel's trailing update: R[e, ms] -= Pe[e, K] P[ms, K]^T, where P = the solved
+// panel's rows below its diagonal square, Pe = P + ms * lda its e extra rows (right-hand sides carried through the
+// factorisation) and R the extra rows right of the panel.  As tiles of the lower-tile launch those e rows are one more
+// 128-row tile row of full-price MFMA work (1 % of C3's trailing updates, 4 % of C2's in a lock-step batch); here they
+// are e dot products per matrix row, on the aux stream underneath that launch.  One wave per 4 matrix rows.
+constexpr int XR_MAXE = 8;
+template <int E>
+__global__ __launch_bounds__(256) void extra_rows_update_kernel(const double* P, double* R, int64_t lda, int ms, int K, int e, int64_t sA) {
+  P += (int64_t)blockIdx.y * sA;
+  R += (int64_t)blockIdx.y * sA;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = (blockIdx.x * 4 + wave) * 4;
+  if (j0 >= ms) return;
+  const double* Pe = P + (int64_t)ms * lda;
+  const double* rows[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rows[r] = P + (int64_t)min(j0 + r, ms - 1) * lda;
+  double acc[4][E];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < E; ++q) acc[r][q] = 0.0;
+  for (int k = 2 * lane; k < K; k += 128) {
+    double2 v[4], pe[E];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = *reinterpret_cast<const double2*>(rows[r] + k);
+#pragma unroll
+    for (int q = 0; q < E; ++q) pe[q] = q < e ? *reinterpret_cast<const double2*>(Pe + (int64_t)q * lda + k) : double2{0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < E; ++q) acc[r][q] = fma(v[r].y, pe[q].y, fma(v[r].x, pe[q].x, acc[r][q]));
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      double t = acc[r][q];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      acc[r][q] = t;
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < E; ++q)
+        if (j0 + r < ms && q < e) R[(int64_t)q * lda + j0 + r] -= acc[r][q];
+  }
+}
+static int extra_rows_update(hipStream_t s, const double* P, double* R, int64_t lda, int64_t ms, int64_t K, int64_t e, int batch, int64_t sA) {
+  const dim3 grid((unsigned)((ms + 15) / 16), (unsigned)batch);
+  if (e <= 1) hipLaunchKernelGGL(extra_rows_update_kernel<1>, grid, dim3(256), 0, s, P, R, lda, (int)ms, (int)K, (int)e, sA);
+  else if (e <= 2) hipLaunchKernelGGL(extra_rows_update_kernel<2>, grid, dim3(256), 0, s, P, R, lda, (int)ms, (int)K, (int)e, sA);
+  else if (e <= 4) hipLaunchKernelGGL(extra_rows_update_kernel<4>, grid, dim3(256), 0, s, P, R, lda, (int)ms, (int)K, (int)e, sA);
+  else hipLaunchKernelGGL(extra_rows_update_kernel<XR_MAXE>, grid, dim3(256), 0, s, P, R, lda, (int)ms, (int)K, (int)e, sA);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
 GPN_SWITCH g_panel_width = 0;        // 0 = by size; debug override
+GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row of the lower-tile launch (A/B)
 // look-ahead over PANELS (A/B, tools' build only): after panel p only the strip of the trailing update that panel p+1 lives in
 // runs on the caller's stream; the rest goes to a second lowest-priority stream, capped to g_bulk_pad KiB of extra LDS per
 // workgroup (= fewer workgroups per CU, so that the chain's kernels always find room), underneath panel p+1's chain
@@ -722,9 +786,10 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
-  bool rest_pending = false, bulk_pending = false;
+  bool rest_pending = false, bulk_pending = false, extra_pending = false;
   for (int64_t p0 = 0; p0 < n && c.rc == GPN_OK; p0 += PW) {
     const int64_t pw = std::min(PW, n - p0), pend = p0 + pw;
+    if (extra_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->extra_done, 0)); extra_pending = false; }   // the extra rows of this panel's columns
     for (int64_t k0 = p0; k0 < pend && c.rc == GPN_OK; k0 += LEAF, ++step) {
       const int64_t kb = std::min<int64_t>(LEAF, n - k0);
       const int64_t c1 = k0 + kb;                 // first row/column after this block
@@ -824,7 +889,18 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
     } else {
       double* P = A + pend * lda + o0;             // [m, pend - o0] solved (outer) panel below the diagonal square
       const int64_t kp = round_up(pend - o0, 16);
-      if (c.corner || e == 0) {
+      // (pays from N ~ 16 k: the fork / join is ~25 us per outer panel -- C2 5.36 -> 5.53 ms with it, x 8 in lock step
+      //  neutral, C3 182.4 -> 181.3 ms)
+      if (e > 0 && e <= XR_MAXE && g_extra_rows_kernel && n >= 16384 && (lda & 1) == 0 && (o0 & 1) == 0) {
+        // matrix rows: lower-tile square here; the few extra rows: dot products on the aux stream underneath it
+        const int64_t ms = n - pend;
+        hip_ok(hipEventRecord(ax->extra_go, c.s));
+        hip_ok(hipStreamWaitEvent(ax->s1, ax->extra_go, 0));
+        c.rc = cgemm(c, c.s, ms, ms, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+        if (c.rc == GPN_OK) c.rc = extra_rows_update(ax->s1, P, A + n * lda + pend, lda, ms, kp, e, c.batch, c.sA);
+        hip_ok(hipEventRecord(ax->extra_done, ax->s1));
+        extra_pending = true;
+      } else if (c.corner || e == 0) {
         c.rc = cgemm(c, c.s, m, m, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
       } else {
         const int64_t ms = n - pend;               // matrix rows / columns left; the e extra rows: rectangular
@@ -834,6 +910,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       }
     }
   }
+  if (extra_pending) hip_ok(hipStreamWaitEvent(c.s, ax->extra_done, 0));     // (error exits: nothing of this call stays in flight unordered)
 }
 
 // U_ii <- W_ii^T for every LEAF x LEAF diagonal block
@@ -1038,6 +1115,8 @@ extern "C" int gpn_release_stream(void* stream) {
     if (a.s2) { (void)hipStreamSynchronize(a.s2); (void)hipStreamDestroy(a.s2); }
     if (a.chain_done) (void)hipEventDestroy(a.chain_done);
     if (a.bulk_done) (void)hipEventDestroy(a.bulk_done);
+    if (a.extra_go) (void)hipEventDestroy(a.extra_go);
+    if (a.extra_done) (void)hipEventDestroy(a.extra_done);
     for (int i = 0; i < 4; ++i) {
       if (a.solve[i]) (void)hipEventDestroy(a.solve[i]);
       if (a.rest[i]) (void)hipEventDestroy(a.rest[i]);
@@ -1087,6 +1166,7 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_chain_kernel = 1 ^ ((v >> 6) & 3);                                   // bit 6: the chain's solve through the generic contraction; bit 7: its next-column update through colpanel.hip
   return GPN_OK;
 }
+extern "C" int gpn_debug_set_extra_rows(int on) { g_extra_rows_kernel = on; return GPN_OK; }
 extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; }
 
 // diagnostic build of the leaf with s_memtime stamps (not part of the public header):

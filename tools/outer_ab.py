@@ -18,8 +18,11 @@ fb1 = fbB = None
 for rep in range(2):
     for pair in sys.argv[3:]:
         pw, ow, fl, ow2 = ([int(v, 0) for v in pair.split(":")] + [0, 0])[:4]      # PW:W1[:variant bits, e.g. 0x20 = right-looking in-panel[:W2]]
-        lib.gpn_debug_set_potrf_variant(((pw // 128) << 8) | fl)
+        lib.gpn_debug_set_potrf_variant(((pw // 128) << 8) | (fl & 0xffff))
         lib.gpn_debug_set_outer_width(ow, ow2)
+        lib.gpn_debug_set_extra_rows(0 if (fl & 0x10000) else 1)     # flag 0x10000: the extra rows as a tile row of the big update
+        fl &= 0xffff
+        lib.gpn_debug_set_big_tile_min_trapezoid(int(os.environ.get('TRAP_MIN', '4096')))
         res = []
         for nb in ((1, B) if B > 1 else (1,)):
             fb = fb1 if nb == 1 else fbB
