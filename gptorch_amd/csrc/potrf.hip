@@ -639,7 +639,8 @@ struct Aux {
   hipEvent_t chain_done = nullptr, bulk_done = nullptr;
   hipEvent_t solve[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t rest[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t extra_go = nullptr, extra_done = nullptr;   // the extra rows' share of an outer panel's trailing update (aux stream)
+  hipEvent_t extra_go = nullptr, extra_done = nullptr;
+  hipEvent_t trap_go = nullptr, trap_done = nullptr;     // the part of an inner panel's update beyond the next inner panel (second aux stream)   // the extra rows' share of an outer panel's trailing update (aux stream)
 };
 static std::mutex g_aux_mutex;
 static std::unordered_map<hipStream_t, Aux> g_aux;
@@ -655,6 +656,8 @@ static Aux* aux_for(hipStream_t s) {
   if (hipStreamCreateWithPriority(&a.s1, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
 #ifdef GPN_DEBUG_SWITCHES
   if (hipStreamCreateWithPriority(&a.s2, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.trap_go, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.trap_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.chain_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.bulk_done, hipEventDisableTiming) != hipSuccess) return nullptr;
 #endif
@@ -730,6 +733,10 @@ static int extra_rows_update(hipStream_t s, const double* P, double* R, int64_t 
 }
 
 GPN_SWITCH g_panel_width = 0;        // 0 = by size; debug override
+// A/B (tools' build): an inner panel's update beyond the next inner panel on the second aux stream, underneath that panel's
+// chain.  Measured neutral (C3 181.4 -> 180.8 ms, N = 16384 28.63 -> 28.77, C2 5.37 -> 5.56): the chain's kernels slow down
+// by what the overlap saves, and each fork / join costs ~25 us.  Off.
+GPN_SWITCH g_inner_lookahead = 0;
 GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row of the lower-tile launch (A/B)
 // look-ahead over PANELS (A/B, tools' build only): after panel p only the strip of the trailing update that panel p+1 lives in
 // runs on the caller's stream; the rest goes to a second lowest-priority stream, capped to g_bulk_pad KiB of extra LDS per
@@ -786,7 +793,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
-  bool rest_pending = false, bulk_pending = false, extra_pending = false;
+  bool rest_pending = false, bulk_pending = false, extra_pending = false, trap_pending = false;
   for (int64_t p0 = 0; p0 < n && c.rc == GPN_OK; p0 += PW) {
     const int64_t pw = std::min(PW, n - p0), pend = p0 + pw;
     if (extra_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->extra_done, 0)); extra_pending = false; }   // the extra rows of this panel's columns
@@ -876,6 +883,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       continue;
     }
     if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }
+    if (trap_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->trap_done, 0)); trap_pending = false; }   // it wrote the columns updated next
     if (pend >= n) break;
     int l = 0;                                     // the widest level that ends here
     while (l + 1 < lev.n && pend % lev.w[l + 1] == 0) ++l;
@@ -885,7 +893,22 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       // ones; lower-only in the top square)
       const int64_t oend = std::min(n, (pend / lev.w[l + 1] + 1) * lev.w[l + 1]);
       double* P = A + pend * lda + o0;
-      c.rc = cgemm(c, c.s, m, oend - pend, round_up(pend - o0, 16), -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
+      const int64_t kp = round_up(pend - o0, 16), ncols = oend - pend;
+      const bool ahead = l == 0 && ncols > PW && g_inner_lookahead != 0 && ax->s2;
+      if (!ahead) {
+        c.rc = cgemm(c, c.s, m, ncols, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
+      } else {
+        // look-ahead inside the outer panel: the next inner panel's columns here, the columns beyond them on the second
+        // aux stream underneath that panel's chain (joined before the next update of those columns is launched)
+        hip_ok(hipEventRecord(ax->trap_go, c.s));
+        hip_ok(hipStreamWaitEvent(ax->s2, ax->trap_go, 0));
+        c.rc = cgemm(c, c.s, m, PW, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
+        if (c.rc == GPN_OK)
+          c.rc = cgemm(c, ax->s2, m - PW, ncols - PW, kp, -1.0, P + PW * lda, lda, P + PW * lda, lda, 1.0,
+                       A + (pend + PW) * lda + pend + PW, lda, 2);
+        hip_ok(hipEventRecord(ax->trap_done, ax->s2));
+        trap_pending = true;
+      }
     } else {
       double* P = A + pend * lda + o0;             // [m, pend - o0] solved (outer) panel below the diagonal square
       const int64_t kp = round_up(pend - o0, 16);
@@ -910,6 +933,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       }
     }
   }
+  if (trap_pending) hip_ok(hipStreamWaitEvent(c.s, ax->trap_done, 0));
   if (extra_pending) hip_ok(hipStreamWaitEvent(c.s, ax->extra_done, 0));     // (error exits: nothing of this call stays in flight unordered)
 }
 
@@ -1117,6 +1141,8 @@ extern "C" int gpn_release_stream(void* stream) {
     if (a.bulk_done) (void)hipEventDestroy(a.bulk_done);
     if (a.extra_go) (void)hipEventDestroy(a.extra_go);
     if (a.extra_done) (void)hipEventDestroy(a.extra_done);
+    if (a.trap_go) (void)hipEventDestroy(a.trap_go);
+    if (a.trap_done) (void)hipEventDestroy(a.trap_done);
     for (int i = 0; i < 4; ++i) {
       if (a.solve[i]) (void)hipEventDestroy(a.solve[i]);
       if (a.rest[i]) (void)hipEventDestroy(a.rest[i]);
@@ -1167,6 +1193,7 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
   return GPN_OK;
 }
 extern "C" int gpn_debug_set_extra_rows(int on) { g_extra_rows_kernel = on; return GPN_OK; }
+extern "C" int gpn_debug_set_inner_lookahead(int v) { g_inner_lookahead = v; return GPN_OK; }
 extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; }
 
 // diagnostic build of the leaf with s_memtime stamps (not part of the public header):
