@@ -44,6 +44,9 @@ int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, in
 // A + b sA, winv + b sW, info + b sInfo
 int leaf16(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* winv, int32_t* info, int batch, int64_t sA,
            int64_t sW, int64_t sInfo);
+// one chain step as one launch (leaf16.hip): the next leaf (diagonal block at Anext) next to the column work of this step
+int chain_step(hipStream_t s, double* Anext, int64_t lda, int col0, double* Wnext, int32_t* info, double* B, const double* W,
+               const double* Xtop, double* C, int64_t m, int batch, int64_t sA, int64_t sW, int64_t sInfo);
 int leaf16_timing(hipStream_t s, double* A, int64_t lda, double* winv, int32_t* info, unsigned long long* diag72);
 
 // `batch` problems of identical shape at constant strides (elements) in one launch

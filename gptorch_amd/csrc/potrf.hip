@@ -737,6 +737,13 @@ GPN_SWITCH g_panel_width = 0;        // 0 = by size; debug override
 // chain.  Measured neutral (C3 181.4 -> 180.8 ms, N = 16384 28.63 -> 28.77, C2 5.37 -> 5.56): the chain's kernels slow down
 // by what the overlap saves, and each fork / join costs ~25 us.  Off.
 GPN_SWITCH g_inner_lookahead = 0;
+// A/B (tools' build): chain steps as [solve of the 128 rows under the diagonal block] [next diagonal block's update] [ONE launch:
+// the next leaf next to the solve + next-column update of all rows below] (leaf16.hip chain_step).  Correct (same LML to 1e-14,
+// lock-step batches bit-identical) and SLOWER: C3 180.8 -> 185.1 ms, N = 16384 28.7 -> 28.9, C2 x 8 26.5 -> 27.1 ms.  Timeline
+// (profiles/r4_fused_step_timeline.txt): the two four-workgroup launches cost 8 + 13 us, and the fused launch 66-80 us at
+// m = 30 k (one 768-thread workgroup per CU, three dependent memory round trips per 32-row tile, nothing to overlap them
+// with) against 20 + 18 + 15 us for leaf, solve and update as separate launches.  Off.
+GPN_SWITCH g_fused_steps = 0;
 GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row of the lower-tile launch (A/B)
 // look-ahead over PANELS (A/B, tools' build only): after panel p only the strip of the trailing update that panel p+1 lives in
 // runs on the caller's stream; the rest goes to a second lowest-priority stream, capped to g_bulk_pad KiB of extra LDS per
@@ -793,6 +800,8 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
+  int64_t leaf_done = -1;                          // the diagonal block a fused step has already factored
+  const bool fused_steps = g_fused_steps != 0;
   bool rest_pending = false, bulk_pending = false, extra_pending = false, trap_pending = false;
   for (int64_t p0 = 0; p0 < n && c.rc == GPN_OK; p0 += PW) {
     const int64_t pw = std::min(PW, n - p0), pend = p0 + pw;
@@ -802,12 +811,55 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       const int64_t c1 = k0 + kb;                 // first row/column after this block
       double* Akk = A + k0 * lda + k0;
       const double* Wk = c.winv + (k0 / LEAF) * (LEAF * LEAF);
-      const int rec = profile_on() ? profile_begin(c.s, c.batch * 2.0 * LEAF * LEAF * LEAF / 3.0, PROF_LEAF) : -1;
-      { const int lrc = launch_leaf(c.s, Akk, lda, (int)kb, (int)k0, const_cast<double*>(Wk), c.info, c.batch, c.sA, c.sW, 1); if (c.rc == GPN_OK) c.rc = lrc; }
-      if (rec >= 0) profile_end(c.s, rec);
+      if (leaf_done != k0) {
+        const int rec = profile_on() ? profile_begin(c.s, c.batch * 2.0 * LEAF * LEAF * LEAF / 3.0, PROF_LEAF) : -1;
+        { const int lrc = launch_leaf(c.s, Akk, lda, (int)kb, (int)k0, const_cast<double*>(Wk), c.info, c.batch, c.sA, c.sW, 1); if (c.rc == GPN_OK) c.rc = lrc; }
+        if (rec >= 0) profile_end(c.s, rec);
+      }
       const int64_t m = n + e - c1;                // rows below (incl. the extra rows)
       if (m <= 0 || c.rc != GPN_OK) continue;
       double* B = A + c1 * lda + k0;               // [m, kb] <- B W_k^T   (in place)
+#ifdef GPN_DEBUG_SWITCHES
+      if (fused_steps && kb == LEAF && c1 + LEAF <= pend && m > LEAF && g_leaf_gen == 2 && (g_chain_kernel & 1)) {
+        // ---- the step as three launches: the 128 rows under the diagonal block (solve, next diagonal block), then ONE
+        // launch with leaf(k+1) next to the solve + next-column update of all rows below (leaf16.hip chain_step)
+        const int64_t c2 = c1 + LEAF;
+        c.rc = ccolpanel(c, c.s, 0, LEAF, LEAF, B, lda, Wk, LEAF, B, lda);
+        if (rest_pending) {                        // column block c1 was last written on the aux stream
+          hip_ok(hipStreamWaitEvent(c.s, ax->rest[rest_idx], 0));
+          rest_pending = false;
+        }
+        if (c.rc == GPN_OK) c.rc = ccolpanel(c, c.s, 1, LEAF, LEAF, B, lda, B, lda, A + c1 * lda + c1, lda);
+        if (c.rc == GPN_OK) {
+          const int rec = profile_on() ? profile_begin(c.s, c.batch * (2.0 * LEAF * LEAF * LEAF / 3.0 + 3.0 * (m - LEAF) * LEAF * LEAF), PROF_GEMM_SOLVE) : -1;
+          c.rc = chain_step(c.s, A + c1 * lda + c1, lda, (int)c1, c.winv + (c1 / LEAF) * (LEAF * LEAF), c.info, A + c2 * lda + k0, Wk, B,
+                            A + c2 * lda + c1, m - LEAF, c.batch, c.sA, c.sW, 1);
+          if (rec >= 0) profile_end(c.s, rec);
+        }
+        leaf_done = c1;
+        if (c.rc != GPN_OK) continue;
+        const bool fork = c2 < pend;
+        if (fork) hip_ok(hipEventRecord(ax->solve[step & 3], c.s));
+        if (fork) {
+          hip_ok(hipStreamWaitEvent(ax->s1, ax->solve[step & 3], 0));
+          const int64_t m2 = n + e - c2;
+          if (!left_looking) {
+            c.rc = cgemm(c, ax->s1, m2, pend - c2, kb, -1.0, A + c2 * lda + k0, lda, A + c2 * lda + k0, lda, 1.0,
+                           A + c2 * lda + c2, lda, 0);
+          } else {
+            const int64_t nb2 = std::min<int64_t>(LEAF, pend - c2);
+            c.rc = cgemm(c, ax->s1, m2, nb2, c1 - p0, -1.0, A + c2 * lda + p0, lda, A + c2 * lda + p0, lda, 1.0,
+                           A + c2 * lda + c2, lda, 0);
+          }
+          rest_idx = step & 3;
+          hip_ok(hipEventRecord(ax->rest[rest_idx], ax->s1));
+          rest_pending = true;
+        }
+        continue;
+      }
+#else
+      (void)fused_steps;
+#endif
       if (g_chain_kernel & 1) c.rc = ccolpanel(c, c.s, 0, m, kb, B, lda, Wk, LEAF, B, lda);
       else if (c.batch == 1) c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
       else c.rc = gemm_nt_strided(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, 1, c.batch, c.sA, c.sW, c.sA);
@@ -1192,6 +1244,7 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_chain_kernel = 1 ^ ((v >> 6) & 3);                                   // bit 6: the chain's solve through the generic contraction; bit 7: its next-column update through colpanel.hip
   return GPN_OK;
 }
+extern "C" int gpn_debug_set_fused_steps(int v) { g_fused_steps = v; return GPN_OK; }
 extern "C" int gpn_debug_set_extra_rows(int on) { g_extra_rows_kernel = on; return GPN_OK; }
 extern "C" int gpn_debug_set_inner_lookahead(int v) { g_inner_lookahead = v; return GPN_OK; }
 extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; }
