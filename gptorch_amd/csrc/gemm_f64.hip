@@ -123,7 +123,7 @@ __device__ __forceinline__ void lower_tile_of_index(int q, int mt, int& ti, int&
 }
 
 template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, bool PIPE = false>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), ((BM / WM) * (BN / WN) > 8 ? 1 : 2)) void gemm_nt_kernel(GemmArgs p) {
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int WAVES_N = BN / WN;
   constexpr int BK = 16;
@@ -193,6 +193,15 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(
     ti = 2 * pi + ((idx >> 1) & 1);
     tj = 2 * pj + (idx & 1);
     if (tj > ti || ti >= p.mt) return;        // the upper-right quarter of a diagonal parent; a ragged parent's empty half
+  } else if (p.lower == 5) {
+    // (A/B: 2:1 macro tiles) lower-tile square with BM = 2 BN: the two column halves of the BM x BM parent tiles of the
+    // grouped lower order, consecutive logical ids (one XCD: they share the parent's row panel)
+    const int idx = xcd_remap(bid, nwg);
+    int pi, pj;
+    lower_tile_of_index(idx >> 1, p.mt, pi, pj, p.group_h);
+    ti = pi;
+    tj = 2 * pj + (idx & 1);
+    if (tj * BN >= p.N) return;
   } else if (p.lower) tile_of_block_lower(bid, nwg, p.mt, spread, ti, tj, p.group_h);
   else tile_of_block(bid, nwg, p.mt, p.nt, spread, ti, tj, p.group_h);
 
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), 2) void gemm_nt_kernel(
 
   // epilogue: reg r of lane l is C[(l>>4) + 4r][l&15] of its 16x16 tile
   const int crow = lane >> 4, ccol = lane & 15;
-  const bool diag_tile = p.lower == 3 ? stair_diag_tile : (p.lower && (ti == tj));     // (lower == 4 included)
+  const bool diag_tile = p.lower == 3 ? stair_diag_tile : p.lower == 5 ? (ti == (tj >> 1)) : (p.lower && (ti == tj));     // (lower == 4 included)
   // beta != 0: ALL loads of one row of 16x16 tiles are issued before the first use (one HBM
   // round trip per TN*4 elements); element-by-element load -> fma -> store serialises 16+ round
   // trips per tile, which is most of the run time of a K = 128 update
@@ -497,6 +506,7 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   const int grid = (a.lower == 3   ? (int)stair_tiles(a.M, a.N, a.st_blk, a.st_step, a.st_diag, BM)
                     : a.lower == 2 ? (a.mt - a.nt) * a.nt + a.nt * (a.nt + 1) / 2
                     : a.lower == 4 ? 4 * a.q_cnt
+                    : a.lower == 5 ? a.mt * (a.mt + 1)
                     : a.lower      ? (a.q_cnt > 0 ? a.q_cnt : a.mt * (a.mt + 1) / 2) : a.mt * a.nt) * std::max(1, a.batch);
   if (grid <= 0) return GPN_OK;
   const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + (g_smem_pad + a.lds_pad_kb) * 1024;
@@ -514,8 +524,9 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
     const double tiles = (a.lower == 3   ? (double)stair_tiles(a.M, a.N, a.st_blk, a.st_step, a.st_diag, BM)
                           : a.lower == 2 ? (double)(a.mt - a.nt) * a.nt + 0.5 * a.nt * (a.nt + 1.0)
                           : a.lower == 4 ? 4.0 * a.q_cnt
+                          : a.lower == 5 ? (double)a.mt * (a.mt + 1.0)
                           : a.lower      ? (a.q_cnt > 0 ? (double)a.q_cnt : 0.5 * a.mt * (a.mt + 1.0)) : (double)a.mt * a.nt) * std::max(1, a.batch);
-    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : ((a.lower == 1 || a.lower == 4) ? PROF_GEMM_SYRK : PROF_GEMM));
+    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : ((a.lower == 1 || a.lower == 4 || a.lower == 5) ? PROF_GEMM_SYRK : PROF_GEMM));
     rec = profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K, cls);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), smem, s, a);
@@ -625,6 +636,17 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   if (g_gemm_variant == 9) return launch<128, 128, 64, 32, true, 2, false, true>(s, a);   // 8 waves x (64x32), pipelined
   if (g_gemm_variant == 10) return launch<128, 128, 64, 32, true, 2, false, false>(s, a); // 8 waves x (64x32), plain loop
   if (g_gemm_variant == 11) return launch<128, 128, 32, 64, true, 2, false, true>(s, a);  // 8 waves x (32x64), pipelined
+#ifdef GPN_DEBUG_SWITCHES
+  // round-3 review item 8: a 256 x 128 macro tile (16 waves of 32 x 64, ONE workgroup / CU, 96 KB LDS: 25 % fewer operand
+  // bytes per flop from L2) against the 128 x 128 tile, both with the plain K loop (the pipelined loop needs whole LDS-DMA
+  // pieces per MFMA group: 3 pieces per wave here)
+  if (g_gemm_variant == 12) return launch<128, 128, 32, 64, true, 2, false, false>(s, a);
+  if (g_gemm_variant == 13) {
+    if (a.lower == 1 && !a.tri && a.batch == 1) a.lower = 5;
+    else if (a.lower) return GPN_E_UNSUPPORTED;
+    return launch<256, 128, 32, 64, true, 2, false, false>(s, a);
+  }
+#endif
   // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
   // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
   // 21: A/B of whole workloads (tools/workload_ab.py): the shipped dispatch with the 4-wave 128x128 kernel

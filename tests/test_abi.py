@@ -199,3 +199,21 @@ def test_gemv_scratch_size_is_monotone_in_the_width():
                 wgs = (cols + 255) // 256
                 chunks = max(1, min((1024 + wgs - 1) // wgs, (rows + 31) // 32))
                 assert lib.gpn_gemv_t_work_bytes(rows, cols, dy) >= chunks * min(dy, 2) * cols * 8
+
+
+def test_panel_levels_nest_and_end_at_the_priced_width():
+    """gpn_potrf_panel_levels: widths ascend, each divides the next, all are multiples of the 128-wide leaf, and the last one is
+    gpn_potrf_panel_width (the lower-tile update bench.py prices); sizes the recursive driver takes report no levels."""
+    import ctypes
+    from gptorch_amd import _native
+    lib = _native.lib()
+    w = (ctypes.c_int64 * 3)()
+    assert lib.gpn_potrf_panel_levels(256, None) == -2
+    assert lib.gpn_potrf_panel_levels(256, ctypes.cast(w, ctypes.c_void_p)) == 0 and lib.gpn_potrf_panel_width(256) == 0
+    for n, expect in ((1000, [256]), (2048, [256]), (4096, [256, 1024]), (8192, [256, 1024]), (16384, [256, 1024]),
+                      (32768, [512, 2048]), (65536, [512, 2048, 4096])):
+        cnt = lib.gpn_potrf_panel_levels(n, ctypes.cast(w, ctypes.c_void_p))
+        got = [int(w[i]) for i in range(cnt)]
+        assert got == expect, (n, got)
+        assert all(v % 128 == 0 for v in got) and all(b % a == 0 and b > a for a, b in zip(got, got[1:]))
+        assert lib.gpn_potrf_panel_width(n) == got[-1]

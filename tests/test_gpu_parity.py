@@ -215,25 +215,41 @@ def test_functions_are_differentiable(device, n):
             ).abs().max().item() < 1e-10
 
 
-@pytest.mark.parametrize("n,e", [(1152, 0), (2500, 3), (8320, 1), (9001, 2)])
+@pytest.mark.parametrize("n,e", [(1152, 0), (2500, 3), (8320, 1), (9001, 2), (16640, 2), (20608, 5)])
 def test_factorisation_drivers_agree(device, n, e):
-    """the look-ahead panel driver (default), its left-looking form (default from N = 24576) and the
-    plain recursion produce the same factor, extra rows and leaf inverses on multi-panel and
-    ragged sizes."""
+    """the nested-panel driver (default: 256-wide inner panels in 1024-wide outer ones below N = 20480, 512 in 2048 above;
+    from N = 16384 the extra rows' share of an outer panel's update as dot products on the aux stream), its one-level and
+    three-level forms, its left-looking in-panel form and the plain recursion produce the same factor, extra rows and
+    leaf inverses on multi-panel and ragged sizes."""
     from gptorch_amd import _native, _ops
     lib = _native.lib()
     x = torch.tensor(rng.normal(5, (n, 6)), device=device)
     one = torch.ones(1, dtype=torch.float64, device=device)
     R = torch.tensor(rng.normal(6, (n, max(e, 1)))[:, :e], device=device) if e else None
     out = []
-    for variant in (1, 0, 8, 0x408):     # recursion | look-ahead (default) | left-looking aux update | + 512-wide panels
-        _native.debug_begin().gpn_debug_set_potrf_variant(variant)
+    # (potrf variant bits, outer width, second outer width, extra-rows kernel)
+    variants = [(1, 0, 0, 1),            # plain recursion
+                (0, 0, 0, 1),            # default
+                (0, 0, 0, 0),            # the extra rows as a tile row of the lower-tile launches
+                (8, 0, 0, 1),            # left-looking aux update
+                (0x408, -1, 0, 1),       # ONE level of 512-wide panels, left-looking
+                (0x200, 512, 2048, 1),   # three levels: 256 in 512 in 2048
+                (0x100, 384, 0, 1)]      # 128 in 384 (outer panels that do not divide N)
+    for variant, w1, w2, xr in variants:
+        dbg = _native.debug_begin()
+        dbg.gpn_debug_set_potrf_variant(variant)
+        dbg.gpn_debug_set_outer_width(w1, w2)
+        dbg.gpn_debug_set_extra_rows(xr)
         try:
             f = _ops.kernel_factor("Matern52", x, one, 2.0 * one, 0.05 * one, R=R)
         finally:
+            dbg.gpn_debug_set_potrf_variant(0)
+            dbg.gpn_debug_set_outer_width(0, 0)
+            dbg.gpn_debug_set_extra_rows(1)
             _native.debug_end()
         assert int(f.info.item()) == 0
         out.append((f.lower(), f.extra().clone(), f.winv.clone(), f.lml_terms().clone()))
+        del f
     L1, E1, W1, T1 = out[0]
     for L0, E0, W0, T0 in out[1:]:
         assert (L0 - L1).abs().max().item() < 1e-11
