@@ -40,6 +40,9 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
 int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B, int64_t ldb,
              double* C, int64_t ldc, int batch = 1, int64_t sA = 0, int64_t sB = 0, int64_t sC = 0);
 
+// both column passes of a chain step in one launch (colpanel.hip colstep_kernel; tools' build): B <- B W^T in place, C -= X X_top^T
+int colstep(hipStream_t s, int64_t m, double* B, const double* W, double* C, int64_t lda, int* flag, int32_t* info, int batch,
+            int64_t sA, int64_t sW);
 // the 128 x 128 factor leaf, second generation (leaf16.hip): `batch` independent leaves in one launch, problem b at
 // A + b sA, winv + b sW, info + b sInfo
 int leaf16(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* winv, int32_t* info, int batch, int64_t sA,

@@ -633,6 +633,7 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
 // square receives finite garbage from the rectangular updates: nothing reads it (the leaf
 // masks j > i on load, every other consumer uses blocks strictly below the diagonal blocks
 // or winv).
+constexpr int64_t AUX_FLAGS = 1 << 18;           // counters per stream (steps x problems of one factorisation)
 struct Aux {
   hipStream_t s1 = nullptr;
   hipStream_t s2 = nullptr;                     // look-ahead over panels (A/B): the bulk of a trailing update
@@ -640,6 +641,7 @@ struct Aux {
   hipEvent_t solve[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t rest[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t extra_go = nullptr, extra_done = nullptr;
+  int* flags = nullptr;                         // zeroed counters of the fused column steps (colpanel.hip colstep): one per step and problem
   hipEvent_t trap_go = nullptr, trap_done = nullptr;     // the part of an inner panel's update beyond the next inner panel (second aux stream)   // the extra rows' share of an outer panel's trailing update (aux stream)
 };
 static std::mutex g_aux_mutex;
@@ -663,6 +665,9 @@ static Aux* aux_for(hipStream_t s) {
 #endif
   if (hipEventCreateWithFlags(&a.extra_go, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.extra_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+#ifdef GPN_DEBUG_SWITCHES
+  if (hipMalloc(reinterpret_cast<void**>(&a.flags), AUX_FLAGS * sizeof(int)) != hipSuccess) return nullptr;
+#endif
   for (int i = 0; i < 4; ++i) {
     if (hipEventCreateWithFlags(&a.solve[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.rest[i], hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -744,6 +749,12 @@ GPN_SWITCH g_inner_lookahead = 0;
 // m = 30 k (one 768-thread workgroup per CU, three dependent memory round trips per 32-row tile, nothing to overlap them
 // with) against 20 + 18 + 15 us for leaf, solve and update as separate launches.  Off.
 GPN_SWITCH g_fused_steps = 0;
+// A/B (tools' build): the two column passes of a chain step in ONE launch (colpanel.hip colstep_kernel: X tile kept in LDS,
+// X_top handed between workgroups through agent-scope stores + a device counter).  Correct and bit-identical across batch
+// sizes, and SLOWER than the two launches: C2 5.36 -> 5.53 ms, C3 180.1 -> 183.8, N = 2048 0.61 -> 0.67 (an acquire fence +
+// plain loads instead of agent-scope loads: the same) -- a workgroup's solve, hand-off wait, operand reload and update run
+// one after the other with two workgroups per CU to hide them, where two launches each fill the chip.  Off.
+GPN_SWITCH g_fused_colstep = 0;
 GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row of the lower-tile launch (A/B)
 // look-ahead over PANELS (A/B, tools' build only): after panel p only the strip of the trailing update that panel p+1 lives in
 // runs on the caller's stream; the rest goes to a second lowest-priority stream, capped to g_bulk_pad KiB of extra LDS per
@@ -801,6 +812,9 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
   int64_t leaf_done = -1;                          // the diagonal block a fused step has already factored
+  const int64_t nsteps = (n + LEAF - 1) / LEAF;
+  const bool colsteps = g_fused_colstep != 0 && (g_chain_kernel & 1) && nsteps * c.batch <= AUX_FLAGS;
+  if (colsteps) hip_ok(hipMemsetAsync(ax->flags, 0, (size_t)(nsteps * c.batch) * sizeof(int), c.s));
   const bool fused_steps = g_fused_steps != 0;
   bool rest_pending = false, bulk_pending = false, extra_pending = false, trap_pending = false;
   for (int64_t p0 = 0; p0 < n && c.rc == GPN_OK; p0 += PW) {
@@ -860,7 +874,21 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
 #else
       (void)fused_steps;
 #endif
-      if (g_chain_kernel & 1) c.rc = ccolpanel(c, c.s, 0, m, kb, B, lda, Wk, LEAF, B, lda);
+      // both column passes in one launch (full blocks; the rows of X_top are matrix rows: c1 + 128 <= pend <= n)
+#ifdef GPN_DEBUG_SWITCHES
+      const bool onepass = colsteps && kb == LEAF && c1 + LEAF <= pend && m >= LEAF;
+#else
+      const bool onepass = false;
+#endif
+      if (onepass) {
+        if (rest_pending) {                        // column block c1 was last written on the aux stream
+          hip_ok(hipStreamWaitEvent(c.s, ax->rest[rest_idx], 0));
+          rest_pending = false;
+        }
+#ifdef GPN_DEBUG_SWITCHES
+        c.rc = colstep(c.s, m, B, Wk, A + c1 * lda + c1, lda, ax->flags + (k0 / LEAF) * c.batch, c.info, c.batch, c.sA, c.sW);
+#endif
+      } else if (g_chain_kernel & 1) c.rc = ccolpanel(c, c.s, 0, m, kb, B, lda, Wk, LEAF, B, lda);
       else if (c.batch == 1) c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
       else c.rc = gemm_nt_strided(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, 1, c.batch, c.sA, c.sW, c.sA);
       if (c.rc != GPN_OK || c1 >= pend) continue;  // last block of the panel: nothing left inside it
@@ -875,7 +903,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       // The aux work is forked AFTER it: launched together, the 1000+ workgroups of the rest
       // update crowd this small launch out (16 us instead of 7); behind it they overlap with
       // the next leaf + solve instead.
-      if (c.rc == GPN_OK) {
+      if (c.rc == GPN_OK && !onepass) {
         if ((g_chain_kernel & 2) && kb == LEAF) c.rc = ccolpanel(c, c.s, 1, m, nb1, B, lda, B, lda, A + c1 * lda + c1, lda);
         else c.rc = cgemm(c, c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
       }
@@ -1193,6 +1221,7 @@ extern "C" int gpn_release_stream(void* stream) {
     if (a.bulk_done) (void)hipEventDestroy(a.bulk_done);
     if (a.extra_go) (void)hipEventDestroy(a.extra_go);
     if (a.extra_done) (void)hipEventDestroy(a.extra_done);
+    if (a.flags) (void)hipFree(a.flags);
     if (a.trap_go) (void)hipEventDestroy(a.trap_go);
     if (a.trap_done) (void)hipEventDestroy(a.trap_done);
     for (int i = 0; i < 4; ++i) {
@@ -1244,6 +1273,7 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_chain_kernel = 1 ^ ((v >> 6) & 3);                                   // bit 6: the chain's solve through the generic contraction; bit 7: its next-column update through colpanel.hip
   return GPN_OK;
 }
+extern "C" int gpn_debug_set_fused_colstep(int v) { g_fused_colstep = v; return GPN_OK; }
 extern "C" int gpn_debug_set_fused_steps(int v) { g_fused_steps = v; return GPN_OK; }
 extern "C" int gpn_debug_set_extra_rows(int on) { g_extra_rows_kernel = on; return GPN_OK; }
 extern "C" int gpn_debug_set_inner_lookahead(int v) { g_inner_lookahead = v; return GPN_OK; }

@@ -50,7 +50,7 @@ out = {"workload": sys.argv[4], "kernel": "gemm_nt_kernel (all variants)", "laun
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --no-extras --no-cpu-baseline`; KB->B; FETCH x2 (gfx950 wide-read correction)"}
 # the SYRK trailing updates alone (bench.py roofline_syrk): per evaluation they are the launches of the 128x128-tile
 # (C2: 64x64-tile) kernel with the largest grids -- 15 at C3, 5 at C2 (one per panel but the last)
-nsyrk = {"c3": 15, "c2": 5, "c4": 31}.get(sys.argv[4])
+nsyrk = {"c3": 15, "c2": 7, "c4": 15}.get(sys.argv[4])      # outer panels but the last (gpn_potrf_panel_width: 2048 | 1024 | 4096)
 if nsyrk:
     import math
     match = "gemm_nt_kernel<"        # 128x128-tile launches and, for the last panels, 64x64-tile ones
