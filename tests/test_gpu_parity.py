@@ -1435,12 +1435,13 @@ def test_repeated_predictions_switch_to_the_inverted_big_blocks(device, n, ns):
     assert getattr(f2, "_wblock", None) is None or f2._wblock[0] != f2.generation or f2 is not f
 
 
-def test_evaluation_captures_into_a_hipgraph(device):
-    """the factorisation forks onto internal streams (look-ahead) and joins back, so a whole
-    LML evaluation still captures into ONE hipGraph; replays reproduce the eager value and
-    follow the inputs (new hyper-parameters written into the captured tensors)."""
+@pytest.mark.parametrize("n,dy", [(1500, 1), (16512, 2)])
+def test_evaluation_captures_into_a_hipgraph(device, n, dy):
+    """the factorisation forks onto internal streams (in-panel updates; from N = 16384 the extra rows' share of the outer
+    panels' updates) and joins back, so a whole LML evaluation still captures into ONE hipGraph; replays reproduce the eager
+    value and follow the inputs (new hyper-parameters written into the captured tensors)."""
     from gptorch_amd import _ops
-    x, y = rng.make_regression(1500, 4, 1, seed=3)
+    x, y = rng.make_regression(n, 4, dy, seed=3)
     m = GPR(x, y, kernels.Matern52(4, length_scales=1.7), likelihood=likelihoods.Gaussian(variance=0.03))
     m.cuda()
     k = m.kernel
