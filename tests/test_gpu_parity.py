@@ -1490,7 +1490,9 @@ def test_batched_restarts_match_sequential(device):
     (1024, 8, 2, 3, "Rbf", False, False),          # each model its own data, two output columns
     (200, 2, 1, 7, "Rbf", False, True),            # recursive driver (n <= 256)
     (128, 3, 1, 4, "Matern32", False, False),      # one leaf
-    (2176, 4, 1, 2, "Rbf", False, True),           # two 1536-column panels: trailing SYRK as a strided-batch lower launch
+    (2176, 4, 1, 2, "Rbf", False, True),           # nested panels: trapezoid + outer lower-tile launches as strided batches
+    (5000, 3, 2, 3, "Matern52", False, True),      # several outer panels, ragged, two right-hand sides
+    (16640, 4, 3, 2, "Rbf", False, True),          # from N = 16384: the extra rows' update on the aux stream, batched
 ])
 def test_lockstep_batch_is_bit_identical_to_sequential(device, n, d, dy, batch, kind, ard, shared):
     """gpn_lml_forward_batched (leaf grid = B, column passes and contractions as strided-batch launches): every model's
