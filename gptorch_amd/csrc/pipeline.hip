@@ -11,9 +11,60 @@
 
 namespace gpn {
 
-__global__ void var_minus_kernel(double* v, const double* variance, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = variance[0] - v[i];            // Kdiag - colsumsq(A), gpr.py:109-113
+// The tail of a prediction in ONE pass over A^T = K(x*, X) L^-T [ns, n]: per test point (one workgroup per row)
+//   mean[i, c] = (m(x*)[i, c]) + sum_k A^T[i, k] V[c][k]   (V = the factor's extra rows, gpr.py:107-108)
+//   var[i]     = variance - sum_k A^T[i, k]^2              (diagonal case, gpr.py:109-113; `var` NULL: mean only)
+// As two launches the mean was a 1-column contraction (32 workgroups walking K = N in 16-wide steps: 127 us at C2) and the
+// sum of squares a second pass over the same 68 MB.  Up to PT_DY right-hand sides per pass; fixed summation order.
+typedef double pd2 __attribute__((ext_vector_type(2)));
+constexpr int PT_DY = 4;
+__global__ __launch_bounds__(256) void predict_tail_kernel(const double* __restrict__ At, int64_t lda, int64_t n, const double* __restrict__ V,
+                                                           int dy, int c0, const double* __restrict__ Ms, const double* __restrict__ variance,
+                                                           double* __restrict__ mean, double* __restrict__ var) {
+  __shared__ double red[PT_DY + 1][256];
+  const int t = threadIdx.x;
+  const int64_t i = blockIdx.x;
+  const double* row = At + i * lda;
+  const int nc = min(PT_DY, dy - c0);
+  double acc[PT_DY], sq = 0.0;
+#pragma unroll
+  for (int c = 0; c < PT_DY; ++c) acc[c] = 0.0;
+  const int64_t n2 = n & ~(int64_t)1;
+  for (int64_t k = 2 * t; k < n2; k += 512) {
+    const pd2 a = *reinterpret_cast<const pd2*>(row + k);
+    sq = fma(a.y, a.y, fma(a.x, a.x, sq));
+#pragma unroll
+    for (int c = 0; c < PT_DY; ++c)
+      if (c < nc) {
+        const pd2 v = *reinterpret_cast<const pd2*>(V + (int64_t)(c0 + c) * lda + k);
+        acc[c] = fma(a.y, v.y, fma(a.x, v.x, acc[c]));
+      }
+  }
+  if (t == 0 && n2 < n) {                                 // odd n: the last entry
+    const double a = row[n2];
+    sq = fma(a, a, sq);
+    for (int c = 0; c < nc; ++c) acc[c] = fma(a, V[(int64_t)(c0 + c) * lda + n2], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < PT_DY; ++c) red[c][t] = acc[c];
+  red[PT_DY][t] = sq;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (t < h) {
+#pragma unroll
+      for (int c = 0; c <= PT_DY; ++c) red[c][t] += red[c][t + h];
+    }
+    __syncthreads();
+  }
+  if (t < nc) mean[i * dy + c0 + t] = (Ms ? Ms[i * dy + c0 + t] : 0.0) + red[t][0];
+  if (t == 0 && var && c0 == 0) var[i] = variance[0] - red[PT_DY][0];
+}
+
+// zero what the assembly / the solves do not write of a [rows_padded, ld] operand buffer: the columns [n, ld) of its `rows`
+// data rows (K padding of the contractions) and the padding rows whole -- instead of a memset of the whole buffer (68 MB at C2)
+__global__ __launch_bounds__(256) void zero_padding_kernel(double* B, int64_t ld, int64_t rows, int64_t n) {
+  double* row = B + (int64_t)blockIdx.x * ld;
+  for (int64_t k = ((int64_t)blockIdx.x < rows ? n : 0) + threadIdx.x; k < ld; k += 256) row[k] = 0.0;
 }
 
 __global__ void neg_transpose_small_kernel(const double* at, int64_t ldat, int64_t n, int dy, double* out) {
@@ -176,7 +227,12 @@ static int predict_impl(void* stream, int kind, const double* X, int64_t n, int 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t one = gpn_predict_work_bytes(n, ns, dy);
   double* Bt = work;                                // [round_up(ns,128), lda], zero padded
-  GPN_HIP_CHECK(hipMemsetAsync(Bt, 0, (size_t)((wb && (n % 16)) ? 2 * one : one), s));    // (the second buffer: only its K padding must be zero)
+  {
+    const int64_t rp = round_up(ns, 128);
+    hipLaunchKernelGGL(zero_padding_kernel, dim3((unsigned)rp), dim3(256), 0, s, Bt, lda, ns, n);
+    if (wb) hipLaunchKernelGGL(zero_padding_kernel, dim3((unsigned)rp), dim3(256), 0, s, work + one / (int64_t)sizeof(double), lda, ns, n);
+    GPN_LAUNCH_CHECK();
+  }
   int rc = GPN_OK;
   if (n > 0) {
     rc = gpn_kernel_matrix(stream, kind, Xs, ns, X, n, d, variance, length_scales, nls, nullptr, GPN_FULL, Bt, lda);  // K(x*, X)
@@ -192,16 +248,13 @@ static int predict_impl(void* stream, int kind, const double* X, int64_t n, int 
   }
   const int64_t kp = round_up(n, 16);
   // mean = m(x*) + A^T V (gpr.py:107-108): the mean function's values at the test points, if any, are the C operand
-  if (Ms) GPN_HIP_CHECK(hipMemcpyAsync(mean, Ms, (size_t)ns * dy * sizeof(double), hipMemcpyDeviceToDevice, s));
-  rc = gpn_gemm_nt(stream, ns, dy, kp, 1.0, Bt, lda, A + n * lda, lda, Ms ? 1.0 : 0.0, mean, dy, 0, 0);   // (+) A^T V
-  if (rc != GPN_OK) return rc;
-  if (!full_cov) {
-    rc = gpn_row_sumsq(stream, Bt, ns, n, lda, var);
-    if (rc != GPN_OK) return rc;
-    hipLaunchKernelGGL(var_minus_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, s, var, variance, ns);
+  // mean = m(x*) + A^T V (gpr.py:107-108) and, for the diagonal case, var = Kdiag - rowsumsq(A^T) (gpr.py:109-113): one pass
+  for (int c0 = 0; c0 < dy; c0 += PT_DY) {
+    hipLaunchKernelGGL(predict_tail_kernel, dim3((unsigned)ns), dim3(256), 0, s, Bt, lda, n, A + n * lda, dy, c0, Ms, variance, mean,
+                       full_cov ? nullptr : var);
     GPN_LAUNCH_CHECK();
-    return GPN_OK;
   }
+  if (!full_cov) return GPN_OK;
   rc = gpn_kernel_matrix(stream, kind, Xs, ns, nullptr, ns, d, variance, length_scales, nls, nullptr, GPN_FULL, var, ns);
   if (rc != GPN_OK) return rc;
   return gpn_gemm_nt(stream, ns, ns, kp, -1.0, Bt, lda, Bt, lda, 1.0, var, ns, 0, 0);  // K(x*) - A^T A
