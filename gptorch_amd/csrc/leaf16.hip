@@ -81,7 +81,7 @@ struct Leaf16Args {
 
 template <bool DIAG>
 __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long long* diag, const int prob) {
-  int tie0 = 0;
+  [[maybe_unused]] int tie0 = 0;      // (placeholder argument of the stamp macros)
   __shared__ unsigned long long stampbuf[DIAG ? 12 * 8 * 8 : 1];
   if constexpr (DIAG) {
     for (int idx = threadIdx.x; idx < 12 * 8 * 8; idx += L16_THREADS) stampbuf[idx] = 0;
