@@ -49,6 +49,7 @@ struct GemmArgs {
   int q_off, q_cnt, q_mt;
   int lds_pad_kb;   // extra dynamic LDS per workgroup: caps the workgroups per CU of a launch that shares the chip (look-ahead)
   int group_h;      // tile rows per group of the grouped tile order (8; A/B of the L2 reuse: tools' build)
+  int thin;         // 1: tiles with at most 16 rows of the matrix skip the MFMAs of their empty blocks (0: A/B, tools' build)
   // staircase: C is M x (nb * st_blk); column block b (st_blk columns) only has the rows from b * st_step on, and with
   // st_diag its first st_blk x st_blk square is lower-only -- the local tile columns of one block-cyclic trailing update
   int st_blk, st_step, st_diag;
@@ -397,7 +398,33 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), ((BM / WM) * (BN / WN) 
         mfma_groups(a1, b1, 1, TM, issue_c, t + 2, s);
         __builtin_amdgcn_sched_barrier(0);
       };
-      if (t0 < nk) {
+      // THIN tiles: at most 16 of the tile's BM rows are rows of the matrix -- the last tile row of a factorisation's
+      // trailing update, which holds the e right-hand-side rows carried below the matrix (1 of 57 tile rows of C2's first
+      // K = 1024 update).  Only the first 16-row block of the first wave row has anything to compute: the other MFMAs are
+      // skipped (plain K loop; the staging and the barriers stay), which makes such a tile ~7x cheaper than a full one.
+      const bool thin = p.thin && (p.M - m0) <= 16 && p.lower != 3;
+      if (thin) {
+        if (t0 < nk) stage_issue(t0, t0 & 1);
+        for (int t = t0; t < nk; ++t) {
+          const int s = t & 1;
+          __syncthreads();
+          if (t + 1 < nk) stage_issue(t + 1, s ^ 1);
+          if (wave_m == 0) {
+            const char* base = smem + s * STAGE;
+#pragma unroll
+            for (int kg8 = 0; kg8 < 2; ++kg8) {
+              const d2 av = *reinterpret_cast<const d2*>(base + (kg8 ? (roff0 ^ 64) : roff0));
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const d2 bv = *reinterpret_cast<const d2*>(base + (A_BLOCKS + (wave_n * TN + j) * 2) * 1024 + (kg8 ? (roff0 ^ 64) : roff0));
+                acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, acc[0][j], 0, 0, 0);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (t0 < nk) {
         stage_issue(t0, t0 & 1);
         __syncthreads();
         read_ops(t0 & 1, 0, a0, b0);
@@ -481,8 +508,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), ((BM / WM) * (BN / WN) 
 // threads of one process can hold different variants and a setter never races another thread's launches.  The product
 // library is compiled with the defaults as constants and exports no setter.
 #ifdef GPN_DEBUG_SWITCHES
+static thread_local int g_thin_tiles = 1;    // (A/B of the thin-tile path; reaches the kernels through GemmArgs)
 static thread_local int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
 #else
+static constexpr int g_thin_tiles = 1;
 static constexpr int g_smem_pad = 0;
 #endif
 
@@ -599,6 +628,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   if (g_group_h == 0) { const char* e = getenv("GPN_GEMM_GROUP_H"); g_group_h = e ? atoi(e) : 8; if (g_group_h < 1 || g_group_h > 64) g_group_h = 8; }
 #endif
   a.group_h = g_group_h;
+  a.thin = g_thin_tiles;
   a.tri = tri;
   a.alpha = alpha; a.beta = beta;
   // Tile choice (same-box sweeps, tools/gemm_ab.py).  The big tile is 128x128 as EIGHT waves of 32x64 (2 workgroups
@@ -705,6 +735,7 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
 }
 
 #ifdef GPN_DEBUG_SWITCHES
+extern "C" int gpn_debug_set_thin_tiles(int on) { gpn::g_thin_tiles = on; return GPN_OK; }
 extern "C" int gpn_debug_set_big_tile_min_trapezoid(int t) { gpn::g_big_tile_min_trapezoid = t; return GPN_OK; }
 extern "C" int gpn_debug_set_gemm_variant(int v) {     // (libgpnative_dbg.so only; the calling thread's launches)
   gpn::g_gemm_variant = v & 0x7f;
