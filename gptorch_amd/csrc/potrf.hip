@@ -683,6 +683,7 @@ static Aux* aux_for(hipStream_t s) {
 // 128-row tile row of full-price MFMA work (1 % of C3's trailing updates, 4 % of C2's in a lock-step batch); here they
 // are e dot products per matrix row, on the aux stream underneath that launch.  One wave per 4 matrix rows.
 constexpr int XR_MAXE = 8;
+constexpr int64_t XR_MIN_N = 20480;
 template <int E>
 __global__ __launch_bounds__(256) void extra_rows_update_kernel(const double* P, double* R, int64_t lda, int ms, int K, int e, int64_t sA) {
   P += (int64_t)blockIdx.y * sA;
@@ -992,9 +993,10 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
     } else {
       double* P = A + pend * lda + o0;             // [m, pend - o0] solved (outer) panel below the diagonal square
       const int64_t kp = round_up(pend - o0, 16);
-      // (pays from N ~ 16 k: the fork / join is ~25 us per outer panel -- C2 5.36 -> 5.53 ms with it, x 8 in lock step
-      //  neutral, C3 182.4 -> 181.3 ms)
-      if (e > 0 && e <= XR_MAXE && g_extra_rows_kernel && n >= 16384 && (lda & 1) == 0 && (o0 & 1) == 0) {
+      // (the fork / join is ~25 us per outer panel: C2 5.36 -> 5.53 ms with it, x 8 in lock step neutral, C3 182.4 -> 181.3;
+      //  against the THIN tile row of gemm_f64.hip that the extra rows are otherwise: N = 16384 28.42 vs 28.14 ms, C3 178.9 vs
+      //  180.2, C4 1329.7 vs 1333 -- on from XR_MIN_N rows)
+      if (e > 0 && e <= XR_MAXE && g_extra_rows_kernel && n >= XR_MIN_N && (lda & 1) == 0 && (o0 & 1) == 0) {
         // matrix rows: lower-tile square here; the few extra rows: dot products on the aux stream underneath it
         const int64_t ms = n - pend;
         hip_ok(hipEventRecord(ax->extra_go, c.s));

@@ -218,7 +218,8 @@ def test_functions_are_differentiable(device, n):
 @pytest.mark.parametrize("n,e", [(1152, 0), (2500, 3), (8320, 1), (9001, 2), (16640, 2), (20608, 5)])
 def test_factorisation_drivers_agree(device, n, e):
     """the nested-panel driver (default: 256-wide inner panels in 1024-wide outer ones below N = 20480, 512 in 2048 above;
-    from N = 16384 the extra rows' share of an outer panel's update as dot products on the aux stream), its one-level and
+    from N = 20480 the extra rows' share of an outer panel's update as dot products on the aux stream, below that a thin
+    tile row of the lower-tile launches), its one-level and
     three-level forms, its left-looking in-panel form and the plain recursion produce the same factor, extra rows and
     leaf inverses on multi-panel and ragged sizes."""
     from gptorch_amd import _native, _ops
@@ -1435,9 +1436,9 @@ def test_repeated_predictions_switch_to_the_inverted_big_blocks(device, n, ns):
     assert getattr(f2, "_wblock", None) is None or f2._wblock[0] != f2.generation or f2 is not f
 
 
-@pytest.mark.parametrize("n,dy", [(1500, 1), (16512, 2)])
+@pytest.mark.parametrize("n,dy", [(1500, 1), (20608, 2)])
 def test_evaluation_captures_into_a_hipgraph(device, n, dy):
-    """the factorisation forks onto internal streams (in-panel updates; from N = 16384 the extra rows' share of the outer
+    """the factorisation forks onto internal streams (in-panel updates; from N = 20480 the extra rows' share of the outer
     panels' updates) and joins back, so a whole LML evaluation still captures into ONE hipGraph; replays reproduce the eager
     value and follow the inputs (new hyper-parameters written into the captured tensors)."""
     from gptorch_amd import _ops
@@ -1492,7 +1493,7 @@ def test_batched_restarts_match_sequential(device):
     (128, 3, 1, 4, "Matern32", False, False),      # one leaf
     (2176, 4, 1, 2, "Rbf", False, True),           # nested panels: trapezoid + outer lower-tile launches as strided batches
     (5000, 3, 2, 3, "Matern52", False, True),      # several outer panels, ragged, two right-hand sides
-    (16640, 4, 3, 2, "Rbf", False, True),          # from N = 16384: the extra rows' update on the aux stream, batched
+    (20608, 4, 3, 2, "Rbf", False, True),          # from N = 20480: the extra rows' update on the aux stream, batched
 ])
 def test_lockstep_batch_is_bit_identical_to_sequential(device, n, d, dy, batch, kind, ard, shared):
     """gpn_lml_forward_batched (leaf grid = B, column passes and contractions as strided-batch launches): every model's
