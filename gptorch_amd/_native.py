@@ -60,6 +60,11 @@ SIGNATURES = {
     "gpn_lml_backward_work_bytes": (c_int64, [c_int64, c_int, c_int]),
     "gpn_lml_backward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                  c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gpn_lml_backward_batched_work_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "gpn_lml_backward_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int,
+                                         c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "gpn_lml_grad_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "gpn_predict_work_bytes": (c_int64, [c_int64, c_int64, c_int]),
     "gpn_predict": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                             c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -149,14 +154,16 @@ def rccl_lib():
     return _rccl_lib
 
 
-# not part of the public header.  The profiler hooks live in the product library; the A/B switches (kernel / driver
-# variants per calling thread, CU-masked streams, the instrumented leaf) only in the tools' build libgpnative_dbg.so
-# (same sources, -DGPN_DEBUG_SWITCHES): the shipped library carries no mutable debug state.
+# The launch profiler (include/gpnative.h, last section) is part of the public header since round 5.
 PROFILE_SIGNATURES = {
     "gpn_profile_enable": (c_int, [c_int]),
     "gpn_profile_collect": (c_int, [ctypes.POINTER(c_double)]),
     "gpn_profile_collect_classes": (c_int, [ctypes.POINTER(c_double), c_int]),
 }
+SIGNATURES.update(PROFILE_SIGNATURES)
+# not part of the public header: the A/B switches (kernel / driver variants per calling thread, CU-masked streams, the
+# instrumented leaf) exist only in the tools' build libgpnative_dbg.so (same sources, -DGPN_DEBUG_SWITCHES): the shipped
+# library carries no mutable debug state.
 DEBUG_SIGNATURES = {
     "gpn_debug_set_gemm_variant": (c_int, [c_int]),
     "gpn_debug_set_potrf_variant": (c_int, [c_int]),
@@ -177,7 +184,7 @@ class NativeError(RuntimeError):
 
 def _load(path, extra):
     handle = ctypes.CDLL(path)
-    for name, (res, args) in list(SIGNATURES.items()) + list(PROFILE_SIGNATURES.items()) + list(extra.items()):
+    for name, (res, args) in list(SIGNATURES.items()) + list(extra.items()):
         fn = getattr(handle, name)
         fn.restype, fn.argtypes = res, args
     return handle

@@ -176,6 +176,12 @@ class FactorBatch:
         self.winv = torch.empty(self.batch * self.sW, dtype=torch.float64, device=device)
         self.info = torch.zeros(self.batch, dtype=torch.int32, device=device)
         self.out = torch.empty(self.batch, 3, dtype=torch.float64, device=device)
+        self.generation = 0          # bumped by every lml_forward_batched into these buffers
+        self._backward_work = None   # workspace of gpn_lml_backward_batched (allocated on first use, reused by a fit loop)
+
+    def nbytes(self):
+        w = 0 if self._backward_work is None else self._backward_work.numel()
+        return 8 * (self.A.numel() + self.winv.numel() + w)
 
     def factor(self, b):
         f = Factor.__new__(Factor)
@@ -207,12 +213,35 @@ def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None):
         fb = FactorBatch(batch, n, e, X.device)
     Xc, Rc = _c(X.detach()), _c(R.detach())
     var, ls, nz = _c(variance.detach().reshape(batch)), _c(length_scales.detach().reshape(batch, -1)), _c(noise.detach().reshape(batch))
+    fb.generation += 1
     st = _native.lib().gpn_lml_forward_batched(
         _stream(X.device), KINDS[kind], batch, _ptr(Xc), 0 if shared_x else n * d, n, d, _ptr(Rc), 0 if shared_r else n * e,
         None, 0, e, _ptr(var), _ptr(ls), ls.shape[1], _ptr(nz), _ptr(fb.A), fb.ld, fb.sA, _ptr(fb.winv), fb.sW,
         _ptr(fb.info), _ptr(fb.out))
     _native.check(st, "gpn_lml_forward_batched")
     return fb, fb.out
+
+
+def lml_backward_batched(kind, X, variance, length_scales, fb, need_resid=False):
+    """the closed-form backward of the `batch` models of an lml_forward_batched call in lock step (gpn_lml_backward_batched):
+    -> (grads [batch, 2 + nls] = dLML/d(variance, length_scales, noise) per model w.r.t. the CONSTRAINED values,
+        dLML/dR [batch, n, dy] or None).  Per model bit-identical to _backward.lml_backward on that model's factor."""
+    _req(X, variance, length_scales)
+    batch, n, dy = fb.batch, fb.n, fb.e
+    ls = _c(length_scales.detach().reshape(batch, -1))
+    nls = ls.shape[1]
+    lib = _native.lib()
+    need = max(1, int(lib.gpn_lml_backward_batched_work_bytes(n, dy, nls, batch)) // 8)
+    if fb._backward_work is None or fb._backward_work.numel() < need:
+        fb._backward_work = torch.empty(need, dtype=torch.float64, device=fb.A.device)
+    out = torch.empty(batch, 2 + nls, dtype=torch.float64, device=fb.A.device)
+    g_R = torch.empty(batch, n, dy, dtype=torch.float64, device=fb.A.device) if need_resid else None
+    Xc = _c(X.detach())
+    st = lib.gpn_lml_backward_batched(_stream(fb.A.device), KINDS[kind], batch, _ptr(Xc), 0 if Xc.dim() == 2 else n * Xc.shape[-1], n,
+                                      Xc.shape[-1], _ptr(_c(variance.detach().reshape(batch))), _ptr(ls), nls, _ptr(fb.A), fb.ld, fb.sA,
+                                      _ptr(fb.winv), fb.sW, dy, _ptr(fb._backward_work), _ptr(out), _ptr(g_R))
+    _native.check(st, "gpn_lml_backward_batched")
+    return out, g_R
 
 
 REFINE_MIN_N = 12288
@@ -593,6 +622,64 @@ class GPRLogLik(torch.autograd.Function):
         g_var, g_ls, g_noise, g_R = _backward.lml_backward(ctx.kind, X, variance, length_scales, noise, f)
         go = grad_out.reshape(())
         return (None, go * g_R if ctx.needs_input_grad[1] else None, go * g_var, go * g_ls, go * g_noise, None, None)
+
+
+class BatchedGPRLogLik(torch.autograd.Function):
+    """GPRLogLik for `batch` independent models of one shape in LOCK STEP (hyper-parameter restarts; the reference runs
+    loss(); backward(); step() one model at a time, gptorch/models/base.py:260-269): X [n, d] shared or [batch, n, d],
+    R = Y - m(X) [n, dy] shared or [batch, n, dy], variance [batch], length_scales [batch, nls], noise [batch] (CONSTRAINED
+    values) -> LML [batch].  Forward = gpn_lml_forward_batched, backward = gpn_lml_backward_batched; a model whose
+    factorisation reports info != 0 is replayed ALONE through lml_forward (jitter ladder of functions.py:20-43) into a
+    private factor, and its backward runs on that factor.  Values and gradients are bit-identical, model by model, to
+    GPRLogLik.  Sizes at which GPRLogLik refines the quadratic form (refine_min_n) are not for this node: the caller
+    (models.gpr) only groups smaller models."""
+
+    @staticmethod
+    def forward(ctx, X, R, variance, length_scales, noise, kind, holder):
+        batch = int(variance.numel())
+        if X.shape[-2] >= refine_min_n():
+            raise NativeError("BatchedGPRLogLik: sizes from refine_min_n() rows on take the sequential path")
+        fb, terms = lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=holder.get("fb"))
+        holder["fb"] = fb
+        out = terms[:, 2].clone()
+        info = fb.info.cpu()                         # ONE read-back for the batch (the reference: one per model and step)
+        replayed = {}
+        for b in range(batch):
+            if int(info[b]) != 0:
+                f, t = lml_forward(kind, X if X.dim() == 2 else X[b], R if R.dim() == 2 else R[b], variance.reshape(batch)[b:b + 1],
+                                   length_scales.reshape(batch, -1)[b], noise.reshape(batch)[b:b + 1], refine=False)
+                out[b] = t[2]
+                replayed[b] = f
+        ctx.kind, ctx.fb, ctx.generation, ctx.replayed = kind, fb, fb.generation, replayed
+        ctx.save_for_backward(X, R, variance, length_scales, noise)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _backward
+        X, R, variance, length_scales, noise = ctx.saved_tensors
+        batch = int(variance.numel())
+        fb = ctx.fb
+        if fb.generation != ctx.generation:
+            # the shared buffers were refactorised by a later forward: rebuild this node's factors privately
+            fb, _ = lml_forward_batched(ctx.kind, X, R, variance, length_scales, noise)
+        need_r = ctx.needs_input_grad[1]
+        grads, g_R = lml_backward_batched(ctx.kind, X, variance, length_scales, fb, need_resid=need_r)
+        nls = grads.shape[1] - 2
+        for b, f in ctx.replayed.items():
+            gv, gl, gn, gr = _backward.lml_backward(ctx.kind, X if X.dim() == 2 else X[b], variance.reshape(batch)[b:b + 1],
+                                                    length_scales.reshape(batch, -1)[b], noise.reshape(batch)[b:b + 1], f)
+            grads[b, 0:1], grads[b, 1:1 + nls], grads[b, 1 + nls:] = gv, gl, gn
+            if need_r:
+                g_R[b] = gr
+        go = grad_out.reshape(batch)
+        g_resid = None
+        if need_r:
+            g_resid = go[:, None, None] * g_R
+            if R.dim() == 2:
+                g_resid = g_resid.sum(0)
+        return (None, g_resid, (go * grads[:, 0]).reshape(variance.shape), (go[:, None] * grads[:, 1:1 + nls]).reshape(length_scales.shape),
+                (go * grads[:, 1 + nls]).reshape(noise.shape), None, None)
 
 
 class DenseLogLik(torch.autograd.Function):

@@ -10,7 +10,14 @@ void set_hip_error(hipError_t e, const char* where) {
 }  // namespace gpn
 
 extern "C" int gpn_version(void) { return GPN_VERSION; }
-extern "C" const char* gpn_arch(void) { return "gfx950"; }
+// the --offload-arch this library was compiled for: build.sh passes it as -DGPN_ARCH=<arch> next to --offload-arch=<arch>
+// (one variable), so a library built for another target says so instead of claiming gfx950
+#ifndef GPN_ARCH
+#error "build with -DGPN_ARCH=<the --offload-arch value> (gptorch_amd/csrc/build.sh does)"
+#endif
+#define GPN_STR2(x) #x
+#define GPN_STR(x) GPN_STR2(x)
+extern "C" const char* gpn_arch(void) { return GPN_STR(GPN_ARCH); }
 extern "C" const char* gpn_last_hip_error(void) { return gpn::g_last_error.c_str(); }
 
 extern "C" int gpn_fill_zero(void* stream, void* dst, int64_t bytes) {

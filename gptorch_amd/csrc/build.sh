@@ -7,7 +7,8 @@ OUT="$HERE/../lib"
 OBJ="$HERE/../../build/obj"
 mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
+ARCH="${GPN_OFFLOAD_ARCH:-gfx950}"     # the one place the target is named: --offload-arch AND what gpn_arch() reports
+FLAGS="--offload-arch=$ARCH -DGPN_ARCH=$ARCH -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 pids=()
 for f in "$HERE"/*.hip; do
   o="$OBJ/$(basename "${f%.hip}").o"
@@ -29,13 +30,13 @@ for f in "$HERE"/gemm_f64.hip "$HERE"/potrf.hip "$HERE"/profile.hip "$HERE"/leaf
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgpnative.so" "$OBJ"/*.o
+$HIPCC --offload-arch=$ARCH -shared -fPIC -o "$OUT/libgpnative.so" "$OBJ"/*.o
 echo "built $OUT/libgpnative.so"
 shared=()
 for o in "$OBJ"/*.o; do
   case "$(basename "$o")" in gemm_f64.o|potrf.o|profile.o|leaf16.o|colpanel.o) ;; *) shared+=("$o") ;; esac
 done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgpnative_dbg.so" "${shared[@]}" "$DBG"/*.o
+$HIPCC --offload-arch=$ARCH -shared -fPIC -o "$OUT/libgpnative_dbg.so" "${shared[@]}" "$DBG"/*.o
 echo "built $OUT/libgpnative_dbg.so"
 # the RCCL adapter of the gpn_dist_comm callback table (a separate library: libgpnative itself links no
 # communication runtime)

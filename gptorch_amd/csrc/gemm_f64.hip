@@ -58,6 +58,10 @@ struct GemmArgs {
   // strided batch: problem z uses A + z*sA, B + z*sB, C + z*sC (batch identical shapes in ONE launch)
   int batch;
   int64_t sA, sB, sC;
+  // two-level batch (lock-step models x equal nodes of one model): problem z = z1 + inner * z2 uses A + z1*sA + z2*sA2 ...
+  // (inner == 0: one level)
+  int inner;
+  int64_t sA2, sB2, sC2;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -142,7 +146,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), ((BM / WM) * (BN / WN) 
     nwg = gridDim.x / p.batch;
     const int z = bid / nwg;
     bid -= z * nwg;
-    p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC;
+    if (p.inner > 0) {
+      const int z2 = z / p.inner, z1 = z - z2 * p.inner;
+      p.A += z1 * p.sA + z2 * p.sA2; p.B += z1 * p.sB + z2 * p.sB2; p.C += z1 * p.sC + z2 * p.sC2;
+    } else {
+      p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC;
+    }
   }
   int diag_off = 0;       // lower launches: the entry (row, col) is on or below ITS diagonal iff col + diag_off <= row
   bool stair_diag_tile = false;
@@ -569,18 +578,21 @@ static thread_local int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = registe
 static thread_local int g_group_h = 0;       // 0 = from GPN_GEMM_GROUP_H at first use (default 8): A/B of the grouped tile order's L2 reuse
 static thread_local int g_big_tile_min_trapezoid = 4096;   // trapezoid launches (nested panels): 128x128 tiles from this many of them
 static thread_local int g_split_tail = 0;    // 1 = the partial last round of a big lower-tile launch as quarter tiles (measured neutral: off)
+static thread_local int g_tri_big_k = 0, g_tri_big_tiles = 0;   // A/B: K-clipped launches of a lock-step batch on 128x128 tiles from this K / tile count
 #else
 static constexpr int g_gemm_variant = 0;
 static constexpr int g_big_tile_min_trapezoid = 4096;
 static constexpr int g_group_h = 8;
 static constexpr int g_split_tail = 0;
+static constexpr int g_tri_big_k = 0, g_tri_big_tiles = 0;
 #endif
 
 struct Stair { int blk = 0, step = 0, diag = 0; };
+struct Outer { int count = 0; int64_t sA = 0, sB = 0, sC = 0; };     // second batch level (count == 0: none)
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair(), int lds_pad_kb = 0);
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair(), int lds_pad_kb = 0, Outer ob = Outer());
 
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
@@ -601,6 +613,17 @@ int gemm_nt_strided(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha
   return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, batch, sA, sB, sC);
 }
 
+int gemm_nt_strided2(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+                     const double* A, int64_t lda, const double* B, int64_t ldb,
+                     double beta, double* C, int64_t ldc, int lower, int tri,
+                     int inner, int64_t sA, int64_t sB, int64_t sC, int outer, int64_t sA2, int64_t sB2, int64_t sC2) {
+  if (inner <= 1) return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, 0, outer, sA2, sB2, sC2);
+  if (outer <= 1) return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, 0, inner, sA, sB, sC);
+  Outer ob;
+  ob.count = outer; ob.sA = sA2; ob.sB = sB2; ob.sC = sC2;
+  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, 0, inner, sA, sB, sC, Stair(), 0, ob);
+}
+
 int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,
                   const double* A, int64_t lda, const double* B, int64_t ldb,
                   double beta, double* C, int64_t ldc, int64_t step, int diag) {
@@ -612,10 +635,15 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st, int lds_pad_kb) {
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st, int lds_pad_kb, Outer ob) {
   if (M <= 0 || N <= 0 || batch <= 0) return GPN_OK;
   GemmArgs a;
   a.batch = batch; a.sA = sA; a.sB = sB; a.sC = sC;
+  a.inner = 0; a.sA2 = a.sB2 = a.sC2 = 0;
+  if (ob.count > 0) {
+    a.inner = batch; a.sA2 = ob.sA; a.sB2 = ob.sB; a.sC2 = ob.sC;
+    a.batch = batch = batch * ob.count;
+  }
   a.A = A; a.B = B; a.C = C;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
@@ -648,7 +676,8 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer.  U U^T (lower):
   // N = 8192 3.02 (64) vs 3.12 ms (128), N = 12288 10.3 vs 9.8, N = 16384 25.3 vs 22.7; the
   // triangular inversion's rectangular products stay on 64x64 tiles up to N = 16384 (28.0 vs 29.2 ms).
-  const bool small = tri ? !(K >= 8192 && t128 >= (lower ? 4096 : 8192) && M > 64 && N > 64)
+  const bool tri_big_ab = g_tri_big_k > 0 && batch > 1 && K >= g_tri_big_k && t128 >= g_tri_big_tiles && M > 64 && N > 64;
+  const bool small = tri ? !((K >= 8192 && t128 >= (lower ? 4096 : 8192) && M > 64 && N > 64) || tri_big_ab)
                          : !(K >= 512 && t128 >= (lower == 2 ? g_big_tile_min_trapezoid : 4096) && M > 64 && N > 64);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
@@ -736,6 +765,7 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
 
 #ifdef GPN_DEBUG_SWITCHES
 extern "C" int gpn_debug_set_thin_tiles(int on) { gpn::g_thin_tiles = on; return GPN_OK; }
+extern "C" int gpn_debug_set_tri_big(int k, int tiles) { gpn::g_tri_big_k = k; gpn::g_tri_big_tiles = tiles; return GPN_OK; }
 extern "C" int gpn_debug_set_big_tile_min_trapezoid(int t) { gpn::g_big_tile_min_trapezoid = t; return GPN_OK; }
 extern "C" int gpn_debug_set_gemm_variant(int v) {     // (libgpnative_dbg.so only; the calling thread's launches)
   gpn::g_gemm_variant = v & 0x7f;

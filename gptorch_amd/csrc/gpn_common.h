@@ -63,6 +63,21 @@ int gemm_nt_strided(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha
                     double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
                     int batch, int64_t sA, int64_t sB, int64_t sC);
 
+// two-level strided batch: `outer` lock-step models (strides s*2) x `inner` equal problems inside each model (strides s*)
+int gemm_nt_strided2(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
+                     const double* A, int64_t lda, const double* B, int64_t ldb,
+                     double beta, double* C, int64_t ldc, int lower, int tri,
+                     int inner, int64_t sA, int64_t sB, int64_t sC, int outer, int64_t sA2, int64_t sB2, int64_t sC2);
+
+// gpn_lml_grad_batched with the models' partial-sum regions sWork doubles apart (grad.hip)
+int lml_grad_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
+                     const double* variance, const double* length_scales, int nls,
+                     const double* Kinv, int64_t ldk, int64_t sK, const double* at, int64_t ldat, int64_t sAt, int dy,
+                     double* work, int64_t sWork, double* out);
+// U_b = L_b^-T of `batch` lock-step models (potrf.hip)
+int trtri_upper_ws_batched(hipStream_t s, const double* L, int64_t n, int64_t ldl, int64_t sL, const double* winv, int64_t sW,
+                           double* U, int64_t ldu, int64_t sU, double* S, int64_t lds, int64_t sS, int batch);
+
 // extra rows <- (Y - M)^T, corner right of them <- 0, *info <- 0 (kmat.hip; used by gpn_lml_forward)
 int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
                   int32_t* info);

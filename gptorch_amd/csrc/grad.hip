@@ -40,7 +40,18 @@ struct GradArgs {
   double* partial;      // [nblocks, nout]
   int n, m, d, nls, dy, nout;
   int tiles_m, tiles_n;
+  // lock-step batch (gridDim.y models, gpn_lml_grad_batched): model z reads X + z sX, variance[z], ls + z nls, G + z sG,
+  // at + z sAt and writes partial + z sPartial
+  int64_t sX = 0, sG = 0, sAt = 0, sPartial = 0;
 };
+
+__device__ __forceinline__ void select_model(GradArgs& p) {
+  if (gridDim.y > 1) {
+    const int64_t z = blockIdx.y;
+    p.X += z * p.sX; p.X2 += z * p.sX; p.variance += z; p.ls += z * p.nls;
+    p.G += z * p.sG; p.at += z * p.sAt; p.partial += z * p.sPartial;
+  }
+}
 
 template <int KIND>
 __device__ __forceinline__ void k_and_base(double r2, double var, double& K, double& B) {
@@ -82,6 +93,7 @@ __device__ __forceinline__ void k_and_base(double r2, double var, double& K, dou
 // (and its one accumulator per dimension: 32-128 VGPRs) is not needed at all
 template <int KIND, int NCH, bool LML, bool ISO>
 __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
+  select_model(p);
   __shared__ __attribute__((aligned(16))) double xs[NCH * GDC][GT];
   __shared__ __attribute__((aligned(16))) double ys[NCH * GDC][GT];
   __shared__ double red[256];
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(256) void grad_sweep_kernel(GradArgs p) {
 // to 64 coordinates of both point blocks in LDS and one accumulator per dimension in registers).
 template <int KIND, bool LML>
 __global__ __launch_bounds__(256) void grad_sweep_chunked_kernel(GradArgs p) {
+  select_model(p);
   __shared__ __attribute__((aligned(16))) double xs[GDC][GT];
   __shared__ __attribute__((aligned(16))) double ys[GDC][GT];
   __shared__ double inv_ell[GDC];
@@ -425,9 +438,12 @@ __global__ __launch_bounds__(256) void grad_sweep_chunked_kernel(GradArgs p) {
   }
 }
 
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partial, int64_t nblocks, int nout, double* out) {
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partial, int64_t nblocks, int nout, double* out,
+                                                          int64_t sPartial = 0, int sOut = 0) {
   __shared__ double red[256];
   const int k = blockIdx.x, tid = threadIdx.x;
+  partial += (int64_t)blockIdx.y * sPartial;       // gridDim.y models of a lock-step batch
+  out += (int64_t)blockIdx.y * sOut;
   double s = 0.0;
   for (int64_t b = tid; b < nblocks; b += 256) s += partial[b * nout + k];
   red[tid] = s;
@@ -440,21 +456,21 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partial,
 }
 
 template <int KIND, bool LML>
-static int launch_sweep(hipStream_t s, const GradArgs& a, int64_t nblocks) {
+static int launch_sweep(hipStream_t s, const GradArgs& a, int64_t nblocks, int batch = 1) {
   const int nch = (a.d + GDC - 1) / GDC;
   int rec = -1;
   if (profile_on())   // algorithmic bytes: the gradient matrix is read once (lower triangle for the LML sweep)
-    rec = profile_begin(s, 8.0 * (LML ? 0.5 * a.n * (a.n + 1.0) : (double)a.n * a.m) + 8.0 * (a.n + (LML ? 0 : a.m)) * a.d, PROF_GRAD);
+    rec = profile_begin(s, batch * (8.0 * (LML ? 0.5 * a.n * (a.n + 1.0) : (double)a.n * a.m) + 8.0 * (a.n + (LML ? 0 : a.m)) * a.d), PROF_GRAD);
   const bool iso = a.nls == 1;
 #define GPN_SWEEP(N_) \
-  if (iso) hipLaunchKernelGGL((grad_sweep_kernel<KIND, N_, LML, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a); \
-  else hipLaunchKernelGGL((grad_sweep_kernel<KIND, N_, LML, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  if (iso) hipLaunchKernelGGL((grad_sweep_kernel<KIND, N_, LML, true>), dim3((unsigned)nblocks, (unsigned)batch), dim3(256), 0, s, a); \
+  else hipLaunchKernelGGL((grad_sweep_kernel<KIND, N_, LML, false>), dim3((unsigned)nblocks, (unsigned)batch), dim3(256), 0, s, a);
   switch (nch) {
     case 1: GPN_SWEEP(1) break;
     case 2: GPN_SWEEP(2) break;
     case 3: GPN_SWEEP(3) break;
     case 4: GPN_SWEEP(4) break;
-    default: hipLaunchKernelGGL((grad_sweep_chunked_kernel<KIND, LML>), dim3((unsigned)nblocks), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((grad_sweep_chunked_kernel<KIND, LML>), dim3((unsigned)nblocks, (unsigned)batch), dim3(256), 0, s, a); break;
   }
 #undef GPN_SWEEP
   if (rec >= 0) profile_end(s, rec);
@@ -463,14 +479,14 @@ static int launch_sweep(hipStream_t s, const GradArgs& a, int64_t nblocks) {
 }
 
 template <bool LML>
-static int dispatch_kind(hipStream_t s, int kind, const GradArgs& a, int64_t nblocks) {
+static int dispatch_kind(hipStream_t s, int kind, const GradArgs& a, int64_t nblocks, int batch = 1) {
   switch (kind) {
-    case GPN_RBF: return launch_sweep<GPN_RBF, LML>(s, a, nblocks);
-    case GPN_MATERN52: return launch_sweep<GPN_MATERN52, LML>(s, a, nblocks);
-    case GPN_MATERN32: return launch_sweep<GPN_MATERN32, LML>(s, a, nblocks);
-    case GPN_EXP: return launch_sweep<GPN_EXP, LML>(s, a, nblocks);
-    case GPN_PERIODIC: return launch_sweep<GPN_PERIODIC, LML>(s, a, nblocks);
-    case GPN_SQDIST: return launch_sweep<GPN_SQDIST, LML>(s, a, nblocks);
+    case GPN_RBF: return launch_sweep<GPN_RBF, LML>(s, a, nblocks, batch);
+    case GPN_MATERN52: return launch_sweep<GPN_MATERN52, LML>(s, a, nblocks, batch);
+    case GPN_MATERN32: return launch_sweep<GPN_MATERN32, LML>(s, a, nblocks, batch);
+    case GPN_EXP: return launch_sweep<GPN_EXP, LML>(s, a, nblocks, batch);
+    case GPN_PERIODIC: return launch_sweep<GPN_PERIODIC, LML>(s, a, nblocks, batch);
+    case GPN_SQDIST: return launch_sweep<GPN_SQDIST, LML>(s, a, nblocks, batch);
     default: return -2;
   }
 }
@@ -670,7 +686,55 @@ extern "C" int gpn_lml_grad(void* stream, int kind, const double* X, int64_t n, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int rc = dispatch_kind<true>(s, kind, a, nblocks);
   if (rc != GPN_OK) return rc;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)a.nout), dim3(256), 0, s, work, nblocks, a.nout, out);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)a.nout), dim3(256), 0, s, work, nblocks, a.nout, out, (int64_t)0, 0);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// gpn_lml_grad for `batch` lock-step models in ONE sweep launch (gridDim.y = batch) + one reduction launch: model b reads
+// X + b sX (sX = 0: shared points), variance[b], length_scales + b nls, Kinv + b sK, at + b sAt and gets out + b (2 + nls);
+// work: batch * gpn_grad_work_bytes(n, n, nls, 1).  Per model the same blocks, the same partial sums in the same order:
+// bit-identical to gpn_lml_grad on that model alone.
+extern "C" int gpn_lml_grad_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
+                                    const double* variance, const double* length_scales, int nls,
+                                    const double* Kinv, int64_t ldk, int64_t sK, const double* at, int64_t ldat, int64_t sAt, int dy,
+                                    double* work, double* out) {
+  return gpn::lml_grad_batched(static_cast<hipStream_t>(stream), kind, batch, X, sX, n, d, variance, length_scales, nls, Kinv, ldk, sK,
+                               at, ldat, sAt, dy, work, 0, out);
+}
+
+// (sWork: doubles between the partial-sum regions of consecutive models; 0 = back to back)
+int gpn::lml_grad_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
+                          const double* variance, const double* length_scales, int nls,
+                          const double* Kinv, int64_t ldk, int64_t sK, const double* at, int64_t ldat, int64_t sAt, int dy,
+                          double* work, int64_t sWork, double* out) {
+  if (batch < 1) return -3;
+  if (!X) return -4;
+  if (n <= 0) return -6;
+  if (d <= 0) return -7;
+  if (!variance) return -8;
+  if (!length_scales) return -9;
+  if (nls != 1 && nls != d) return -10;
+  if (!Kinv) return -11;
+  if (ldk < n) return -12;
+  if (!at) return -14;
+  if (ldat < n) return -15;
+  if (dy <= 0) return -17;
+  if (!work) return -18;
+  if (!out) return -19;
+  if (batch > 65535) return GPN_E_UNSUPPORTED;
+  GradArgs a;
+  a.X = X; a.X2 = X; a.variance = variance; a.ls = length_scales;
+  a.G = Kinv; a.ldg = ldk; a.at = at; a.ldat = ldat; a.partial = work;
+  a.n = (int)n; a.m = (int)n; a.d = d; a.nls = nls; a.dy = dy; a.nout = 2 + nls;
+  a.tiles_m = a.tiles_n = (int)((n + GT - 1) / GT);
+  const int64_t nblocks = (int64_t)a.tiles_m * (a.tiles_m + 1) / 2;
+  a.sX = sX; a.sG = sK; a.sAt = sAt; a.sPartial = sWork > 0 ? sWork : nblocks * a.nout;
+  if (sWork > 0 && sWork < nblocks * a.nout) return -18;
+  const int rc = dispatch_kind<true>(s, kind, a, nblocks, batch);
+  if (rc != GPN_OK) return rc;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)a.nout, (unsigned)batch), dim3(256), 0, s, work, nblocks, a.nout, out,
+                     a.sPartial, a.nout);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
@@ -701,7 +765,7 @@ extern "C" int gpn_kernel_grad(void* stream, int kind, const double* X, int64_t 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int rc = dispatch_kind<false>(s, kind, a, nblocks);
   if (rc != GPN_OK) return rc;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(1 + nls)), dim3(256), 0, s, work, nblocks, a.nout, out);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(1 + nls)), dim3(256), 0, s, work, nblocks, a.nout, out, (int64_t)0, 0);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

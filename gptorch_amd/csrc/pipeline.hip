@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void zero_padding_kernel(double* B, int64_t ld
   for (int64_t k = ((int64_t)blockIdx.x < rows ? n : 0) + threadIdx.x; k < ld; k += 256) row[k] = 0.0;
 }
 
-__global__ void neg_transpose_small_kernel(const double* at, int64_t ldat, int64_t n, int dy, double* out) {
+__global__ void neg_transpose_small_kernel(const double* at, int64_t ldat, int64_t n, int dy, double* out, int64_t sAt = 0) {
+  at += (int64_t)blockIdx.y * sAt;                  // gridDim.y models of a lock-step batch, out [batch, n, dy]
+  out += (int64_t)blockIdx.y * n * dy;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   for (int c = 0; c < dy; ++c) out[i * dy + c] = -at[(int64_t)c * ldat + i];   // dLML/d(y-m) = -a
@@ -197,7 +199,79 @@ extern "C" int gpn_lml_backward(void* stream, int kind, const double* X, int64_t
   rc = gpn_lml_grad(stream, kind, X, n, d, variance, length_scales, nls, Kinv, b.ld, at, b.ld, dy, work + b.sweep, grads);
   if (rc != GPN_OK) return rc;
   if (grad_resid) {
-    hipLaunchKernelGGL(neg_transpose_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, at, b.ld, n, dy, grad_resid);
+    hipLaunchKernelGGL(neg_transpose_small_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, at, b.ld, n, dy, grad_resid, (int64_t)0);
+    GPN_LAUNCH_CHECK();
+  }
+  return GPN_OK;
+}
+
+// The backward of `batch` lock-step models (gpn_lml_forward_batched's factors, FactorBatch layout: model b at A + b sA,
+// winv + b sW) in lock step: the reference runs loss(); backward(); step() one model at a time (gptorch/models/base.py:260-269).
+// Every launch of gpn_lml_backward's schedule -- leaf transposes, the level-parallel triangular inversion, Kyy^-1 = U U^T,
+// a^T = alpha^T U^T, the gradient sweep and its reduction -- goes out ONCE over all models (strided batches; equal nodes of one
+// inversion level x models as a two-level batch).  Per model the same kernels in the same per-entry summation order:
+// grads + b (2 + nls) and grad_resid + b n dy are BIT-IDENTICAL to gpn_lml_backward on model b alone.
+// X + b sX (sX = 0: shared points), variance[b], length_scales + b nls.  work: gpn_lml_backward_batched_work_bytes.
+extern "C" int64_t gpn_lml_backward_batched_work_bytes(int64_t n, int dy, int nls, int batch) {
+  if (n < 0 || dy <= 0 || nls <= 0 || batch < 1) return 0;
+  return (int64_t)batch * round_up(backward_layout(n, dy, nls).total, 2) * (int64_t)sizeof(double);
+}
+
+extern "C" int gpn_lml_backward_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
+                                        const double* variance, const double* length_scales, int nls,
+                                        const double* A, int64_t lda, int64_t sA, const double* winv, int64_t sW, int dy,
+                                        double* work, double* grads, double* grad_resid) {
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
+  if (batch < 1) return -3;
+  if (!X) return -4;
+  if (n < 0) return -6;
+  if (d <= 0) return -7;
+  if (!variance) return -8;
+  if (!length_scales) return -9;
+  if (nls != 1 && nls != d) return -10;
+  if (!A) return -11;
+  if (lda != gpn_factor_ld(n, dy)) return -12;
+  if (batch > 1 && (sA < gpn_factor_rows(n, dy) * lda || (sA & 1))) return -13;
+  if (!winv) return -14;
+  if (batch > 1 && sW < gpn_winv_bytes(n) / (int64_t)sizeof(double)) return -15;
+  if (dy <= 0) return -16;
+  if (!work) return -17;
+  if (!grads) return -18;
+  if (n == 0) return GPN_OK;
+  const BackwardLayout b = backward_layout(n, dy, nls);
+  const int64_t sWk = round_up(b.total, 2);         // one model's workspace (doubles)
+  if (batch == 1 || n <= 256) {
+    // (the recursive inversion below 257 rows has no lock-step form: a few microseconds per model)
+    for (int z = 0; z < batch; ++z) {
+      const int rc = gpn_lml_backward(stream, kind, X + z * sX, n, d, variance + z, length_scales + (int64_t)z * nls, nls, A + z * sA, lda,
+                                      winv + z * sW, dy, work + z * sWk, grads + (int64_t)z * (2 + nls),
+                                      grad_resid ? grad_resid + (int64_t)z * n * dy : nullptr);
+      if (rc != GPN_OK) return rc;
+    }
+    return GPN_OK;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* U = work + b.u;
+  double* S = work + b.s;
+  double* at = work + b.at;
+  // U and S of every model start as zero (one clear when the models' workspaces are back to back up to the sweep partials)
+  for (int z = 0; z < batch; ++z)
+    GPN_HIP_CHECK(hipMemsetAsync(U + z * sWk, 0, (size_t)(b.at - b.u) * sizeof(double), s));
+  int rc = trtri_upper_ws_batched(s, A, n, lda, sA, winv, sW, U, b.ld, sWk, S, b.ld, sWk, batch);
+  if (rc != GPN_OK) return rc;
+  const int64_t kp = round_up(n, 16);
+  double* Kinv = S;                                 // the scratch is free again: Kyy^-1 = U U^T (lower)
+  rc = gemm_nt_strided(s, n, n, kp, 1.0, U, b.ld, U, b.ld, 0.0, Kinv, b.ld, 1, GPN_TRI_A_UPPER | GPN_TRI_B_UPPER, 0, batch, sWk, sWk, sWk);
+  if (rc != GPN_OK) return rc;
+  // a^T = alpha^T U^T (alpha^T = the extra rows of the factor buffers)
+  rc = gemm_nt_strided(s, dy, n, kp, 1.0, A + n * lda, lda, U, b.ld, 0.0, at, b.ld, 0, GPN_TRI_B_UPPER, 0, batch, sA, sWk, sWk);
+  if (rc != GPN_OK) return rc;
+  rc = lml_grad_batched(s, kind, batch, X, sX, n, d, variance, length_scales, nls, Kinv, b.ld, sWk, at, b.ld, sWk, dy,
+                        work + b.sweep, sWk, grads);
+  if (rc != GPN_OK) return rc;
+  if (grad_resid) {
+    hipLaunchKernelGGL(neg_transpose_small_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, s, at, b.ld, n, dy,
+                       grad_resid, sWk);
     GPN_LAUNCH_CHECK();
   }
   return GPN_OK;

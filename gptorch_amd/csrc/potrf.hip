@@ -1020,9 +1020,12 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
 }
 
 // U_ii <- W_ii^T for every LEAF x LEAF diagonal block
-__global__ __launch_bounds__(256) void diag_transpose_kernel(const double* winv, double* U, int64_t ldu, int n) {
-  // 32x32 sub-tiles through LDS: blockIdx.y enumerates the (LEAF/32)^2 sub-tiles of W
+__global__ __launch_bounds__(256) void diag_transpose_kernel(const double* winv, double* U, int64_t ldu, int n, int64_t sW = 0,
+                                                             int64_t sU = 0) {
+  // 32x32 sub-tiles through LDS: blockIdx.y enumerates the (LEAF/32)^2 sub-tiles of W; blockIdx.z = model of a lock-step batch
   __shared__ double t[32][33];
+  winv += (int64_t)blockIdx.z * sW;
+  U += (int64_t)blockIdx.z * sU;
   const int blk = blockIdx.x, tid = threadIdx.x;
   const int si = blockIdx.y / (LEAF / 32), sj = blockIdx.y % (LEAF / 32);
   const double* W = winv + (int64_t)blk * LEAF * LEAF;
@@ -1121,11 +1124,18 @@ __global__ void transpose_kernel(const double* src, int64_t rows, int64_t cols, 
 }
 
 // `gridDim.z` square blocks at constant strides: dst_z[c, r] = src_z[r, c]
+// (inner > 0: block z = z1 + inner * z2 -- node z1 of lock-step model z2, models at strides ssrc2 / sdst2)
 __global__ void transpose_batched_kernel(const double* src, int64_t n, int64_t lds, int64_t ssrc,
-                                         double* dst, int64_t ldd, int64_t sdst) {
+                                         double* dst, int64_t ldd, int64_t sdst, int inner = 0, int64_t ssrc2 = 0, int64_t sdst2 = 0) {
   __shared__ double t[32][33];
-  src += (int64_t)blockIdx.z * ssrc;
-  dst += (int64_t)blockIdx.z * sdst;
+  if (inner > 0) {
+    const int z2 = blockIdx.z / inner, z1 = blockIdx.z - z2 * inner;
+    src += (int64_t)z1 * ssrc + (int64_t)z2 * ssrc2;
+    dst += (int64_t)z1 * sdst + (int64_t)z2 * sdst2;
+  } else {
+    src += (int64_t)blockIdx.z * ssrc;
+    dst += (int64_t)blockIdx.z * sdst;
+  }
   const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int k = ty; k < 32; k += 8) {
@@ -1410,8 +1420,11 @@ static void trtri_collect(std::vector<TNode>& v, int64_t off, int64_t n, int dep
   trtri_collect(v, off + h, n - h, depth + 1);
 }
 
+// batch > 1: `batch` lock-step models (L, U, S of model b at b * sLm / sUm / sSm): every launch of the single-model schedule
+// becomes ONE launch over all models (equal nodes of a level x models: two-level strided batch).  Same launches per model,
+// same per-entry summation order: each model's U is bit-identical to its own gpn_trtri_upper_ws.
 static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, int64_t ldu, double* S, int64_t lds,
-                        int64_t n) {
+                        int64_t n, int batch = 1, int64_t sLm = 0, int64_t sUm = 0, int64_t sSm = 0) {
   std::vector<TNode> nodes;
   trtri_collect(nodes, 0, n, 0);
   int maxd = -1;
@@ -1436,15 +1449,15 @@ static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, 
         const TNode& t = *lvl[i0];
         const int64_t h = t.h, m2 = t.n - t.h, o = t.off, step = lvl[i0 + 1]->off - o;
         const int64_t sU = step * (ldu + 1), sL = step * (ldl + 1), sS = step * (lds + 1);
-        dim3 grid((unsigned)((m2 + 31) / 32), (unsigned)((m2 + 31) / 32), (unsigned)cnt);
+        dim3 grid((unsigned)((m2 + 31) / 32), (unsigned)((m2 + 31) / 32), (unsigned)(cnt * batch));
         hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(256), 0, s, U + (o + h) * ldu + o + h, m2, ldu, sU,
-                           S + (o + h) * lds + o + h, lds, sS);
+                           S + (o + h) * lds + o + h, lds, sS, batch > 1 ? cnt : 0, sUm, sSm);
         GPN_LAUNCH_CHECK();
-        int rc = gemm_nt_batched(s, h, m2, h, 1.0, U + o * ldu + o, ldu, sU, L + (o + h) * ldl + o, ldl, sL, 0.0,
-                                 S + o * lds + o + h, lds, sS, GPN_TRI_A_UPPER, cnt);
+        int rc = gemm_nt_strided2(s, h, m2, h, 1.0, U + o * ldu + o, ldu, L + (o + h) * ldl + o, ldl, 0.0,
+                                  S + o * lds + o + h, lds, 0, GPN_TRI_A_UPPER, cnt, sU, sL, sS, batch, sUm, sLm, sSm);
         if (rc != GPN_OK) return rc;
-        rc = gemm_nt_batched(s, h, m2, round_up(m2, 16), -1.0, S + o * lds + o + h, lds, sS, S + (o + h) * lds + o + h, lds, sS,
-                             0.0, U + o * ldu + o + h, ldu, sU, GPN_TRI_B_LOWER, cnt);
+        rc = gemm_nt_strided2(s, h, m2, round_up(m2, 16), -1.0, S + o * lds + o + h, lds, S + (o + h) * lds + o + h, lds,
+                              0.0, U + o * ldu + o + h, ldu, 0, GPN_TRI_B_LOWER, cnt, sS, sS, sU, batch, sSm, sSm, sUm);
         if (rc != GPN_OK) return rc;
       } else {
         for (size_t i = i0; i < i1; ++i) single.push_back(lvl[i]);
@@ -1459,16 +1472,33 @@ static int trtri_levels(hipStream_t s, const double* L, int64_t ldl, double* U, 
       const double* U22 = U + (o + h) * ldu + o + h;
       double* S12 = S + o * lds + o + h;
       double* S22 = S + (o + h) * lds + o + h;
-      dim3 grid((unsigned)((m2 + 31) / 32), (unsigned)((m2 + 31) / 32));
-      hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, U22, m2, m2, ldu, S22, lds);
+      if (batch > 1) {
+        dim3 grid((unsigned)((m2 + 31) / 32), (unsigned)((m2 + 31) / 32), (unsigned)batch);
+        hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(256), 0, s, U22, m2, ldu, sUm, S22, lds, sSm, 0, (int64_t)0, (int64_t)0);
+      } else {
+        dim3 grid((unsigned)((m2 + 31) / 32), (unsigned)((m2 + 31) / 32));
+        hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, U22, m2, m2, ldu, S22, lds);
+      }
       GPN_LAUNCH_CHECK();
-      int rc = gemm_nt(s, h, m2, h, 1.0, U11, ldu, L21, ldl, 0.0, S12, lds, 0, GPN_TRI_A_UPPER);
+      int rc = gemm_nt_strided2(s, h, m2, h, 1.0, U11, ldu, L21, ldl, 0.0, S12, lds, 0, GPN_TRI_A_UPPER, 1, 0, 0, 0, batch, sUm, sLm, sSm);
       if (rc != GPN_OK) return rc;
-      rc = gemm_nt(s, h, m2, round_up(m2, 16), -1.0, S12, lds, S22, lds, 0.0, U + o * ldu + o + h, ldu, 0, GPN_TRI_B_LOWER);
+      rc = gemm_nt_strided2(s, h, m2, round_up(m2, 16), -1.0, S12, lds, S22, lds, 0.0, U + o * ldu + o + h, ldu, 0, GPN_TRI_B_LOWER,
+                            1, 0, 0, 0, batch, sSm, sSm, sUm);
       if (rc != GPN_OK) return rc;
     }
   }
   return GPN_OK;
+}
+
+// U_b = L_b^-T for `batch` lock-step models (gpn_lml_backward_batched): model b's factor at L + b sL, leaf inverses at
+// winv + b sW, U / S at + b sU / + b sS (zero-initialised by the caller)
+int gpn::trtri_upper_ws_batched(hipStream_t s, const double* L, int64_t n, int64_t ldl, int64_t sL, const double* winv, int64_t sW,
+                                double* U, int64_t ldu, int64_t sU, double* S, int64_t lds, int64_t sS, int batch) {
+  const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
+  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb, (LEAF / 32) * (LEAF / 32), (unsigned)batch), dim3(256), 0, s, winv, U, ldu, (int)n,
+                     sW, sU);
+  GPN_LAUNCH_CHECK();
+  return trtri_levels(s, L, ldl, U, ldu, S, lds, n, batch, sL, sU, sS);
 }
 
 extern "C" int gpn_trtri_upper_ws(void* stream, const double* L, int64_t n, int64_t ldl, const double* winv,
@@ -1486,7 +1516,7 @@ extern "C" int gpn_trtri_upper_ws(void* stream, const double* L, int64_t n, int6
   if (n == 0) return GPN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
-  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb, (LEAF / 32) * (LEAF / 32)), dim3(256), 0, s, winv, U, ldu, (int)n);
+  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb, (LEAF / 32) * (LEAF / 32)), dim3(256), 0, s, winv, U, ldu, (int)n, (int64_t)0, (int64_t)0);
   GPN_LAUNCH_CHECK();
   return trtri_levels(s, L, ldl, U, ldu, S, lds, n);
 }
@@ -1503,7 +1533,7 @@ extern "C" int gpn_trtri_upper(void* stream, const double* L, int64_t n, int64_t
   if (n == 0) return GPN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
-  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb, (LEAF / 32) * (LEAF / 32)), dim3(256), 0, s, winv, U, ldu, (int)n);
+  hipLaunchKernelGGL(diag_transpose_kernel, dim3(nb, (LEAF / 32) * (LEAF / 32)), dim3(256), 0, s, winv, U, ldu, (int)n, (int64_t)0, (int64_t)0);
   GPN_LAUNCH_CHECK();
   Ctx c{s, ldl, const_cast<double*>(winv), nullptr, GPN_OK};
   trtri_rec(c, L, ldl, U, ldu, n, 0);

@@ -7,6 +7,8 @@ as extra rows (forward substitution for free) -> log-det / ||alpha||^2
 reduction.  _predict re-uses the cached factor when neither the parameters nor
 the inputs changed (the reference re-factorises on every call, gpr.py:104).
 """
+import collections
+
 import torch
 
 from .. import _ops, mean_functions
@@ -126,7 +128,32 @@ class GPR(GPModel):
 
 
 _LANES = {}          # device -> two HIP streams shared by every batched call (streams= placement only)
-_BATCH_BUFFERS = {}  # (device, batch, n, dy) -> _ops.FactorBatch reused by batched_log_likelihood
+
+# Lock-step buffers reused between calls (a search calls batched_log_likelihood / batched_loss_and_grad once per optimiser
+# step): keyed by the FULL group key + batch size -- two groups of one call can never share an entry (round-4 advice: keyed
+# by (device, batch, n, dy) only, two groups of equal count / N / dy but different kernel kind or ARD shared one buffer and
+# the first group read the second group's results) -- least recently used first out, bounded in entries and bytes;
+# release_batch_buffers() drops them all.
+_BATCH_BUFFERS = collections.OrderedDict()    # (group key, batch) -> holder dict {"fb": _ops.FactorBatch}
+BATCH_BUFFER_MAX_ENTRIES = 4
+BATCH_BUFFER_MAX_BYTES = 48 << 30
+
+
+def _batch_holder(key):
+    h = _BATCH_BUFFERS.pop(key, None)
+    if h is None:
+        h = {}
+    _BATCH_BUFFERS[key] = h                     # most recently used last
+    def total():
+        return sum(v["fb"].nbytes() for v in _BATCH_BUFFERS.values() if "fb" in v)
+    while len(_BATCH_BUFFERS) > 1 and (len(_BATCH_BUFFERS) > BATCH_BUFFER_MAX_ENTRIES or total() > BATCH_BUFFER_MAX_BYTES):
+        _BATCH_BUFFERS.popitem(last=False)
+    return h
+
+
+def release_batch_buffers():
+    """free the factor buffers batched_log_likelihood / batched_loss_and_grad keep between calls."""
+    _BATCH_BUFFERS.clear()
 
 
 def _stacked_values(params):
@@ -137,23 +164,50 @@ def _stacked_values(params):
     return torch.stack([p.transform() for p in params])
 
 
-def _lockstep_groups(models):
-    """indices of the models that can share one gpn_lml_forward_batched call, grouped by (kernel kind, n, d, dy, ARD, device):
-    stationary kernels below the size from which log_likelihood() refines the quadratic form."""
+def _group_key(m):
+    k = m._stationary()
+    return (k._kind, tuple(m.X.shape), m.Y.shape[1], int(k.length_scales.numel()), m.X.device)
+
+
+def _lockstep_groups(models, for_grad=False):
+    """[(key, indices)] of the models that can share one lock-step call, grouped by (kernel kind, n, d, dy, ARD, device):
+    stationary kernels below the size from which log_likelihood() refines the quadratic form.  for_grad: also no priors
+    (loss() = -(LML + log prior), model.py:158-197: a model with priors takes the sequential path)."""
     groups = {}
     for i, m in enumerate(models):
         k = m._stationary()
-        if k is None or m.X.shape[0] >= _ops.refine_min_n() or not m.X.is_cuda:
+        if k is None or m.X.shape[0] >= _ops.refine_min_n() or not m.X.is_cuda or m.X.shape[0] == 0:
             continue
-        key = (k._kind, tuple(m.X.shape), m.Y.shape[1], int(k.length_scales.numel()), m.X.device)
-        groups.setdefault(key, []).append(i)
-    return [g for g in groups.values() if len(g) >= 2]
+        if for_grad and any(getattr(p, "prior", None) is not None for p in m.parameters()):
+            continue
+        groups.setdefault(_group_key(m), []).append(i)
+    return [(key, g) for key, g in groups.items() if len(g) >= 2]
+
+
+def _group_data(ms, differentiable=False):
+    """(X, R) of a lock-step group: shared [n, d] / [n, dy] when every model holds the same tensors (restarts on one data
+    set), else stacked [B, ...].  differentiable: R keeps the autograd graph of trainable mean functions."""
+    m0 = ms[0]
+    same_x = all(m.X.data_ptr() == m0.X.data_ptr() for m in ms)
+    zero_mean = all(type(m.mean_function) is mean_functions.Zero for m in ms)
+    same_r = same_x and zero_mean and all(m.Y.data_ptr() == m0.Y.data_ptr() for m in ms)
+    X = m0.X if same_x else torch.stack([m.X for m in ms])
+    if same_r:
+        R = m0.Y
+    elif zero_mean:
+        R = torch.stack([m.Y for m in ms])
+    elif differentiable:
+        R = torch.stack([m.Y - m.mean_function(m.X) for m in ms])
+    else:
+        with torch.no_grad():
+            R = torch.stack([m.Y - m.mean_function(m.X) for m in ms])
+    return X, R
 
 
 def batched_log_likelihood(models, streams=None):
     """log_likelihood() of several INDEPENDENT GPR models (multi-start hyper-parameter search: one model per restart; the
-    reference evaluates them one per optimiser step, gptorch/models/base.py:260-269).  No gradients; returns a list of
-    (1,) tensors, each BIT-IDENTICAL to that model's own log_likelihood().
+    reference evaluates them one per optimiser step, gptorch/models/base.py:260-269).  No gradients (batched_loss_and_grad
+    has them); returns a list of (1,) tensors, each BIT-IDENTICAL to that model's own log_likelihood().
 
     streams=None (default): models of one shape (kernel kind, N, D, dy) run in LOCK STEP through ONE
     gpn_lml_forward_batched call -- one assembly launch, the 128x128 leaf as a grid of B workgroups, every column pass and
@@ -168,29 +222,17 @@ def batched_log_likelihood(models, streams=None):
     out = [None] * len(models)
     with torch.no_grad():
         pending = []
-        for g in _lockstep_groups(models):
+        for key, g in _lockstep_groups(models):
             ms = [models[i] for i in g]
-            m0 = ms[0]
-            k0 = m0._stationary()
-            dev = m0.X.device
             # host side: a handful of launches per GROUP, none per model (a per-model exp / subtraction / comparison costs
             # more than the model's share of the batch at N = 512)
-            same_x = all(m.X.data_ptr() == m0.X.data_ptr() for m in ms)
-            zero_mean = all(type(m.mean_function) is mean_functions.Zero for m in ms)
-            same_r = same_x and zero_mean and all(m.Y.data_ptr() == m0.Y.data_ptr() for m in ms)
-            X = m0.X if same_x else torch.stack([m.X for m in ms])
-            if same_r:
-                R = m0.Y
-            elif zero_mean:
-                R = torch.stack([m.Y for m in ms])
-            else:
-                R = torch.stack([m.Y - m.mean_function(m.X) for m in ms])
+            X, R = _group_data(ms)
             var = _stacked_values([m._stationary().variance for m in ms]).reshape(len(ms))
             ls = _stacked_values([m._stationary().length_scales for m in ms]).reshape(len(ms), -1)
             nz = _stacked_values([m.likelihood.variance for m in ms]).reshape(len(ms))
-            key = (dev, len(ms), m0.X.shape[0], m0.Y.shape[1])
-            fb, terms = _ops.lml_forward_batched(k0._kind, X, R, var, ls, nz, fb=_BATCH_BUFFERS.get(key))
-            _BATCH_BUFFERS[key] = fb
+            holder = _batch_holder((key, len(ms)))
+            fb, terms = _ops.lml_forward_batched(key[0], X, R, var, ls, nz, fb=holder.get("fb"))
+            holder["fb"] = fb
             pending.append((g, fb, terms))
         for g, fb, terms in pending:
             info = fb.info.cpu()                   # one read-back per group (synchronises the stream)
@@ -202,6 +244,121 @@ def batched_log_likelihood(models, streams=None):
             if out[i] is None:
                 out[i] = m.log_likelihood()
     return out
+
+
+def _group_param_lists(ms):
+    return ([m._stationary().variance for m in ms], [m._stationary().length_scales for m in ms],
+            [m.likelihood.variance for m in ms])
+
+
+def _shared_transform(params):
+    t0 = params[0]._transform
+    return t0 if all(p._transform == t0 for p in params) else None
+
+
+def batched_loss_and_grad(models):
+    """`loss = m.loss(); loss.backward()` for several INDEPENDENT GPR models -- the body of the reference's optimiser step
+    (gptorch/models/base.py:260-269: `closure()`), which the reference can only run one model at a time.  Gradients are
+    ACCUMULATED into every trainable parameter's `.grad` exactly as backward() does; returns the list of detached (1,) loss
+    tensors.
+
+    Models of one shape (kernel kind, N, D, dy, ARD) run in LOCK STEP: one gpn_lml_forward_batched + one
+    gpn_lml_backward_batched call per group (_ops.BatchedGPRLogLik), the hyper-parameters of the group stacked so that the
+    transforms and their chain rule are one small launch per parameter kind.  Each model's loss AND gradients are
+    BIT-IDENTICAL to its own `loss(); backward()`; a model whose factorisation fails is replayed alone through the jitter
+    ladder.  Composite / dense-K kernels, singletons, models with priors and sizes that refine the quadratic form take the
+    sequential path."""
+    out = [None] * len(models)
+    for key, g in _lockstep_groups(models, for_grad=True):
+        ms = [models[i] for i in g]
+        B = len(ms)
+        X, R = _group_data(ms, differentiable=True)
+        stacks = []
+        for plist in _group_param_lists(ms):
+            t0 = _shared_transform(plist)
+            if t0 is not None:
+                stacks.append(t0(torch.stack(list(plist))))          # StackBackward hands every Param its own gradient row
+            else:
+                stacks.append(torch.stack([p.transform() for p in plist]))
+        var, ls, nz = stacks[0].reshape(B), stacks[1].reshape(B, -1), stacks[2].reshape(B)
+        lml = _ops.BatchedGPRLogLik.apply(X, R, var, ls, nz, key[0], _batch_holder((key, B)))
+        loss = -(lml + 0.0)                                          # model.py:_loss with an empty log prior
+        if loss.requires_grad:
+            loss.sum().backward()
+        ld = loss.detach()
+        for b, i in enumerate(g):
+            out[i] = ld[b:b + 1]
+    for i, m in enumerate(models):
+        if out[i] is None:
+            loss = m.loss()
+            if loss.requires_grad:
+                loss.backward()
+            out[i] = loss.detach()
+    return out
+
+
+def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, learning_rate=None):
+    """GPModel.optimize (gptorch/models/base.py:111-296) for several INDEPENDENT restarts at once: every iteration is ONE
+    lock-step loss + backward over each group of equally shaped models (see batched_loss_and_grad) and ONE optimiser step
+    on the group's STACKED raw parameters -- the torch optimisers the reference offers are elementwise (all but LBFGS), so
+    every restart follows the trajectory its own `optimize()` would.  Given equal parameters the losses and gradients are
+    bit-identical to the sequential ones; the optimiser step itself is PyTorch's multi-tensor kernel, which rounds
+    `p + value * (a / b)` with or without a fused multiply-add depending on a tensor's size and alignment (measured: 1 ulp
+    on a parameter after 2 Adam steps for [4, 1] against [1]), so trajectories agree to ~1e-12 relative, not bit for bit.
+    Returns (losses [len(models), max_iter] numpy, seconds).  The models' Params hold the final values afterwards.
+
+    Groups: as batched_loss_and_grad, and additionally every model of the group trains the same subset of (variance,
+    length_scales, noise) with a shared transform and no trainable mean function; other models (and method="LBFGS" / the
+    scipy methods) are optimised one after the other by their own optimize()."""
+    import time
+    import numpy as np
+    from .base import _TORCH_DEFAULT_LR
+    if learning_rate is None and method in _TORCH_DEFAULT_LR:
+        learning_rate = _TORCH_DEFAULT_LR[method]
+    losses = np.zeros((len(models), max_iter))
+    done = [False] * len(models)
+    tic = time.time()
+    groups = _lockstep_groups(models, for_grad=True) if (method in _TORCH_DEFAULT_LR and method != "LBFGS") else []
+    for key, g in groups:
+        ms = [models[i] for i in g]
+        B = len(ms)
+        plists = _group_param_lists(ms)
+        transforms = [_shared_transform(pl) for pl in plists]
+        flags = [{bool(p.requires_grad) for p in pl} for pl in plists]
+        mean_trainable = any(p.requires_grad for m in ms for p in m.mean_function.parameters())
+        if any(t is None for t in transforms) or any(len(f) != 1 for f in flags) or mean_trainable:
+            continue
+        X, R = _group_data(ms)
+        raws = [torch.nn.Parameter(torch.stack([p.data for p in pl]), requires_grad=f.pop()) for pl, f in zip(plists, flags)]
+        trainable = [r for r in raws if r.requires_grad]
+        optimizer = ms[0]._make_optimizer(method, trainable, learning_rate)
+        holder = {}
+        dev_losses = torch.empty(max_iter, B, dtype=torch.float64, device=X.device)
+        print("multi_start_optimize: %d x %s in lock step via %s" % (B, ms[0].__class__.__name__, method))
+        for idx in range(max_iter):
+            optimizer.zero_grad()
+            var, ls, nz = (t(r) for t, r in zip(transforms, raws))
+            lml = _ops.BatchedGPRLogLik.apply(X, R, var.reshape(B), ls.reshape(B, -1), nz.reshape(B), key[0], holder)
+            loss = -(lml + 0.0)
+            if trainable:
+                loss.sum().backward()
+            optimizer.step()
+            dev_losses[idx] = loss.detach()
+            if verbose:
+                print("Iter: %d\tLoss: %s" % (idx, dev_losses[idx].tolist()))
+        losses[g, :] = dev_losses.t().cpu().numpy()
+        with torch.no_grad():
+            for pl, r in zip(plists, raws):
+                for b, p in enumerate(pl):
+                    p.data = r.data[b].clone()
+        for i in g:
+            done[i] = True
+    for i, m in enumerate(models):
+        if not done[i]:
+            res = m.optimize(method=method, max_iter=max_iter, verbose=verbose, learning_rate=learning_rate)
+            if isinstance(res, tuple):
+                losses[i, :len(res[0])] = res[0]
+    return losses, time.time() - tic
 
 
 def _batched_on_streams(models, streams):

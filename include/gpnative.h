@@ -207,6 +207,13 @@ int gpn_lml_grad(void* stream, int kind, const double* X, int64_t n, int d,
                  const double* variance, const double* length_scales, int nls,
                  const double* Kinv, int64_t ldk, const double* at, int64_t ldat, int dy,
                  double* work, double* out);
+/* gpn_lml_grad for `batch` lock-step models as one sweep launch + one reduction launch: model b reads X + b*sX (0: shared),
+ * variance[b], length_scales[b*nls ..], Kinv + b*sK, at + b*sAt and writes out[b*(2+nls) ..]; work: batch *
+ * gpn_grad_work_bytes(n, n, nls, 1).  Bit-identical per model to gpn_lml_grad. */
+int gpn_lml_grad_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
+                         const double* variance, const double* length_scales, int nls,
+                         const double* Kinv, int64_t ldk, int64_t sK, const double* at, int64_t ldat, int64_t sAt, int dy,
+                         double* work, double* out);
 
 /* autograd backward of gpn_kernel_matrix: out[0] = sum G*dK/dvariance,
  * out[1..nls] = sum G*dK/dlength_scales for a given dense G [n, m]. */
@@ -358,6 +365,20 @@ int gpn_lml_backward(void* stream, int kind, const double* X, int64_t n, int d,
                      const double* A, int64_t lda, const double* winv, int dy,
                      double* work, double* grads, double* grad_resid);
 
+/* gpn_lml_backward for the `batch` models of a gpn_lml_forward_batched call, in lock step: the reference's training loop is
+ * loss(); backward(); step() one model at a time (gptorch/models/base.py:260-269; the backward itself: gpr.py:47-67 through
+ * autograd).  Model b: points X + b*sX (sX = 0: shared), variance[b], length_scales[b*nls ..], factor A + b*sA and leaf
+ * inverses winv + b*sW exactly as gpn_lml_forward_batched left them (info[b] == 0).  Every launch of gpn_lml_backward's
+ * schedule (leaf transposes, level-parallel triangular inversion, Kyy^-1 = U U^T, a^T = alpha^T U^T, gradient sweep,
+ * reduction) goes out once over all models; grads [batch, 2 + nls] and grad_resid [batch, n, dy] (may be NULL) are
+ * BIT-IDENTICAL per model to gpn_lml_backward on that model alone.  work: gpn_lml_backward_batched_work_bytes bytes
+ * (2 factor-sized matrices per model). */
+int64_t gpn_lml_backward_batched_work_bytes(int64_t n, int dy, int nls, int batch);
+int gpn_lml_backward_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
+                             const double* variance, const double* length_scales, int nls,
+                             const double* A, int64_t lda, int64_t sA, const double* winv, int64_t sW, int dy,
+                             double* work, double* grads, double* grad_resid);
+
 /* gpn_predict = GPR._predict (gpr.py:88-117), given the factor of gpn_lml_forward (whose extra rows hold
  * V = L^-1 (Y - m(X)), i.e. the training-side mean function went in through gpn_lml_forward's M):
  * mean [ns, dy] = Ms + A^T V with A = L^-1 K(X, x*) and Ms [ns, dy] = the mean function at the test points
@@ -495,6 +516,20 @@ int gpn_copy_matrix(void* stream, const double* src, int64_t rows, int64_t cols,
 /* out[r] = sum_c A[r,c]^2  (the (A*A).sum(0) of gpr.py:109-113 in transposed storage) */
 int gpn_row_sumsq(void* stream, const double* A, int64_t rows, int64_t cols, int64_t lda,
                   double* out);
+
+
+/* ---- optional launch profiler (bench.py's roofline legs) ---------------------- */
+/* While enabled, every contraction / assembly / gradient-sweep / leaf launch of this library is bracketed by two HIP events
+ * recorded ON THE LAUNCH STREAM (what SURVEY 8(d) asks the SYRK fraction to be measured with).  Off by default; the
+ * events serialise nothing, but enabling it inside a timed region adds two event records per launch. */
+int gpn_profile_enable(int on);
+/* Synchronises every recorded event and clears the list.  out3_host[0] = launches, [1] = total ms, [2] = executed flops of all
+ * contraction launches (2 M N K per launch; lower-tile launches count the tiles on or below the diagonal only). */
+int gpn_profile_collect(double* out3_host);
+/* ... per launch class c < nclasses (0 rectangular contraction, 1 lower-tile SYRK update, 2 in-place panel solve,
+ * 3 K-clipped contraction, 4 K assembly, 5 gradient sweep, 6 leaf): out_host[3c] = launches, [3c+1] = ms, [3c+2] = work
+ * (flops for 0-3, algorithmic bytes for 4-5). */
+int gpn_profile_collect_classes(double* out_host, int nclasses);
 
 #ifdef __cplusplus
 }

@@ -297,6 +297,43 @@ def gen_adam(out):
         json.dump(res, f, indent=1)
 
 
+ADAM_MID_CASE = dict(name="adam_mid_m52_12288_16", kind="Matern52", n=12288, d=16, dy=1, variance=1.0, length_scales=4.0, ARD=False, noise=1e-2)
+
+
+def gen_adam_mid(out, steps=10):
+    """config 3's training loop ABOVE the refinement threshold (12288 rows): a 10-step Adam trajectory of the reference
+    (base.py:149-151, 260-269) on C3's model shape at N = 12288 -- the refined LML, its backward and the optimiser pinned
+    jointly (round-4 review item 2; adam_cases.json stops at N = 1024).  ~1-2 min per step on 8 threads, ~25 GB."""
+    case = ADAM_MID_CASE
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    m = ref_model(case, x, y)
+    t0 = time.time()
+    with quiet():
+        losses, _ = m.optimize(method="Adam", max_iter=steps, verbose=False)
+    entry = dict(case)
+    entry["steps"] = steps
+    entry["learning_rate"] = 0.01
+    entry["x_checksum"], entry["y_checksum"] = rng.checksum(x), rng.checksum(y)
+    entry["losses"] = [float(v) for v in losses]
+    entry["final_raw"] = {
+        "kernel.variance": m.kernel.variance.detach().numpy().tolist(),
+        "kernel.length_scales": m.kernel.length_scales.detach().numpy().tolist(),
+        "likelihood.variance": m.likelihood.variance.detach().numpy().tolist(),
+    }
+    entry["ref_seconds"] = time.time() - t0
+    print(f"adam mid: {losses[0]:.8f} -> {losses[-1]:.8f} in {entry['ref_seconds']:.0f}s")
+    with open(os.path.join(out, "adam_mid_case.json"), "w") as f:
+        json.dump(entry, f, indent=1)
+    del m
+    o = oracle_model(case, x, y)
+    ol = o.optimize_adam(steps, 0.01)
+    entry["oracle_rel_diff"] = rel(ol, losses)
+    print("adam mid: oracle rel diff", entry["oracle_rel_diff"])
+    with open(os.path.join(out, "adam_mid_case.json"), "w") as f:
+        json.dump(entry, f, indent=1)
+    assert entry["oracle_rel_diff"] < 1e-9
+
+
 def gen_functions(out):
     """functions.cholesky / trtrs / lt_log_determinant direct (unpinned by the
     reference's tests -- test_functions.py only imports) + jitter ladder."""
@@ -592,9 +629,9 @@ if __name__ == "__main__":
     args = ap.parse_args()
     torch.manual_seed(0)
     steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
-                 lml=lambda: gen_lml(HERE, args.big), mid=lambda: gen_mid(HERE), adam=lambda: gen_adam(HERE),
+                 lml=lambda: gen_lml(HERE, args.big), mid=lambda: gen_mid(HERE), adam=lambda: gen_adam(HERE), adammid=lambda: gen_adam_mid(HERE),
                  func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE),
                  comp=lambda: gen_composite(HERE), compbig=lambda: gen_composite_big(HERE), comp16k=lambda: gen_composite_16k(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), lbfgs=lambda: gen_lbfgs(HERE))
     for k, fn in steps.items():
-        if not args.only or k in args.only.split(","):
+        if (not args.only and k != "adammid") or k in args.only.split(","):      # adammid: ~30 min, by name only
             fn()

@@ -1,0 +1,279 @@
+"""Lock-step loss + backward + optimiser step over several independent GPR restarts (round 5): the reference's training
+loop is `loss(); backward(); step()` ONE model at a time (gptorch/models/base.py:260-269, gptorch/models/gpr.py:47-67);
+gpn_lml_backward_batched / batched_loss_and_grad / multi_start_optimize run B models of one shape through every launch
+together.  The bar: every model's numbers are BIT-IDENTICAL to its own sequential evaluation, and the goldens generated
+from the reference hold through the batched path at the same tolerances."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import load_json
+from gptorch_amd import kernels, likelihoods, mean_functions, rng
+from gptorch_amd.models import GPR, batched_log_likelihood, batched_loss_and_grad, multi_start_optimize
+
+pytestmark = pytest.mark.gpu
+
+KERN = {"Rbf": kernels.Rbf, "Matern52": kernels.Matern52, "Matern32": kernels.Matern32, "Exp": kernels.Exp}
+
+
+def _quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+@pytest.mark.parametrize("n,d,dy,batch,kind,ard,shared", [
+    (1500, 5, 1, 5, "Matern52", True, True),       # ragged last block, uneven inversion tree (single nodes per level)
+    (1024, 8, 2, 3, "Rbf", False, False),          # power-of-two tree: equal nodes x models as two-level batches; dy = 2
+    (200, 2, 1, 7, "Rbf", False, True),            # n <= 256: the recursive inversion, model by model inside the call
+    (128, 3, 1, 4, "Matern32", False, False),      # one leaf
+    (2176, 4, 1, 2, "Rbf", False, True),           # 17 leaves
+    (5000, 3, 2, 3, "Matern52", False, True),      # ragged, two right-hand sides
+    (4096, 20, 1, 3, "Exp", True, False),          # d > 16: two coordinate chunks in the sweep, per-dimension sums
+])
+def test_lockstep_backward_is_bit_identical_to_sequential(device, n, d, dy, batch, kind, ard, shared):
+    """gpn_lml_backward_batched on the factors of gpn_lml_forward_batched: every model's constrained gradients and
+    dLML/d(y - m) are BIT-IDENTICAL to gpn_lml_backward on that model's own factor (closed form of SURVEY 8(a) a9)."""
+    from gptorch_amd import _backward, _ops
+    g = torch.Generator().manual_seed(n + batch)
+    xs, ys = [], []
+    for b in range(batch):
+        x, y = rng.make_regression(n, d, dy, seed=3 if shared else 3 + b)
+        xs.append(torch.as_tensor(x).to(device))
+        ys.append(torch.as_tensor(y).to(device))
+    var = (0.5 + torch.rand(batch, generator=g, dtype=torch.float64)).to(device)
+    ls = (0.7 + torch.rand(batch, d if ard else 1, generator=g, dtype=torch.float64)).to(device) * float(np.sqrt(d))
+    nz = (0.01 + 0.05 * torch.rand(batch, generator=g, dtype=torch.float64)).to(device)
+    X = xs[0] if shared else torch.stack(xs)
+    R = ys[0] if shared else torch.stack(ys)
+    fb, terms = _ops.lml_forward_batched(kind, X, R, var, ls, nz)
+    assert int(fb.info.cpu().abs().max()) == 0
+    grads, g_R = _ops.lml_backward_batched(kind, X, var, ls, fb, need_resid=True)
+    nls = ls.shape[1]
+    for b in range(batch):
+        f, t = _ops.lml_forward(kind, xs[b], ys[b], var[b:b + 1], ls[b], nz[b:b + 1], refine=False)
+        gv, gl, gn, gr = _backward.lml_backward(kind, xs[b], var[b:b + 1], ls[b], nz[b:b + 1], f)
+        assert torch.equal(grads[b, 0:1], gv), (b, grads[b], gv)
+        assert torch.equal(grads[b, 1:1 + nls], gl), (b, grads[b], gl)
+        assert torch.equal(grads[b, 1 + nls:], gn), (b, grads[b], gn)
+        assert torch.equal(g_R[b], gr), b
+    # and the same call once more into the same workspace (a fit loop reuses it): same bits
+    grads2, _ = _ops.lml_backward_batched(kind, X, var, ls, fb, need_resid=False)
+    assert torch.equal(grads, grads2)
+
+
+def _restarts(device, n, d, specs, seed=5, dy=1, mean=None):
+    x, y = rng.make_regression(n, d, dy, seed=seed)
+    X, Y = torch.as_tensor(x).to(device), torch.as_tensor(y).to(device)
+    ms = []
+    for kind, ard, var, ell, nzv in specs:
+        ls = np.full(d, ell) * (1.0 + 0.1 * np.arange(d)) if ard else ell
+        mf = None if mean is None else mean_functions.Constant(dy, val=torch.full((dy,), mean, dtype=torch.float64))
+        m = GPR(X, Y, KERN[kind](d, variance=var, length_scales=ls, ARD=ard), likelihood=likelihoods.Gaussian(variance=nzv), mean_function=mf)
+        m.cuda()
+        m.X, m.Y = X, Y                            # restarts over ONE data set: the same device tensors
+        ms.append(m)
+    return ms
+
+
+def _grads(m):
+    return [None if p.grad is None else p.grad.clone() for p in m.parameters()]
+
+
+MIXED = [("Rbf", False, 1.0, 1.5, 0.02), ("Matern52", False, 0.8, 2.0, 0.03), ("Rbf", False, 1.3, 1.1, 0.05),
+         ("Matern52", False, 1.1, 1.7, 0.01), ("Rbf", True, 0.9, 1.4, 0.02), ("Rbf", True, 1.2, 1.9, 0.04),
+         ("Exp", False, 1.0, 2.5, 0.02)]                     # two Rbf, two Matern52, two ARD Rbf: three groups; one singleton
+
+
+def test_batched_loss_and_grad_is_bit_identical_with_several_groups_in_one_call(device):
+    """three lock-step groups of EQUAL count, N and dy in one call (different kernel kind / ARD: the case in which round 4's
+    buffer cache handed two groups the same buffers) plus a singleton: every loss and every .grad equals the model's own
+    loss(); backward() bit for bit (base.py:260-269)."""
+    ms = _restarts(device, 900, 3, MIXED)
+    seq_loss, seq_grads = [], []
+    for m in ms:
+        m.zero_grad()
+        loss = m.loss()
+        loss.backward()
+        seq_loss.append(loss.detach().clone())
+        seq_grads.append(_grads(m))
+        m.zero_grad()
+    out = batched_loss_and_grad(ms)
+    for i, m in enumerate(ms):
+        assert out[i].shape == (1,) and torch.equal(out[i], seq_loss[i]), (i, out[i], seq_loss[i])
+        for ga, gb in zip(_grads(m), seq_grads[i]):
+            assert (ga is None) == (gb is None)
+            if ga is not None:
+                assert torch.equal(ga, gb), (i, ga, gb)
+    # gradients ACCUMULATE like backward(): a second call doubles them
+    batched_loss_and_grad(ms)
+    for i, m in enumerate(ms):
+        for ga, gb in zip(_grads(m), seq_grads[i]):
+            if ga is not None:
+                assert torch.equal(ga, gb + gb)
+    # the forward-only entry point with the same three groups (round-4 advice, high): values of the right models
+    vals = batched_log_likelihood(ms)
+    for i, m in enumerate(ms):
+        assert torch.equal(vals[i], -seq_loss[i]), i
+
+
+def test_batched_loss_and_grad_trainable_mean_and_fixed_parameters(device):
+    """a trainable Constant mean function (dLML/d(y - m) flows back through the stacked residuals) and a parameter frozen
+    in every model: same gradients as the sequential path, nothing for the frozen one."""
+    ms = _restarts(device, 700, 2, [("Rbf", False, 1.0, 1.2, 0.02), ("Rbf", False, 0.7, 0.9, 0.04), ("Rbf", False, 1.4, 1.6, 0.03)],
+                   dy=2, mean=0.3)
+    for m in ms:
+        m.mean_function.val.requires_grad_(True)
+        m.kernel.variance.requires_grad_(False)
+    seq = []
+    for m in ms:
+        m.loss().backward()
+        seq.append(_grads(m))
+        m.zero_grad()
+    batched_loss_and_grad(ms)
+    for m, ref in zip(ms, seq):
+        assert m.kernel.variance.grad is None
+        for (name, p), gb in zip(m.named_parameters(), ref):
+            if gb is None:
+                continue
+            if name.startswith("mean_function"):
+                # the mean's gradient sums n entries of -a in a different reduction (stack + sum vs per-model sum)
+                assert torch.allclose(p.grad, gb, rtol=1e-12, atol=1e-12), (name, p.grad, gb)
+            else:
+                assert torch.equal(p.grad, gb), (name, p.grad, gb)
+
+
+def test_lockstep_backward_replays_the_ladder_per_failing_model(device):
+    """one model of the batch is singular at its own noise level: the forward replays THAT model through the jitter ladder
+    (functions.py:20-43) into a private factor, the backward runs on it; all models match their sequential gradients."""
+    n, d = 600, 2
+    x, y = rng.make_regression(n, d, 1, seed=21)
+    xdup = np.array(x)
+    xdup[300:] = xdup[:300]
+    ms = []
+    for b in range(4):
+        m = GPR(xdup if b == 2 else x, y, kernels.Rbf(d, variance=1.0 + 0.1 * b, length_scales=1.3), likelihood=likelihoods.Gaussian(variance=0.03))
+        m.cuda()
+        if b == 2:
+            m.likelihood.variance.data.fill_(-80.0)
+        ms.append(m)
+    seq_loss, seq = [], []
+    for m in ms:
+        loss = m.loss()
+        loss.backward()
+        seq_loss.append(loss.detach().clone())
+        seq.append(_grads(m))
+        m.zero_grad()
+    assert ms[2]._holder["factor"].jitter_rung >= 0
+    out = batched_loss_and_grad(ms)
+    for i, m in enumerate(ms):
+        assert torch.equal(out[i], seq_loss[i]), i
+        for ga, gb in zip(_grads(m), seq[i]):
+            assert (ga is None) == (gb is None)
+            if ga is not None:
+                assert torch.equal(ga, gb), (i, ga, gb)
+
+
+def test_c2_gradient_golden_through_the_lockstep_path(device):
+    """BASELINE config 2 at FULL size (N = 8192, D = 8, Rbf) as one member of a batch of three restarts: the reference's
+    LML (1e-8 absolute) and d loss / d raw parameters (1e-8, tests/golden/lml_c2_grad.json) through gpn_lml_forward_batched
+    + gpn_lml_backward_batched."""
+    case = load_json("lml_c2_grad.json")
+    specs = [("Rbf", False, 0.7, 3.5, 0.02), ("Rbf", False, case["variance"], case["length_scales"], case["noise"]), ("Rbf", False, 1.4, 2.2, 0.05)]
+    ms = _restarts(device, case["n"], case["d"], specs, seed=0)
+    assert rng.checksum(ms[1].X.cpu().numpy()) == case["x_checksum"] and rng.checksum(ms[1].Y.cpu().numpy()) == case["y_checksum"]
+    out = batched_loss_and_grad(ms)
+    m = ms[1]
+    assert abs(-out[1].item() - case["lml"]) < 1e-8
+    for name, g in [("kernel.variance", m.kernel.variance.grad), ("kernel.length_scales", m.kernel.length_scales.grad),
+                    ("likelihood.variance", m.likelihood.variance.grad)]:
+        ref = np.asarray(case["grad_loss"][name])
+        err = np.max(np.abs(g.cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref)))
+        assert err < 1e-8, (name, g, ref)
+    # and bit-identical to the model alone
+    ref_grads = _grads(m)
+    m.zero_grad()
+    loss = m.loss()
+    loss.backward()
+    assert torch.equal(loss.detach(), out[1])
+    for ga, gb in zip(_grads(m), ref_grads):
+        assert (ga is None) == (gb is None)
+        if ga is not None:
+            assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("method", ["Adam", "SGD", "RMSprop"])
+def test_multi_start_optimize_follows_each_models_own_trajectory(device, method):
+    """multi_start_optimize (one lock-step loss + backward + ONE optimiser step on the stacked raw parameters per
+    iteration) against GPModel.optimize restart by restart (base.py:111-296).  Loss and gradients are bit-identical given
+    equal parameters (tests above); PyTorch's multi-tensor optimiser kernels round the update itself with or without an FMA
+    depending on a tensor's size / alignment (1 ulp after 2 Adam steps, [4, 1] vs [1]), so the trajectories are held to
+    1e-10 relative, two orders inside the goldens' 1e-8."""
+    specs = [("Matern52", True, 1.0, 1.5, 0.02), ("Matern52", True, 0.6, 2.5, 0.05), ("Matern52", True, 1.5, 1.0, 0.01),
+             ("Matern52", True, 1.2, 3.0, 0.03)]
+    a = _restarts(device, 640, 4, specs)
+    b = _restarts(device, 640, 4, specs)
+    steps = 12
+    with _quiet():
+        losses, _ = multi_start_optimize(a, method=method, max_iter=steps)
+    assert losses.shape == (4, steps)
+    for i, m in enumerate(b):
+        with _quiet():
+            ref, _ = m.optimize(method=method, max_iter=steps, verbose=False)
+        assert np.max(np.abs(losses[i] - ref) / np.maximum(1.0, np.abs(ref))) < 1e-10, (i, losses[i] - ref)
+        assert losses[i][0] == ref[0]                      # before the first optimiser step: bit for bit
+        for pa, pb in zip(a[i].parameters(), m.parameters()):
+            assert torch.allclose(pa.data, pb.data, rtol=1e-10, atol=1e-12), (i, pa, pb)
+
+
+def test_adam_trajectory_golden_through_multi_start(device):
+    """the reference's 50-step Adam trajectories (tests/golden/adam_cases.json; base.py:149-151, 260-269), each run as one
+    of three restarts stepped in lock step: the golden restart's losses and final parameters at the sequential tolerances."""
+    for case in load_json("adam_cases.json"):
+        d = case["d"]
+        x, y = rng.make_regression(case["n"], d, case["dy"], seed=0)
+        X, Y = torch.as_tensor(x).to(device), torch.as_tensor(y).to(device)
+        ms = []
+        for scale in (0.7, 1.0, 1.6):
+            ls = np.asarray(case["length_scales"], dtype=np.float64) * scale * (np.ones(d) if case["ARD"] else 1.0)
+            m = GPR(X, Y, KERN[case["kind"]](d, variance=case["variance"] * scale, length_scales=ls, ARD=case["ARD"]),
+                    likelihood=likelihoods.Gaussian(variance=case["noise"]))
+            m.cuda()
+            m.X, m.Y = X, Y
+            ms.append(m)
+        with _quiet():
+            losses, _ = multi_start_optimize(ms, method="Adam", max_iter=50)
+        ref = np.asarray(case["losses"])
+        assert np.max(np.abs(losses[1] - ref) / np.maximum(1.0, np.abs(ref))) < 1e-8, case["name"]
+        m = ms[1]
+        for name, p in [("kernel.variance", m.kernel.variance), ("kernel.length_scales", m.kernel.length_scales),
+                        ("likelihood.variance", m.likelihood.variance)]:
+            assert np.max(np.abs(p.detach().cpu().numpy() - np.asarray(case["final"][name]))) < 1e-8, (case["name"], name)
+
+
+def test_multi_start_falls_back_for_what_cannot_run_in_lock_step(device):
+    """LBFGS (a global line search per model), composite kernels and singletons are optimised by their own optimize()."""
+    ms = _restarts(device, 300, 2, [("Rbf", False, 1.0, 1.0, 0.05), ("Rbf", False, 0.8, 1.4, 0.05)])
+    ref = _restarts(device, 300, 2, [("Rbf", False, 1.0, 1.0, 0.05), ("Rbf", False, 0.8, 1.4, 0.05)])
+    with _quiet():
+        losses, _ = multi_start_optimize(ms, method="LBFGS", max_iter=3)
+        for i, m in enumerate(ref):
+            r, _ = m.optimize(method="LBFGS", max_iter=3, verbose=False)
+            assert np.array_equal(losses[i, :len(r)], r)
+    with pytest.raises(ValueError):
+        with _quiet():
+            multi_start_optimize(ms, method="NoSuchOptimiser", max_iter=1)
+
+
+def test_batch_buffers_are_bounded_and_releasable(device):
+    """round-4 advice: the lock-step buffer cache is keyed by the full group key, evicts least recently used entries and
+    can be released."""
+    from gptorch_amd.models import gpr as G
+    G.release_batch_buffers()
+    for n in (256, 384, 512, 640, 768, 896):
+        ms = _restarts(device, n, 2, [("Rbf", False, 1.0, 1.0, 0.05), ("Rbf", False, 0.8, 1.4, 0.05)])
+        batched_log_likelihood(ms)
+    assert len(G._BATCH_BUFFERS) <= G.BATCH_BUFFER_MAX_ENTRIES
+    G.release_batch_buffers()
+    assert len(G._BATCH_BUFFERS) == 0

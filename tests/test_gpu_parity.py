@@ -576,6 +576,27 @@ def test_adam_trajectory_golden(device):
             assert np.max(np.abs(p.detach().cpu().numpy() - np.asarray(case["final"][name]))) < 1e-8, (case["name"], name)
 
 
+def test_adam_trajectory_mid_golden(device):
+    """config 3's training loop ABOVE the refinement threshold: 10 Adam steps of the reference (base.py:149-151, 260-269) on
+    C3's model shape at N = 12288 (Matern52, D = 16; tests/golden/adam_mid_case.json, make_golden.py --only adammid, 9 min
+    of the reference on 8 threads) -- the refined LML (gpn_lml_refine), its closed-form backward and the optimiser pinned
+    JOINTLY: losses 1e-8 relative, final raw parameters 1e-9."""
+    import contextlib, io
+    from gptorch_amd import _ops
+    case = load_json("adam_mid_case.json")
+    assert case["n"] >= _ops.refine_min_n()
+    m, x, y = _model(case, device)
+    assert rng.checksum(x) == case["x_checksum"] and rng.checksum(y) == case["y_checksum"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        losses, _ = m.optimize(method="Adam", max_iter=case["steps"], verbose=False, learning_rate=case["learning_rate"])
+    assert m._holder["factor"].refined
+    ref = np.asarray(case["losses"])
+    assert np.max(np.abs(losses - ref) / np.abs(ref)) < 1e-8, (losses - ref)
+    for name, p in [("kernel.variance", m.kernel.variance), ("kernel.length_scales", m.kernel.length_scales),
+                    ("likelihood.variance", m.likelihood.variance)]:
+        assert np.max(np.abs(p.detach().cpu().numpy() - np.asarray(case["final_raw"][name]))) < 1e-9, (name, p)
+
+
 def test_block_cyclic_single_rank_native(device):
     """gptorch_amd/dist.py with the product's NativeTileOps on one GPU (grid 1x1): the same
     tile code path every rank runs under RCCL; several tiles incl. a ragged last one."""
