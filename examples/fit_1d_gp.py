@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """Switching a gptorch script to gptorch_amd: the workflow of the reference's 1-D regression example
 (GPR over a sum kernel -- or a sparse VFE model --, scipy L-BFGS-B, predictions and posterior samples) on an MI355X.  Only the
-import lines differ from a gptorch script -- and `model.cuda()` is mandatory here (there is no CPU path).
+import lines differ from a gptorch script, plus ONE line: `settings.auto_device = True` (or GPTORCH_AMD_AUTO_DEVICE=1 in the
+environment) lets the CPU-constructed model place itself on the GPU at its first call, like the reference's example, which
+never calls .cuda() (examples/regression_1d.py:89-95).  Without it `model.cuda()` is mandatory: there is no CPU path.
 
     python examples/fit_1d_gp.py [--sparse] [--n 100]
 """
 import argparse
+import os
+import sys
 
 import numpy as np
 import torch
 
-from gptorch_amd import kernels            # was: from gptorch import kernels
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # run from a checkout without installing
+
+from gptorch_amd import kernels, settings  # was: from gptorch import kernels
 from gptorch_amd.models import GPR, VFE    # was: from gptorch.models.gpr import GPR / sparse_gpr import VFE
 
 
@@ -31,7 +37,7 @@ def main():
         model = VFE(x, y, kernels.Matern52(1), num_inducing_points=20)
     else:
         model = GPR(x, y, kernels.Linear(1) + kernels.Rbf(1) + kernels.Constant(1))
-    model.cuda()
+    settings.auto_device = True          # opt-in: the model moves itself to the GPU at its first loss() / predict call
     model.optimize(method="L-BFGS-B", max_iter=100)
     print(model)
 

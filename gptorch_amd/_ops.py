@@ -341,7 +341,7 @@ def refine_min_n(expression=False, grid=False):
     (gpn_lml_refine).  The plain value's distance to the exact one grows like N^1.85 (5.8e-10 at N = 8192, 7.6e-9 at
     32768, measured) and north_star's tolerance is 1e-8 ABSOLUTE against a reference that is itself 3.4e-9 off at
     32768: below about 10^4 rows the step buys nothing, above it costs about 3 %.  GPN_REFINE_MIN_N overrides
-    (0 = never).
+    (0 = never) and is taken VERBATIM for every caller: the 1/2 and 2/3 factors below scale the built-in default only.
     expression=True: covariance expressions (Linear / Constant terms grow the top eigenvalue like N |x|^2, so the
     quadratic form's sensitivity to the factor's rounding is an order of magnitude above a stationary kernel's: the
     reference's example model at N = 8192 sits 2e-8 from its golden unrefined, whichever leaf kernel factors it) refine
@@ -350,11 +350,15 @@ def refine_min_n(expression=False, grid=False):
     different rounding profile from the single-GPU panels: C2's matrix on a 1 x 1 grid of 2048-wide tiles sits 0.9-1.1e-8
     from the golden unrefined) refine from two thirds of that size on (8192 rows)."""
     import os
-    v = int(os.environ.get("GPN_REFINE_MIN_N", REFINE_MIN_N))
-    if expression and v > 0:
-        v = v // 2
-    elif grid and v > 0:
-        v = (2 * v) // 3
+    env = os.environ.get("GPN_REFINE_MIN_N")
+    if env is not None:
+        v = int(env)
+    elif expression:
+        v = REFINE_MIN_N // 2
+    elif grid:
+        v = (2 * REFINE_MIN_N) // 3
+    else:
+        v = REFINE_MIN_N
     return v if v > 0 else 1 << 62
 
 

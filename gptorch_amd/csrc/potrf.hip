@@ -1341,8 +1341,14 @@ extern "C" int gpn_trsm_right_lt(void* stream, const double* L, int64_t n, int64
 // gpr.py:104-106) its <= 512-wide levels are ~190 latency-bound launches -- 2.3 ms at N = 8192 for 6.9e10 flops (33
 // TFLOP/s).  With the inverses of the BIGB x BIGB diagonal blocks formed once per factor (n BIGB^2 / 3 flops), the same
 // solve is n / BIGB steps of two large contractions:  X_k = B_k W_k^T  (K-clipped),  B_rest -= X_k L(rest, k)^T.
+#ifdef GPN_DEBUG_SWITCHES
+// (GPN_BIGB: A/B of the block size in the TOOLS' build only -- the product library's block is the 1024 the header documents: a
+// stray environment variable must not change the gpn_block_inverse layout or the summation order of predict / VFE results)
 static int64_t bigb_env() { const char* e = getenv("GPN_BIGB"); const int64_t v = e ? atoll(e) : 0; return (v >= 256 && v % 128 == 0) ? v : 1024; }
-static const int64_t BIGB = bigb_env();      // (GPN_BIGB: A/B of the block size, tools only)
+static const int64_t BIGB = bigb_env();
+#else
+static constexpr int64_t BIGB = 1024;
+#endif
 
 extern "C" int64_t gpn_block_inverse_bytes(int64_t n) {
   if (n <= 0) return 0;

@@ -21,6 +21,7 @@ def input_as_tensor(predict_func):
     (base.py:21-55)."""
 
     def predict(obj, input_new, *args, **kwargs):
+        obj._auto_place()
         from_numpy = isinstance(input_new, np.ndarray)
         if from_numpy:
             input_new = torch.as_tensor(input_new, dtype=torch_dtype).to(obj.Y.device)
@@ -58,6 +59,14 @@ class GPModel(Model):
         y.requires_grad_(False)
         self.X, self.Y = x, y
         self.__class__.__name__ = name
+
+    def _auto_place(self):
+        """settings.auto_device (opt-in): a CPU-resident model moves to the GPU once, as `model.cuda()` would
+        (base.py:392-399), before its first native call.  Without a visible GPU nothing happens and the native call raises
+        as always -- there is no CPU arithmetic to fall back to."""
+        from .. import settings
+        if settings.auto_device and not self.X.is_cuda and torch.cuda.is_available():
+            self.cuda()
 
     @property
     def num_data(self):
@@ -105,6 +114,7 @@ class GPModel(Model):
     def optimize(self, method="Adam", max_iter=2000, verbose=True, learning_rate=None):
         """Minimise loss() over the trainable parameters; returns (losses, seconds)
         for torch optimisers, the scipy result for scipy methods (base.py:111-296)."""
+        self._auto_place()
         parameters = [p for p in self.parameters() if p.requires_grad]
         if learning_rate is None and method in _TORCH_DEFAULT_LR:
             learning_rate = _TORCH_DEFAULT_LR[method]
@@ -208,4 +218,5 @@ class GPModel(Model):
         self.X, self.Y = self.X.cpu(), self.Y.cpu()
 
     def _loss(self, *args, **kwargs):
+        self._auto_place()
         return -(self.log_likelihood(*args, **kwargs) + self.log_prior())

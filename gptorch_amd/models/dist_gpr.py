@@ -52,6 +52,22 @@ class DistGPR(GPR):
         self._tile, self._grid, self._tile_ops = int(tile), grid, tile_ops
         self._schedule = schedule        # panel exchange: "bcast" | "mesh" (dist.BlockCyclicGP); None = GPN_DIST_SCHEDULE / "bcast"
         self._engine = None
+        self._other = None               # (x, y, engine) for data passed to log_likelihood / _predict explicitly
+
+    def _eng_for(self, x, y):
+        """the engine for data other than the model's own (gpr.py:47-57 / 88-100 accept x and y): a second block-cyclic
+        layout on the SAME grid, sharing the first engine's row / column sub-communicators; kept while the same tensors
+        are passed again.  Collective like everything else: every rank passes the same data."""
+        from .. import dist as gdist
+        if x.shape[0] != y.shape[0]:
+            raise ValueError("X and Y must have same # data.")
+        base = self._eng()
+        o = self._other
+        if o is None or o[0] is not x or o[1] is not y or o[2].X.device != x.device:
+            e = gdist.BlockCyclicGP(x, y, self.kernel._kind, tile=self._tile, grid=self._grid, ops=self._tile_ops,
+                                    schedule=self._schedule, share=base)
+            self._other = o = (x, y, e)
+        return o[2]
 
     def _eng(self):
         from .. import dist as gdist
@@ -63,23 +79,26 @@ class DistGPR(GPR):
         return e
 
     def log_likelihood(self, x=None, y=None):
-        """gpr.py:47-67 on the grid; shape (1,).  (x, y default to the training data -- other data would
-        need an engine of its own.)"""
-        if x is not None or y is not None:
-            raise NotImplementedError("DistGPR.log_likelihood evaluates the model's own (x, y)")
+        """gpr.py:47-67 on the grid; shape (1,).  x / y other than the training data (gpr.py:47-57 accepts them) get a
+        block-cyclic layout of their own on the same grid (_eng_for)."""
+        own = x is None and y is None
+        x = x if x is not None else self.X
+        y = y if y is not None else self.Y
+        if not x.shape[0] == y.shape[0]:
+            raise ValueError("X and Y must have same # data.")
         k = self.kernel
-        resid = self.Y - self.mean_function(self.X)
+        resid = y - self.mean_function(x)
         return _DistLogLik.apply(k.variance.transform(), k.length_scales.transform(), self.likelihood.variance.transform(),
-                                 resid, self._eng())
+                                 resid, self._eng() if own else self._eng_for(x, y))
 
     def _predict(self, x_new, diag=True, x=None):
         """gpr.py:88-117 on the grid: mean [n*, dy]; var [n*, dy] (diag) or cov [n*, n*]."""
-        if x is not None:
-            raise NotImplementedError("DistGPR predicts from the model's own training inputs")
         k = self.kernel
+        eng = self._eng() if x is None else self._eng_for(x, self.Y)
+        x = x if x is not None else self.X
         with torch.no_grad():
-            resid = self.Y - self.mean_function(self.X)
-            mean, v = self._eng().predict(k.variance.transform(), k.length_scales.transform(), self.likelihood.variance.transform(),
+            resid = self.Y - self.mean_function(x)
+            mean, v = eng.predict(k.variance.transform(), k.length_scales.transform(), self.likelihood.variance.transform(),
                                           resid, x_new, diag=diag)
             mean_f = mean + self.mean_function(x_new)
             var_f = v[:, None].expand_as(mean_f) if diag else v

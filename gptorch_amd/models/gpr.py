@@ -76,16 +76,19 @@ class GPR(GPModel):
         k = self._stationary()
         with torch.no_grad():
             var, ls, noise = k.variance.transform(), k.length_scales.transform(), self.likelihood.variance.transform()
-            # the factor depends on the inputs (identity + version counter: large, never edited through
-            # .data) and on EVERY model parameter, mean function included.  Parameters are compared by
+            # the factor depends on the inputs and on EVERY model parameter, mean function included.  Inputs: the cache HOLDS
+            # the tensors it was built from and compares identity + version counter (large, never edited through .data) -- a
+            # held tensor cannot be freed, so a temporary `x=` re-allocated at the same address with equal shape and version
+            # can never pass for the cached one (round-4 review: the key used data_ptr()).  Parameters are compared by
             # value on the device (edits through `.data` do not bump a version counter): one
             # concatenation + one torch.equal = a single host sync per prediction
-            key = (x.data_ptr(), x._version, tuple(x.shape), self.Y.data_ptr(), self.Y._version, k._kind)
+            key = (x._version, tuple(x.shape), self.Y._version, k._kind)
             params = torch.cat([p.detach().reshape(-1) for p in self.parameters()])
             c = self._predict_cache
-            if c is None or c[0] != key or c[2].shape != params.shape or not torch.equal(c[2], params):
+            if c is None or c[0] != key or c[3] is not x or c[4] is not self.Y or c[2].shape != params.shape \
+                    or not torch.equal(c[2], params):
                 f = _ops.kernel_factor(k._kind, x, var, ls, noise, R=self.Y - self.mean_function(x))
-                self._predict_cache = (key, f, params)
+                self._predict_cache = (key, f, params, x, self.Y)
                 self._predict_calls = 0
             self._predict_calls += 1
         return self._predict_cache[1], var, ls

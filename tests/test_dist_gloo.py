@@ -319,9 +319,20 @@ def _dist_gpr_worker(rank, world, port, out_path):
         xs = rng.normal(9, (7, d))
         mu, var = m.predict_f(xs)
         _, cov = m.predict_y(xs, diag=False)
+        # other data than the model's own (gpr.py:47-57 / 88-100 accept x, y): a second layout on the same grid
+        x2, y2 = torch.tensor(x[:450]), torch.tensor(y[:450])
+        with torch.no_grad():
+            lml_other = m.log_likelihood(x=x2, y=y2).item()
+            lml_other_again = m.log_likelihood(x=x2, y=y2).item()          # the cached second engine
+        try:
+            m.log_likelihood(x=x2, y=torch.tensor(y[:449]))
+            mismatch = "no error"
+        except ValueError as exc:
+            mismatch = str(exc)
         losses, _ = m.optimize(method="Adam", max_iter=3, verbose=False)
         if rank == 0:
-            np.savez(out_path, loss=loss.item(), g0=grads[0], g1=grads[1], g2=grads[2], g3=grads[3], mu=mu, var=var, cov=cov, losses=losses)
+            np.savez(out_path, loss=loss.item(), g0=grads[0], g1=grads[1], g2=grads[2], g3=grads[3], mu=mu, var=var, cov=cov, losses=losses,
+                     lml_other=lml_other, lml_other_again=lml_other_again, mismatch=mismatch)
     finally:
         dist.destroy_process_group()
 
@@ -353,6 +364,11 @@ def test_dist_gpr_model_matches_oracle(tmp_path, world):
     assert np.abs(z["mu"] - omu.numpy()).max() < 1e-9 and np.abs(z["var"] - ovar.numpy()).max() < 1e-9
     assert np.abs(z["cov"] - ocov.numpy()).max() < 1e-9
     assert z["losses"].shape == (3,) and abs(z["losses"][0] - lo.item()) < 1e-9 * abs(lo.item()) and z["losses"][2] < z["losses"][0]
+    o2 = orc.GPROracle(x[:450], y[:450], kind="Matern52", variance=1.3, length_scales=np.array([1.1, 1.7, 2.3]), noise=0.05, ARD=True, mean=[0.3, -0.2])
+    with torch.no_grad():
+        ref2 = o2.log_likelihood().item()
+    assert abs(float(z["lml_other"]) - ref2) < 1e-9 * abs(ref2) and float(z["lml_other_again"]) == float(z["lml_other"])
+    assert str(z["mismatch"]) == "X and Y must have same # data."           # gpr.py:56-57
 
 
 # ------------------------------------------------------------------------------------------------------------

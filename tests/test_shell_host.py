@@ -105,6 +105,33 @@ def test_cpu_tensors_fail_loudly_no_fallback():
         GPR(x, y, kernels.Rbf(2) + kernels.Linear(2)).loss()
 
 
+def test_auto_device_flag_defaults_off_and_needs_a_gpu(monkeypatch):
+    """settings.auto_device (opt-in placement of CPU-constructed models): off by default; switched on without a visible GPU
+    it changes nothing -- the native call still fails loudly, there is no CPU arithmetic to fall back to."""
+    from gptorch_amd import settings
+    assert settings.auto_device is False
+    monkeypatch.setattr(settings, "auto_device", True)
+    x, y = rng.make_regression(12, 2, 1, seed=1)
+    m = GPR(x, y, kernels.Rbf(2))
+    if not torch.cuda.is_available():
+        with pytest.raises(NativeError, match="no CPU fallback"):
+            m.loss()
+        assert not m.X.is_cuda
+
+
+def test_refine_threshold_override_is_taken_verbatim(monkeypatch):
+    """GPN_REFINE_MIN_N overrides the size from which the quadratic form is refined for EVERY caller as given (round-4
+    advice: expression / grid callers used to scale an explicit override by 1/2 and 2/3); the factors apply to the
+    built-in default only."""
+    from gptorch_amd import _ops
+    monkeypatch.delenv("GPN_REFINE_MIN_N", raising=False)
+    assert _ops.refine_min_n() == 12288 and _ops.refine_min_n(expression=True) == 6144 and _ops.refine_min_n(grid=True) == 8192
+    monkeypatch.setenv("GPN_REFINE_MIN_N", "16384")
+    assert _ops.refine_min_n() == _ops.refine_min_n(expression=True) == _ops.refine_min_n(grid=True) == 16384
+    monkeypatch.setenv("GPN_REFINE_MIN_N", "0")
+    assert _ops.refine_min_n() == _ops.refine_min_n(expression=True) == _ops.refine_min_n(grid=True) == 1 << 62
+
+
 def test_jit_op_is_the_same_ladder():
     """functions.jit_op (functions.py:20-43) for a caller-supplied op: plain try, then
     x + 10^(-10+i) I, then RuntimeError("Max tries exceeded.") -- on top of _ops._ladder."""
