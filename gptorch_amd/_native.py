@@ -120,6 +120,7 @@ SIGNATURES.update({
     "gpn_dist_lml_grad": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_void_p]),
+    "gpn_dist_layout": (c_int, [c_int, c_int, c_int, c_int, c_int64, c_int, c_int, c_int64, ctypes.POINTER(c_int64), c_int]),
     "gpn_dist_predict_work_bytes": (c_int64, [c_int, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int64, c_int]),
     "gpn_dist_predict": (c_int, [c_void_p, ctypes.POINTER(DistComm), c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                  c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
@@ -130,7 +131,7 @@ SIGNATURES.update({
                                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
 })
 # libgpnative_rccl.so: the RCCL adapter of that table (declared in the same header)
-RCCL_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libgpnative_rccl.so")
+RCCL_LIB_PATH = os.environ.get("GPN_RCCL_LIB", os.path.join(os.path.dirname(LIB_PATH), "libgpnative_rccl.so"))   # (GPN_RCCL_LIB: the sanitizer leg)
 RCCL_SIGNATURES = {
     "gpn_rccl_comm_create": (ctypes.POINTER(DistComm), [c_void_p, c_void_p, c_void_p]),
     "gpn_rccl_comm_destroy": (None, [ctypes.POINTER(DistComm)]),

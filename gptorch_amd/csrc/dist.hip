@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 #include "gpn_common.h"
 
 namespace gpn {
@@ -75,13 +76,19 @@ struct DistLayout {
   // backward only
   int64_t kinv, alphaT, aT, al, part, arow, acol, gwork, gout, acc;
 };
-static DistLayout make_layout(const DistGeom& g, int d) {
+// (rec: optional recorder of (offset, reserved doubles) per sub-buffer in declaration order -- gpn_dist_layout)
+static DistLayout make_layout(const DistGeom& g, int d, std::vector<int64_t>* rec = nullptr) {
   DistLayout L;
   const int64_t T = g.T;
   const int64_t lrows = (g.rows + T - 1) / T * T + 16;
   const int64_t wn = gpn_winv_bytes(T) / 8;
   int64_t o = 0;
-  auto take = [&](int64_t cnt) { const int64_t at = o; o += round_up(cnt, 32); return at; };   // 256-byte granules
+  auto take = [&](int64_t cnt) {                                                               // 256-byte granules
+    const int64_t at = o;
+    o += round_up(cnt, 32);
+    if (rec) { rec->push_back(at); rec->push_back(o - at); }
+    return at;
+  };
   L.A = take(g.rows * g.ld);
   for (int i = 0; i < 2; ++i) L.left[i] = take(lrows * T);
   for (int i = 0; i < 2; ++i) L.right[i] = take((std::max<int64_t>(g.ncol_t, 1) * T + 16) * T);
@@ -716,7 +723,7 @@ extern "C" int gpn_dist_lml_grad(void* stream, const gpn_dist_comm* comm, int ra
 // The sequence of gptorch_amd/dist.py BlockCyclicGP._refine over the callback table (world all-reduces only: a sum in which all
 // ranks but one contribute zeros is the broadcast).  `work` is the forward call's workspace, untouched since: it holds L and alpha.
 struct DistRefineLayout { int64_t alpha, a, owed, buf, sj, aj, ar, ka, U, S, W, winv, gwork, rwork, total; int64_t lv, lds, q0, q1; int ndiag; };
-static DistRefineLayout refine_layout_dist(const DistGeom& g) {
+static DistRefineLayout refine_layout_dist(const DistGeom& g, std::vector<int64_t>* rec = nullptr) {
   DistRefineLayout R;
   const int64_t T = g.T;
   R.lv = g.nt * T;
@@ -728,7 +735,12 @@ static DistRefineLayout refine_layout_dist(const DistGeom& g) {
   R.q0 = ntri * g.rank / world;
   R.q1 = ntri * (g.rank + 1) / world;
   int64_t o = 0;
-  auto take = [&](int64_t cnt) { const int64_t at = o; o += round_up(std::max<int64_t>(cnt, 1), 32); return at; };
+  auto take = [&](int64_t cnt) {
+    const int64_t at = o;
+    o += round_up(std::max<int64_t>(cnt, 1), 32);
+    if (rec) { rec->push_back(at); rec->push_back(o - at); }
+    return at;
+  };
   R.alpha = take((int64_t)g.dy * R.lv);
   R.a = take((int64_t)g.dy * R.lv);
   R.owed = take((int64_t)g.dy * std::max<int64_t>(g.ncol_t, 1) * T);
@@ -745,6 +757,27 @@ static DistRefineLayout refine_layout_dist(const DistGeom& g) {
   R.rwork = take(gpn_refine_resid_part_work_bytes(g.dy, R.q1 - R.q0) / 8);
   R.total = o;
   return R;
+}
+
+// The sub-buffers of a rank's workspace as (offset, reserved size) pairs in doubles, in the order the layout declares them
+// (which = 0: gpn_dist_lml_forward -- A, left[2], right[2], diag, winv, xrow, xcol, stats, info, sums; 1: gpn_dist_lml_grad --
+// the same + kinv, alphaT, aT, al, part, arow, acol, gwork, gout, acc; 2: gpn_dist_lml_refine -- alpha, a, owed, buf, sj, aj,
+// ar, ka, U, S, W, winv, gwork, rwork).  Pure host function: the layout sweep of the sanitizer leg (tests/test_host_sanitizer.py)
+// checks every offset + size against gpn_dist_*_work_bytes and against the sizes the driver's calls need.  Returns the number of
+// sub-buffers (pairs written: min(that, cap)), < 0: bad arguments.
+extern "C" int gpn_dist_layout(int which, int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile, int64_t* out, int cap) {
+  if (which < 0 || which > 2) return -1;
+  if (d <= 0 || dy <= 0 || n <= 0) return -5;
+  if (!out && cap > 0) return -9;
+  DistGeom g;
+  const int rc = make_geom(g, rank, pr, pc, n, dy, tile, which == 1);
+  if (rc != GPN_OK) return rc;
+  std::vector<int64_t> rec;
+  if (which == 2) (void)refine_layout_dist(g, &rec);
+  else (void)make_layout(g, d, &rec);
+  const int cnt = (int)(rec.size() / 2);
+  for (int i = 0; i < std::min(cnt, cap); ++i) { out[2 * i] = rec[2 * i]; out[2 * i + 1] = rec[2 * i + 1]; }
+  return cnt;
 }
 
 extern "C" int64_t gpn_dist_lml_refine_work_bytes(int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile) {

@@ -476,6 +476,13 @@ int gpn_dist_lml_refine(void* stream, const gpn_dist_comm* comm, int rank, int p
                         const double* X, int64_t n, int d, const double* Y, int dy,
                         const double* variance, const double* length_scales, int nls, const double* noise,
                         int64_t tile, const double* work, double* rwork, int64_t rwork_bytes, double* out4);
+/* The sub-buffers of a rank's workspace as (offset, reserved size) pairs in doubles, in declaration order: which = 0 the
+ * workspace of gpn_dist_lml_forward (A, left[2], right[2], diag, winv, xrow, xcol, stats, info, sums), 1 of gpn_dist_lml_grad
+ * (those + kinv, alphaT, aT, al, part, arow, acol, gwork, gout, acc), 2 of gpn_dist_lml_refine (alpha, a, owed, buf, sj, aj, ar,
+ * ka, U, S, W, winv, gwork, rwork).  Pure host function, for layout checks (the sanitizer leg of the CPU suite sweeps it over
+ * grids / sizes / tiles); returns the number of sub-buffers (min(that, cap) pairs written to out), < 0: bad arguments. */
+int gpn_dist_layout(int which, int rank, int pr, int pc, int64_t n, int d, int dy, int64_t tile, int64_t* out, int cap);
+
 /* GPR._predict (gpr.py:88-117) on the grid (gptorch_amd/dist.py BlockCyclicGP.predict): the ns test points ride through ONE
  * factorisation as further residual rows -- K(x*, X) below (y - m)^T comes out as A^T = (L^-1 K(X, x*))^T exactly like alpha^T
  * does, spread over the tile columns of the residual's process row -- and mean = Ms + A^T alpha [ns, dy], var = variance -
