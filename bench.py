@@ -152,12 +152,19 @@ x, y = rng.make_regression(w["n"], w["d"], w["dy"], seed=0)
 ns = int(spec["rows"])
 o = orc.GPROracle(x[:ns], y[:ns], kind=w["kind"], variance=w["variance"], length_scales=w["length_scales"], noise=w["noise"])
 times, val = [], None
+warm, reps, budget = int(spec["warmup"]), int(spec["reps"]), float(spec.get("budget") or 0.0)
+t_start = time.time()
 with torch.no_grad():
-    for i in range(int(spec["warmup"]) + int(spec["reps"])):
+    i = 0
+    while i < warm + reps:
         t0 = time.time()
         val = float(o.log_likelihood().item())
-        if i >= int(spec["warmup"]):
-            times.append(time.time() - t0)
+        dt = time.time() - t0
+        if i >= warm:
+            times.append(dt)
+        i += 1
+        if budget > 0 and i >= warm + 1 and (time.time() - t_start) + dt > budget:
+            break          # one more evaluation would overrun the budget: stop with what there is (never fewer than one)
 try:
     import resource
     peak_gb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
@@ -174,12 +181,12 @@ print("CPU_CHILD_RESULT " + json.dumps({"times": times, "lml": val, "threads": t
 """
 
 
-def cpu_child(w, rows, threads, warmup, reps, timeout):
+def cpu_child(w, rows, threads, warmup, reps, timeout, budget=0.0):
     """the oracle in a CHILD process (CPU only; it never touches the GPU): a host OOM-kill or a time-out there costs this
     leg only, never the line.  -> dict or raises."""
     import subprocess
     spec = {"w": {k: w[k] for k in ("n", "d", "dy", "kind", "variance", "length_scales", "noise")}, "rows": rows, "threads": threads,
-            "warmup": warmup, "reps": reps}
+            "warmup": warmup, "reps": reps, "budget": budget}
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     out = subprocess.run([sys.executable, "-c", CPU_CHILD % {"root": ROOT}, json.dumps(spec)], capture_output=True, text=True, timeout=timeout, env=env)
     for ln in out.stdout.splitlines():
@@ -288,12 +295,12 @@ def cpu_baseline(w, x, y, full=True, full_timeout=900.0, budget=260.0):
             out["full_size_skipped"] = "host MemAvailable %.0f GB < %.0f GB needed for ~4.5 live N x N fp64" % (avail, need)
         else:
             try:
-                # the (N/8192)^3 extrapolation of the sample prices one evaluation; MKL runs the big factorisation more
-                # efficiently than the small one, so this over-estimates: reps = what fits the budget after the warm-up
-                est = med * scale
-                reps = int(max(1, min(3, (budget - est) // est))) if budget > 0 else 3
-                r = cpu_child(w, w["n"], best_th, 1, reps, full_timeout)
+                # 1 warm-up + 3 timed evaluations; the child stops earlier (never before one timed evaluation) when the next
+                # one would overrun the budget -- decided from the evaluations it has timed itself, not from the sample's
+                # (N/8192)^3 extrapolation, which over-estimates 3x (MKL runs the big factorisation far more efficiently)
+                r = cpu_child(w, w["n"], best_th, 1, 3, full_timeout, budget=budget)
                 ts = [float(v) for v in r["times"]]
+                reps = len(ts)
                 t = float(np.median(ts))
                 out.update({"value": 1.0 / t, "seconds_per_eval": t, "extrapolated": False, "lml": r["lml"], "peak_rss_gb": r.get("peak_rss_gb"),
                             "full_size_seconds": ts, "full_size_warmups": 1, "full_size_reps": reps,
