@@ -17,14 +17,14 @@ for f in "$HERE"/*.hip; do
     pids+=($!)
   fi
 done
-# the tools' build: the five sources that carry A/B switches once more with -DGPN_DEBUG_SWITCHES (per-thread variant
+# the tools' build: the six sources that carry A/B switches once more with -DGPN_DEBUG_SWITCHES (per-thread variant
 # setters, masked streams, the instrumented leaf); everything else is shared with the product library, which exports
 # none of it
 DBG="$OBJ/dbg"
 mkdir -p "$DBG"
-for f in "$HERE"/gemm_f64.hip "$HERE"/potrf.hip "$HERE"/profile.hip "$HERE"/leaf16.hip "$HERE"/colpanel.hip; do
+for f in "$HERE"/gemm_f64.hip "$HERE"/potrf.hip "$HERE"/profile.hip "$HERE"/leaf16.hip "$HERE"/colpanel.hip "$HERE"/refine.hip; do
   o="$DBG/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/refine_tail.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ]; then
     $HIPCC $FLAGS -DGPN_DEBUG_SWITCHES -c "$f" -o "$o" &
     pids+=($!)
   fi
@@ -34,7 +34,7 @@ $HIPCC --offload-arch=$ARCH -shared -fPIC -o "$OUT/libgpnative.so" "$OBJ"/*.o
 echo "built $OUT/libgpnative.so"
 shared=()
 for o in "$OBJ"/*.o; do
-  case "$(basename "$o")" in gemm_f64.o|potrf.o|profile.o|leaf16.o|colpanel.o) ;; *) shared+=("$o") ;; esac
+  case "$(basename "$o")" in gemm_f64.o|potrf.o|profile.o|leaf16.o|colpanel.o|refine.o) ;; *) shared+=("$o") ;; esac
 done
 $HIPCC --offload-arch=$ARCH -shared -fPIC -o "$OUT/libgpnative_dbg.so" "${shared[@]}" "$DBG"/*.o
 echo "built $OUT/libgpnative_dbg.so"

@@ -131,6 +131,135 @@ __global__ __launch_bounds__(256) void backsub_step_kernel(const double* __restr
       a[(int64_t)(c0 + c) * lds + col0 + t] = t < jbn ? (part[0][c][t] + part[1][c][t]) + (part[2][c][t] + part[3][c][t]) : 0.0;
 }
 
+// The whole back-substitution as ONE launch (round 5): the chain of nb dependent steps above costs a kernel launch each
+// (8.1 us x 256 = 2.1 ms at N = 32768, for a pass over L that HBM serves in under 1 ms).  Here every column block has its
+// workgroup for the whole solve, and the steps are ordered through the DATA instead of launches:
+//   workgroup b owns column block j = nb - 1 - b (so that a workgroup only ever waits for workgroups with a SMALLER index:
+//   dispatched before it, hence resident or finished -- no deadlock however many fit the chip at once);
+//   a_hat starts as a SENTINEL bit pattern (a NaN payload no arithmetic produces); the owner of block k publishes a_k with
+//   agent-scope stores, and a reader's 128 threads each spin on THEIR entry until it is no sentinel -- no flag, no fence, no
+//   second round trip: the values validate themselves (first version: flag + release fence + reload of a_k, 12 us per step);
+//   for k = nb - 1 ... j + 1:  [L(k, j) is already in registers]  wait for a_k, s_j -= L(k, j)^T a_k  (s_j stays in LDS),
+//       and the loads of L(k - 1, j) go out before the next wait;
+//   then a_j = W_j^T s_j with the stored leaf inverse (its loads in flight under the last reduction), published.
+// The arithmetic per block -- four row groups, their partial sums added as (p0 + p1) + (p2 + p3), the blocks applied in
+// descending k -- is backsub_step_kernel's: a_hat is bit-identical.  A bounded spin that runs out publishes NaN: the
+// evaluation ends with a NaN value instead of hanging.
+constexpr unsigned BS_SPIN_LIMIT = 1u << 26;
+constexpr unsigned long long BS_SENTINEL = 0x7FF4DEADBEEF5A5Aull;        // a signalling-NaN payload: never a computed value
+__global__ void backsub_sentinel_kernel(unsigned long long* a, int64_t count, int* tickets, int ntickets) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) a[i] = BS_SENTINEL;
+  if (i < ntickets) tickets[i] = 0;
+}
+template <int NRHS>
+__global__ __launch_bounds__(256) void backsub_persistent_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ winv,
+                                                                 int nb, int64_t n, int dy, int c0, double* a, int64_t lds, int* ticket) {
+  __shared__ double ak[NRHS][LEAF];
+  __shared__ double part[4][NRHS][BS_COLS];
+  __shared__ double sj[NRHS][LEAF];
+  __shared__ int failed, my_turn;
+  const int t = threadIdx.x;
+  const int nc = min(NRHS, dy - c0);
+  // column blocks are handed out in the order workgroups START (a ticket, not blockIdx): whoever a workgroup waits for
+  // drew its ticket earlier, so it is running or done whatever order the hardware dispatches in
+  if (t == 0) my_turn = atomicAdd(ticket, 1);
+  __syncthreads();
+  const int jb = nb - 1 - my_turn;
+  const int64_t col0 = (int64_t)jb * LEAF;
+  const int cp = t & 63, g = t >> 6;
+  const int jbn = (int)min((int64_t)LEAF, n - col0);
+  const double* W = winv + (int64_t)jb * LEAF * LEAF;
+  if (t < LEAF)
+    for (int c = 0; c < nc; ++c) sj[c][t] = col0 + t < n ? A[(n + c0 + c) * lda + col0 + t] : 0.0;   // s_j <- alpha_j (the factor's extra rows)
+  if (t == 0) failed = 0;
+  d2 l[32];
+  auto fetch = [&](int k) {                                   // rows of block k, my columns
+    const int64_t r0 = (int64_t)k * LEAF;
+    const int kb = (int)min((int64_t)LEAF, n - r0);
+    const d2* Lp = reinterpret_cast<const d2*>(A + (r0 + g * 32) * lda + col0 + 2 * cp);
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) l[rr] = (g * 32 + rr < kb) ? Lp[(int64_t)rr * (lda / 2)] : d2{0.0, 0.0};
+  };
+  // the leaf inverse of my block takes the tile registers once the last tile of L has been used: its loads are in flight
+  // under the last reduction, like a tile's
+  auto fetch_w = [&]() {
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) {
+      const int r = g * 32 + rr;
+      l[rr] = (r < jbn && r >= 2 * cp) ? *reinterpret_cast<const d2*>(W + (int64_t)r * LEAF + 2 * cp) : d2{0.0, 0.0};
+    }
+  };
+  if (jb + 1 < nb) fetch(nb - 1);
+  else fetch_w();
+  __syncthreads();
+  for (int k = nb - 1; k > jb; --k) {
+    if (t < LEAF) {
+      for (int c = 0; c < nc; ++c) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a + (int64_t)(c0 + c) * lds + (int64_t)k * LEAF + t);
+        unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (v == BS_SENTINEL) {
+          if (++spins > BS_SPIN_LIMIT) { failed = 1; v = 0x7FF8000000000000ull; break; }
+          if (k == jb + 1) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(16);      // the chain's next link polls hardest
+          v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ak[c][t] = __longlong_as_double((long long)v);
+      }
+    }
+    __syncthreads();
+    double upd0[NRHS], upd1[NRHS];
+#pragma unroll
+    for (int c = 0; c < NRHS; ++c) upd0[c] = upd1[c] = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr)
+#pragma unroll
+      for (int c = 0; c < NRHS; ++c) {
+        const double av = ak[c][g * 32 + rr];
+        upd0[c] = fma(l[rr].x, av, upd0[c]);
+        upd1[c] = fma(l[rr].y, av, upd1[c]);
+      }
+    if (k - 1 > jb) fetch(k - 1);                             // in flight under the reduction and the next wait
+    else fetch_w();
+#pragma unroll
+    for (int c = 0; c < NRHS; ++c) {
+      part[g][c][2 * cp] = upd0[c];
+      part[g][c][2 * cp + 1] = upd1[c];
+    }
+    __syncthreads();
+    if (t < LEAF)
+      for (int c = 0; c < nc; ++c)
+        sj[c][t] = sj[c][t] - ((part[0][c][t] + part[1][c][t]) + (part[2][c][t] + part[3][c][t]));
+    __syncthreads();
+  }
+  // a_j[i] = sum_{r >= i} W[r][i] s_j[r]
+  double acc0[NRHS], acc1[NRHS];
+#pragma unroll
+  for (int c = 0; c < NRHS; ++c) acc0[c] = acc1[c] = 0.0;
+#pragma unroll
+  for (int rr = 0; rr < 32; ++rr) {
+    const int r = g * 32 + rr;
+#pragma unroll
+    for (int c = 0; c < NRHS; ++c) {
+      const double sv = sj[c][r];
+      acc0[c] = fma(l[rr].x, sv, acc0[c]);
+      acc1[c] = (r >= 2 * cp + 1) ? fma(l[rr].y, sv, acc1[c]) : acc1[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NRHS; ++c) {
+    part[g][c][2 * cp] = acc0[c];
+    part[g][c][2 * cp + 1] = acc1[c];
+  }
+  __syncthreads();
+  const bool bad = failed != 0;
+  if (t < LEAF)
+    for (int c = 0; c < nc; ++c) {
+      const double v = t < jbn ? (part[0][c][t] + part[1][c][t]) + (part[2][c][t] + part[3][c][t]) : 0.0;
+      __hip_atomic_store(a + (int64_t)(c0 + c) * lds + col0 + t, bad ? __builtin_nan("") : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // Kyy a_hat in double-double, Kyy re-computed from the points: ONE workgroup per 64 x 64 tile on or below the diagonal (the
 // assembly's own enumeration; tile structure, staging and the order of the sum over coordinates are kmat_kernel's, so that
 // every entry is bit for bit the one the assembly wrote into the factor buffer).  Tile (I, J), I > J, is evaluated once and used twice: its rows times a_J go to the row partial of tile
@@ -401,6 +530,13 @@ static int gemv_t_chunks(int64_t rows, int64_t cols) {
   return (int)nchunk;
 }
 
+#ifdef GPN_DEBUG_SWITCHES
+static thread_local int g_backsub_persistent = 1;
+#else
+static constexpr int g_backsub_persistent = 1;
+#endif
+//   // 0 = one launch per 128-column block (backsub_step_kernel; A/B and bit-identity test, tools' build)
+
 struct RefineLayout { int64_t lds, s, a, partial, norm, prow, pcol, total; int nseg, tiles_per_seg; };
 static RefineLayout refine_layout(int64_t n, int dy) {
   RefineLayout L;
@@ -424,6 +560,10 @@ static RefineLayout refine_layout(int64_t n, int dy) {
 
 using namespace gpn;
 
+#ifdef GPN_DEBUG_SWITCHES
+extern "C" int gpn_debug_set_backsub_persistent(int on) { gpn::g_backsub_persistent = on; return GPN_OK; }
+#endif
+
 extern "C" int64_t gpn_lml_refine_work_bytes(int64_t n, int dy) {
   if (n < 0 || dy <= 0) return 0;
   return refine_layout(n, dy).total * (int64_t)sizeof(double);
@@ -433,6 +573,22 @@ extern "C" int64_t gpn_lml_refine_work_bytes(int64_t n, int dy) {
 static int refine_backsub(hipStream_t s, const double* A, int64_t lda, const double* winv, int64_t n, int dy, double* work, const RefineLayout& L) {
   double* sv = work + L.s;
   double* av = work + L.a;
+  const int nb_ = (int)((n + LEAF - 1) / LEAF);
+  const int passes = dy == 1 ? 1 : (dy + RDY - 1) / RDY;
+  if (g_backsub_persistent) {
+    // one launch per group of right-hand sides; a_hat starts as the sentinel its readers spin on
+    const int64_t cnt = (int64_t)dy * L.lds;
+    int* tickets = reinterpret_cast<int*>(sv);               // (this path holds s_j in LDS: the s buffer carries one ticket counter per pass)
+    hipLaunchKernelGGL(backsub_sentinel_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(av), cnt,
+                       tickets, passes);
+    int pass = 0;
+    for (int c0 = 0; c0 < dy; c0 += (dy == 1 ? 1 : RDY), ++pass) {
+      if (dy == 1) hipLaunchKernelGGL(backsub_persistent_kernel<1>, dim3((unsigned)nb_), dim3(256), 0, s, A, lda, winv, nb_, n, dy, c0, av, L.lds, tickets + pass);
+      else hipLaunchKernelGGL(backsub_persistent_kernel<RDY>, dim3((unsigned)nb_), dim3(256), 0, s, A, lda, winv, nb_, n, dy, c0, av, L.lds, tickets + pass);
+    }
+    GPN_LAUNCH_CHECK();
+    return GPN_OK;
+  }
   hipLaunchKernelGGL(refine_init_kernel, dim3((unsigned)((L.lds + 255) / 256)), dim3(256), 0, s, A, lda, n, dy, sv, L.lds);
   GPN_LAUNCH_CHECK();
   const int nb = (int)((n + LEAF - 1) / LEAF);
