@@ -763,6 +763,11 @@ GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row 
 GPN_SWITCH g_panel_lookahead = 0;
 GPN_SWITCH g_bulk_pad = 32;
 GPN_SWITCH g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
+// Left-looking formation of the INNER panels (round 5): after an inner panel, instead of the K = inner-width trapezoid over all
+// remaining columns of the outer panel, ONLY the next inner panel's columns are updated -- by every solved column of the outer
+// panel so far (K = 1, 2, 3 ... inner widths): the same flops in launches with two to three times the K (the 64 x 64 tile ran the
+// K = 512 trapezoids at 48 TFLOP/s, L2 -> LDS bound) and each block of the outer panel read and written once.
+GPN_SWITCH g_inner_left = -1;        // -1 = by size; 0 / 1 = forced (A/B)
 // Same-box sweeps (r1z, tools/potrf_ab.py): panel width 1024 / 1536 / 2048 -> C2 7.10 / 7.00 / 7.01 ms,
 // N = 16384 31.9 (1536) vs 32.2 (2048), C3 201.5 / 200.0 / 201.1, C4 1492 / 1473 / 1472; with the
 // left-looking aux update (below) the large sizes prefer 2048: C3 198.1, C4 1454 ms.
@@ -804,12 +809,15 @@ static inline PanelLevels panel_levels(int64_t n) {
   return L;
 }
 
+static inline bool inner_left_by_size(int64_t n) { (void)n; return false; }
+
 static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   Aux* ax = aux_for(c.s);
   if (!ax) { c.rc = GPN_E_HIP; return; }
   const PanelLevels lev = panel_levels(n);
   const int64_t lda = c.lda, PW = lev.w[0];
   const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
+  const bool inner_left = lev.n >= 2 && (g_inner_left < 0 ? inner_left_by_size(n) : g_inner_left != 0);
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
   int64_t leaf_done = -1;                          // the diagonal block a fused step has already factored
@@ -973,6 +981,14 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       // below the top level: the columns up to the end of the panel one level up only (all rows below incl. the extra
       // ones; lower-only in the top square)
       const int64_t oend = std::min(n, (pend / lev.w[l + 1] + 1) * lev.w[l + 1]);
+      if (l == 0 && inner_left) {
+        // left-looking: the next inner panel's columns only, by all solved columns of the enclosing outer panel
+        const int64_t ostart = (pend / lev.w[1]) * lev.w[1];
+        const int64_t nc1 = std::min(PW, oend - pend);
+        double* Pl = A + pend * lda + ostart;
+        c.rc = cgemm(c, c.s, m, nc1, round_up(pend - ostart, 16), -1.0, Pl, lda, Pl, lda, 1.0, A + pend * lda + pend, lda, 2);
+        continue;
+      }
       double* P = A + pend * lda + o0;
       const int64_t kp = round_up(pend - o0, 16), ncols = oend - pend;
       const bool ahead = l == 0 && ncols > PW && g_inner_lookahead != 0 && ax->s2;
@@ -1289,6 +1305,7 @@ extern "C" int gpn_debug_set_fused_colstep(int v) { g_fused_colstep = v; return 
 extern "C" int gpn_debug_set_fused_steps(int v) { g_fused_steps = v; return GPN_OK; }
 extern "C" int gpn_debug_set_extra_rows(int on) { g_extra_rows_kernel = on; return GPN_OK; }
 extern "C" int gpn_debug_set_inner_lookahead(int v) { g_inner_lookahead = v; return GPN_OK; }
+extern "C" int gpn_debug_set_inner_left(int v) { g_inner_left = v; return GPN_OK; }
 extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; }
 
 // diagnostic build of the leaf with s_memtime stamps (not part of the public header):

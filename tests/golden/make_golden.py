@@ -521,6 +521,45 @@ def gen_composite_16k(out):
     print("composite 16k:", case["loss"], "%.1f s" % case["ref_seconds"])
 
 
+def gen_sparse_wellcond(out):
+    """a WELL-CONDITIONED VFE case held to north_star's 1e-8 ABSOLUTE (round-4 review item 3): inducing points = k-means
+    centres of the data (distinct, spread like the data: K(Z) factors without any jitter rung, cond(K(Z)) recorded), noise 1e-2,
+    N = 8192, M = 256, D = 4.  The bound, its raw-parameter / inducing-point gradients and predictions from the reference
+    (sparse_gpr.py:108-195); the centres are stored with the fixture (k-means is not bit-reproducible across library versions)."""
+    from gptorch.models.sparse_gpr import VFE
+    from scipy.cluster.vq import kmeans2
+    n, d, m = 8192, 4, 256
+    x, y = rng.make_regression(n, d, 1, seed=0)
+    z, _ = kmeans2(x, m, minit="points", seed=1234, iter=20)
+    case = dict(name="vfe_wellcond_rbf_8192_256_4", n=n, d=d, dy=1, m=m, kind="Rbf", variance=1.2, length_scales=1.0, noise=1e-2, seed_xs=71)
+
+    def build():
+        return VFE(x, y, rk.Rbf(d, variance=case["variance"], length_scales=case["length_scales"]), inducing_points=z.copy(),
+                   likelihood=rl.Gaussian(variance=case["noise"]), mean_function=rm.Zero(1))
+    mm = build()
+    with torch.no_grad():
+        Kuu = mm.kernel.K(mm.Z)
+        ev = torch.linalg.eigvalsh(Kuu)
+        case["cond_Kuu"] = float(ev[-1] / ev[0])
+        torch.linalg.cholesky(Kuu)                      # factors as it is: no ladder rung
+        case["elbo"] = float(mm.log_likelihood().item())
+        xs = rng.normal(case["seed_xs"], (16, d))
+        mu, var = mm._predict(torch.tensor(xs))
+        _, cov = mm._predict(torch.tensor(xs), diag=False)
+    oo = orc.VFEOracle(x, y, z, "Rbf", case["variance"], case["length_scales"], case["noise"])
+    case["oracle_abs_diff"] = float(abs(oo.log_likelihood().item() - case["elbo"]))
+    assert case["oracle_abs_diff"] < 1e-8, case["oracle_abs_diff"]
+    mg = build()
+    mg.zero_grad()
+    mg.loss().backward()
+    case.update(g_variance=mg.kernel.variance.grad.tolist(), g_length_scales=mg.kernel.length_scales.grad.tolist(),
+                g_noise=mg.likelihood.variance.grad.tolist())
+    np.savez(os.path.join(out, "vfe_wellcond_case.npz"), z=z, mean=mu.numpy(), var=var.numpy(), cov=cov.numpy(), g_Z=mg.Z.grad.numpy())
+    with open(os.path.join(out, "vfe_wellcond_case.json"), "w") as f:
+        json.dump(case, f, indent=1)
+    print("sparse well-conditioned: elbo %.10f cond(Kuu) %.3e oracle diff %.2e" % (case["elbo"], case["cond_Kuu"], case["oracle_abs_diff"]))
+
+
 def gen_sparse_composite(out):
     """VFE over kernels without a single native kind (sparse_gpr.py:126-129 takes any kernel object):
     bound, raw-parameter / inducing-point gradients and predictions from the reference."""
@@ -631,7 +670,7 @@ if __name__ == "__main__":
     steps = dict(refk=lambda: gen_ref_kernel_fixtures(HERE), kern=lambda: gen_kernel_cases(HERE),
                  lml=lambda: gen_lml(HERE, args.big), mid=lambda: gen_mid(HERE), adam=lambda: gen_adam(HERE), adammid=lambda: gen_adam_mid(HERE),
                  func=lambda: gen_functions(HERE), api=lambda: gen_api(HERE), sparse=lambda: gen_sparse(HERE),
-                 comp=lambda: gen_composite(HERE), compbig=lambda: gen_composite_big(HERE), comp16k=lambda: gen_composite_16k(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), lbfgs=lambda: gen_lbfgs(HERE))
+                 comp=lambda: gen_composite(HERE), compbig=lambda: gen_composite_big(HERE), comp16k=lambda: gen_composite_16k(HERE), c2grad=lambda: gen_c2_grad(HERE), spcomp=lambda: gen_sparse_composite(HERE), spwell=lambda: gen_sparse_wellcond(HERE), lbfgs=lambda: gen_lbfgs(HERE))
     for k, fn in steps.items():
         if (not args.only and k != "adammid") or k in args.only.split(","):      # adammid: ~30 min, by name only
             fn()

@@ -934,6 +934,36 @@ def test_vfe_medium_golden(device):
     assert np.max(np.abs(cov - np.asarray(case["cov"]))) < 1e-8
 
 
+def test_vfe_wellconditioned_golden_absolute(device):
+    """a WELL-CONDITIONED VFE case (inducing points = k-means centres of the data, cond(K(Z)) = 3.8e4: no ladder rung; noise
+    1e-2; N = 8192, M = 256) from the reference (sparse_gpr.py:108-195; tests/golden/vfe_wellcond_case.*, make_golden.py --only
+    spwell), held to north_star's 1e-8 ABSOLUTE on the bound like the GPR goldens -- the C5-shaped goldens, whose K(Z) is
+    singular up to the ladder's jitter, can only be held relative.  Gradients (raw parameters and inducing points) 1e-8
+    relative, predictions 1e-8.  Measured: bound 2.3e-10 absolute (|bound| = 2.5e4), gradients 4e-12 / 2e-12 / 2e-15, inducing
+    points 1.8e-10.  (At cond(K(Z)) = 1.4e7 -- length scale 1.5 -- the reference's AUTOGRAD gradients and the native closed form
+    differ by 2e-8 ... 1.2e-7 relative with the bound still inside 1e-8 absolute: the conditioning of the gradient, not of
+    either implementation; profiles/r3_vfe_grad_cpu_parity.json has the same picture for C5's shape.)"""
+    from gptorch_amd.models import VFE
+    case = load_json("vfe_wellcond_case.json")
+    z = load_npz("vfe_wellcond_case.npz")
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    m = VFE(x, y, kernels.Rbf(case["d"], variance=case["variance"], length_scales=case["length_scales"]), inducing_points=z["z"].copy(),
+            likelihood=likelihoods.Gaussian(variance=case["noise"]), mean_function=mean_functions.Zero(1))
+    m.cuda()
+    loss, got = _vfe_grads(m)
+    with torch.no_grad():
+        _, st = m._bound(m.X)
+    assert st.f_uu.jitter_rung < 0 and st.fB.jitter_rung < 0            # both factorisations succeed as they are: no jitter
+    assert abs(-loss - case["elbo"]) < 1e-8, (-loss, case["elbo"])
+    ref = [np.asarray(case["g_variance"]), np.asarray(case["g_length_scales"]), np.asarray(case["g_noise"]), z["g_Z"]]
+    for g, r in zip(got, ref):
+        assert np.abs(g.reshape(r.shape) - r).max() < 1e-8 * max(1.0, np.abs(r).max()), (np.abs(g.reshape(r.shape) - r).max(), np.abs(r).max())
+    xs = rng.normal(case["seed_xs"], (16, case["d"]))
+    mu, var = m.predict_f(xs)
+    _, cov = m.predict_f(xs, diag=False)
+    assert np.max(np.abs(mu - z["mean"])) < 1e-8 and np.max(np.abs(var - z["var"])) < 1e-8 and np.max(np.abs(cov - z["cov"])) < 1e-8
+
+
 def _vfe_case_model(case):
     from gptorch_amd.models import VFE
     x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)

@@ -25,6 +25,7 @@ for rep in range(2):
         lib.gpn_debug_set_fused_steps(1 if (fl & 0x100000) else 0)     # 0x100000: fused chain steps
         lib.gpn_debug_set_fused_colstep(1 if (fl & 0x200000) else 0)     # 0x200000: the chain's two column passes in one launch
         lib.gpn_debug_set_thin_tiles(0 if (fl & 0x400000) else 1)     # 0x400000: no thin-tile path in the contraction kernels
+        lib.gpn_debug_set_inner_left(1 if (fl & 0x800000) else 0)     # 0x800000: left-looking formation of the inner panels (round 5)
         fl &= 0xffff
         lib.gpn_debug_set_big_tile_min_trapezoid(int(os.environ.get('TRAP_MIN', '4096')))
         res = []
