@@ -673,9 +673,19 @@ def run_single(args, device):
                         return mod.log_likelihood()
                 t, o = timed(st, 2, 1)
                 fl = 2.0 * n * m * m + 2.0 * m ** 3 / 3.0
-                return {"config": "C5: sparse VFE GP, Rbf, N=1e6, M=4096 inducing, D=8 fp64: collapsed-bound evaluation (sparse_gpr.py:108-151)",
-                        "value": 1.0 / t, "unit": "bound evals/s", "ms_per_step": t * 1e3, "elbo": o.item(),
-                        "tflops_on_2NM2_plus_2M3_3": fl / t / 1e12, "frac_of_fp64_peak": fl / t / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+                res = {"config": "C5: sparse VFE GP, Rbf, N=1e6, M=4096 inducing, D=8 fp64: collapsed-bound evaluation (sparse_gpr.py:108-151)",
+                       "value": 1.0 / t, "unit": "bound evals/s", "ms_per_step": t * 1e3, "elbo": o.item(),
+                       "tflops_on_2NM2_plus_2M3_3": fl / t / 1e12, "frac_of_fp64_peak": fl / t / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+                try:     # the CPU oracle's value at full size (evaluated once on a GPU box's host: the reference does not fit the build container)
+                    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "vfe_c5_cpu_oracle.json")))["elbo"]
+                    res["elbo_abs_err_vs_cpu_oracle_golden"] = abs(res["elbo"] - gold)
+                    res["elbo_rel_err_vs_cpu_oracle_golden"] = abs(res["elbo"] - gold) / abs(gold)
+                    res["elbo_golden_provenance"] = "cpu_oracle"
+                    res["elbo_golden_note"] = ("K(Z) is singular up to the ladder's jitter at this shape: the oracle itself moves by 2e-11 relative with its thread "
+                                               "count; the quarter-size case pinned in extended precision is tests/golden/vfe_extended_262144_2048.json")
+                except Exception:
+                    pass
+                return res
             leg("c5_vfe", vfe)
         else:
             leg("loss_backward", lambda: backward_leg(lib, held["model"], w, max(2, args.steps // 4) if w["n"] <= 8192 else 2))

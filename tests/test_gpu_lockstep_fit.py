@@ -277,3 +277,42 @@ def test_batch_buffers_are_bounded_and_releasable(device):
     assert len(G._BATCH_BUFFERS) <= G.BATCH_BUFFER_MAX_ENTRIES
     G.release_batch_buffers()
     assert len(G._BATCH_BUFFERS) == 0
+
+
+@pytest.mark.parametrize("n,dy,batch", [(384, 1, 3), (512, 2, 2), (1536, 1, 2), (2176, 1, 2), (4096, 2, 2), (5120, 1, 2), (8192, 1, 2), (1000, 1, 2)])
+def test_backward_on_poisoned_workspaces(device, n, dy, batch):
+    """gpn_lml_backward / gpn_lml_backward_batched clear their U / scratch matrices only when a ragged block or K padding
+    makes a contraction read what no launch wrote (n not a multiple of 128): with the workspace filled with NaN beforehand the
+    gradients are finite and BIT-IDENTICAL to a run on a zeroed workspace (n = 1000: the cleared path, same check)."""
+    from gptorch_amd import _native, _ops
+    d = 3
+    x, y = rng.make_regression(n, d, dy, seed=2)
+    X, Y = torch.as_tensor(x).to(device), torch.as_tensor(y).to(device)
+    var = torch.linspace(0.9, 1.3, batch, dtype=torch.float64, device=device)
+    ls = torch.linspace(1.2, 2.0, batch, dtype=torch.float64, device=device)[:, None]
+    nz = torch.full((batch,), 0.03, dtype=torch.float64, device=device)
+    fb, _ = _ops.lml_forward_batched("Matern52", X, Y, var, ls, nz)
+    assert int(fb.info.cpu().abs().max()) == 0
+    lib = _native.lib()
+    words = int(lib.gpn_lml_backward_batched_work_bytes(n, dy, 1, batch)) // 8
+    outs = []
+    for fill in (0.0, float("nan")):
+        fb._backward_work = torch.full((words,), fill, dtype=torch.float64, device=device)
+        g, gr = _ops.lml_backward_batched("Matern52", X, var, ls, fb, need_resid=True)
+        assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(gr).all()), fill
+        outs.append((g.clone(), gr.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # the single-model entry point on model 0's factor
+    f = fb.factor(0)
+    one = int(lib.gpn_lml_backward_work_bytes(n, dy, 1)) // 8
+    res = []
+    for fill in (0.0, float("nan")):
+        work = torch.full((one,), fill, dtype=torch.float64, device=device)
+        out = torch.empty(3, dtype=torch.float64, device=device)
+        g_R = torch.empty(n, dy, dtype=torch.float64, device=device)
+        st = lib.gpn_lml_backward(_ops._stream(device), _ops.KINDS["Matern52"], _ops._ptr(X), n, d, _ops._ptr(var[0:1]), _ops._ptr(ls[0]), 1,
+                                  _ops._ptr(f.A), f.ld, _ops._ptr(f.winv), dy, _ops._ptr(work), _ops._ptr(out), _ops._ptr(g_R))
+        assert st == 0 and bool(torch.isfinite(out).all())
+        res.append((out, g_R))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][0], outs[0][0][0])

@@ -964,6 +964,31 @@ def test_vfe_wellconditioned_golden_absolute(device):
     assert np.max(np.abs(mu - z["mean"])) < 1e-8 and np.max(np.abs(var - z["var"])) < 1e-8 and np.max(np.abs(cov - z["cov"])) < 1e-8
 
 
+def test_vfe_c5_shaped_extended_precision(device):
+    """a C5-SHAPED bound (BASELINE config 5 at a quarter of its size: N = 262144 -- four streamed chunks of 65536 rows, two
+    pipelines, split-K accumulation --, M = 2048, D = 8, Rbf, length scale sqrt(8), noise 1e-2: K(Z) singular up to the ladder's
+    jitter, like C5's) against its EXTENDED-PRECISION value: sparse_gpr.py:108-153 evaluated in 80-bit long double with the
+    jitter the reference's ladder ends on (tests/golden/vfe_extended.c, make_vfe_extended.py; ~10 min of the build
+    container).  The native path must land on the same rung and within 1e-10 RELATIVE of that value (measured: 6.6e-11; the CPU
+    oracle's own fp64 number: 6.7e-11, 1e-12 from the native one) -- at full size (vfe_c5_cpu_oracle.json) only two fp64 numbers
+    can be compared, which is why that golden is held to 1e-9.  How much any fp64 value of this expression means: the same
+    long-double evaluation with every KERNEL ENTRY first rounded to fp64 (`elbo_extended_fp64_entries`) is 4.5e-10 relative
+    away -- K(Z) at this length scale turns one-ulp changes of its entries into that much of the bound."""
+    from gptorch_amd.models import VFE
+    case = load_json("vfe_extended_262144_2048.json")
+    x, y = rng.make_regression(case["n"], case["d"], 1, seed=case["seed_x"])
+    assert rng.checksum(x) == case["x_checksum"] and rng.checksum(y) == case["y_checksum"]
+    z = rng.normal(case["seed_z"], (case["m"], case["d"]))
+    m = VFE(x, y, kernels.Rbf(case["d"], variance=case["variance"], length_scales=case["length_scales"]), inducing_points=z,
+            likelihood=likelihoods.Gaussian(variance=case["noise"]), mean_function=mean_functions.Zero(1))
+    m.cuda()
+    with torch.no_grad():
+        elbo, st = m._bound(m.X)
+    assert st.f_uu.jitter_rung == case["jitter_rung"], (st.f_uu.jitter_rung, case["jitter_rung"])
+    rel = abs(elbo.item() - case["elbo_extended"]) / abs(case["elbo_extended"])
+    assert rel < 1e-10, (elbo.item(), case["elbo_extended"], rel, case["oracle_rel_err_vs_extended"])
+
+
 def _vfe_case_model(case):
     from gptorch_amd.models import VFE
     x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
