@@ -173,6 +173,7 @@ DEBUG_SIGNATURES = {
     "gpn_debug_leaf16_timing": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_debug_set_backsub_persistent": (c_int, [c_int]),
     "gpn_debug_set_inner_left": (c_int, [c_int]),
+    "gpn_debug_set_split_assembly": (c_int, [c_int]),
     "gpn_debug_set_tri_big": (c_int, [c_int, c_int]),
 }
 DEBUG_LIB_PATH = os.path.join(_HERE, "lib", "libgpnative_dbg.so")

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Build libgpnative.so for gfx950 (hipcc cross-compiles without a GPU).
 # Usage: gptorch_amd/csrc/build.sh [extra hipcc flags]
+# Incremental by modification time (an object is rebuilt when its source, a shared header or THIS script is newer);
+# GPN_FORCE_REBUILD=1 rebuilds everything (what a fresh checkout does anyway: build/ is not tracked).
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
@@ -12,7 +14,7 @@ FLAGS="--offload-arch=$ARCH -DGPN_ARCH=$ARCH -O3 -std=c++17 -fPIC -Wall -Wno-unu
 pids=()
 for f in "$HERE"/*.hip; do
   o="$OBJ/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/refine_tail.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ]; then
+  if [ -n "${GPN_FORCE_REBUILD:-}" ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/refine_tail.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ] || [ "$HERE/build.sh" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi
@@ -24,7 +26,7 @@ DBG="$OBJ/dbg"
 mkdir -p "$DBG"
 for f in "$HERE"/gemm_f64.hip "$HERE"/potrf.hip "$HERE"/profile.hip "$HERE"/leaf16.hip "$HERE"/colpanel.hip "$HERE"/refine.hip; do
   o="$DBG/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/refine_tail.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ]; then
+  if [ -n "${GPN_FORCE_REBUILD:-}" ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/refine_tail.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ] || [ "$HERE/build.sh" -nt "$o" ]; then
     $HIPCC $FLAGS -DGPN_DEBUG_SWITCHES -c "$f" -o "$o" &
     pids+=($!)
   fi

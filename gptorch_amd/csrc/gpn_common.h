@@ -82,6 +82,16 @@ int trtri_upper_ws_batched(hipStream_t s, const double* L, int64_t n, int64_t ld
 int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
                   int32_t* info);
 
+// one part of K(X) + noise I, lower tiles (kmat.hip): part 1 = the first `cols` columns, 2 = the rest
+int assemble_lower_part(hipStream_t s, int kind, const double* X, int64_t n, int d, const double* variance, const double* length_scales,
+                        int nls, const double* noise, double* A, int64_t lda, int part, int64_t cols);
+// the factorisation of gpn_potrf_lower with the columns from `split` on still being written on a side stream (potrf.hip):
+// split_columns = how many leading columns the driver needs before its first top-level trailing update (0: no split at this size);
+// side = the stream for that work and the event to record on it when it is done
+int64_t potrf_split_columns(int64_t n);
+int potrf_side_stream(hipStream_t s, hipStream_t* side, hipEvent_t* go, hipEvent_t* done);
+int potrf_lower_after(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda, double* winv, int32_t* info, hipEvent_t rest_ready);
+
 // K(X_b) + noise_b I (lower tiles) + right-hand sides + info words of `batch` models (kmat.hip; gpn_lml_forward_batched)
 int assemble_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d, const double* Y, int64_t sY,
                      const double* M, int64_t sM, int dy, const double* variance, const double* length_scales, int nls,

@@ -534,6 +534,9 @@ struct Ctx {
   // A + b sA, winv + b sW, info + b; every launch of the drivers below covers all of them
   int batch = 1;
   int64_t sA = 0, sW = 0;
+  // gpn_lml_forward at large N: the columns right of the first top-level panel are still being assembled on a side stream;
+  // the first top-level trailing update waits for this event (nullptr: nothing pending)
+  hipEvent_t rest_ready = nullptr;
 };
 
 // the drivers' contraction / column-pass launches, batched when the context is
@@ -643,6 +646,8 @@ struct Aux {
   hipEvent_t extra_go = nullptr, extra_done = nullptr;
   int* flags = nullptr;                         // zeroed counters of the fused column steps (colpanel.hip colstep): one per step and problem
   hipEvent_t trap_go = nullptr, trap_done = nullptr;     // the part of an inner panel's update beyond the next inner panel (second aux stream)   // the extra rows' share of an outer panel's trailing update (aux stream)
+  hipStream_t s_asm = nullptr;                   // gpn_lml_forward: assembly of the columns right of the first top-level panel
+  hipEvent_t asm_go = nullptr, asm_done = nullptr;
 };
 static std::mutex g_aux_mutex;
 static std::unordered_map<hipStream_t, Aux> g_aux;
@@ -663,6 +668,9 @@ static Aux* aux_for(hipStream_t s) {
   if (hipEventCreateWithFlags(&a.chain_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.bulk_done, hipEventDisableTiming) != hipSuccess) return nullptr;
 #endif
+  if (hipStreamCreateWithPriority(&a.s_asm, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.asm_go, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.asm_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.extra_go, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.extra_done, hipEventDisableTiming) != hipSuccess) return nullptr;
 #ifdef GPN_DEBUG_SWITCHES
@@ -1007,6 +1015,10 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
         trap_pending = true;
       }
     } else {
+      if (c.rest_ready) {                          // the columns right of this panel were assembled on a side stream
+        hip_ok(hipStreamWaitEvent(c.s, c.rest_ready, 0));
+        c.rest_ready = nullptr;
+      }
       double* P = A + pend * lda + o0;             // [m, pend - o0] solved (outer) panel below the diagonal square
       const int64_t kp = round_up(pend - o0, 16);
       // (the fork / join is ~25 us per outer panel: C2 5.36 -> 5.53 ms with it, x 8 in lock step neutral, C3 182.4 -> 181.3;
@@ -1033,6 +1045,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   }
   if (trap_pending) hip_ok(hipStreamWaitEvent(c.s, ax->trap_done, 0));
   if (extra_pending) hip_ok(hipStreamWaitEvent(c.s, ax->extra_done, 0));     // (error exits: nothing of this call stays in flight unordered)
+  if (c.rest_ready) { hip_ok(hipStreamWaitEvent(c.s, c.rest_ready, 0)); c.rest_ready = nullptr; }
 }
 
 // U_ii <- W_ii^T for every LEAF x LEAF diagonal block
@@ -1219,6 +1232,36 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
   else potrf_lookahead(c, A, n, e);
   return c.rc;
 }
+
+// ---- assembly of the trailing columns underneath the first top-level panel (gpn_lml_forward, pipeline.hip) -------------------
+// The first top-level panel's chain (leaves, HBM-bound column passes, K = 128 ... 512 updates) leaves most of the chip's vector
+// ALUs idle for 2-3 ms at N = 32768, and the K assembly of everything RIGHT of that panel (88 % of the matrix, VALU-bound) is not
+// needed before the panel's trailing update: it runs on a third stream underneath the chain.
+// Measured NEUTRAL (tools/split_asm_ab.py, same box, two passes: C3 179.88 / 180.07 -> 180.01 / 180.15 ms, N = 20480 49.96 / 49.85 ->
+// 49.79 / 49.89, N = 24000 76.03 / 76.01 -> 75.91 / 76.11; factors bit-identical): the chain's kernels slow down by what the
+// overlap saves, like every other overlap tried on this chain (LAB.md 8, 10-10).  OFF in the product; kept as a tools'-build A/B.
+GPN_SWITCH g_split_assembly = 0;     // 1 = split (A/B, tools' build)
+int64_t gpn::potrf_split_columns(int64_t n) {
+  if (!g_split_assembly || g_potrf_variant == 1 || n < XR_MIN_N) return 0;
+  const PanelLevels L = panel_levels(n);
+  const int64_t w = L.w[L.n - 1];
+  return (L.n >= 2 && w % 64 == 0 && w < n) ? w : 0;
+}
+int gpn::potrf_side_stream(hipStream_t s, hipStream_t* side, hipEvent_t* go, hipEvent_t* done) {
+  Aux* ax = aux_for(s);
+  if (!ax) return GPN_E_HIP;
+  *side = ax->s_asm; *go = ax->asm_go; *done = ax->asm_done;
+  return GPN_OK;
+}
+int gpn::potrf_lower_after(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda, double* winv, int32_t* info, hipEvent_t rest_ready) {
+  Ctx c{s, lda, winv, info, GPN_OK};
+  c.rest_ready = rest_ready;
+  potrf_lookahead(c, A, n, e);
+  return c.rc;
+}
+#ifdef GPN_DEBUG_SWITCHES
+extern "C" int gpn_debug_set_split_assembly(int v) { g_split_assembly = v; return GPN_OK; }
+#endif
 
 // panel width of the look-ahead driver for an n x n factorisation (what bench.py needs to count the
 // algorithmic flops of the SYRK trailing updates: one lower-tile K = width contraction per panel)
