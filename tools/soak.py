@@ -99,5 +99,28 @@ for i in range(max(1, n_big // 8)):
         nb += 1
 print("4 restarts on two lanes: %d rounds, %d differ, %.1f s" % (max(1, n_big // 8), nb, time.perf_counter() - t0), flush=True)
 bad += nb
+# lock-step loss + backward (round 5): gpn_lml_forward_batched + gpn_lml_backward_batched over 4 restarts sharing the data
+from gptorch_amd.models import batched_loss_and_grad  # noqa: E402
+x2, y2 = rng.make_regression(4096, 6, 1, seed=8)
+X2, Y2 = torch.tensor(x2, device=dev), torch.tensor(y2, device=dev)
+restarts = []
+for r in range(4):
+    mr = GPR(X2, Y2, kernels.Matern52(6, variance=1.0 + 0.1 * r, length_scales=2.0 + 0.3 * r), likelihood=likelihoods.Gaussian(variance=0.02))
+    mr.cuda()
+    mr.X, mr.Y = X2, Y2
+    restarts.append(mr)
+ref, nb, t0 = None, 0, time.perf_counter()
+rounds = max(1, n_big // 5)
+for i in range(rounds):
+    for mr in restarts:
+        mr.zero_grad()
+    losses = batched_loss_and_grad(restarts)
+    cur = torch.cat([l.reshape(-1) for l in losses] + [p.grad.reshape(-1) for mr in restarts for p in mr.parameters() if p.grad is not None]).cpu().numpy().tobytes()
+    if ref is None:
+        ref = cur
+    elif cur != ref:
+        nb += 1
+print("N=4096 x 4 restarts, lock-step loss + backward: %d rounds, %d differ, %.1f s" % (rounds, nb, time.perf_counter() - t0), flush=True)
+bad += nb
 print("SOAK", "OK" if bad == 0 else "MISMATCHES %d" % bad)
 sys.exit(0 if bad == 0 else 1)
