@@ -7,6 +7,7 @@
 // what gptorch_amd/_ops.py and _backward.py issue call by call -- for callers that are not
 // Python (or do not want ~10 FFI crossings per evaluation).  No host synchronisation, no
 // allocation: the caller owns the factor buffer and the workspaces.
+#include <algorithm>
 #include "gpn_common.h"
 
 namespace gpn {
@@ -275,6 +276,19 @@ extern "C" int gpn_lml_backward_batched(void* stream, int kind, int batch, const
       const int rc = gpn_lml_backward(stream, kind, X + z * sX, n, d, variance + z, length_scales + (int64_t)z * nls, nls, A + z * sA, lda,
                                       winv + z * sW, dy, work + z * sWk, grads + (int64_t)z * (2 + nls),
                                       grad_resid ? grad_resid + (int64_t)z * n * dy : nullptr);
+      if (rc != GPN_OK) return rc;
+    }
+    return GPN_OK;
+  }
+  // (a grid dimension holds 65535 blocks: the inversion's transposes put equal nodes x models into gridDim.z, the sweep the
+  //  models into gridDim.y -- larger batches go out in chunks of models)
+  const int64_t max_models = std::max<int64_t>(1, 65535 / std::max<int64_t>(1, n / 256 + 1));
+  if (batch > max_models) {
+    for (int z0 = 0; z0 < batch; z0 += (int)max_models) {
+      const int nb = (int)std::min<int64_t>(max_models, batch - z0);
+      const int rc = gpn_lml_backward_batched(stream, kind, nb, X + z0 * sX, sX, n, d, variance + z0, length_scales + (int64_t)z0 * nls, nls,
+                                              A + z0 * sA, lda, sA, winv + z0 * sW, sW, dy, work + z0 * sWk, grads + (int64_t)z0 * (2 + nls),
+                                              grad_resid ? grad_resid + (int64_t)z0 * n * dy : nullptr);
       if (rc != GPN_OK) return rc;
     }
     return GPN_OK;
