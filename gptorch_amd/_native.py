@@ -54,6 +54,8 @@ SIGNATURES = {
                                    c_int, c_void_p, c_int64, c_double, c_int, c_void_p, c_void_p]),
     "gpn_lml_forward": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                 c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "gpn_lml_forward_saving": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gpn_lml_refine_work_bytes": (c_int64, [c_int64, c_int]),
     "gpn_lml_refine": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -367,7 +367,11 @@ def lml_forward(kind, X, R, variance, length_scales, noise, factor=None, refine=
     factorisation with the residual riding along -> reductions) plus the jitter ladder of
     functions.py:20-43 on its info word.  -> (Factor, terms [3]: sum log L_ii, |alpha|^2, LML).
     refine (default: N >= refine_min_n()): follow it with gpn_lml_refine, after which terms[1] is
-    y^T Kyy^-1 y corrected to second order in the factor's rounding error (and terms[2] the LML with it)."""
+    y^T Kyy^-1 y corrected to second order in the factor's rounding error (and terms[2] the LML with it).
+    GPN_REFINE_SAVED_K=1 (opt-in): the assembly also keeps a pristine copy of Kyy (gpn_lml_forward_saving: n * ld * 8 more
+    bytes) that the refinement's residual pass reads back instead of re-computing every entry -- the same refined value bit
+    for bit; C3: refinement 3.3 -> 2.1 ms, assembly 1.8 -> 2.6 ms (twice the writes), evaluation 183.3 -> 182.8 ms.  Off by
+    default: 0.25 % for 8.6 GB."""
     _req(X, R, variance, length_scales, noise)
     n, e = R.shape
     if X.shape[0] != n:
@@ -383,6 +387,21 @@ def lml_forward(kind, X, R, variance, length_scales, noise, factor=None, refine=
         nz = nz0 if jitter is None else nz0 + jitter
         f.generation += 1
         f._winv_full = None
+        if do_refine and f._refine_work is None:
+            f._refine_work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=X.device)
+        if do_refine and save_k:
+            # the assembly also leaves a pristine copy of Kyy's lower triangle (the factorisation overwrites it in place): the
+            # refinement's residual pass READS it instead of re-computing every kernel entry
+            if getattr(f, "_ksave", None) is None:
+                f._ksave = torch.empty(n, f.ld, dtype=torch.float64, device=X.device)
+            st = lib.gpn_lml_forward_saving(_stream(X.device), KINDS[kind], _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e,
+                                            _ptr(var), _ptr(ls), ls.numel(), _ptr(nz), _ptr(f.A), f.ld, _ptr(f.winv),
+                                            _ptr(f.info), _ptr(out), _ptr(f._ksave))
+            _native.check(st, "gpn_lml_forward_saving")
+            st = lib.gpn_lml_refine_dense(_stream(X.device), _ptr(f._ksave), f.ld, 0.0, n, _ptr(Rc), None, e, _ptr(f.A), f.ld,
+                                          _ptr(f.winv), _ptr(f._refine_work), _ptr(out))
+            _native.check(st, "gpn_lml_refine_dense")
+            return int(f.info.item())
         st = lib.gpn_lml_forward(_stream(X.device), KINDS[kind], _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e,
                                  _ptr(var), _ptr(ls), ls.numel(), _ptr(nz), _ptr(f.A), f.ld, _ptr(f.winv),
                                  _ptr(f.info), _ptr(out))
@@ -390,8 +409,6 @@ def lml_forward(kind, X, R, variance, length_scales, noise, factor=None, refine=
         if do_refine:
             # enqueued before the info word is read back (no idle GPU during the host round trip); if the
             # factorisation failed its result is discarded with the attempt
-            if f._refine_work is None:
-                f._refine_work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=X.device)
             st = lib.gpn_lml_refine(_stream(X.device), KINDS[kind], _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e,
                                     _ptr(var), _ptr(ls), ls.numel(), _ptr(nz), _ptr(f.A), f.ld, _ptr(f.winv),
                                     _ptr(f._refine_work), _ptr(out))
@@ -399,6 +416,8 @@ def lml_forward(kind, X, R, variance, length_scales, noise, factor=None, refine=
         return int(f.info.item())
 
     do_refine = (n >= refine_min_n()) if refine is None else bool(refine)
+    import os
+    save_k = os.environ.get("GPN_REFINE_SAVED_K", "0") == "1"
     f.jitter_rung = _ladder(attempt)
     f.refined = do_refine
     return f, out

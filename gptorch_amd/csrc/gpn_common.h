@@ -82,6 +82,9 @@ int trtri_upper_ws_batched(hipStream_t s, const double* L, int64_t n, int64_t ld
 int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
                   int32_t* info);
 
+// K(X) + noise I (lower tiles) into A and into Ksave (kmat.hip; gpn_lml_forward_saving)
+int assemble_lower_saving(hipStream_t s, int kind, const double* X, int64_t n, int d, const double* variance, const double* length_scales,
+                          int nls, const double* noise, double* A, double* Ksave, int64_t lda);
 // one part of K(X) + noise I, lower tiles (kmat.hip): part 1 = the first `cols` columns, 2 = the rest
 int assemble_lower_part(hipStream_t s, int kind, const double* X, int64_t n, int d, const double* variance, const double* length_scales,
                         int nls, const double* noise, double* A, int64_t lda, int part, int64_t cols);

@@ -37,6 +37,9 @@ struct KmatArgs {
   // triangle of the first tc tile rows, then the tc-wide rectangle of the rows below); part 2 = the triangle of the tile rows /
   // columns from tc on
   int part = 0, tc = 0;
+  // gpn_lml_forward_saving: every entry is also stored here (same leading dimension) -- a pristine copy of Kyy for the refinement
+  // step's residual pass, which otherwise re-computes every entry (the factorisation overwrites K in place)
+  double* K2 = nullptr;
 };
 
 template <int KIND>
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   if (gridDim.z > 1) {                       // problem z of a strided batch (gpn_lml_forward_batched)
     const int z = blockIdx.z;
     p.X += z * p.sX; p.X2 += z * p.sX; p.K += z * p.sK;
+    if (p.K2) p.K2 += z * p.sK;
     p.variance += z; p.ls += z * p.nls;
     if (p.noise) p.noise += z;
   }
@@ -145,9 +149,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
       }
       if (p.vec_ok && col + 1 < p.m) {
         *reinterpret_cast<d2*>(krow + col) = d2{v0, v1};
+        if (p.K2) *reinterpret_cast<d2*>(p.K2 + (int64_t)row * p.ldk + col) = d2{v0, v1};
       } else {
         if (col < p.m) krow[col] = v0;
         if (col + 1 < p.m) krow[col + 1] = v1;
+        if (p.K2) {
+          if (col < p.m) p.K2[(int64_t)row * p.ldk + col] = v0;
+          if (col + 1 < p.m) p.K2[(int64_t)row * p.ldk + col + 1] = v1;
+        }
       }
     }
   }
@@ -205,6 +214,34 @@ int assemble_lower_part(hipStream_t s, int kind, const double* X, int64_t n, int
   const dim3 grid((unsigned)tiles);
   int rec = -1;
   if (profile_on()) rec = profile_begin(s, 8.0 * ((double)tiles * KT * KT + (part == 1 ? (double)n * d : 0.0)), PROF_KMAT);
+  switch (kind) {
+    case GPN_RBF: hipLaunchKernelGGL(kmat_kernel<GPN_RBF>, grid, dim3(256), 0, s, a); break;
+    case GPN_MATERN52: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN52>, grid, dim3(256), 0, s, a); break;
+    case GPN_MATERN32: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN32>, grid, dim3(256), 0, s, a); break;
+    case GPN_EXP: hipLaunchKernelGGL(kmat_kernel<GPN_EXP>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(kmat_kernel<GPN_PERIODIC>, grid, dim3(256), 0, s, a); break;
+  }
+  if (rec >= 0) profile_end(s, rec);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// K(X) + noise I, lower tiles, into A AND into Ksave (same leading dimension): gpn_lml_forward_saving
+int assemble_lower_saving(hipStream_t s, int kind, const double* X, int64_t n, int d, const double* variance, const double* length_scales,
+                          int nls, const double* noise, double* A, double* Ksave, int64_t lda) {
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
+  KmatArgs a;
+  a.X = X; a.X2 = X;
+  a.variance = variance; a.ls = length_scales; a.noise = noise;
+  a.K = A; a.K2 = Ksave; a.ldk = lda;
+  a.n = (int)n; a.m = (int)n; a.d = d; a.nls = nls;
+  a.symmetric = 1; a.lower = 1;
+  a.vec_ok = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(Ksave) & 15) == 0);
+  a.sX = 0; a.sK = 0;
+  const unsigned tm = (unsigned)((n + KT - 1) / KT);
+  const dim3 grid(tm * (tm + 1) / 2);
+  int rec = -1;
+  if (profile_on()) rec = profile_begin(s, 8.0 * (0.5 * n * (n + 1.0) + (double)n * d), PROF_KMAT);     // (algorithmic bytes: the copy earns nothing)
   switch (kind) {
     case GPN_RBF: hipLaunchKernelGGL(kmat_kernel<GPN_RBF>, grid, dim3(256), 0, s, a); break;
     case GPN_MATERN52: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN52>, grid, dim3(256), 0, s, a); break;

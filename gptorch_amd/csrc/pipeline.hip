@@ -147,6 +147,38 @@ extern "C" int gpn_lml_forward(void* stream, int kind, const double* X, int64_t 
   return gpn_lml_reduce(stream, A, n, dy, lda, out3);
 }
 
+// gpn_lml_forward that also keeps a pristine copy of the lower triangle of Kyy in Ksave [n, lda] (the factorisation overwrites it
+// in A): gpn_lml_refine_dense(stream, Ksave, lda, 0.0, ...) then READS the matrix for its residual pass instead of re-computing
+// every kernel entry -- the refinement step of large evaluations (gpn_lml_refine) spends two thirds of its time there.
+extern "C" int gpn_lml_forward_saving(void* stream, int kind, const double* X, int64_t n, int d,
+                                      const double* Y, const double* M, int dy,
+                                      const double* variance, const double* length_scales, int nls,
+                                      const double* noise, double* A, int64_t lda, double* winv,
+                                      int32_t* info, double* out3, double* Ksave) {
+  if (!X) return -3;
+  if (n <= 0) return -4;
+  if (d <= 0) return -5;
+  if (!Y) return -6;
+  if (dy <= 0) return -8;
+  if (!variance) return -9;
+  if (!length_scales) return -10;
+  if (nls != 1 && nls != d) return -11;
+  if (!A) return -13;
+  if (lda != gpn_factor_ld(n, dy)) return -14;
+  if (!winv) return -15;
+  if (!info) return -16;
+  if (!out3) return -17;
+  if (!Ksave) return -18;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = assemble_lower_saving(s, kind, X, n, d, variance, length_scales, nls, noise, A, Ksave, lda);
+  if (rc != GPN_OK) return rc;
+  rc = pack_rhs_full(s, Y, M, n, dy, A + n * lda, lda, info);
+  if (rc != GPN_OK) return rc;
+  rc = gpn_potrf_lower(stream, A, n, dy, lda, winv, info);
+  if (rc != GPN_OK) return rc;
+  return gpn_lml_reduce(stream, A, n, dy, lda, out3);
+}
+
 // `batch` evaluations of GPR.log_likelihood in lock step (hyper-parameter restarts, one model per entry): the reference
 // can only evaluate them one after the other (gptorch/models/base.py:260-269).  Model b: points X + b sX (sX = 0: shared),
 // targets Y + b sY, mean values M + b sM (or NULL), hyper-parameters variance[b], length_scales[b nls ..], noise[b];

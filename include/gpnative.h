@@ -290,6 +290,17 @@ int gpn_lml_forward(void* stream, int kind, const double* X, int64_t n, int d,
                     const double* noise, double* A, int64_t lda, double* winv,
                     int32_t* info, double* out3);
 
+/* gpn_lml_forward that ALSO keeps a pristine copy of the lower triangle of Kyy (noise on the diagonal) in Ksave [n, lda] -- the
+ * factorisation overwrites it in A.  With it the refinement step reads the matrix back,
+ *     gpn_lml_refine_dense(stream, Ksave, lda, 0.0, n, Y, M, dy, A, lda, winv, work, out3),
+ * instead of re-computing every kernel entry for its residual pass as gpn_lml_refine does (same entries bit for bit, same
+ * partial sums: the same refined value).  Costs n * lda * 8 bytes of memory and a second stream of writes in the assembly. */
+int gpn_lml_forward_saving(void* stream, int kind, const double* X, int64_t n, int d,
+                           const double* Y, const double* M, int dy,
+                           const double* variance, const double* length_scales, int nls,
+                           const double* noise, double* A, int64_t lda, double* winv,
+                           int32_t* info, double* out3, double* Ksave);
+
 /* gpn_lml_forward for `batch` models of one shape (n, d, dy, nls) in lock step -- hyper-parameter restarts: the reference
  * evaluates one model per optimiser step (gptorch/models/base.py:260-269).  Model b: points X + b*sX (sX = 0: shared),
  * targets Y + b*sY (sY = 0: shared), mean values M + b*sM (M may be NULL), variance[b], length_scales[b*nls ..],
