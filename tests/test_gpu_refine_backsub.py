@@ -76,3 +76,26 @@ def test_persistent_back_substitution_while_the_chip_is_busy(device):
         busy = _refined_terms(lib, "Rbf", X, Y, var, ls, nz, f, plain)
         torch.cuda.synchronize()
         assert torch.equal(busy, quiet)
+
+
+@pytest.mark.parametrize("n,d,dy,kind", [(12288, 8, 1, "Matern52"), (5000, 3, 2, "Rbf")])
+def test_refinement_from_the_saved_copy_is_bit_identical(device, monkeypatch, n, d, dy, kind):
+    """gpn_lml_forward_saving keeps a pristine copy of Kyy's lower triangle next to the factor (opt-in, GPN_REFINE_SAVED_K=1);
+    gpn_lml_refine_dense then READS the matrix for its residual pass where gpn_lml_refine re-computes every entry: the same
+    entries, the same partial sums -- the same refined terms bit for bit (and the factor itself is untouched by the copy)."""
+    x, y = rng.make_regression(n, d, dy, seed=5)
+    X, Y = torch.as_tensor(x).to(device), torch.as_tensor(y).to(device)
+    var = torch.tensor([0.9], dtype=torch.float64, device=device)
+    ls = torch.tensor([float(np.sqrt(d)) * 0.8], dtype=torch.float64, device=device)
+    nz = torch.tensor([3e-2], dtype=torch.float64, device=device)
+    monkeypatch.setenv("GPN_REFINE_SAVED_K", "0")
+    f0, t0 = _ops.lml_forward(kind, X, Y, var, ls, nz, refine=True)
+    monkeypatch.setenv("GPN_REFINE_SAVED_K", "1")
+    f1, t1 = _ops.lml_forward(kind, X, Y, var, ls, nz, refine=True)
+    assert getattr(f0, "_ksave", None) is None and f1._ksave is not None
+    assert torch.equal(t0, t1), (t0, t1)
+    assert torch.equal(torch.tril(f0.A[:n, :n]), torch.tril(f1.A[:n, :n]))
+    # the copy IS Kyy: sampled rows against the assembly
+    K = _ops.kernel_matrix(kind, X[:64], X, var, ls)
+    K[:, :64] += torch.eye(64, dtype=torch.float64, device=device) * nz
+    assert torch.equal(torch.tril(f1._ksave[:64, :64]), torch.tril(K[:64, :64]))
