@@ -942,6 +942,37 @@ def run_multi(args, rank, local_rank, world, device):
             del mr
         except Exception as exc:
             notes["replicas_error"] = repr(exc)
+        # ... and GP FITS / s the same way (north_star: "GP-fits/sec at 1, 2, 4 and 8 GPUs"): every GPU steps its own 8 restarts of
+        # C2 in lock step (multi_start_optimize: gpn_lml_forward_batched + gpn_lml_backward_batched + one optimiser step per
+        # iteration), no collective on the data path; a fit = 50 Adam steps, 10 are timed
+        try:
+            import contextlib
+            from gptorch_amd.models import multi_start_optimize
+            wf = WORKLOADS["c2"]
+            Bf, iters = 8, 10
+            ms_ = []
+            for b in range(Bf):
+                mb = build_model(dict(wf, variance=wf["variance"] * (1.0 + 0.01 * b), length_scales=wf["length_scales"] * (1.0 + 0.02 * b)),
+                                 rank, device)[0]
+                if ms_:
+                    mb.X, mb.Y = ms_[0].X, ms_[0].Y
+                ms_.append(mb)
+            with contextlib.redirect_stdout(sys.stderr):
+                multi_start_optimize(ms_, method="Adam", max_iter=2, learning_rate=0.01)
+                barrier()
+                t0 = time.perf_counter()
+                multi_start_optimize(ms_, method="Adam", max_iter=iters, learning_rate=0.01)
+                barrier()
+            tf = max_over_ranks(time.perf_counter() - t0)
+            extra["replicas_c2_fit_batched"] = {
+                "config": "C2 x %d restarts per GPU in lock step x %d GPUs (independent replicas, rank r = seed r, no collective); a fit = 50 Adam steps, %d timed"
+                          % (Bf, world, iters),
+                "value": world * Bf / (tf / iters * 50.0), "unit": "GP fits/s", "scaling": "weak", "ms_per_lockstep_step": tf / iters * 1e3,
+                "frac_of_fp64_peak_on_N3": world * Bf * iters * float(wf["n"]) ** 3 / tf / 1e12 / (world * PEAK_FP64_MFMA_TFLOPS)}
+            del ms_
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            notes["replicas_fit_error"] = repr(exc)
 
     def line_text():
         best = min(per_schedule, key=lambda k: per_schedule[k]["ms_per_step"])
