@@ -334,6 +334,8 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
         X, R = _group_data(ms)
         raws = [torch.nn.Parameter(torch.stack([p.data for p in pl]), requires_grad=f.pop()) for pl, f in zip(plists, flags)]
         trainable = [r for r in raws if r.requires_grad]
+        if not trainable:
+            continue                     # nothing to optimise in lock step: each model's own optimize() reports as the reference does
         optimizer = ms[0]._make_optimizer(method, trainable, learning_rate)
         holder = {}
         dev_losses = torch.empty(max_iter, B, dtype=torch.float64, device=X.device)
