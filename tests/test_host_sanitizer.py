@@ -185,6 +185,12 @@ def test_sanitizer_leg():
     asan_lib = os.path.join(ROOT, "gptorch_amd", "lib", "libgpnative_asan.so")
     rccl_asan = os.path.join(ROOT, "gptorch_amd", "lib", "libgpnative_rccl_asan.so")
     rt = _asan_runtime()
+    # the instrumented build follows the sources: rebuilt here (a few seconds, host code only) when a source is newer than it
+    csrc = os.path.join(ROOT, "gptorch_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")))
+    newest = max(newest, os.path.getmtime(os.path.join(ROOT, "include", "gpnative.h")))
+    if not (os.path.exists(asan_lib) and os.path.exists(rccl_asan)) or os.path.getmtime(asan_lib) < newest:
+        subprocess.check_call(["bash", os.path.join(csrc, "build_asan.sh")], stdout=subprocess.DEVNULL)
     assert os.path.exists(asan_lib) and os.path.exists(rccl_asan), "run __graft_entry__.build() (gptorch_amd/csrc/build_asan.sh) first"
     assert rt is not None, "clang's ASan runtime not found under /opt/rocm/lib/llvm"
     if os.environ.get("GPN_SANITIZER_CHILD") == "1":
