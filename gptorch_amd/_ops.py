@@ -667,7 +667,7 @@ class BatchedGPRLogLik(torch.autograd.Function):
         out = terms[:, 2].clone()
         info = fb.info.cpu()                         # ONE read-back for the batch (the reference: one per model and step)
         replayed = {}
-        for b in range(batch):
+        for b in (torch.nonzero(info).reshape(-1).tolist() if bool(info.any()) else ()):
             if int(info[b]) != 0:
                 f, t = lml_forward(kind, X if X.dim() == 2 else X[b], R if R.dim() == 2 else R[b], variance.reshape(batch)[b:b + 1],
                                    length_scales.reshape(batch, -1)[b], noise.reshape(batch)[b:b + 1], refine=False)
