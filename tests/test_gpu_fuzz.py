@@ -44,3 +44,11 @@ def test_fuzz_fused_expressions_against_composed_kernels(device):
     """random Sum / Product trees: K(X), K(X, X2), parameter gradients, GPR loss + backward on the fused path against the same
     tree composed from its children's dense matrices."""
     print(_run("fuzz_expr.py", 24, 77, 600))
+
+
+@pytest.mark.gpu
+def test_fuzz_lockstep_fit_against_sequential(device):
+    """random lock-step groups (sizes around every blocking edge, all kinds, ARD, dy 1..3, shared / own data, two groups
+    interleaved per call) through batched_loss_and_grad against each model's own loss(); backward() (base.py:260-269):
+    losses and gradients bit for bit."""
+    print(_run("fuzz_lockstep.py", 16, 3, 600))
