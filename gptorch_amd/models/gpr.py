@@ -300,6 +300,116 @@ def batched_loss_and_grad(models):
     return out
 
 
+def _multi_start_scipy(models, method, max_iter, verbose):
+    """scipy.optimize.minimize for every model AT ONCE (base.py:298-320; what examples/regression_1d.py:53 and the
+    reference's notebooks run is L-BFGS-B): each restart's `minimize` runs in its own host thread and only ever waits -- its
+    `fun(x)` posts the parameter vector it wants evaluated and sleeps; the calling thread collects one request per
+    still-running restart, evaluates ALL of them in one batched_loss_and_grad call (lock-step groups + sequential rest),
+    and hands every restart its (loss, gradient).  Line searches make the restarts ask for different numbers of
+    evaluations, and restarts finish at different iterations: a round simply covers whoever is still running.  Each
+    restart sees exactly the values Model._loss_and_grad (model.py:123-133) would have given it -- bit for bit -- so its
+    iterates, its result and its printed losses are those of its own optimize(); only the order in which the restarts'
+    "loss: ..." lines interleave differs.  -> list of scipy OptimizeResult."""
+    import threading
+    import numpy as np
+    from scipy.optimize import minimize
+    B = len(models)
+    cond = threading.Condition()
+    pending, answers = {}, {}
+    done = [False] * B
+    results = [None] * B
+    x0 = [m._get_param_array() for m in models]
+
+    def make_fun(i):
+        def fun(x):
+            with cond:
+                pending[i] = np.array(x, dtype=np.float64, copy=True)
+                cond.notify_all()
+                while i not in answers:
+                    cond.wait()
+                ans = answers.pop(i)
+            if isinstance(ans, BaseException):
+                raise ans
+            return ans
+        return fun
+
+    def worker(i):
+        try:
+            results[i] = minimize(fun=make_fun(i), x0=x0[i], method=method, jac=True, tol=None, callback=None,
+                                  options=dict(disp=verbose, maxiter=max_iter))
+        except BaseException as exc:             # delivered to the caller after every restart has finished
+            results[i] = exc
+        finally:
+            with cond:
+                done[i] = True
+                cond.notify_all()
+
+    threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(B)]
+    for t in threads:
+        t.start()
+    while True:
+        with cond:
+            while True:
+                active = [i for i in range(B) if not done[i]]
+                if not active or all(i in pending for i in active):
+                    break
+                cond.wait()
+            if not active:
+                break
+            batch = {i: pending.pop(i) for i in active}
+        idx = sorted(batch)
+        out = {}
+        try:
+            # Model._loss_and_grad (model.py:123-133) for all requests of the round at once.  The requested vectors travel to the
+            # device as ONE copy and every parameter becomes a slice of it (model.py:66-76 makes one tensor per parameter: 3 small
+            # copies per model and round); the gradients come back as ONE copy.
+            dev = models[idx[0]].X.device
+            flat = torch.as_tensor(np.concatenate([batch[i] for i in idx]), dtype=torch.float64).to(dev)
+            at = 0
+            for i in idx:
+                for p in models[i].parameters():
+                    if p.requires_grad:
+                        nxt = at + p.numel()
+                        p.data = flat[at:nxt].reshape(p.shape)
+                        at = nxt
+                    p.grad = None                    # (a fresh gradient: what zeroing + accumulating gives)
+            losses = batched_loss_and_grad([models[i] for i in idx])
+            trainable = [[p for p in models[i].parameters() if p.requires_grad] for i in idx]
+            allg = torch.cat([p.grad.reshape(-1) for ps in trainable for p in ps] + [l.reshape(-1) for l in losses]).cpu().numpy()
+            lvals = allg[len(allg) - len(idx):]
+            at = 0
+            for k, i in enumerate(idx):
+                cnt = sum(p.numel() for p in trainable[k])
+                grad = np.array(allg[at:at + cnt])
+                at += cnt
+                value = float(lvals[k])
+                print("loss: %s" % value)
+                finite = np.isfinite(grad)
+                if np.all(finite):
+                    out[i] = (float(value), grad.astype(np.float64))
+                else:
+                    print("Warning: inf or nan in gradient: replacing with zeros")
+                    out[i] = (value, np.where(finite, grad, 0.0).astype(np.float64))
+        except BaseException:
+            # one request of the round failed (e.g. the jitter ladder ran out for one model): evaluate them one by one so
+            # that only the restart it belongs to sees the exception
+            out = {}
+            for i in idx:
+                try:
+                    out[i] = models[i]._loss_and_grad(batch[i])
+                except BaseException as exc:
+                    out[i] = exc
+        with cond:
+            answers.update(out)
+            cond.notify_all()
+    for t in threads:
+        t.join()
+    for r in results:
+        if isinstance(r, BaseException):
+            raise r
+    return results
+
+
 def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, learning_rate=None):
     """GPModel.optimize (gptorch/models/base.py:111-296) for several INDEPENDENT restarts at once: every iteration is ONE
     lock-step loss + backward over each group of equally shaped models (see batched_loss_and_grad) and ONE optimiser step
@@ -311,11 +421,19 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
     Returns (losses [len(models), max_iter] numpy, seconds).  The models' Params hold the final values afterwards.
 
     Groups: as batched_loss_and_grad, and additionally every model of the group trains the same subset of (variance,
-    length_scales, noise) with a shared transform and no trainable mean function; other models (and method="LBFGS" / the
-    scipy methods) are optimised one after the other by their own optimize()."""
+    length_scales, noise) with a shared transform and no trainable mean function; other models (and method="LBFGS") are
+    optimised one after the other by their own optimize().
+
+    scipy methods ("L-BFGS-B", "CG", "BFGS" ...: base.py:203-215, 298-320): every restart's scipy.optimize.minimize runs at
+    once and each round of function evaluations is ONE batched_loss_and_grad call (_multi_start_scipy); returns
+    (list of scipy results, seconds) -- each bit-identical to the model's own optimize(method=...)."""
     import time
     import numpy as np
-    from .base import _TORCH_DEFAULT_LR
+    from .base import _TORCH_DEFAULT_LR, _SCIPY_METHODS
+    if method in _SCIPY_METHODS:
+        print("Scipy.optimize.minimize...")
+        tic = time.time()
+        return _multi_start_scipy(models, method, max_iter, verbose), time.time() - tic
     if learning_rate is None and method in _TORCH_DEFAULT_LR:
         learning_rate = _TORCH_DEFAULT_LR[method]
     losses = np.zeros((len(models), max_iter))

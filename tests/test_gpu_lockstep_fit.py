@@ -316,3 +316,48 @@ def test_backward_on_poisoned_workspaces(device, n, dy, batch):
         res.append((out, g_R))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][0], outs[0][0][0])
+
+
+@pytest.mark.parametrize("method", ["L-BFGS-B", "CG"])
+def test_multi_start_scipy_is_bit_identical_to_each_models_own_run(device, method):
+    """multi_start_optimize with a scipy method (base.py:298-320; L-BFGS-B is what examples/regression_1d.py:53 runs): every
+    restart's scipy.optimize.minimize runs at once and each round of evaluations is one lock-step loss + backward -- every
+    restart sees bit for bit what Model._loss_and_grad (model.py:123-133) would have given it, so iterates, result and the
+    number of evaluations are those of its own optimize(); restarts that finish early leave the rounds."""
+    specs = [("Rbf", True, 1.0, 1.5, 0.05), ("Rbf", True, 0.5, 3.0, 0.1), ("Rbf", True, 1.8, 0.8, 0.02), ("Matern52", False, 1.0, 2.0, 0.05)]
+    a = _restarts(device, 400, 3, specs)
+    b = _restarts(device, 400, 3, specs)
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        res, _ = multi_start_optimize(a, method=method, max_iter=15)
+    assert len(res) == 4
+    evals = 0
+    for i, m in enumerate(b):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ref = m.optimize(method=method, max_iter=15)
+        assert np.array_equal(res[i].x, ref.x) and res[i].fun == ref.fun and res[i].nit == ref.nit and res[i].nfev == ref.nfev, (i, res[i], ref)
+        for pa, pb in zip(a[i].parameters(), m.parameters()):
+            assert torch.equal(pa.data, pb.data)
+        evals += ref.nfev
+    # every evaluation was printed exactly once ("loss: ..." as model.py:129), whichever round it ran in
+    assert len([ln for ln in out.getvalue().splitlines() if ln.startswith("loss:")]) == evals
+    assert len({r.nfev for r in res}) > 1              # the restarts really needed different numbers of evaluations
+
+
+def test_lbfgs_golden_through_multi_start(device):
+    """the reference's L-BFGS-B run of its example model (Linear + Rbf + Constant, n = 100; tests/golden/lbfgs_case.json) as ONE of
+    three restarts optimised at once: final parameters and loss at the tolerances of the sequential golden test.  (A composite
+    kernel: its requests take batched_loss_and_grad's sequential path inside the shared rounds.)"""
+    g = load_json("lbfgs_case.json")
+    x, y = np.asarray(g["x"]).reshape(-1, 1), np.asarray(g["y"]).reshape(-1, 1)
+    ms = []
+    for scale in (1.0, 0.6, 1.7):
+        k = kernels.Linear(1) + kernels.Rbf(1, length_scales=scale) + kernels.Constant(1)
+        m = GPR(x, y, k)
+        m.cuda()
+        ms.append(m)
+    with _quiet():
+        res, _ = multi_start_optimize(ms, method="L-BFGS-B", max_iter=g["max_iter"])
+    assert np.max(np.abs(res[0].x - np.asarray(g["final_params"]))) < 1e-5
+    assert abs(ms[0].loss().item() - g["final_loss"]) < 1e-6
