@@ -178,6 +178,10 @@ def _lockstep_groups(models, for_grad=False):
     (loss() = -(LML + log prior), model.py:158-197: a model with priors takes the sequential path)."""
     groups = {}
     for i, m in enumerate(models):
+        # GPR's own log_likelihood only: other GPModels (VFE), and subclasses that evaluate differently (DistGPR: collective, on the
+        # process grid), take their own path
+        if not isinstance(m, GPR) or type(m).log_likelihood is not GPR.log_likelihood:
+            continue
         k = m._stationary()
         if k is None or m.X.shape[0] >= _ops.refine_min_n() or not m.X.is_cuda or m.X.shape[0] == 0:
             continue

@@ -361,3 +361,30 @@ def test_lbfgs_golden_through_multi_start(device):
         res, _ = multi_start_optimize(ms, method="L-BFGS-B", max_iter=g["max_iter"])
     assert np.max(np.abs(res[0].x - np.asarray(g["final_params"]))) < 1e-5
     assert abs(ms[0].loss().item() - g["final_loss"]) < 1e-6
+
+
+def test_batched_calls_accept_any_gp_model(device):
+    """models that are not plain GPR (a sparse VFE model; a GPR over a composite kernel) simply take their own loss();
+    backward() inside batched_loss_and_grad / multi_start_optimize -- same numbers as calling them directly."""
+    from gptorch_amd.models import VFE
+    x, y = rng.make_regression(500, 2, 1, seed=3)
+    def build():
+        ms = _restarts(device, 500, 2, [("Rbf", False, 1.0, 1.2, 0.05), ("Rbf", False, 0.7, 0.8, 0.05)], seed=3)
+        v = VFE(x, y, kernels.Matern52(2), num_inducing_points=20)
+        v.cuda()
+        c = GPR(x, y, kernels.Rbf(2) + kernels.Linear(2), likelihood=likelihoods.Gaussian(variance=0.05))
+        c.cuda()
+        return ms + [v, c]
+    torch.manual_seed(0); np.random.seed(0)
+    a = build()
+    torch.manual_seed(0); np.random.seed(0)
+    b = build()
+    out = batched_loss_and_grad(a)
+    for i, m in enumerate(b):
+        loss = m.loss()
+        loss.backward()
+        assert torch.equal(out[i].reshape(-1), loss.detach().reshape(-1)), i
+        for pa, pb in zip(a[i].parameters(), m.parameters()):
+            assert (pa.grad is None) == (pb.grad is None)
+            if pa.grad is not None:
+                assert torch.equal(pa.grad, pb.grad), i
