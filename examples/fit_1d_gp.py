@@ -5,7 +5,12 @@ import lines differ from a gptorch script, plus ONE line: `settings.auto_device 
 environment) lets the CPU-constructed model place itself on the GPU at its first call, like the reference's example, which
 never calls .cuda() (examples/regression_1d.py:89-95).  Without it `model.cuda()` is mandatory: there is no CPU path.
 
-    python examples/fit_1d_gp.py [--sparse] [--n 100]
+    python examples/fit_1d_gp.py [--sparse] [--n 100] [--restarts 6]
+
+--restarts K (not in the reference, which fits one model per optimize() call): K exact-GP restarts with an Rbf kernel from
+different initial length scales, all K L-BFGS-B runs AT ONCE -- every round of function evaluations is one lock-step
+loss + backward on the GPU (gptorch_amd.models.multi_start_optimize), each restart ends where its own optimize() would --
+and the best one predicts.
 """
 import argparse
 import os
@@ -18,6 +23,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 from gptorch_amd import kernels, settings  # was: from gptorch import kernels
 from gptorch_amd.models import GPR, VFE    # was: from gptorch.models.gpr import GPR / sparse_gpr import VFE
+from gptorch_amd.models import multi_start_optimize
 
 
 def target(x):
@@ -28,6 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sparse", action="store_true", help="variational sparse GP (VFE) instead of the exact one")
     ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--restarts", type=int, default=0, help="multi-start: this many Rbf restarts optimised in lock step")
     args = ap.parse_args()
     rs = np.random.RandomState(42)
     x = np.linspace(0.0, 1.0, args.n).reshape(-1, 1)
@@ -38,7 +45,19 @@ def main():
     else:
         model = GPR(x, y, kernels.Linear(1) + kernels.Rbf(1) + kernels.Constant(1))
     settings.auto_device = True          # opt-in: the model moves itself to the GPU at its first loss() / predict call
-    model.optimize(method="L-BFGS-B", max_iter=100)
+    if args.restarts > 1 and not args.sparse:
+        xs_, ys_ = torch.as_tensor(x).cuda(), torch.as_tensor(y).cuda()          # the restarts share the data on the device
+        restarts = []
+        for ell in np.geomspace(0.02, 2.0, args.restarts):
+            m = GPR(xs_, ys_, kernels.Rbf(1, length_scales=float(ell)))
+            m.cuda()
+            restarts.append(m)
+        results, seconds = multi_start_optimize(restarts, method="L-BFGS-B", max_iter=100)
+        best = int(np.argmin([r.fun for r in results]))
+        print("multi-start: %d restarts in %.2f s, final losses %s -> restart %d" % (args.restarts, seconds, [round(float(r.fun), 3) for r in results], best))
+        model = restarts[best]
+    else:
+        model.optimize(method="L-BFGS-B", max_iter=100)
     print(model)
 
     x_test = np.linspace(-1.0, 2.0, 200).reshape(-1, 1)
