@@ -174,8 +174,8 @@ def _group_key(m):
 
 def _lockstep_groups(models, for_grad=False):
     """[(key, indices)] of the models that can share one lock-step call, grouped by (kernel kind, n, d, dy, ARD, device):
-    stationary kernels below the size from which log_likelihood() refines the quadratic form.  for_grad: also no priors
-    (loss() = -(LML + log prior), model.py:158-197: a model with priors takes the sequential path)."""
+    stationary kernels below the size from which log_likelihood() refines the quadratic form.  for_grad (the stacked-parameter
+    optimiser loop of multi_start_optimize): also no priors (loss() = -(LML + log prior), model.py:158-197, is formed per model)."""
     groups = {}
     for i, m in enumerate(models):
         # GPR's own log_likelihood only: other GPModels (VFE), and subclasses that evaluate differently (DistGPR: collective, on the
@@ -273,10 +273,10 @@ def batched_loss_and_grad(models):
     gpn_lml_backward_batched call per group (_ops.BatchedGPRLogLik), the hyper-parameters of the group stacked so that the
     transforms and their chain rule are one small launch per parameter kind.  Each model's loss AND gradients are
     BIT-IDENTICAL to its own `loss(); backward()`; a model whose factorisation fails is replayed alone through the jitter
-    ladder.  Composite / dense-K kernels, singletons, models with priors and sizes that refine the quadratic form take the
-    sequential path."""
+    ladder; parameters with priors add their model's own log_prior() (model.py:158-197).  Composite / dense-K kernels,
+    singletons and sizes that refine the quadratic form take the sequential path."""
     out = [None] * len(models)
-    for key, g in _lockstep_groups(models, for_grad=True):
+    for key, g in _lockstep_groups(models):
         ms = [models[i] for i in g]
         B = len(ms)
         X, R = _group_data(ms, differentiable=True)
@@ -289,7 +289,12 @@ def batched_loss_and_grad(models):
                 stacks.append(torch.stack([p.transform() for p in plist]))
         var, ls, nz = stacks[0].reshape(B), stacks[1].reshape(B, -1), stacks[2].reshape(B)
         lml = _ops.BatchedGPRLogLik.apply(X, R, var, ls, nz, key[0], _batch_holder((key, B)))
-        loss = -(lml + 0.0)                                          # model.py:_loss with an empty log prior
+        if any(getattr(p, "prior", None) is not None for m in ms for p in m.parameters()):
+            # parameters with priors (model.py:158-197: loss = -(LML + log prior)): each model's own log_prior(), added to its
+            # entry of the lock-step LML exactly as Model._loss adds it
+            loss = torch.cat([-(lml[b:b + 1] + m.log_prior()) for b, m in enumerate(ms)])
+        else:
+            loss = -(lml + 0.0)                                      # model.py:_loss with an empty log prior
         if loss.requires_grad:
             loss.sum().backward()
         ld = loss.detach()

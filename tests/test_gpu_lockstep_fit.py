@@ -388,3 +388,32 @@ def test_batched_calls_accept_any_gp_model(device):
             assert (pa.grad is None) == (pb.grad is None)
             if pa.grad is not None:
                 assert torch.equal(pa.grad, pb.grad), i
+
+
+def test_batched_loss_and_grad_with_priors(device):
+    """parameters with priors (model.py:158-197: loss = -(LML + log prior)): the lock-step path adds each model's own
+    log_prior() to its entry -- loss and gradients bit-identical to loss(); backward(), also through a scipy multi-start."""
+    def build():
+        ms = _restarts(device, 600, 2, [("Rbf", False, 1.0, 1.2, 0.05), ("Rbf", False, 0.7, 0.8, 0.03), ("Rbf", False, 1.5, 2.0, 0.08)])
+        g = lambda a, b: torch.distributions.Gamma(torch.tensor(a, dtype=torch.float64, device=device), torch.tensor(b, dtype=torch.float64, device=device))
+        ms[0].kernel.variance.prior = g(2.0, 1.0)
+        ms[0].kernel.length_scales.prior = g(3.0, 2.0)
+        ms[2].likelihood.variance.prior = g(1.5, 10.0)            # model 1 has none
+        return ms
+    a, b = build(), build()
+    out = batched_loss_and_grad(a)
+    for i, m in enumerate(b):
+        loss = m.loss()
+        loss.backward()
+        assert torch.equal(out[i], loss.detach()), (i, out[i], loss)
+        for pa, pb in zip(a[i].parameters(), m.parameters()):
+            assert (pa.grad is None) == (pb.grad is None)
+            if pa.grad is not None:
+                assert torch.equal(pa.grad, pb.grad), (i, pa.grad, pb.grad)
+    assert out[0].item() != (-(a[0].log_likelihood())).item()      # the prior really is in the loss
+    a, b = build(), build()
+    with _quiet():
+        res, _ = multi_start_optimize(a, method="L-BFGS-B", max_iter=8)
+        for i, m in enumerate(b):
+            ref = m.optimize(method="L-BFGS-B", max_iter=8)
+            assert np.array_equal(res[i].x, ref.x) and res[i].nfev == ref.nfev
