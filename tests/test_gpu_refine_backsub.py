@@ -99,3 +99,40 @@ def test_refinement_from_the_saved_copy_is_bit_identical(device, monkeypatch, n,
     K = _ops.kernel_matrix(kind, X[:64], X, var, ls)
     K[:, :64] += torch.eye(64, dtype=torch.float64, device=device) * nz
     assert torch.equal(torch.tril(f1._ksave[:64, :64]), torch.tril(K[:64, :64]))
+
+
+def test_refined_evaluation_captures_into_a_hipgraph(device):
+    """the refinement step -- the sentinel fill, the persistent back-substitution (workgroups handing a_k on through device
+    memory), the double-double residual pass -- captures into ONE hipGraph together with the evaluation before it; replays
+    reproduce the eager refined terms bit for bit and follow new hyper-parameters written into the captured tensors."""
+    n, d = 12288, 8
+    x, y = rng.make_regression(n, d, 1, seed=2)
+    X, Y = torch.as_tensor(x).to(device), torch.as_tensor(y).to(device)
+    var = torch.tensor([1.0], dtype=torch.float64, device=device)
+    ls = torch.tensor([float(np.sqrt(d))], dtype=torch.float64, device=device)
+    nz = torch.tensor([2e-2], dtype=torch.float64, device=device)
+    lib = _native.lib()
+    f, eager = _ops.lml_forward("Matern52", X, Y, var, ls, nz, refine=True)      # warm-up: creates side streams, workspaces
+    out = torch.empty(3, dtype=torch.float64, device=device)
+
+    def enqueue():
+        st = lib.gpn_lml_forward(_ops._stream(device), _ops.KINDS["Matern52"], _ops._ptr(X), n, d, _ops._ptr(Y), None, 1, _ops._ptr(var),
+                                 _ops._ptr(ls), 1, _ops._ptr(nz), _ops._ptr(f.A), f.ld, _ops._ptr(f.winv), _ops._ptr(f.info), _ops._ptr(out))
+        assert st == 0
+        st = lib.gpn_lml_refine(_ops._stream(device), _ops.KINDS["Matern52"], _ops._ptr(X), n, d, _ops._ptr(Y), None, 1, _ops._ptr(var),
+                                _ops._ptr(ls), 1, _ops._ptr(nz), _ops._ptr(f.A), f.ld, _ops._ptr(f.winv), _ops._ptr(f._refine_work), _ops._ptr(out))
+        assert st == 0
+
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        enqueue()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(f.info.item()) == 0 and torch.equal(out, eager), (out, eager)
+    ls.mul_(1.2)                                         # same graph, new hyper-parameters
+    g.replay()
+    torch.cuda.synchronize()
+    _, eager2 = _ops.lml_forward("Matern52", X, Y, var, ls, nz, refine=True)
+    assert torch.equal(out, eager2)
