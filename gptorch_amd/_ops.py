@@ -197,11 +197,13 @@ class FactorBatch:
         return f
 
 
-def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None):
+def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None, refine=False):
     """GPR.log_likelihood (gpr.py:47-67) of `batch` models in lock step (gpn_lml_forward_batched): X [n, d] shared or
     [batch, n, d]; R = Y - m(X) [n, dy] shared or [batch, n, dy]; variance [batch], length_scales [batch, nls],
     noise [batch].  -> (FactorBatch, terms [batch, 3]); NO host synchronisation: the caller reads fb.info and
-    replays the models whose info != 0 through the sequential path (jitter ladder)."""
+    replays the models whose info != 0 through the sequential path (jitter ladder).
+    refine: follow the lock-step factorisation with gpn_lml_refine on every model's factor (what lml_forward does from
+    refine_min_n() rows on: the same call on the same factor, so the refined terms are bit-identical too)."""
     _req(X, R, variance, length_scales, noise)
     batch = int(variance.numel())
     shared_x, shared_r = X.dim() == 2, R.dim() == 2
@@ -219,6 +221,17 @@ def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None):
         None, 0, e, _ptr(var), _ptr(ls), ls.shape[1], _ptr(nz), _ptr(fb.A), fb.ld, fb.sA, _ptr(fb.winv), fb.sW,
         _ptr(fb.info), _ptr(fb.out))
     _native.check(st, "gpn_lml_forward_batched")
+    if refine and n > 0:
+        lib = _native.lib()
+        if getattr(fb, "_refine_work", None) is None:
+            fb._refine_work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=X.device)
+        for b in range(batch):                       # (3 % of an evaluation each; enqueued before anybody reads `info`)
+            Xb = Xc if shared_x else Xc[b]
+            Rb = Rc if shared_r else Rc[b]
+            st = lib.gpn_lml_refine(_stream(X.device), KINDS[kind], _ptr(Xb), n, d, _ptr(Rb), None, e, _ptr(var[b:b + 1]), _ptr(ls[b]), ls.shape[1],
+                                    _ptr(nz[b:b + 1]), _ptr(fb.A[b * fb.rows:]), fb.ld, _ptr(fb.winv[b * fb.sW:]), _ptr(fb._refine_work),
+                                    _ptr(fb.out[b]))
+            _native.check(st, "gpn_lml_refine")
     return fb, fb.out
 
 
@@ -654,15 +667,13 @@ class BatchedGPRLogLik(torch.autograd.Function):
     values) -> LML [batch].  Forward = gpn_lml_forward_batched, backward = gpn_lml_backward_batched; a model whose
     factorisation reports info != 0 is replayed ALONE through lml_forward (jitter ladder of functions.py:20-43) into a
     private factor, and its backward runs on that factor.  Values and gradients are bit-identical, model by model, to
-    GPRLogLik.  Sizes at which GPRLogLik refines the quadratic form (refine_min_n) are not for this node: the caller
-    (models.gpr) only groups smaller models."""
+    GPRLogLik -- also from refine_min_n() rows on, where every model's quadratic form is refined as GPRLogLik's is."""
 
     @staticmethod
     def forward(ctx, X, R, variance, length_scales, noise, kind, holder):
         batch = int(variance.numel())
-        if X.shape[-2] >= refine_min_n():
-            raise NativeError("BatchedGPRLogLik: sizes from refine_min_n() rows on take the sequential path")
-        fb, terms = lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=holder.get("fb"))
+        fb, terms = lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=holder.get("fb"),
+                                        refine=X.shape[-2] >= refine_min_n())
         holder["fb"] = fb
         out = terms[:, 2].clone()
         info = fb.info.cpu()                         # ONE read-back for the batch (the reference: one per model and step)
@@ -670,7 +681,7 @@ class BatchedGPRLogLik(torch.autograd.Function):
         for b in (torch.nonzero(info).reshape(-1).tolist() if bool(info.any()) else ()):
             if int(info[b]) != 0:
                 f, t = lml_forward(kind, X if X.dim() == 2 else X[b], R if R.dim() == 2 else R[b], variance.reshape(batch)[b:b + 1],
-                                   length_scales.reshape(batch, -1)[b], noise.reshape(batch)[b:b + 1], refine=False)
+                                   length_scales.reshape(batch, -1)[b], noise.reshape(batch)[b:b + 1])
                 out[b] = t[2]
                 replayed[b] = f
         ctx.kind, ctx.fb, ctx.generation, ctx.replayed = kind, fb, fb.generation, replayed

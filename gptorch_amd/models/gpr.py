@@ -174,7 +174,7 @@ def _group_key(m):
 
 def _lockstep_groups(models, for_grad=False):
     """[(key, indices)] of the models that can share one lock-step call, grouped by (kernel kind, n, d, dy, ARD, device):
-    stationary kernels below the size from which log_likelihood() refines the quadratic form.  for_grad (the stacked-parameter
+    GPR over a native stationary kernel.  for_grad (the stacked-parameter
     optimiser loop of multi_start_optimize): also no priors (loss() = -(LML + log prior), model.py:158-197, is formed per model)."""
     groups = {}
     for i, m in enumerate(models):
@@ -183,7 +183,7 @@ def _lockstep_groups(models, for_grad=False):
         if not isinstance(m, GPR) or type(m).log_likelihood is not GPR.log_likelihood:
             continue
         k = m._stationary()
-        if k is None or m.X.shape[0] >= _ops.refine_min_n() or not m.X.is_cuda or m.X.shape[0] == 0:
+        if k is None or not m.X.is_cuda or m.X.shape[0] == 0:
             continue
         if for_grad and any(getattr(p, "prior", None) is not None for p in m.parameters()):
             continue
@@ -219,8 +219,9 @@ def batched_log_likelihood(models, streams=None):
     streams=None (default): models of one shape (kernel kind, N, D, dy) run in LOCK STEP through ONE
     gpn_lml_forward_batched call -- one assembly launch, the 128x128 leaf as a grid of B workgroups, every column pass and
     contraction as a strided-batch launch -- and the `info` words are read once at the end; a model whose factorisation
-    reports info != 0 is re-evaluated through the sequential path (jitter ladder of functions.py:20-43).  Dense-K /
-    composite kernels, singletons and sizes at which log_likelihood() refines the quadratic form take the sequential path.
+    reports info != 0 is re-evaluated through the sequential path (jitter ladder of functions.py:20-43); from
+    refine_min_n() rows on every model's quadratic form is refined as log_likelihood() refines it.  Dense-K / composite
+    kernels and singletons take the sequential path.
 
     streams = a list of HIP streams (one per model): the round-3 placement instead -- whole evaluations alternating
     over the given streams (the current stream itself gives back-to-back execution)."""
@@ -238,7 +239,7 @@ def batched_log_likelihood(models, streams=None):
             ls = _stacked_values([m._stationary().length_scales for m in ms]).reshape(len(ms), -1)
             nz = _stacked_values([m.likelihood.variance for m in ms]).reshape(len(ms))
             holder = _batch_holder((key, len(ms)))
-            fb, terms = _ops.lml_forward_batched(key[0], X, R, var, ls, nz, fb=holder.get("fb"))
+            fb, terms = _ops.lml_forward_batched(key[0], X, R, var, ls, nz, fb=holder.get("fb"), refine=ms[0].X.shape[0] >= _ops.refine_min_n())
             holder["fb"] = fb
             pending.append((g, fb, terms))
         for g, fb, terms in pending:
@@ -273,8 +274,8 @@ def batched_loss_and_grad(models):
     gpn_lml_backward_batched call per group (_ops.BatchedGPRLogLik), the hyper-parameters of the group stacked so that the
     transforms and their chain rule are one small launch per parameter kind.  Each model's loss AND gradients are
     BIT-IDENTICAL to its own `loss(); backward()`; a model whose factorisation fails is replayed alone through the jitter
-    ladder; parameters with priors add their model's own log_prior() (model.py:158-197).  Composite / dense-K kernels,
-    singletons and sizes that refine the quadratic form take the sequential path."""
+    ladder; parameters with priors add their model's own log_prior() (model.py:158-197); sizes that refine the quadratic
+    form refine it per model.  Composite / dense-K kernels and singletons take the sequential path."""
     out = [None] * len(models)
     for key, g in _lockstep_groups(models):
         ms = [models[i] for i in g]

@@ -417,3 +417,32 @@ def test_batched_loss_and_grad_with_priors(device):
         for i, m in enumerate(b):
             ref = m.optimize(method="L-BFGS-B", max_iter=8)
             assert np.array_equal(res[i].x, ref.x) and res[i].nfev == ref.nfev
+
+
+def test_lockstep_above_the_refinement_threshold(device):
+    """from refine_min_n() rows on (12288) log_likelihood() refines the quadratic form (gpn_lml_refine); the lock-step path
+    refines every model's factor the same way: values, losses and gradients of two restarts at N = 12288 bit-identical to
+    their sequential ones, and the values carry the refinement."""
+    from gptorch_amd import _ops
+    n = _ops.refine_min_n()
+    ms = _restarts(device, n, 6, [("Matern52", False, 1.0, 2.5, 0.01), ("Matern52", False, 0.8, 2.0, 0.02)])
+    seq_v = [m.log_likelihood().detach().clone() for m in ms]
+    assert all(m._holder["factor"].refined for m in ms)
+    vals = batched_log_likelihood(ms)
+    for a, b in zip(vals, seq_v):
+        assert torch.equal(a, b)
+    seq = []
+    for m in ms:
+        loss = m.loss()
+        loss.backward()
+        seq.append((loss.detach().clone(), _grads(m)))
+        m.zero_grad()
+    out = batched_loss_and_grad(ms)
+    for i, m in enumerate(ms):
+        assert torch.equal(out[i], seq[i][0])
+        for ga, gb in zip(_grads(m), seq[i][1]):
+            assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb))
+    fb, terms = _ops.lml_forward_batched("Matern52", ms[0].X, ms[0].Y, torch.stack([m.kernel.variance.transform().reshape(()) for m in ms]),
+                                         torch.stack([m.kernel.length_scales.transform().reshape(-1) for m in ms]),
+                                         torch.stack([m.likelihood.variance.transform().reshape(()) for m in ms]), refine=False)
+    assert not torch.equal(terms[0, 2:3], seq_v[0])            # unrefined differs: the refinement really ran in the batch
