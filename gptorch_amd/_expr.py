@@ -55,6 +55,11 @@ class Program:
         self.gstart = (ctypes.c_int * len(starts))(*starts)
         self.ngroups = len(groups)
 
+    def signature(self):
+        """hashable structure of the expression (leaf types / kinds / parameter counts per instance, grouping): two kernels
+        with equal signatures run through the same kernels with the same launch shapes (lock-step groups)."""
+        return (tuple((t.type, t.kind, t.var_off, t.ls_off, t.nls, t.nvar) for t in self.terms), tuple(self.gstart), self.ntheta)
+
     def params(self):
         """the leaves' parameter tensors in packing order (constrained values, autograd-connected)."""
         out = []
@@ -214,30 +219,9 @@ class ExprLogLik(torch.autograd.Function):
         if f is None or f.n != n or f.e != e or f.device != X.device:
             f = _ops.Factor(n, e, X.device)
         holder["factor"] = f
-        nz0 = _c(noise.detach())
-
-        def attempt(jitter):
-            kernel_matrix(prog, theta, X, None, noise=nz0 if jitter is None else nz0 + jitter, out=f.A, ldk=f.ld, lower=True)
-            f.pack_rhs(R)
-            return f.potrf()
-
-        f.jitter_rung = _ops._ladder(attempt)
+        terms = _factor_single(prog, theta, X, R, _c(noise.detach()), f)
         ctx.prog, ctx.factor, ctx.generation = prog, f, f.generation
         ctx.save_for_backward(X, R, noise, theta, *params)
-        terms = f.lml_terms()
-        f.refined = False
-        if n >= _ops.refine_min_n(expression=True):
-            # the refinement step of the quadratic form, with the residual pass over the expression program
-            lib = _native.lib()
-            nz = nz0 if f.jitter_rung < 0 else nz0 + 10.0 ** (-_ops.JITTER_TRIES + f.jitter_rung)
-            if f._refine_work is None:
-                f._refine_work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=X.device)
-            Xc, Rc = _c(X.detach()), _c(R.detach())
-            st = lib.gpn_lml_refine_expr(_stream(X.device), prog.terms, len(prog.instances), prog.gstart, prog.ngroups, _ptr(theta),
-                                         _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e, _ptr(nz), _ptr(f.A), f.ld, _ptr(f.winv),
-                                         _ptr(f._refine_work), _ptr(terms))
-            _native.check(st, "gpn_lml_refine_expr")
-            f.refined = True
         return terms[2:3].clone()
 
     @staticmethod
@@ -263,3 +247,142 @@ class ExprLogLik(torch.autograd.Function):
         g_params = [go * g for g in prog.scatter(outs, params)]
         return (None, -go * at.t() if ctx.needs_input_grad[1] else None, go * trace if ctx.needs_input_grad[2] else None,
                 None, None) + tuple(g_params)
+
+
+def _factor_single(prog, theta, X, R, nz0, f):
+    """assembly -> factorisation (+ jitter ladder) -> terms (+ refinement from refine_min_n(expression=True) rows on) of ONE model
+    into the factor buffer f: the body of ExprLogLik.forward, shared with the replay of a model that failed inside a lock-step batch."""
+    n, e = R.shape
+
+    def attempt(jitter):
+        kernel_matrix(prog, theta, X, None, noise=nz0 if jitter is None else nz0 + jitter, out=f.A, ldk=f.ld, lower=True)
+        f.pack_rhs(R)
+        return f.potrf()
+
+    f.jitter_rung = _ops._ladder(attempt)
+    terms = f.lml_terms()
+    f.refined = False
+    if n >= _ops.refine_min_n(expression=True):
+        lib = _native.lib()
+        nz = nz0 if f.jitter_rung < 0 else nz0 + 10.0 ** (-_ops.JITTER_TRIES + f.jitter_rung)
+        if f._refine_work is None:
+            f._refine_work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=X.device)
+        Xc, Rc = _c(X.detach()), _c(R.detach())
+        st = lib.gpn_lml_refine_expr(_stream(X.device), prog.terms, len(prog.instances), prog.gstart, prog.ngroups, _ptr(theta),
+                                     _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e, _ptr(nz), _ptr(f.A), f.ld, _ptr(f.winv),
+                                     _ptr(f._refine_work), _ptr(terms))
+        _native.check(st, "gpn_lml_refine_expr")
+        f.refined = True
+    return terms
+
+
+class BatchedExprLogLik(torch.autograd.Function):
+    """ExprLogLik for `batch` independent models with composite kernels of ONE structure (equal Program.signature()) in LOCK
+    STEP -- the reference's own example model, Linear + Rbf + Constant (examples/regression_1d.py:34-53), in a multi-start
+    search.  The assembly and the gradient sweeps are the expression's, model by model (their parameters differ); everything
+    kernel-independent goes out once over all models: the factorisation (gpn_potrf_lower_batched), the reductions
+    (gpn_lml_reduce_batched) and the backward's U = L^-T, Kyy^-1 = U U^T, a^T = alpha^T U^T (gpn_lml_kinv_batched).  A model whose
+    factorisation reports info != 0 is replayed alone through the jitter ladder into a private factor.  Per model, values and
+    gradients are bit-identical to ExprLogLik.
+    Inputs: X [n, d] shared or [batch, n, d]; R [n, dy] shared or [batch, n, dy]; noise [batch]; progs: one Program per model;
+    params: the models' constrained leaf parameters, model after model (len(progs[0].params()) each)."""
+
+    @staticmethod
+    def forward(ctx, X, R, noise, progs, holder, *params):
+        batch = len(progs)
+        npar = len(params) // batch
+        n, e = R.shape[-2], R.shape[-1]
+        lib = _native.lib()
+        fb = holder.get("fb")
+        if fb is None or fb.batch != batch or fb.n != n or fb.e != e or fb.A.device != X.device:
+            fb = _ops.FactorBatch(batch, n, e, X.device)
+        holder["fb"] = fb
+        fb.generation += 1
+        thetas = [progs[b].theta(params[b * npar:(b + 1) * npar]) for b in range(batch)]
+        nz = _c(noise.detach().reshape(batch))
+        Xb = lambda b: X if X.dim() == 2 else X[b]
+        Rb = lambda b: R if R.dim() == 2 else R[b]
+        factors = [fb.factor(b) for b in range(batch)]
+        for b in range(batch):
+            kernel_matrix(progs[b], thetas[b], Xb(b), None, noise=nz[b:b + 1], out=factors[b].A, ldk=fb.ld, lower=True)
+            factors[b].pack_rhs(Rb(b))
+        fb.info.zero_()
+        st = lib.gpn_potrf_lower_batched(_stream(X.device), _ptr(fb.A), n, e, fb.ld, fb.sA, _ptr(fb.winv), fb.sW, _ptr(fb.info), batch)
+        _native.check(st, "gpn_potrf_lower_batched")
+        st = lib.gpn_lml_reduce_batched(_stream(X.device), _ptr(fb.A), n, e, fb.ld, fb.sA, _ptr(fb.out), batch)
+        _native.check(st, "gpn_lml_reduce_batched")
+        if n >= _ops.refine_min_n(expression=True):
+            if getattr(fb, "_refine_work", None) is None:
+                fb._refine_work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=X.device)
+            for b in range(batch):
+                Xc, Rc = _c(Xb(b).detach()), _c(Rb(b).detach())
+                st = lib.gpn_lml_refine_expr(_stream(X.device), progs[b].terms, len(progs[b].instances), progs[b].gstart, progs[b].ngroups,
+                                             _ptr(thetas[b]), _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e, _ptr(nz[b:b + 1]), _ptr(factors[b].A),
+                                             fb.ld, _ptr(factors[b].winv), _ptr(fb._refine_work), _ptr(fb.out[b]))
+                _native.check(st, "gpn_lml_refine_expr")
+        out = fb.out[:, 2].clone()
+        info = fb.info.cpu()                         # one read-back for the batch
+        replayed = {}
+        for b in (torch.nonzero(info).reshape(-1).tolist() if bool(info.any()) else ()):
+            if int(info[b]) < 0:
+                raise _ops.NativeError("factorisation reported the internal status %d (not a property of the matrix)" % int(info[b]))
+            f = _ops.Factor(n, e, X.device)
+            out[b] = _factor_single(progs[b], thetas[b], Xb(b), Rb(b), nz[b:b + 1], f)[2]
+            replayed[b] = f
+        ctx.progs, ctx.fb, ctx.generation, ctx.replayed, ctx.npar = progs, fb, fb.generation, replayed, npar
+        ctx.save_for_backward(X, R, noise, *thetas, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _backward
+        X, R, noise, *rest = ctx.saved_tensors
+        progs, npar = ctx.progs, ctx.npar
+        batch = len(progs)
+        thetas, params = rest[:batch], rest[batch:]
+        n, dy = R.shape[-2], R.shape[-1]
+        Xb = lambda b: X if X.dim() == 2 else X[b]
+        Rb = lambda b: R if R.dim() == 2 else R[b]
+        lib = _native.lib()
+        fb = ctx.fb
+        if fb.generation != ctx.generation:
+            # the shared buffers were refactorised by a later forward: rebuild this node's factors privately (one by one)
+            fb = None
+        lay = (ctypes.c_int64 * 4)()
+        _native.check(lib.gpn_lml_kinv_layout(n, dy, lay), "gpn_lml_kinv_layout")
+        ld, koff, aoff, stride = (int(v) for v in lay)
+        kinvs, ats = {}, {}
+        if fb is not None:
+            need = max(1, int(lib.gpn_lml_kinv_batched_work_bytes(n, dy, batch)) // 8)
+            if fb._backward_work is None or fb._backward_work.numel() < need:
+                fb._backward_work = torch.empty(need, dtype=torch.float64, device=X.device)
+            st = lib.gpn_lml_kinv_batched(_stream(X.device), batch, n, _ptr(fb.A), fb.ld, fb.sA, _ptr(fb.winv), fb.sW, dy, _ptr(fb._backward_work))
+            _native.check(st, "gpn_lml_kinv_batched")
+            rows = _ops.round_up(max(n, 1), 64)
+            for b in range(batch):
+                blk = fb._backward_work[b * stride:(b + 1) * stride]
+                kinvs[b] = blk[koff:koff + rows * ld].view(rows, ld)
+                ats[b] = blk[aoff:aoff + dy * ld].view(dy, ld)
+        nz = noise.detach().reshape(batch)
+        for b in range(batch):
+            if fb is None or b in ctx.replayed:
+                f = ctx.replayed.get(b)
+                if f is None:
+                    f = _ops.Factor(n, dy, X.device)
+                    _factor_single(progs[b], thetas[b], Xb(b), Rb(b), _c(nz[b:b + 1]), f)
+                U = _backward._upper_inverse(f)
+                kinvs[b] = _backward._kinv_lower(f, U)
+                ats[b] = _ops.gemm_nt(f.A[n:], U, dy, n, _ops.round_up(n, 16), tri=_ops.TRI_B_UPPER)
+        go = grad_out.reshape(batch)
+        g_params, g_noise, g_R = [], [], []
+        for b in range(batch):
+            pb = params[b * npar:(b + 1) * npar]
+            outs, trace = _sweeps(progs[b], thetas[b], Xb(b), None, kinvs[b], kinvs[b].stride(0), at=ats[b], ldat=ats[b].stride(0), dy=dy)
+            g_params += [go[b] * g for g in progs[b].scatter(outs, pb)]
+            g_noise.append(go[b] * trace)
+            if ctx.needs_input_grad[1]:
+                g_R.append(-go[b] * ats[b][:, :n].t())
+        g_resid = None
+        if ctx.needs_input_grad[1]:
+            g_resid = torch.stack(g_R) if R.dim() == 3 else torch.stack(g_R).sum(0)
+        return (None, g_resid, torch.cat(g_noise).reshape(noise.shape) if ctx.needs_input_grad[2] else None, None, None) + tuple(g_params)

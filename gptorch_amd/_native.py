@@ -65,6 +65,9 @@ SIGNATURES = {
     "gpn_lml_backward_batched_work_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
     "gpn_lml_backward_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int,
                                          c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "gpn_lml_kinv_layout": (c_int, [c_int64, c_int, ctypes.POINTER(c_int64)]),
+    "gpn_lml_kinv_batched_work_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "gpn_lml_kinv_batched": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "gpn_lml_grad_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int,
                                      c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "gpn_predict_work_bytes": (c_int64, [c_int64, c_int64, c_int]),

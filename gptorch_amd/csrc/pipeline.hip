@@ -267,6 +267,83 @@ extern "C" int gpn_lml_backward(void* stream, int kind, const double* X, int64_t
   return GPN_OK;
 }
 
+// The KERNEL-INDEPENDENT half of the lock-step backward: for each of `batch` factors (model z at A + z sA, winv + z sW) U = L^-T,
+// Kyy^-1 = U U^T (lower) at work + z stride + b.s and a^T = alpha^T U^T at work + z stride + b.at -- every launch once over all
+// models; per model the launches of gpn_lml_backward, bit for bit.  (batch == 1 or n <= 256: model by model, the single-model form.)
+static int kinv_batched_impl(hipStream_t s, int batch, int64_t n, const double* A, int64_t lda, int64_t sA, const double* winv, int64_t sW,
+                             int dy, double* work, int64_t stride, const BackwardLayout& b) {
+  const int64_t kp = round_up(n, 16);
+  if (batch == 1 || n <= 256) {
+    for (int z = 0; z < batch; ++z) {
+      double* U = work + z * stride + b.u;
+      double* S = work + z * stride + b.s;
+      double* at = work + z * stride + b.at;
+      const double* Az = A + z * sA;
+      const double* wz = winv + z * sW;
+      if (!(n > 256 && n % 128 == 0)) GPN_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)(b.at - b.u) * sizeof(double), s));
+      int rc = (n > 256) ? gpn_trtri_upper_ws(s, Az, n, lda, wz, U, b.ld, S, b.ld) : gpn_trtri_upper(s, Az, n, lda, wz, U, b.ld);
+      if (rc != GPN_OK) return rc;
+      rc = gpn_gemm_nt(s, n, n, kp, 1.0, U, b.ld, U, b.ld, 0.0, S, b.ld, 1, GPN_TRI_A_UPPER | GPN_TRI_B_UPPER);
+      if (rc != GPN_OK) return rc;
+      rc = gpn_gemm_nt(s, dy, n, kp, 1.0, Az + n * lda, lda, U, b.ld, 0.0, at, b.ld, 0, GPN_TRI_B_UPPER);
+      if (rc != GPN_OK) return rc;
+    }
+    return GPN_OK;
+  }
+  double* U = work + b.u;
+  double* S = work + b.s;
+  double* at = work + b.at;
+  // U and S of every model start as zero where anything unwritten is read (see gpn_lml_backward: only with a ragged block)
+  if (n % 128 != 0)
+    for (int z = 0; z < batch; ++z)
+      GPN_HIP_CHECK(hipMemsetAsync(U + z * stride, 0, (size_t)(b.at - b.u) * sizeof(double), s));
+  int rc = trtri_upper_ws_batched(s, A, n, lda, sA, winv, sW, U, b.ld, stride, S, b.ld, stride, batch);
+  if (rc != GPN_OK) return rc;
+  // the scratch is free again: Kyy^-1 = U U^T (lower)
+  rc = gemm_nt_strided(s, n, n, kp, 1.0, U, b.ld, U, b.ld, 0.0, S, b.ld, 1, GPN_TRI_A_UPPER | GPN_TRI_B_UPPER, 0, batch, stride, stride, stride);
+  if (rc != GPN_OK) return rc;
+  // a^T = alpha^T U^T (alpha^T = the extra rows of the factor buffers)
+  return gemm_nt_strided(s, dy, n, kp, 1.0, A + n * lda, lda, U, b.ld, 0.0, at, b.ld, 0, GPN_TRI_B_UPPER, 0, batch, sA, stride, stride);
+}
+
+// gpn_lml_kinv_batched: that half as an entry point of its own -- for callers whose dKyy/dtheta is not one of the native
+// stationary kinds (gptorch_amd/_expr.py: composite kernels sweep their own expression against Kyy^-1 and a, model by model).
+// Layout (gpn_lml_kinv_layout): out4 = {ld, offset of Kyy^-1 (lower, [n, ld]), offset of a^T ([dy, ld]), doubles from one model to the next}.
+extern "C" int gpn_lml_kinv_layout(int64_t n, int dy, int64_t* out4) {
+  if (n < 0) return -1;
+  if (dy <= 0) return -2;
+  if (!out4) return -3;
+  const BackwardLayout b = backward_layout(n, dy, 1);
+  out4[0] = b.ld; out4[1] = b.s; out4[2] = b.at; out4[3] = round_up(b.sweep, 2);
+  return GPN_OK;
+}
+extern "C" int64_t gpn_lml_kinv_batched_work_bytes(int64_t n, int dy, int batch) {
+  if (n < 0 || dy <= 0 || batch < 1) return 0;
+  return (int64_t)batch * round_up(backward_layout(n, dy, 1).sweep, 2) * (int64_t)sizeof(double);
+}
+extern "C" int gpn_lml_kinv_batched(void* stream, int batch, int64_t n, const double* A, int64_t lda, int64_t sA, const double* winv, int64_t sW,
+                                    int dy, double* work) {
+  if (batch < 1) return -2;
+  if (n < 0) return -3;
+  if (!A) return -4;
+  if (dy <= 0) return -9;
+  if (lda != gpn_factor_ld(n, dy)) return -5;
+  if (batch > 1 && (sA < gpn_factor_rows(n, dy) * lda || (sA & 1))) return -6;
+  if (!winv) return -7;
+  if (batch > 1 && sW < gpn_winv_bytes(n) / (int64_t)sizeof(double)) return -8;
+  if (!work) return -10;
+  if (n == 0) return GPN_OK;
+  const BackwardLayout b = backward_layout(n, dy, 1);
+  const int64_t stride = round_up(b.sweep, 2);
+  const int64_t max_models = std::max<int64_t>(1, 65535 / std::max<int64_t>(1, n / 256 + 1));
+  for (int z0 = 0; z0 < batch; z0 += (int)max_models) {
+    const int nb = (int)std::min<int64_t>(max_models, batch - z0);
+    const int rc = kinv_batched_impl(static_cast<hipStream_t>(stream), nb, n, A + z0 * sA, lda, sA, winv + z0 * sW, sW, dy, work + z0 * stride, stride, b);
+    if (rc != GPN_OK) return rc;
+  }
+  return GPN_OK;
+}
+
 // The backward of `batch` lock-step models (gpn_lml_forward_batched's factors, FactorBatch layout: model b at A + b sA,
 // winv + b sW) in lock step: the reference runs loss(); backward(); step() one model at a time (gptorch/models/base.py:260-269).
 // Every launch of gpn_lml_backward's schedule -- leaf transposes, the level-parallel triangular inversion, Kyy^-1 = U U^T,
@@ -326,21 +403,9 @@ extern "C" int gpn_lml_backward_batched(void* stream, int kind, int batch, const
     return GPN_OK;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  double* U = work + b.u;
-  double* S = work + b.s;
+  double* Kinv = work + b.s;
   double* at = work + b.at;
-  // U and S of every model start as zero
-  if (n % 128 != 0)          // (see gpn_lml_backward: nothing unwritten is read when there is no ragged block)
-    for (int z = 0; z < batch; ++z)
-      GPN_HIP_CHECK(hipMemsetAsync(U + z * sWk, 0, (size_t)(b.at - b.u) * sizeof(double), s));
-  int rc = trtri_upper_ws_batched(s, A, n, lda, sA, winv, sW, U, b.ld, sWk, S, b.ld, sWk, batch);
-  if (rc != GPN_OK) return rc;
-  const int64_t kp = round_up(n, 16);
-  double* Kinv = S;                                 // the scratch is free again: Kyy^-1 = U U^T (lower)
-  rc = gemm_nt_strided(s, n, n, kp, 1.0, U, b.ld, U, b.ld, 0.0, Kinv, b.ld, 1, GPN_TRI_A_UPPER | GPN_TRI_B_UPPER, 0, batch, sWk, sWk, sWk);
-  if (rc != GPN_OK) return rc;
-  // a^T = alpha^T U^T (alpha^T = the extra rows of the factor buffers)
-  rc = gemm_nt_strided(s, dy, n, kp, 1.0, A + n * lda, lda, U, b.ld, 0.0, at, b.ld, 0, GPN_TRI_B_UPPER, 0, batch, sA, sWk, sWk);
+  int rc = kinv_batched_impl(s, batch, n, A, lda, sA, winv, sW, dy, work, sWk, b);
   if (rc != GPN_OK) return rc;
   rc = lml_grad_batched(s, kind, batch, X, sX, n, d, variance, length_scales, nls, Kinv, b.ld, sWk, at, b.ld, sWk, dy,
                         work + b.sweep, sWk, grads);

@@ -11,7 +11,7 @@ import collections
 
 import torch
 
-from .. import _ops, mean_functions
+from .. import _expr, _ops, mean_functions
 from .. import kernels
 from .base import GPModel
 
@@ -191,6 +191,25 @@ def _lockstep_groups(models, for_grad=False):
     return [(key, g) for key, g in groups.items() if len(g) >= 2]
 
 
+def _expression_groups(models):
+    """[(key, indices, programs)] of the GPR models over COMPOSITE kernels of one structure (equal _expr.Program.signature(),
+    n, d, dy, device) that can share the kernel-independent launches of an evaluation (_expr.BatchedExprLogLik)."""
+    groups = {}
+    for i, m in enumerate(models):
+        if not isinstance(m, GPR) or type(m).log_likelihood is not GPR.log_likelihood or m._stationary() is not None:
+            continue
+        if not m.X.is_cuda or m.X.shape[0] == 0:
+            continue
+        prog = m._expression(m.X)
+        if prog is None:
+            continue
+        key = ("expr", prog.signature(), tuple(m.X.shape), m.Y.shape[1], m.X.device)
+        groups.setdefault(key, ([], []))
+        groups[key][0].append(i)
+        groups[key][1].append(prog)
+    return [(key, g, progs) for key, (g, progs) in groups.items() if len(g) >= 2]
+
+
 def _group_data(ms, differentiable=False):
     """(X, R) of a lock-step group: shared [n, d] / [n, dy] when every model holds the same tensors (restarts on one data
     set), else stacked [B, ...].  differentiable: R keeps the autograd graph of trainable mean functions."""
@@ -248,6 +267,14 @@ def batched_log_likelihood(models, streams=None):
                 if int(info[b]) == 0:
                     out[i] = terms[b, 2:3].clone()
                     # (the per-model factor cache is NOT pointed at the shared buffer: the next batched call overwrites it)
+        for key, g, progs in _expression_groups(models):
+            ms = [models[i] for i in g]
+            X, R = _group_data(ms)
+            nz = _stacked_values([m.likelihood.variance for m in ms]).reshape(len(ms))
+            flat = [p for prog in progs for p in prog.params()]
+            lml = _expr.BatchedExprLogLik.apply(X, R, nz, progs, _batch_holder((key, len(ms))), *flat)
+            for b, i in enumerate(g):
+                out[i] = lml[b:b + 1].clone()
         for i, m in enumerate(models):
             if out[i] is None:
                 out[i] = m.log_likelihood()
@@ -296,6 +323,26 @@ def batched_loss_and_grad(models):
             loss = torch.cat([-(lml[b:b + 1] + m.log_prior()) for b, m in enumerate(ms)])
         else:
             loss = -(lml + 0.0)                                      # model.py:_loss with an empty log prior
+        if loss.requires_grad:
+            loss.sum().backward()
+        ld = loss.detach()
+        for b, i in enumerate(g):
+            out[i] = ld[b:b + 1]
+    for key, g, progs in _expression_groups(models):
+        # composite kernels of one structure (the reference's example model Linear + Rbf + Constant in a multi-start search):
+        # the expression's assembly and sweeps per model, everything kernel-independent once over the group
+        ms = [models[i] for i in g]
+        B = len(ms)
+        X, R = _group_data(ms, differentiable=True)
+        plist = [m.likelihood.variance for m in ms]
+        t0 = _shared_transform(plist)
+        nz = (t0(torch.stack(list(plist))) if t0 is not None else torch.stack([p.transform() for p in plist])).reshape(B)
+        flat = [p for prog in progs for p in prog.params()]
+        lml = _expr.BatchedExprLogLik.apply(X, R, nz, progs, _batch_holder((key, B)), *flat)
+        if any(getattr(p, "prior", None) is not None for m in ms for p in m.parameters()):
+            loss = torch.cat([-(lml[b:b + 1] + m.log_prior()) for b, m in enumerate(ms)])
+        else:
+            loss = -(lml + 0.0)
         if loss.requires_grad:
             loss.sum().backward()
         ld = loss.detach()

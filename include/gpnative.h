@@ -390,6 +390,19 @@ int gpn_lml_backward_batched(void* stream, int kind, int batch, const double* X,
                              const double* A, int64_t lda, int64_t sA, const double* winv, int64_t sW, int dy,
                              double* work, double* grads, double* grad_resid);
 
+/* The kernel-INDEPENDENT half of gpn_lml_backward_batched as an entry point of its own: for each of the `batch` factors of a
+ * lock-step factorisation (gpn_potrf_lower_batched layout: model b at A + b*sA, winv + b*sW, alpha^T in the extra rows)
+ * Kyy^-1 = U U^T (lower triangle) and a^T = alpha^T U^T, every launch once over all models, per model bit-identical to the
+ * sequence gpn_trtri_upper_ws + gpn_gemm_nt(lower, A_UPPER|B_UPPER) + gpn_gemm_nt(B_UPPER) on that factor alone.  For
+ * callers whose dKyy/dtheta is not a native stationary kind: composite kernels (kernels.py:286-306) sweep their own
+ * expression against these with gpn_kernel_expr_grad, model by model (gptorch_amd/_expr.py BatchedExprLogLik).
+ * gpn_lml_kinv_layout: out4 = {leading dimension, offset of Kyy^-1 [n, ld], offset of a^T [dy, ld], doubles from one model's
+ * block of `work` to the next}; work: gpn_lml_kinv_batched_work_bytes bytes. */
+int gpn_lml_kinv_layout(int64_t n, int dy, int64_t* out4);
+int64_t gpn_lml_kinv_batched_work_bytes(int64_t n, int dy, int batch);
+int gpn_lml_kinv_batched(void* stream, int batch, int64_t n, const double* A, int64_t lda, int64_t sA,
+                         const double* winv, int64_t sW, int dy, double* work);
+
 /* gpn_predict = GPR._predict (gpr.py:88-117), given the factor of gpn_lml_forward (whose extra rows hold
  * V = L^-1 (Y - m(X)), i.e. the training-side mean function went in through gpn_lml_forward's M):
  * mean [ns, dy] = Ms + A^T V with A = L^-1 K(X, x*) and Ms [ns, dy] = the mean function at the test points

@@ -446,3 +446,92 @@ def test_lockstep_above_the_refinement_threshold(device):
                                          torch.stack([m.kernel.length_scales.transform().reshape(-1) for m in ms]),
                                          torch.stack([m.likelihood.variance.transform().reshape(()) for m in ms]), refine=False)
     assert not torch.equal(terms[0, 2:3], seq_v[0])            # unrefined differs: the refinement really ran in the batch
+
+
+def _composites(device, n, d, dy, builders, seed=4):
+    x, y = rng.make_regression(n, d, dy, seed=seed)
+    X, Y = torch.as_tensor(x).to(device), torch.as_tensor(y).to(device)
+    ms = []
+    for mk, nzv in builders:
+        m = GPR(X, Y, mk(), likelihood=likelihoods.Gaussian(variance=nzv))
+        m.cuda()
+        m.X, m.Y = X, Y
+        ms.append(m)
+    return ms
+
+
+@pytest.mark.parametrize("n,d,dy", [(100, 1, 1), (700, 3, 2), (2176, 2, 1), (6144, 4, 1)])
+def test_lockstep_composite_kernels_are_bit_identical_to_sequential(device, n, d, dy):
+    """composite kernels of one structure in lock step (_expr.BatchedExprLogLik; kernels.py:286-306 Sum / Product): the
+    reference's example model Linear + Rbf + Constant (examples/regression_1d.py:34-53) as three restarts, a second group of two
+    Matern52 * Rbf(ARD) products, and a singleton -- the expression's assembly and sweeps per model, the factorisation, the
+    reductions and Kyy^-1 / a once over each group.  Losses and gradients bit-identical to loss(); backward(); n = 6144 is
+    the size from which composite kernels refine the quadratic form."""
+    lin = lambda v, ell, c: (lambda: kernels.Linear(d, variance=v) + kernels.Rbf(d, length_scales=ell) + kernels.Constant(d, variance=c))
+    prod = lambda v, ell: (lambda: kernels.Matern52(d, variance=v, length_scales=ell) * kernels.Rbf(d, length_scales=np.full(d, 1.5 * ell), ARD=True))
+    builders = [(lin(0.5, 1.0, 0.3), 0.05), (prod(0.8, 1.2), 0.04), (lin(0.9, 0.6, 0.5), 0.03), (lin(0.2, 2.0, 1.0), 0.08), (prod(1.3, 0.7), 0.06),
+                (lambda: kernels.Rbf(d) + kernels.White(d, variance=0.01), 0.05)]
+    a = _composites(device, n, d, dy, builders)
+    b = _composites(device, n, d, dy, builders)
+    from gptorch_amd.models import gpr as G
+    groups = G._expression_groups(a)
+    assert sorted(len(g) for _, g, _ in groups) == [2, 3]
+    out = batched_loss_and_grad(a)
+    for i, m in enumerate(b):
+        loss = m.loss()
+        loss.backward()
+        assert torch.equal(out[i], loss.detach()), (i, out[i], loss)
+        for (name, pa), pb in zip(a[i].named_parameters(), m.parameters()):
+            assert (pa.grad is None) == (pb.grad is None), name
+            if pa.grad is not None:
+                assert torch.equal(pa.grad, pb.grad), (i, name, pa.grad, pb.grad)
+    vals = batched_log_likelihood(a)
+    for i, m in enumerate(b):
+        with torch.no_grad():
+            assert torch.equal(vals[i], m.log_likelihood()), i
+    if n >= 6144:
+        assert b[0]._holder["factor"].refined
+
+
+def test_lockstep_composite_replays_the_ladder_and_fits_with_scipy(device):
+    """(1) one composite model of the group is singular at its noise level (duplicated points, noise ~ 0): it is replayed alone
+    through the jitter ladder, values and gradients equal its sequential ones; (2) the reference's example model as three
+    restarts of an L-BFGS-B multi-start (base.py:298-320): results bit-identical to each restart's own optimize()."""
+    n, d = 300, 2
+    x, y = rng.make_regression(n, d, 1, seed=9)
+    xdup = np.array(x)
+    xdup[150:] = xdup[:150]
+    def build():
+        ms = []
+        for b in range(3):
+            m = GPR(xdup if b == 1 else x, y, kernels.Linear(d, variance=0.3 + 0.1 * b) + kernels.Rbf(d, length_scales=1.0 + 0.2 * b) + kernels.Constant(d),
+                    likelihood=likelihoods.Gaussian(variance=0.03))
+            m.cuda()
+            if b == 1:
+                m.likelihood.variance.data.fill_(-80.0)
+            ms.append(m)
+        return ms
+    a, b = build(), build()
+    out = batched_loss_and_grad(a)
+    for i, m in enumerate(b):
+        loss = m.loss()
+        loss.backward()
+        assert torch.equal(out[i], loss.detach()), i
+        for pa, pb in zip(a[i].parameters(), m.parameters()):
+            assert (pa.grad is None) == (pb.grad is None) and (pa.grad is None or torch.equal(pa.grad, pb.grad)), i
+    assert b[1]._holder["factor"].jitter_rung >= 0
+    g = load_json("lbfgs_case.json")
+    xs, ys = np.asarray(g["x"]).reshape(-1, 1), np.asarray(g["y"]).reshape(-1, 1)
+    def restarts():
+        ms = []
+        for scale in (1.0, 0.6, 1.7):
+            m = GPR(xs, ys, kernels.Linear(1) + kernels.Rbf(1, length_scales=scale) + kernels.Constant(1))
+            m.cuda()
+            ms.append(m)
+        return ms
+    a, b = restarts(), restarts()
+    with _quiet():
+        res, _ = multi_start_optimize(a, method="L-BFGS-B", max_iter=25)
+        for i, m in enumerate(b):
+            ref = m.optimize(method="L-BFGS-B", max_iter=25)
+            assert np.array_equal(res[i].x, ref.x) and res[i].nfev == ref.nfev and res[i].fun == ref.fun, i

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """GPU-box tool: one optimiser step (loss + backward + Adam) of B restarts in lock step (multi_start_optimize /
 batched_loss_and_grad -> gpn_lml_forward_batched + gpn_lml_backward_batched) against the same restarts stepped one after the
-other by their own optimize().  Usage: fit_batched_bench.py [c2|c1|n=<N>,d=<D>] [B ...] [--steps K] [--parts]"""
+other by their own optimize().  Usage: fit_batched_bench.py [c2|c1|n=<N>,d=<D>] [B ...] [--steps K] [--parts] [--composite]
+--composite: the reference's example kernel Linear + Rbf + Constant (examples/regression_1d.py:34-53) instead of Rbf: the lock-step
+path of composite kernels (_expr.BatchedExprLogLik), timed through batched_loss_and_grad + one Adam step per model."""
 import contextlib, io, os, sys, time
 import numpy as np
 import torch
@@ -22,11 +24,16 @@ PEAK = 78.6e12
 x, y = rng.make_regression(n, d, 1, seed=0)
 
 
+COMPOSITE = "--composite" in sys.argv
+
+
 def models(B):
     ms = []
     for b in range(B):
-        m = GPR(x, y, kernels.Rbf(d, variance=1.0 + 0.01 * b, length_scales=float(np.sqrt(d)) * (1.0 + 0.02 * b)),
-                likelihood=likelihoods.Gaussian(variance=1e-2))
+        k = kernels.Rbf(d, variance=1.0 + 0.01 * b, length_scales=float(np.sqrt(d)) * (1.0 + 0.02 * b))
+        if COMPOSITE:
+            k = kernels.Linear(d, variance=0.1 + 0.01 * b) + k + kernels.Constant(d)
+        m = GPR(x, y, k, likelihood=likelihoods.Gaussian(variance=1e-2))
         m.cuda()
         ms.append(m)
     for m in ms[1:]:
@@ -46,8 +53,38 @@ def wall(fn):
     return time.perf_counter() - t0
 
 
+def composite_step_times(ms, steps):
+    """composite kernels have no stacked-parameter loop: one lock-step loss + backward, then every model's own Adam step"""
+    from gptorch_amd.models import batched_loss_and_grad
+    opts = [torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=0.01) for m in ms]
+    def lock():
+        for o in opts:
+            o.zero_grad()
+        batched_loss_and_grad(ms)
+        for o in opts:
+            o.step()
+    def seq():
+        for m, o in zip(ms, opts):
+            o.zero_grad()
+            m.loss().backward()
+            o.step()
+    for fn in (lock, seq):
+        fn(); fn()
+    t_lock = wall(lambda: [lock() for _ in range(steps)]) / steps
+    t_seq = wall(lambda: [seq() for _ in range(steps)]) / steps
+    return t_seq, t_lock
+
+
 for B in Bs:
     ms = models(B)
+    if COMPOSITE:
+        t_seq, t_bat = composite_step_times(ms, steps)
+        flops = B * float(n) ** 3
+        print("N %d D %d B %3d Linear + Rbf + Constant: sequential %8.2f ms / step (%.1f %% of peak on N^3) | lock step %8.2f ms / step (%.1f %%)  -> %.2fx"
+              % (n, d, B, t_seq * 1e3, 100 * flops / t_seq / PEAK, t_bat * 1e3, 100 * flops / t_bat / PEAK, t_seq / t_bat), flush=True)
+        del ms
+        torch.cuda.empty_cache()
+        continue
     with quiet():
         multi_start_optimize(ms, max_iter=2)                                         # warm-up (allocations, first launches)
         for m in ms:
