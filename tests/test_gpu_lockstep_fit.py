@@ -227,6 +227,24 @@ def test_multi_start_optimize_follows_each_models_own_trajectory(device, method)
             assert torch.allclose(pa.data, pb.data, rtol=1e-10, atol=1e-12), (i, pa, pb)
 
 
+def test_multi_start_with_per_model_optimisers_is_bitwise(device):
+    """multi_start_optimize(stacked=False): every restart keeps its own optimiser over its own parameter tensors (the layouts of
+    its own optimize()), only the evaluation is shared -- the 12-step Adam trajectories that differ by one ulp through the
+    stacked path are bit-identical here."""
+    specs = [("Matern52", True, 1.0, 1.5, 0.02), ("Matern52", True, 0.6, 2.5, 0.05), ("Matern52", True, 1.5, 1.0, 0.01),
+             ("Matern52", True, 1.2, 3.0, 0.03)]
+    a = _restarts(device, 640, 4, specs)
+    b = _restarts(device, 640, 4, specs)
+    with _quiet():
+        losses, _ = multi_start_optimize(a, method="Adam", max_iter=12, stacked=False)
+    for i, m in enumerate(b):
+        with _quiet():
+            ref, _ = m.optimize(method="Adam", max_iter=12, verbose=False)
+        assert np.array_equal(losses[i], ref), (i, losses[i] - ref)
+        for pa, pb in zip(a[i].parameters(), m.parameters()):
+            assert torch.equal(pa.data, pb.data), i
+
+
 def test_adam_trajectory_golden_through_multi_start(device):
     """the reference's 50-step Adam trajectories (tests/golden/adam_cases.json; base.py:149-151, 260-269), each run as one
     of three restarts stepped in lock step: the golden restart's losses and final parameters at the sequential tolerances."""
@@ -535,3 +553,28 @@ def test_lockstep_composite_replays_the_ladder_and_fits_with_scipy(device):
         for i, m in enumerate(b):
             ref = m.optimize(method="L-BFGS-B", max_iter=25)
             assert np.array_equal(res[i].x, ref.x) and res[i].nfev == ref.nfev and res[i].fun == ref.fun, i
+
+
+def test_multi_start_shares_the_evaluation_of_models_that_cannot_be_stacked(device):
+    """composite kernels of one structure and stationary models with priors cannot share a stacked parameter tensor;
+    multi_start_optimize still evaluates them together every iteration (one batched_loss_and_grad) while each keeps its own
+    optimiser over its own parameters -- the very tensors of its own optimize(), so losses and final parameters are
+    BIT-IDENTICAL to it (base.py:260-269)."""
+    d = 2
+    def build():
+        lin = lambda v, ell: (lambda: kernels.Linear(d, variance=v) + kernels.Rbf(d, length_scales=ell) + kernels.Constant(d))
+        ms = _composites(device, 500, d, 1, [(lin(0.5, 1.0), 0.05), (lin(0.9, 0.6), 0.03), (lin(0.2, 2.0), 0.08)])
+        ps = _restarts(device, 500, d, [("Rbf", False, 1.0, 1.2, 0.05), ("Rbf", False, 0.7, 0.8, 0.03)], seed=4)
+        for m in ps:
+            m.kernel.variance.prior = torch.distributions.Gamma(torch.tensor(2.0, dtype=torch.float64, device=device),
+                                                                 torch.tensor(1.0, dtype=torch.float64, device=device))
+        return ms + ps
+    a, b = build(), build()
+    with _quiet():
+        losses, _ = multi_start_optimize(a, method="Adam", max_iter=8)
+    for i, m in enumerate(b):
+        with _quiet():
+            ref, _ = m.optimize(method="Adam", max_iter=8, verbose=False)
+        assert np.array_equal(losses[i], ref), (i, losses[i] - ref)
+        for pa, pb in zip(a[i].parameters(), m.parameters()):
+            assert torch.equal(pa.data, pb.data), i
