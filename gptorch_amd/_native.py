@@ -32,6 +32,9 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "gpn_potrf_panel_width": (c_int64, [c_int64]),
     "gpn_potrf_panel_levels": (c_int, [c_int64, c_void_p]),
+    "gpn_potrf_lower_persistent": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "gpn_potrf_persistent_supported": (c_int, [c_int64, c_int64]),
+    "gpn_potrf_persistent_plan": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
     "gpn_release_stream": (c_int, [c_void_p]),
     "gpn_trtri_diag": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gpn_trsm_right_lt": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
@@ -180,6 +183,9 @@ DEBUG_SIGNATURES = {
     "gpn_debug_set_inner_left": (c_int, [c_int]),
     "gpn_debug_set_split_assembly": (c_int, [c_int]),
     "gpn_debug_set_tri_big": (c_int, [c_int, c_int]),
+    "gpn_debug_set_outer_lookahead": (c_int, [c_int, c_int, c_int, c_int]),
+    "gpn_debug_set_persistent": (c_int, [c_int, c_int]),
+    "gpn_debug_persistent_trace": (c_int, [c_void_p]),
 }
 DEBUG_LIB_PATH = os.path.join(_HERE, "lib", "libgpnative_dbg.so")
 

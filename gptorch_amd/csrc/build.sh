@@ -11,10 +11,19 @@ mkdir -p "$OUT" "$OBJ"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 ARCH="${GPN_OFFLOAD_ARCH:-gfx950}"     # the one place the target is named: --offload-arch AND what gpn_arch() reports
 FLAGS="--offload-arch=$ARCH -DGPN_ARCH=$ARCH -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
+# an object is stale when its source, ANY header of this directory, the public header or this script is newer
+stale() {
+  local f="$1" o="$2" h
+  [ -n "${GPN_FORCE_REBUILD:-}" ] && return 0
+  [ ! -f "$o" ] && return 0
+  [ "$f" -nt "$o" ] && return 0
+  for h in "$HERE"/*.h "$HERE/../../include/gpnative.h" "$HERE/build.sh"; do [ "$h" -nt "$o" ] && return 0; done
+  return 1
+}
 pids=()
 for f in "$HERE"/*.hip; do
   o="$OBJ/$(basename "${f%.hip}").o"
-  if [ -n "${GPN_FORCE_REBUILD:-}" ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/refine_tail.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ] || [ "$HERE/build.sh" -nt "$o" ]; then
+  if stale "$f" "$o"; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi
@@ -24,9 +33,9 @@ done
 # none of it
 DBG="$OBJ/dbg"
 mkdir -p "$DBG"
-for f in "$HERE"/gemm_f64.hip "$HERE"/potrf.hip "$HERE"/profile.hip "$HERE"/leaf16.hip "$HERE"/colpanel.hip "$HERE"/refine.hip; do
+for f in "$HERE"/gemm_f64.hip "$HERE"/potrf.hip "$HERE"/profile.hip "$HERE"/leaf16.hip "$HERE"/colpanel.hip "$HERE"/refine.hip "$HERE"/ppotrf.hip; do
   o="$DBG/$(basename "${f%.hip}").o"
-  if [ -n "${GPN_FORCE_REBUILD:-}" ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/gpn_common.h" -nt "$o" ] || [ "$HERE/kernel_fn.h" -nt "$o" ] || [ "$HERE/refine_tail.h" -nt "$o" ] || [ "$HERE/../../include/gpnative.h" -nt "$o" ] || [ "$HERE/build.sh" -nt "$o" ]; then
+  if stale "$f" "$o"; then
     $HIPCC $FLAGS -DGPN_DEBUG_SWITCHES -c "$f" -o "$o" &
     pids+=($!)
   fi
@@ -36,7 +45,7 @@ $HIPCC --offload-arch=$ARCH -shared -fPIC -o "$OUT/libgpnative.so" "$OBJ"/*.o
 echo "built $OUT/libgpnative.so"
 shared=()
 for o in "$OBJ"/*.o; do
-  case "$(basename "$o")" in gemm_f64.o|potrf.o|profile.o|leaf16.o|colpanel.o|refine.o) ;; *) shared+=("$o") ;; esac
+  case "$(basename "$o")" in gemm_f64.o|potrf.o|profile.o|leaf16.o|colpanel.o|refine.o|ppotrf.o) ;; *) shared+=("$o") ;; esac
 done
 $HIPCC --offload-arch=$ARCH -shared -fPIC -o "$OUT/libgpnative_dbg.so" "${shared[@]}" "$DBG"/*.o
 echo "built $OUT/libgpnative_dbg.so"

@@ -29,6 +29,15 @@ int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
             double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0, int lds_pad_kb = 0);
 
+// lower-tile C[M, M] = alpha A B^T + beta C (K a multiple of 16) as ONE persistent launch of at most `nwg` 128 x 128-tile
+// workgroups with `lds_pad_kb` KiB of LDS padding each (gemm_f64.hip gemm_nt_persistent_kernel); bit-identical to gemm_nt(lower = 1)
+int gemm_nt_lower_persistent(hipStream_t s, int64_t M, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
+                             int64_t ldb, double beta, double* C, int64_t ldc, int nwg, int lds_pad_kb);
+
+// gpn_potrf_lower as one persistent launch (ppotrf.hip); GPN_E_UNSUPPORTED = not this size / not under this capture
+int potrf_persistent(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda, double* winv, int32_t* info);
+void potrf_persistent_release(hipStream_t s);
+
 // staircase: C is M x (nblocks * blk); column block b has the rows from b * step on; diag: its first blk x blk square
 // is lower-only (gpnative.h gpn_gemm_nt_stair)
 int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,

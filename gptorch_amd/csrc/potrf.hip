@@ -20,6 +20,7 @@
 // trailing update of the right spine of the recursion; on exit they hold
 // (L^-1 R)^T -- alpha^T of gpr.py:62 -- for free.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -661,12 +662,13 @@ static Aux* aux_for(hipStream_t s) {
   int least = 0, greatest = 0;     // aux work is off the critical path: lowest priority
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
   if (hipStreamCreateWithPriority(&a.s1, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-#ifdef GPN_DEBUG_SWITCHES
+  // (the second helper stream: the persistent bulk of an outer panel's trailing update, underneath the next panel's chain)
   if (hipStreamCreateWithPriority(&a.s2, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.trap_go, hipEventDisableTiming) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.trap_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.chain_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.bulk_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+#ifdef GPN_DEBUG_SWITCHES
+  if (hipEventCreateWithFlags(&a.trap_go, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a.trap_done, hipEventDisableTiming) != hipSuccess) return nullptr;
 #endif
   if (hipStreamCreateWithPriority(&a.s_asm, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.asm_go, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -771,6 +773,34 @@ GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row 
 GPN_SWITCH g_panel_lookahead = 0;
 GPN_SWITCH g_bulk_pad = 32;
 GPN_SWITCH g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
+// ---- look-ahead over OUTER panels with a PERSISTENT bulk (round 6) ----------------------------------------------------------
+// After outer panel o only the columns the NEXT outer panel lives in (the "strip", a trapezoid launch) are updated on the
+// caller's stream; the rest of the lower-tile K = outer-width update goes to the second helper stream as ONE persistent
+// launch (gemm_f64.hip gemm_nt_persistent_kernel): one 128 x 128-tile workgroup per compute unit on all compute units BUT
+// ONE, underneath the next panel's chain.  Every earlier look-ahead (LAB.md 8-1c, 10-10) failed on DISPATCH -- the leaf
+// needs an empty compute unit and found none while tiles of an ordinary launch kept arriving (priorities order dispatch,
+// nothing is pre-empted) -- and an ordinary launch capped to one workgroup per compute unit still refilled every compute
+// unit it emptied.  A persistent grid of (compute units - 1) workgroups that cannot share a compute unit (LDS padding)
+// leaves one compute unit empty for as long as it runs: the leaf starts at once, and the column passes and short-K updates of
+// the chain move in beside the bulk's workgroups (each leaves 256 of 512 vector registers per SIMD and ~76 KB of LDS).
+// Every entry keeps its K grouping and summation order: the factor is bit-identical to the plain schedule.
+GPN_SWITCH g_outer_lookahead = -1;   // -1 = by size; 0 / 1 = forced (A/B)
+GPN_SWITCH g_la_strip_extra = 0;     // extra 128-column blocks in the strip beyond the next outer panel (A/B: balance)
+GPN_SWITCH g_la_nwg = 0;             // persistent workgroups (0 = compute units - 1)
+GPN_SWITCH g_la_pad_kb = 20;         // LDS padding of the persistent workgroups: 64 + 20 KB > half a compute unit's 160 KB
+static inline bool outer_lookahead_by_size(int64_t n) { (void)n; return false; }   // measured slower (see above): off
+static int device_cus() {
+  static std::atomic<int> cus{0};
+  int v = cus.load(std::memory_order_acquire);
+  if (v == 0) {
+    int dev = 0, count = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || count <= 1)
+      count = 256;
+    cus.store(count, std::memory_order_release);
+    v = count;
+  }
+  return v;
+}
 // Left-looking formation of the INNER panels (round 5): after an inner panel, instead of the K = inner-width trapezoid over all
 // remaining columns of the outer panel, ONLY the next inner panel's columns are updated -- by every solved column of the outer
 // panel so far (K = 1, 2, 3 ... inner widths): the same flops in launches with two to three times the K (the 64 x 64 tile ran the
@@ -826,6 +856,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   const int64_t lda = c.lda, PW = lev.w[0];
   const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
   const bool inner_left = lev.n >= 2 && (g_inner_left < 0 ? inner_left_by_size(n) : g_inner_left != 0);
+  const bool lookahead = lev.n >= 2 && c.batch == 1 && ax->s2 && !c.rest_ready && (g_outer_lookahead < 0 ? outer_lookahead_by_size(n) : g_outer_lookahead != 0);
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
   int64_t leaf_done = -1;                          // the diagonal block a fused step has already factored
@@ -979,7 +1010,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       bulk_pending = true;
       continue;
     }
-    if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }
+    if (bulk_pending && lev.n == 1) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }
     if (trap_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->trap_done, 0)); trap_pending = false; }   // it wrote the columns updated next
     if (pend >= n) break;
     int l = 0;                                     // the widest level that ends here
@@ -1021,6 +1052,24 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       }
       double* P = A + pend * lda + o0;             // [m, pend - o0] solved (outer) panel below the diagonal square
       const int64_t kp = round_up(pend - o0, 16);
+      if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }   // the previous bulk wrote these columns
+      // look-ahead over outer panels: strip here, persistent bulk on the second helper stream (see g_outer_lookahead)
+      const int64_t W1 = lev.w[lev.n - 1];
+      const int64_t S = std::min(n - pend, W1 + (int64_t)g_la_strip_extra * LEAF);     // the next outer panel's columns (+ A/B extra)
+      const bool la = lookahead && (c.corner || e == 0) && pend + S < n && (pend + S) % LEAF == 0 && (kp % 16) == 0;
+      if (la) {
+        c.rc = cgemm(c, c.s, m, S, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
+        if (c.rc != GPN_OK) break;
+        hip_ok(hipEventRecord(ax->chain_done, c.s));
+        hip_ok(hipStreamWaitEvent(ax->s2, ax->chain_done, 0));
+        const int64_t m2 = m - S;                  // rows / columns from pend + S on (incl. the extra rows: corner form)
+        const int nwg = g_la_nwg > 0 ? g_la_nwg : device_cus() - 1;
+        c.rc = gemm_nt_lower_persistent(ax->s2, m2, kp, -1.0, P + S * lda, lda, P + S * lda, lda, 1.0, A + (pend + S) * lda + pend + S, lda, nwg,
+                                        g_la_pad_kb);
+        hip_ok(hipEventRecord(ax->bulk_done, ax->s2));
+        bulk_pending = true;
+        continue;
+      }
       // (the fork / join is ~25 us per outer panel: C2 5.36 -> 5.53 ms with it, x 8 in lock step neutral, C3 182.4 -> 181.3;
       //  against the THIN tile row of gemm_f64.hip that the extra rows are otherwise: N = 16384 28.42 vs 28.14 ms, C3 178.9 vs
       //  180.2, C4 1329.7 vs 1333 -- on from XR_MIN_N rows)
@@ -1043,6 +1092,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       }
     }
   }
+  if (bulk_pending) hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0));
   if (trap_pending) hip_ok(hipStreamWaitEvent(c.s, ax->trap_done, 0));
   if (extra_pending) hip_ok(hipStreamWaitEvent(c.s, ax->extra_done, 0));     // (error exits: nothing of this call stays in flight unordered)
   if (c.rest_ready) { hip_ok(hipStreamWaitEvent(c.s, c.rest_ready, 0)); c.rest_ready = nullptr; }
@@ -1284,6 +1334,7 @@ extern "C" int gpn_potrf_panel_levels(int64_t n, int64_t* widths3) {
 // recycled hipStream_t handle never meets stale helpers.  stream == NULL releases all of them.
 extern "C" int gpn_release_stream(void* stream) {
   dist_release(static_cast<hipStream_t>(stream));
+  potrf_persistent_release(static_cast<hipStream_t>(stream));
   std::lock_guard<std::mutex> lock(g_aux_mutex);
   auto drop = [](Aux& a) {
     if (a.s1) { (void)hipStreamSynchronize(a.s1); (void)hipStreamDestroy(a.s1); }
@@ -1350,6 +1401,11 @@ extern "C" int gpn_debug_set_extra_rows(int on) { g_extra_rows_kernel = on; retu
 extern "C" int gpn_debug_set_inner_lookahead(int v) { g_inner_lookahead = v; return GPN_OK; }
 extern "C" int gpn_debug_set_inner_left(int v) { g_inner_left = v; return GPN_OK; }
 extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; }
+// mode: -1 by size, 0 off, 1 on; strip_extra: 128-column blocks added to the strip; nwg: persistent workgroups (0 = CUs - 1); pad_kb: their LDS padding
+extern "C" int gpn_debug_set_outer_lookahead(int mode, int strip_extra, int nwg, int pad_kb) {
+  g_outer_lookahead = mode; g_la_strip_extra = strip_extra; g_la_nwg = nwg; g_la_pad_kb = pad_kb < 0 ? 20 : pad_kb;
+  return GPN_OK;
+}
 
 // diagnostic build of the leaf with s_memtime stamps (not part of the public header):
 // diag[wave*8 + k] = cycles summed over the pivot blocks in segment k

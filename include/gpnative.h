@@ -105,6 +105,28 @@ int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
 int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
                           double* winv, int32_t* info);
 
+/* gpn_potrf_lower as ONE PERSISTENT LAUNCH (csrc/ppotrf.hip, round 6): a dataflow over 128 x 128 tiles -- leaf, tile solve
+ * and tile update tasks with the K grouping and per-entry summation order of gpn_potrf_lower's schedule, so the factor, the
+ * leaf inverses and the extra rows are BIT-IDENTICAL to gpn_potrf_lower's -- run by one workgroup per compute unit, the first
+ * few of which serve only the critical chain (leaf -> solve -> update of the next diagonal block) while the others stream the
+ * trailing updates: the N/128 leaves no longer run alone on the chip.  For the latency regime of one model per optimiser step
+ * (gptorch/models/base.py:260-269; functions.py:46-47): gpn_potrf_persistent_supported(n, e) says which sizes it takes
+ * (n a multiple of 128 in [2560, 20480), e <= 16); for any other size, and on a stream under capture before the size's first
+ * call outside capture, it returns GPN_E_UNSUPPORTED and nothing is enqueued.  The task table of a size is built on the host
+ * and kept on the device by the library (a few hundred KB per size; a runtime area per caller stream and size:
+ * gpn_release_stream frees those).  Same contract for A, winv, info as gpn_potrf_lower; an internal failure (a bounded spin
+ * that ran out) is reported as info = GPN_INFO_INTERNAL. */
+int gpn_potrf_lower_persistent(void* stream, double* A, int64_t n, int64_t e, int64_t lda,
+                               double* winv, int32_t* info);
+int gpn_potrf_persistent_supported(int64_t n, int64_t e);
+/* The task graph of gpn_potrf_lower_persistent, for inspection (tests replay it on the host in random valid orders):
+ * counts5 = {tasks, successor entries, tasks of queue 0 (chain), 1, 2}; tasks8 (8 ints per task: type 0 leaf / 1 solve /
+ * 2 update, queue, tile row i, tile column j, K range [k0, k1) in 128-column blocks, predecessor count, index of the first
+ * successor -- the successors of task t are succ[tasks8[8 t + 7] .. tasks8[8 (t + 1) + 7]), of the last task up to counts5[1])
+ * and succ are filled when given (capacities in entries).  Tasks are listed in a valid sequential order. */
+int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts5, int32_t* tasks8, int64_t cap_tasks, int32_t* succ,
+                              int64_t cap_succ);
+
 /* `batch` factorisations of identical shape in LOCK STEP: problem b at A + b*sA (a factor buffer each: sA >=
  * gpn_factor_rows(n,e)*lda, even), winv + b*sW (sW >= gpn_winv_bytes(n)/8), info[b].  Same drivers and kernels as
  * gpn_potrf_lower with every launch covering all problems -- the 128x128 leaf as a grid of `batch` workgroups, the
