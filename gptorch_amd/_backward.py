@@ -45,16 +45,6 @@ def _kinv_lower(f, U):
     return Kinv
 
 
-MAX_POINT_GRAD_DIM = 64      # grad.hip GMAXD: gpn_kernel_grad_x2 keeps one accumulator per dimension in registers
-
-
-def _check_dim(d):
-    if d > MAX_POINT_GRAD_DIM:
-        raise NotImplementedError("gptorch_amd: gradients w.r.t. the POINTS (inducing points, Kernel.K inputs) support "
-                                  "input dimension <= %d (got %d); hyper-parameter gradients, evaluation and "
-                                  "prediction have no such limit" % (MAX_POINT_GRAD_DIM, d))
-
-
 def lml_backward(kind, X, variance, length_scales, noise, f):
     """-> (dLML/dvariance [1], dLML/dlength_scales [nls], dLML/dnoise [1], dLML/dR [n, dy]):
     ONE library call (gpn_lml_backward: U = L^-T, Kyy^-1 = U U^T, a = U alpha, gradient sweep)."""
@@ -109,7 +99,6 @@ def kernel_backward_x2(kind, X, X2, variance, length_scales, gK, scale=1.0, out=
     lib = _native.lib()
     Xc, X2c = _c(X.detach()), _c(X2.detach())
     n, d = Xc.shape
-    _check_dim(d)
     m = X2c.shape[0]
     nls = length_scales.numel()
     g = _rowmajor(gK)

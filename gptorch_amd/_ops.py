@@ -181,6 +181,8 @@ class FactorBatch:
 
     def nbytes(self):
         w = 0 if self._backward_work is None else self._backward_work.numel()
+        r = getattr(self, "_refine_work", None)
+        w += 0 if r is None else r.numel()
         return 8 * (self.A.numel() + self.winv.numel() + w)
 
     def factor(self, b):

@@ -148,6 +148,7 @@ int gemm_nt_lower_persistent(hipStream_t s, int64_t M, int64_t K, double alpha, 
   GemmArgs a;
   a.batch = 1; a.sA = a.sB = a.sC = 0;
   a.inner = 0; a.sA2 = a.sB2 = a.sC2 = 0;
+  a.acc_in = nullptr; a.acc_out = nullptr;
   a.A = A; a.B = B; a.C = C;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.M = (int)M; a.N = (int)M; a.K = (int)K;
@@ -216,6 +217,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   GemmArgs a;
   a.batch = batch; a.sA = sA; a.sB = sB; a.sC = sC;
   a.inner = 0; a.sA2 = a.sB2 = a.sC2 = 0;
+  a.acc_in = nullptr; a.acc_out = nullptr;
   if (ob.count > 0) {
     a.inner = batch; a.sA2 = ob.sA; a.sB2 = ob.sB; a.sC2 = ob.sC;
     a.batch = batch = batch * ob.count;

@@ -35,6 +35,11 @@ struct GemmArgs {
   // (inner == 0: one level)
   int inner;
   int64_t sA2, sB2, sC2;
+  // WT instances only (the persistent factorisation, ppotrf.hip): a tile's accumulators carried between two tasks -- acc_in:
+  // start from these raw sums instead of zero; acc_out: dump the raw sums and skip the epilogue.  128 KB per 128 x 128 tile,
+  // element ((wave * TM + i) * TN + j) * 4 + r of lane l at [...] * 64 + l.  NULL: off.  (Ordinary launches never read them.)
+  const double* acc_in;
+  double* acc_out;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -425,6 +430,18 @@ __device__ __forceinline__ void gemm_nt_tile(GemmArgs p, int bid, int nwg, const
         }
       } else if (t0 < nk) {
         stage_issue(t0, t0 & 1);
+        if constexpr (WT) {
+          // the sums so far (see GemmArgs::acc_in), requested behind the first K-step's operands: one round trip for both
+          if (p.acc_in) {
+            const double* ai = p.acc_in + (int64_t)wave * (TM * TN * 4 * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = ai[((i * TN + j) * 4 + r) * 64];
+          }
+        }
         __syncthreads();
         read_ops(t0 & 1, 0, a0, b0);
         if (t0 + 1 < nk) stage_issue(t0 + 1, (t0 + 1) & 1);
@@ -476,6 +493,19 @@ __device__ __forceinline__ void gemm_nt_tile(GemmArgs p, int bid, int nwg, const
   // round trip per TN*4 elements); element-by-element load -> fma -> store serialises 16+ round
   // trips per tile, which is most of the run time of a K = 128 update
   const bool use_c = p.beta != 0.0;
+  if constexpr (WT) {
+    if (p.acc_out) {               // raw sums to scratch (write-through): the tile is finished by a later task (acc_in)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_store(&p.acc_out[((((int64_t)wave * TM + i) * TN + j) * 4 + r) * 64 + lane], acc[i][j][r], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     double cold[TN][4];

@@ -574,6 +574,91 @@ __global__ __launch_bounds__(256) void grad_x2_kernel(GradX2Args p) {
   }
 }
 
+// Any input dimension (round 6; the kernel above keeps one accumulator per coordinate in registers and stops at GMAXD = 64):
+// gridDim.z enumerates blocks of GDC = 16 OUTPUT coordinates.  Per 64 x 64 tile of (rows, columns) a thread first forms the
+// squared distances of its 16 rows over ALL coordinates, 16 at a time through LDS (the direct differences of util.py:73-88's
+// result, as everywhere else on the path), turns them into the weights g B(r), and then sweeps its block's 16 coordinates
+// once more for the sums.  The distances are recomputed per output block: d / 16 times the arithmetic of the kernel above --
+// this is the rarely used wide-input case, and the reference's autograd (util.py:73-88 through kernels.py:149-222) has no limit.
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_x2_chunked_kernel(GradX2Args p) {
+  __shared__ double xs[GT][GDC];
+  __shared__ double red[4][GDC][GT];
+  __shared__ double inv_ell[GDC];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, ph = tid >> 6;
+  const int j0 = blockIdx.x * GT, col = j0 + lane;
+  const int r_begin = blockIdx.y * p.slab_rows;
+  const int r_end = min(p.n, r_begin + p.slab_rows);
+  const int c0 = blockIdx.z * GDC;
+  const double var = p.variance[0];
+  double acc[GDC];
+#pragma unroll
+  for (int c = 0; c < GDC; ++c) acc[c] = 0.0;
+  // stage the coordinates [ch, ch + 16) of the rows i0 .. (scaled by 1 / ell) and this thread's column point
+  auto stage = [&](int i0, int ch, double (&z)[GDC]) {
+    __syncthreads();
+    if (tid < GDC) inv_ell[tid] = ch + tid < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : ch + tid] : 0.0;
+    __syncthreads();
+    for (int idx = tid; idx < GT * GDC; idx += 256) {
+      const int pt = idx / GDC, c = idx - pt * GDC;
+      double v = 0.0;
+      if (ch + c < p.d && i0 + pt < r_end) v = p.X[(int64_t)(i0 + pt) * p.d + ch + c] * inv_ell[c];
+      xs[pt][c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < GDC; ++c) z[c] = (ch + c < p.d && col < p.m) ? p.X2[(int64_t)col * p.d + ch + c] * inv_ell[c] : 0.0;
+    __syncthreads();
+  };
+  for (int i0 = r_begin; i0 < r_end; i0 += GT) {
+    const int lim = min(GT, r_end - i0);
+    double r2[GT / 4];
+#pragma unroll
+    for (int q = 0; q < GT / 4; ++q) r2[q] = 0.0;
+    double z[GDC];
+    for (int ch = 0; ch < p.d; ch += GDC) {
+      stage(i0, ch, z);
+#pragma unroll
+      for (int q = 0; q < GT / 4; ++q) {
+        const int ii = ph + 4 * q;
+        if (ii < lim) {
+#pragma unroll
+          for (int c = 0; c < GDC; ++c) {
+            const double df = xs[ii][c] - z[c];
+            r2[q] = fma(df, df, r2[q]);
+          }
+        }
+      }
+    }
+    stage(i0, c0, z);
+#pragma unroll
+    for (int q = 0; q < GT / 4; ++q) {
+      const int ii = ph + 4 * q;
+      if (ii < lim) {
+        const double g = (col < p.m) ? p.G[(int64_t)(i0 + ii) * p.ldg + col] : 0.0;
+        double K, B;
+        k_and_base<KIND>(r2[q], var, K, B);
+        const double w = g * B;
+#pragma unroll
+        for (int c = 0; c < GDC; ++c) acc[c] = fma(w, xs[ii][c] - z[c], acc[c]);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < GDC) inv_ell[tid] = c0 + tid < p.d ? 1.0 / p.ls[p.nls == 1 ? 0 : c0 + tid] : 0.0;
+#pragma unroll
+  for (int c = 0; c < GDC; ++c) red[ph][c][lane] = acc[c];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < GDC / 4; ++q) {
+    const int c = ph * (GDC / 4) + q;
+    if (c0 + c < p.d && col < p.m) {
+      const double t = (red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]);
+      p.partial[((int64_t)blockIdx.y * p.m + col) * p.d + c0 + c] = t * inv_ell[c];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void grad_x2_reduce_kernel(const double* partial, int slabs, int64_t md, double scale,
                                                              int accumulate, double* out) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -596,7 +681,7 @@ static int launch_x2(hipStream_t s, const GradX2Args& a, dim3 grid) {
   if (a.d <= 16) hipLaunchKernelGGL((grad_x2_kernel<KIND, 16>), grid, dim3(256), 0, s, a);
   else if (a.d <= 32) hipLaunchKernelGGL((grad_x2_kernel<KIND, 32>), grid, dim3(256), 0, s, a);
   else if (a.d <= 64) hipLaunchKernelGGL((grad_x2_kernel<KIND, 64>), grid, dim3(256), 0, s, a);
-  else return GPN_E_UNSUPPORTED;
+  else hipLaunchKernelGGL((grad_x2_chunked_kernel<KIND>), dim3(grid.x, grid.y, (unsigned)((a.d + GDC - 1) / GDC)), dim3(256), 0, s, a);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
@@ -618,7 +703,7 @@ extern "C" int gpn_kernel_grad_x2(void* stream, int kind, const double* X, int64
   if (n <= 0) return -4;
   if (!X2) return -5;
   if (m <= 0) return -6;
-  if (d <= 0 || d > GMAXD) return -7;
+  if (d <= 0 || d > 65535 * GDC) return -7;       // (above GMAXD: the chunked kernel, one grid layer per 16 coordinates)
   if (!variance) return -8;
   if (!length_scales) return -9;
   if (nls != 1 && nls != d) return -10;

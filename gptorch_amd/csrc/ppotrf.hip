@@ -6,17 +6,26 @@
 // chain's kernels ran 4-5 x slower next to resident tile workgroups: on one SIMD the older wave wins the matrix pipe).
 //
 // Here one workgroup per compute unit stays resident for the whole factorisation and the schedule is a task graph:
-//   LEAF(k)            the 128 x 128 diagonal block: Cholesky + inverse (leaf16_body.h, the shipped leaf)
+//   LEAF(0)            the first 128 x 128 diagonal block: Cholesky + inverse (leaf16_body.h, the shipped leaf)
+//   STEP(c), c >= 1    the critical chain's step as ONE task of ONE workgroup, no hand-off inside:
+//                        X(c,c-1) = A(c,c-1) W_{c-1}^T  (kept in LDS; stored; its readers are released at once: "phase 1")
+//                        A(c,c) -= X(c, G) X(c, G)^T    (lower 16 x 16 blocks only; G = the K group that ends at column c-1)
+//                        leaf(c)
 //   TRSM(i, k)         X(i,k) = A(i,k) W_k^T, in place, one 128-row tile (the arithmetic of colpanel.hip, mode 0)
 //   UPD(i, j, k0..k1)  A(i,j) -= X(i, k0..k1) X(j, k0..k1)^T: one 128 x 128 tile of ONE of the shipped driver's update launches
 //                      (next-column K = 128, inner-panel trapezoid K = 256, outer-panel K = 1024; gemm_tile.h, the shipped tile)
+//   PRE / FIN          the two tiles every step waits for -- (c,c) and (c+1,c) -- get the last update of their column in two
+//                      parts when its K group has more than one block: all blocks but the last as soon as THEY are solved
+//                      (PRED(c), PRE2(c): raw sums to scratch), the last block when the step's solve is out (inside STEP(c);
+//                      FIN2(c)).  The sums continue where they stopped: nothing is rounded in between.
 // with exactly the K grouping and per-entry summation order of potrf_lookahead: THE FACTOR IS BIT-IDENTICAL to gpn_potrf_lower's.
-// Every task has <= 3 predecessors (TRSMs of a tile row complete in column order, so the last column of a K group stands for
+// Every task has <= 4 predecessors (TRSMs of a tile row complete in column order, so the last column of a K group stands for
 // all of them) and a successor list; a finished task decrements its successors' counters and pushes the ones that reach zero
-// onto one of three queues.  Roles are fixed at start by ticket: the first R workgroups serve queue 0 only -- the tasks inside
-// the current outer panel's diagonal triangle, i.e. the critical chain leaf -> solve -> update -> leaf -- and never hold a
-// long tile when a leaf becomes ready; the others serve queue 1 (tiles whose row panel is at most one outer panel below their
-// column panel: what the NEXT panel's chain waits for), then queue 2 (the bulk), then queue 0.
+// onto one of four queues.  Roles are fixed at start by ticket: the first R workgroups serve queue 0 (the two interleaved
+// critical chains: STEP, the solve and the FIN of the tile below the next diagonal block, the PREs) and queue 1 (the rest of
+// the current outer panel's diagonal triangle) only, and never hold a long tile when a step becomes ready; the others serve
+// queue 2 (tiles whose row panel is at most one outer panel below their column panel: what the NEXT panel's chain waits for),
+// then queue 3 (the bulk), then 1 and 0.
 // A workgroup only ever COMMITS to a task whose predecessors are done, so there is nothing to deadlock on; all spins are
 // bounded and end in info = GPN_INFO_INTERNAL.
 //
@@ -36,19 +45,25 @@
 
 namespace gpn {
 
-enum { PT_LEAF = 0, PT_TRSM = 1, PT_UPD = 2 };
+enum { PT_LEAF = 0, PT_TRSM = 1, PT_UPD = 2, PT_STEP = 3, PT_PRED = 4, PT_SUB = 5 };
+// UPD: PF_ACC_OUT = raw sums to the column's scratch tile (PRE2); SUB / STEP: PF_ACC_IN = continue from the scratch sums;
+// SUB: PF_HALF1 = rows 64 .. 127 of the tile (else rows 0 .. 63)
+enum { PF_ACC_OUT = 1, PF_ACC_IN = 2, PF_HALF1 = 4 };
 struct PTask {                 // 32 bytes
   int16_t type, queue;
-  int16_t i, j, k0, k1;        // tile row / column (TRSM, LEAF: j = the column block k); UPD: K range in column blocks [k0, k1)
+  int16_t i, j, k0, k1;        // tile row / column (TRSM, LEAF, STEP: j = the column block); K range in column blocks [k0, k1)
   int32_t ndeps;
   int32_t succ_begin, succ_end;
-  int32_t pad[2];
+  int32_t succ_mid;            // successors [succ_begin, succ_mid) are released at the task's phase 1 (STEP: the solve is out)
+  int32_t flags;
 };
 static_assert(sizeof(PTask) == 32, "PTask layout");
 
 // runtime words (ints): control, then per queue a head and a tail on lines of their own
-constexpr int RT_TICKET = 0, RT_COMPLETED = 1, RT_DONE = 2, RT_ABORT = 3, RT_Q0 = 32, RT_QSTRIDE = 64, RT_FIXED = RT_Q0 + 3 * RT_QSTRIDE;
-constexpr int PP_NQ = 3;
+constexpr int PP_NQ = 4;
+constexpr int RT_TICKET = 0, RT_COMPLETED = 1, RT_DONE = 2, RT_ABORT = 3, RT_Q0 = 32, RT_QSTRIDE = 64, RT_FIXED = RT_Q0 + PP_NQ * RT_QSTRIDE;
+// scratch per column block: the diagonal tile's 36 lower 16 x 16 blocks (raw sums, [block][r][lane]) + one 128 x 128 tile
+constexpr int64_t PP_SCR_DIAG = 36 * 256, PP_SCR_SUB = LEAF * LEAF, PP_SCR_SLOT = PP_SCR_DIAG + PP_SCR_SUB;
 
 struct PArgs {
   double* A;
@@ -59,6 +74,7 @@ struct PArgs {
   const PTask* tasks;
   const int* succ;
   int* rt;
+  double* scratch;             // PP_SCR_SLOT doubles per column block
   int ntasks;
   int off_dep;
   int off_slots[PP_NQ];
@@ -73,10 +89,10 @@ __device__ __forceinline__ void pp_st(int* p, int v) { __hip_atomic_store(p, v, 
 // thread 0: the next task of this workgroup's queues, -1 when the factorisation is over (or aborted)
 __device__ __forceinline__ int pp_pop(const PArgs& a, const bool chain) {
   int* rt = a.rt;
-  const int order[3] = {chain ? 0 : 1, chain ? -1 : 2, chain ? -1 : 0};
+  const int order[4] = {chain ? 0 : 2, chain ? 1 : 3, chain ? -1 : 1, chain ? -1 : 0};
   for (int spins = 0;; ++spins) {
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
+    for (int o = 0; o < 4; ++o) {
       const int q = order[o];
       if (q < 0) continue;
       int* head = rt + RT_Q0 + RT_QSTRIDE * q;
@@ -104,13 +120,13 @@ __device__ __forceinline__ int pp_pop(const PArgs& a, const bool chain) {
 }
 
 // wave 0, after the workgroup's stores have drained: release the successors
-__device__ __forceinline__ void pp_notify(const PArgs& a, const PTask& tk, const int lane) {
+__device__ __forceinline__ void pp_notify(const PArgs& a, const int sbegin, const int send, const bool last, const int lane) {
   int* rt = a.rt;
-  for (int base = tk.succ_begin; base < tk.succ_end; base += 64) {
+  for (int base = sbegin; base < send; base += 64) {
     const int idx = base + lane;
     int s = -1, q = -1;
     bool ready = false;
-    if (idx < tk.succ_end) {
+    if (idx < send) {
       s = a.succ[idx];
       const int old = __hip_atomic_fetch_sub(rt + a.off_dep + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       ready = old == 1;
@@ -132,9 +148,34 @@ __device__ __forceinline__ void pp_notify(const PArgs& a, const PTask& tk, const
       }
     }
   }
-  if (lane == 0) {
+  if (last && lane == 0) {
     const int c = __hip_atomic_fetch_add(rt + RT_COMPLETED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c == a.ntasks - 1) pp_st(rt + RT_DONE, 1);
+  }
+}
+
+constexpr int PP_LDS_ROW = LEAF * 8 + 16;
+constexpr int PP_TILE_PER = (LEAF * 64 + L16_THREADS - 1) / L16_THREADS;      // 16-byte segments per thread of a 128 x 128 tile: 11
+typedef double pd2 __attribute__((ext_vector_type(2)));
+typedef double pd4 __attribute__((ext_vector_type(4)));
+
+// a [rows, 128] tile (ld lda) into LDS, row stride PP_LDS_ROW, rows padded with zeros to a multiple of 16: all loads of the
+// workgroup in flight at once; the caller puts a barrier behind it
+__device__ __forceinline__ void pp_tile_load(pd2 (&v)[PP_TILE_PER], const double* B, const int64_t lda, const int rows, const int tid) {
+  const int total = ((rows + 15) >> 4) * 16 * 64;
+#pragma unroll
+  for (int u = 0; u < PP_TILE_PER; ++u) {
+    const int idx = tid + u * L16_THREADS;
+    const int row = idx >> 6, seg = idx & 63;
+    v[u] = (idx < total && row < rows) ? *reinterpret_cast<const pd2*>(B + (int64_t)row * lda + seg * 2) : pd2{0.0, 0.0};
+  }
+}
+__device__ __forceinline__ void pp_tile_park(const pd2 (&v)[PP_TILE_PER], char* lds, const int rows, const int tid) {
+  const int total = ((rows + 15) >> 4) * 16 * 64;
+#pragma unroll
+  for (int u = 0; u < PP_TILE_PER; ++u) {
+    const int idx = tid + u * L16_THREADS;
+    if (idx < total) *reinterpret_cast<pd2*>(lds + (idx >> 6) * PP_LDS_ROW + (idx & 63) * 16) = v[u];
   }
 }
 
@@ -143,56 +184,263 @@ __device__ __forceinline__ void pp_notify(const PArgs& a, const PTask& tk, const
 // column of the tile) / 8 in order, the pair of MFMAs (k = 8j + {0,2,4,6}, then + {1,3,5,7}) per group, accumulators from zero.
 // The whole tile is parked in LDS (row stride 1 KiB + 16 B) with all its loads in flight at once; the 8 matrix waves own one
 // 16-column tile each ({w, 7 - w} on the two waves of a SIMD: equal work in the triangular product); 12 waves load.
-constexpr int PP_LDS_ROW = LEAF * 8 + 16;
+// KEEP: afterwards the LDS tile holds X (row-major, same stride) instead of B -- rows are replaced half by half, each half once
+// every wave is done reading it (a row of X needs its own row of B only) -- and the workgroup has met at a barrier.
+template <bool KEEP>
 __device__ __forceinline__ void pp_trsm_tile(double* B, const int64_t lda, const int rows, const double* W, const int tid) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  typedef double d4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) char pp_lds[];
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   const int rt16 = (rows + 15) >> 4;                   // 16-row tiles
-  const int total = rt16 * 16 * 64;                    // 16-byte segments of the padded tile
-  constexpr int PER = (LEAF * 64 + L16_THREADS - 1) / L16_THREADS;      // 11
-  d2 v[PER];
-#pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int idx = tid + u * L16_THREADS;
-    const int row = idx >> 6, seg = idx & 63;
-    v[u] = (idx < total && row < rows) ? *reinterpret_cast<const d2*>(B + (int64_t)row * lda + seg * 2) : d2{0.0, 0.0};
-  }
+  pd2 v[PP_TILE_PER];
+  pp_tile_load(v, B, lda, rows, tid);
   const bool mm = wave < 8;
   const int ct = wave < 4 ? wave : 11 - wave;          // (waves w and w + 4 share a SIMD)
-  d2 b[16];
+  pd2 b[16];
   if (mm) {
     const double* wsrc = W + (int64_t)(ct * 16 + lr) * LEAF + 2 * lq;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) b[j] = (8 * j <= ct * 16 + 15) ? *reinterpret_cast<const d2*>(wsrc + 8 * j) : d2{0.0, 0.0};
+    for (int j = 0; j < 16; ++j) b[j] = (8 * j <= ct * 16 + 15) ? *reinterpret_cast<const pd2*>(wsrc + 8 * j) : pd2{0.0, 0.0};
+  }
+  pp_tile_park(v, pp_lds, rows, tid);
+  __syncthreads();
+  auto solve_row_tile = [&](int i) -> pd4 {
+    pd4 acc = pd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (8 * j > ct * 16 + 15) continue;              // W[col][k] = 0 for k > col (wave-uniform)
+      const pd2 av = *reinterpret_cast<const pd2*>(pp_lds + (i * 16 + lr) * PP_LDS_ROW + (4 * j + lq) * 16);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b[j].y, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = i * 16 + lq + 4 * r;
+      if (row < rows) __hip_atomic_store(B + (int64_t)row * lda + ct * 16 + lr, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return acc;
+  };
+  if constexpr (!KEEP) {
+    if (mm) {
+#pragma unroll 1
+      for (int i = 0; i < rt16; ++i) (void)solve_row_tile(i);
+    }
+  } else {
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      pd4 x[4];
+      if (mm) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = solve_row_tile(4 * half + q);
+      }
+      __syncthreads();                                 // every wave is done with this half's rows of B
+      if (mm) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<double*>(pp_lds + ((4 * half + q) * 16 + lq + 4 * r) * PP_LDS_ROW + (ct * 16 + lr) * 8) = x[q][r];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // X's write-through stores have left (the caller releases its readers)
+    __syncthreads();
+  }
+}
+
+// The lower 16 x 16 blocks of a diagonal tile, dealt to the 8 matrix waves: block idx = bi (bi + 1) / 2 + bj (bj <= bi) goes
+// to wave idx % 8 (9 blocks per SIMD).  One 128-column block of the update  D -= X X^T  from the X tile parked in LDS: per
+// block the 8-k groups in order, two MFMAs each -- gemm_tile.h's order for the same entries.
+constexpr int PP_DQ = 5;
+__device__ __forceinline__ void pp_diag_blocks(const int wave, int (&bi)[PP_DQ], int (&bj)[PP_DQ], int& nb) {
+  nb = 0;
+#pragma unroll
+  for (int q = 0; q < PP_DQ; ++q) {
+    const int idx = wave + 8 * q;
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+    bi[q] = i; bj[q] = idx - i * (i + 1) / 2;
+    if (idx < 36) nb = q + 1;
+  }
+}
+__device__ __forceinline__ void pp_diag_mfma(const char* lds, pd4 (&dacc)[PP_DQ], const int (&bi)[PP_DQ], const int (&bj)[PP_DQ], const int nb,
+                                             const int lr, const int lq) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+#pragma unroll
+    for (int q = 0; q < PP_DQ; ++q) {
+      if (q >= nb) continue;                           // (wave-uniform)
+      const pd2 av = *reinterpret_cast<const pd2*>(lds + (bi[q] * 16 + lr) * PP_LDS_ROW + (4 * j + lq) * 16);
+      const pd2 bv = *reinterpret_cast<const pd2*>(lds + (bj[q] * 16 + lr) * PP_LDS_ROW + (4 * j + lq) * 16);
+      dacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, dacc[q], 0, 0, 0);
+      dacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, dacc[q], 0, 0, 0);
+    }
+  }
+}
+// the blocks [k0, k1) of row panel c's solved tiles, one after the other through the LDS tile
+__device__ __forceinline__ void pp_diag_accumulate(const PArgs& a, const int c, const int k0, const int k1, pd4 (&dacc)[PP_DQ],
+                                                   const int (&bi)[PP_DQ], const int (&bj)[PP_DQ], const int nb, const int tid) {
+  extern __shared__ __attribute__((aligned(16))) char pp_lds[];
+  const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const bool mm = __builtin_amdgcn_readfirstlane(tid >> 6) < 8;
+#pragma unroll 1
+  for (int kb = k0; kb < k1; ++kb) {
+    pd2 v[PP_TILE_PER];
+    pp_tile_load(v, a.A + (int64_t)c * LEAF * a.lda + (int64_t)kb * LEAF, a.lda, LEAF, tid);
+    pp_tile_park(v, pp_lds, LEAF, tid);
+    __syncthreads();
+    if (mm) pp_diag_mfma(pp_lds, dacc, bi, bj, nb, lr, lq);
+    __syncthreads();                                   // before the next block (or the solve) overwrites the tile
+  }
+}
+
+// PRED(c): the diagonal tile's raw sums over the blocks [k0, k1) -> scratch
+__device__ __forceinline__ void pp_pred(const PArgs& a, const PTask& tk, const int tid) {
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bi[PP_DQ], bj[PP_DQ], nb;
+  pp_diag_blocks(wave & 7, bi, bj, nb);
+  pd4 dacc[PP_DQ];
+#pragma unroll
+  for (int q = 0; q < PP_DQ; ++q) dacc[q] = pd4{0.0, 0.0, 0.0, 0.0};
+  pp_diag_accumulate(a, tk.i, tk.k0, tk.k1, dacc, bi, bj, nb, tid);
+  if (wave < 8) {
+    double* scr = a.scratch + (int64_t)tk.i * PP_SCR_SLOT;
+#pragma unroll
+    for (int q = 0; q < PP_DQ; ++q)
+      if (q < nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __hip_atomic_store(scr + ((int64_t)(wave + 8 * q) * 4 + r) * 64 + lane, dacc[q][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// SUB: the LAST 128-column block (k1 - 1) of the update of tile (i, j) -- the tile below the next diagonal block, which the next
+// step's solve waits for -- for 64 of its rows:  C -= (sums so far) + X(i, k1-1) X(j, k1-1)^T.  Two such tasks share the tile, on
+// two compute units: the update sits on the second critical chain (solve of (c+1, c-1) -> this -> next step) and the generic
+// 128 x 128 tile task took 37-43 us there against a window of ~32.  K = 128 is the whole problem (colpanel.hip's scheme): the
+// left operand's 64 rows are parked in LDS with all loads in flight at once, a wave keeps its 16 columns of the right operand
+// in registers; sums, K order and epilogue are gemm_tile.h's for the same entries (accumulators from zero or from the
+// scratch sums, 8-k groups in order, C = fma(1, C, -sums)).
+__device__ __forceinline__ void pp_sub(const PArgs& a, const PTask& tk, const int tid) {
+  extern __shared__ __attribute__((aligned(16))) char pp_lds[];
+  const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = (tk.flags & PF_HALF1) ? 1 : 0;
+  const int kb = tk.k1 - 1;
+  const double* Ai = a.A + ((int64_t)tk.i * LEAF + 64 * h) * a.lda + (int64_t)kb * LEAF;     // X(i, kb), rows 64 h ..
+  const double* Bj = a.A + (int64_t)tk.j * LEAF * a.lda + (int64_t)kb * LEAF;               // X(j, kb)
+  double* C = a.A + ((int64_t)tk.i * LEAF + 64 * h) * a.lda + (int64_t)tk.j * LEAF;
+  constexpr int PER = (64 * 64 + L16_THREADS - 1) / L16_THREADS;                              // 6
+  pd2 v[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int idx = tid + u * L16_THREADS;
+    v[u] = idx < 64 * 64 ? *reinterpret_cast<const pd2*>(Ai + (int64_t)(idx >> 6) * a.lda + (idx & 63) * 2) : pd2{0.0, 0.0};
+  }
+  const bool mm = wave < 8;
+  const int ct = wave & 7;
+  pd2 b[16];
+  pd4 acc[4];
+  double cold[4][4];
+  if (mm) {
+    const double* bsrc = Bj + (int64_t)(ct * 16 + lr) * a.lda + 2 * lq;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) b[j] = *reinterpret_cast<const pd2*>(bsrc + 8 * j);
+    if (tk.flags & PF_ACC_IN) {
+      // gemm_tile.h's dump of the 128 x 128 tile (8 waves of 32 x 64): row tile I, column tile ct -> wave (I / 2) * 2 + ct / 4
+      const double* scr = a.scratch + (int64_t)tk.j * PP_SCR_SLOT + PP_SCR_DIAG;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int I = 4 * h + i;
+        const int64_t base = ((((int64_t)((I >> 1) * 2 + (ct >> 2)) * 2 + (I & 1)) * 4 + (ct & 3)) * 4) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = scr[base + r * 64];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = pd4{0.0, 0.0, 0.0, 0.0};
+    }
   }
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int idx = tid + u * L16_THREADS;
-    if (idx < total) *reinterpret_cast<d2*>(pp_lds + (idx >> 6) * PP_LDS_ROW + (idx & 63) * 16) = v[u];
+    if (idx < 64 * 64) *reinterpret_cast<pd2*>(pp_lds + (idx >> 6) * PP_LDS_ROW + (idx & 63) * 16) = v[u];
   }
   __syncthreads();
   if (mm) {
-#pragma unroll 1
-    for (int i = 0; i < rt16; ++i) {
-      d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    // the old tile: requested here (the staging registers are free again), needed behind the MFMAs
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (8 * j > ct * 16 + 15) continue;            // W[col][k] = 0 for k > col (wave-uniform)
-        const d2 av = *reinterpret_cast<const d2*>(pp_lds + (i * 16 + lr) * PP_LDS_ROW + (4 * j + lq) * 16);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b[j].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b[j].y, acc, 0, 0, 0);
-      }
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = i * 16 + lq + 4 * r;
-        if (row < rows) __hip_atomic_store(B + (int64_t)row * lda + ct * 16 + lr, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int r = 0; r < 4; ++r) cold[i][r] = C[(int64_t)(i * 16 + lq + 4 * r) * a.lda + ct * 16 + lr];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const pd2 av = *reinterpret_cast<const pd2*>(pp_lds + (i * 16 + lr) * PP_LDS_ROW + (4 * j + lq) * 16);
+        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b[j].x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b[j].y, acc[i], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __hip_atomic_store(C + (int64_t)(i * 16 + lq + 4 * r) * a.lda + ct * 16 + lr, fma(1.0, cold[i][r], -1.0 * acc[i][r]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// STEP(c) up to the leaf: solve of tile (c, c-1), release of its readers, the diagonal tile's last update
+__device__ __forceinline__ void pp_step(const PArgs& a, const PTask& tk, const int tid) {
+  extern __shared__ __attribute__((aligned(16))) char pp_lds[];
+  const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = tk.i;
+  int bi[PP_DQ], bj[PP_DQ], nb;
+  pp_diag_blocks(wave & 7, bi, bj, nb);
+  double* Ccc = a.A + (int64_t)c * LEAF * (a.lda + 1);
+  pp_trsm_tile<true>(a.A + (int64_t)c * LEAF * a.lda + (int64_t)(c - 1) * LEAF, a.lda, LEAF, a.winv + (int64_t)(c - 1) * LEAF * LEAF, tid);
+  // X(c, c-1) is out (stores drained, barrier passed): an idle wave releases its readers while the matrix waves go on
+  if (wave == 8) pp_notify(a, tk.succ_begin, tk.succ_mid, false, lane);
+  // the sums so far: PRED(c)'s over the earlier blocks of the group (the builder makes one whenever the group has any), or zero
+  pd4 dacc[PP_DQ];
+  if ((tk.flags & PF_ACC_IN) && wave < 8) {
+    const double* scr = a.scratch + (int64_t)c * PP_SCR_SLOT;
+#pragma unroll
+    for (int q = 0; q < PP_DQ; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dacc[q][r] = q < nb ? scr[((int64_t)(wave + 8 * q) * 4 + r) * 64 + lane] : 0.0;
+  } else {
+#pragma unroll
+    for (int q = 0; q < PP_DQ; ++q) dacc[q] = pd4{0.0, 0.0, 0.0, 0.0};
+  }
+  // the old diagonal tile, requested now and needed after the MFMAs; `sc1` loads: they bypass this compute unit's L1, which must
+  // not keep lines of a tile the leaf below re-reads after this workgroup has rewritten it
+  double cold[PP_DQ][4];
+  if (wave < 8) {
+#pragma unroll
+    for (int q = 0; q < PP_DQ; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bi[q] * 16 + lq + 4 * r, col = bj[q] * 16 + lr;
+        cold[q][r] = (q < nb && col <= row) ? __hip_atomic_load(Ccc + (int64_t)row * a.lda + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+  }
+  if (wave < 8) {
+    pp_diag_mfma(pp_lds, dacc, bi, bj, nb, lr, lq);
+#pragma unroll
+    for (int q = 0; q < PP_DQ; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bi[q] * 16 + lq + 4 * r, col = bj[q] * 16 + lr;
+        if (q < nb && col <= row)
+          __hip_atomic_store(Ccc + (int64_t)row * a.lda + col, fma(1.0, cold[q][r], -1.0 * dacc[q][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the diagonal tile is out before the leaf reads it back
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
@@ -227,7 +475,8 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
     asm volatile("" : "+v"(tid_it));
     const PTask tk = a.tasks[task];
     const int rows_i = tk.i < a.T ? LEAF : a.e;
-    if (tk.type == PT_LEAF) {
+    if (tk.type == PT_LEAF || tk.type == PT_STEP) {
+      if (tk.type == PT_STEP) pp_step(a, tk, tid_it);
       Leaf16Args la;
       la.A = a.A + (int64_t)tk.i * LEAF * (a.lda + 1);
       la.lda = a.lda;
@@ -238,7 +487,11 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
       la.sA = la.sW = la.sInfo = 0;
       leaf16_body<false, true>(la, nullptr, 0, tid_it);
     } else if (tk.type == PT_TRSM) {
-      pp_trsm_tile(a.A + (int64_t)tk.i * LEAF * a.lda + (int64_t)tk.j * LEAF, a.lda, rows_i, a.winv + (int64_t)tk.j * LEAF * LEAF, tid_it);
+      pp_trsm_tile<false>(a.A + (int64_t)tk.i * LEAF * a.lda + (int64_t)tk.j * LEAF, a.lda, rows_i, a.winv + (int64_t)tk.j * LEAF * LEAF, tid_it);
+    } else if (tk.type == PT_PRED) {
+      pp_pred(a, tk, tid_it);
+    } else if (tk.type == PT_SUB) {
+      pp_sub(a, tk, tid_it);
     } else {
       GemmArgs g;
       g.A = a.A + (int64_t)tk.i * LEAF * a.lda + (int64_t)tk.k0 * LEAF;
@@ -255,13 +508,16 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
       g.alpha = -1.0; g.beta = 1.0;
       g.batch = 1; g.sA = g.sB = g.sC = 0;
       g.inner = 0; g.sA2 = g.sB2 = g.sC2 = 0;
+      double* sub = a.scratch + (int64_t)tk.j * PP_SCR_SLOT + PP_SCR_DIAG;
+      g.acc_in = (tk.flags & PF_ACC_IN) ? sub : nullptr;
+      g.acc_out = (tk.flags & PF_ACC_OUT) ? sub : nullptr;
       gemm_nt_tile<128, 128, 32, 64, true, 2, false, true, true, true>(g, 0, 1, true, tid_it);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave's write-through stores have left
     __syncthreads();
     unsigned long long t_end = 0;
     if (a.trace && tid == 0) t_end = __builtin_amdgcn_s_memrealtime();
-    if (wave == 0) pp_notify(a, tk, lane);
+    if (wave == 0) pp_notify(a, tk.succ_mid, tk.succ_end, true, lane);
     if (a.trace && tid == 0) {
       unsigned long long* o = a.trace + 6 * (size_t)task;
       o[0] = t_pop0; o[1] = t_pop1; o[2] = t_run; o[3] = t_end; o[4] = __builtin_amdgcn_s_memrealtime();
@@ -280,8 +536,8 @@ struct PPlan {
   std::vector<int> succ;
   std::vector<int> dep0;
   std::vector<int> initial[PP_NQ];
-  int qcount[PP_NQ] = {0, 0, 0};
-  int off_dep = 0, off_slots[PP_NQ] = {0, 0, 0}, rt_ints = 0;
+  int qcount[PP_NQ] = {0, 0, 0, 0};
+  int off_dep = 0, off_slots[PP_NQ] = {0, 0, 0, 0}, rt_ints = 0;
 };
 
 static bool pp_supported(int64_t n, int64_t e) {
@@ -291,7 +547,9 @@ static bool pp_supported(int64_t n, int64_t e) {
 }
 
 // Walks gpn_potrf_lower's schedule for this size (potrf.hip potrf_lookahead: inner panels of w0 columns -- two blocks --, outer
-// panels of w1) and emits one task per 128 x 128 tile of every launch; predecessors from the last writer of each tile.
+// panels of w1) and emits one task per 128 x 128 tile of every launch -- with the chain's pieces fused / split as described at
+// the top of this file; predecessors from the last writer of each tile.  A predecessor is (task, phase): phase 1 of a STEP = its
+// solved tile (c, c-1), phase 2 = everything.  Tasks are created after their predecessors: the list is a sequential order.
 static int pp_build(int64_t n, int64_t e, PPlan& P) {
   if (!pp_supported(n, e)) return GPN_E_UNSUPPORTED;
   int64_t w[3];
@@ -299,36 +557,78 @@ static int pp_build(int64_t n, int64_t e, PPlan& P) {
   const int PW = (int)(w[0] / LEAF), OW = (int)(w[1] / LEAF);
   const int T = (int)(n / LEAF), TR = T + (e > 0 ? 1 : 0);
   P.n = n; P.e = e; P.T = T; P.TR = TR;
-  std::vector<int> lastw((size_t)TR * T, -1);            // last task that wrote tile (i, j)
-  std::vector<int> trsm((size_t)TR * T, -1);
-  std::vector<std::vector<int>> preds;
+  struct Dep { int id, phase; };
+  typedef std::vector<Dep> Deps;
+  std::vector<Deps> lastw((size_t)TR * T);               // last writer(s) of tile (i, j)
+  std::vector<Deps> trsm((size_t)TR * T);                // who solved tile (i, k)
+  std::vector<Deps> leafof((size_t)T);
+  std::vector<Deps> preds;
   auto panel = [&](int t) { return t < T ? t / OW : (1 << 20); };
-  auto add = [&](int type, int i, int j, int k0, int k1, std::initializer_list<int> deps, bool top) {
+  auto add = [&](int type, int i, int j, int k0, int k1, int flags, int queue, std::initializer_list<Deps> deps) {
     PTask t{};
     t.type = (int16_t)type; t.i = (int16_t)i; t.j = (int16_t)j; t.k0 = (int16_t)k0; t.k1 = (int16_t)k1;
-    std::vector<int> d;
-    for (int x : deps) if (x >= 0 && std::find(d.begin(), d.end(), x) == d.end()) d.push_back(x);
+    t.flags = flags;
+    Deps d;
+    for (const Deps& xs : deps)
+      for (const Dep& x : xs) {
+        bool seen = false;
+        for (Dep& y : d) if (y.id == x.id) { y.phase = std::max(y.phase, x.phase); seen = true; }
+        if (!seen) d.push_back(x);
+      }
     t.ndeps = (int)d.size();
-    const int pi = panel(i), pj = panel(j);
-    t.queue = (int16_t)((!top && pi == pj) ? 0 : (pi - pj <= 1 ? 1 : 2));
+    t.queue = (int16_t)queue;
     P.tasks.push_back(t);
     preds.push_back(d);
     return (int)P.tasks.size() - 1;
   };
+  // queue of an ordinary task: 1 = inside one outer panel's diagonal triangle (not a top-level update), 2 = row panel at most
+  // one outer panel below the column panel, 3 = the bulk
+  auto queue_of = [&](int i, int j, bool top) {
+    const int pi = panel(i), pj = panel(j);
+    return (!top && pi == pj) ? 1 : (pi - pj <= 1 ? 2 : 3);
+  };
+  // start of the K group whose update is the LAST one of column c's tiles (it ends at column c - 1)
+  auto group_start = [&](int c) { return c % PW != 0 ? c - 1 : (c % OW != 0 ? c - PW : c - OW); };
+  auto at = [&](int i, int j) { return (size_t)i * T + j; };
+  // update of tile (i, j) by the K group [k0, k1); top: an outer panel's (K = outer width)
   auto upd = [&](int i, int j, int k0, int k1, bool top) {
     const int kl = k1 - 1;
-    const int id = add(PT_UPD, i, j, k0, k1, {trsm[(size_t)i * T + kl], trsm[(size_t)j * T + kl], lastw[(size_t)i * T + j]}, top);
-    lastw[(size_t)i * T + j] = id;
+    const bool last_of_column = k1 == j;                 // the group that ends right left of the tile's column
+    if (last_of_column && i == j) return;                // fused into STEP(j)
+    if (last_of_column && i == j + 1 && i < T) {         // the tile below the next diagonal block: on the second critical chain
+      Deps pre;
+      if (k1 - k0 >= 2) pre = Deps{Dep{add(PT_UPD, i, j, k0, kl, PF_ACC_OUT, 0, {trsm[at(i, kl - 1)], trsm[at(j, kl - 1)]}), 2}};
+      const int fl = pre.empty() ? 0 : PF_ACC_IN;
+      const int h0 = add(PT_SUB, i, j, kl, k1, fl, 0, {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)], pre});
+      const int h1 = add(PT_SUB, i, j, kl, k1, fl | PF_HALF1, 0, {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)], pre});
+      lastw[at(i, j)] = Deps{Dep{h0, 2}, Dep{h1, 2}};
+      return;
+    }
+    const int id = add(PT_UPD, i, j, k0, k1, 0, queue_of(i, j, top), {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)]});
+    lastw[at(i, j)] = Deps{Dep{id, 2}};
   };
   for (int p0 = 0; p0 < T; p0 += PW) {
     const int pend = std::min(p0 + PW, T);
     for (int k = p0; k < pend; ++k) {
-      const int leaf = add(PT_LEAF, k, k, k, k + 1, {lastw[(size_t)k * T + k]}, false);
-      lastw[(size_t)k * T + k] = leaf;
+      if (k == 0) {
+        const int leaf = add(PT_LEAF, 0, 0, 0, 1, 0, 0, {});
+        leafof[0] = lastw[at(0, 0)] = Deps{Dep{leaf, 2}};
+      }
+      // (for k >= 1 the leaf of column k is the end of STEP(k), created with column k - 1's solves below)
       for (int i = k + 1; i < TR; ++i) {
-        const int id = add(PT_TRSM, i, k, k, k + 1, {leaf, lastw[(size_t)i * T + k]}, false);
-        trsm[(size_t)i * T + k] = id;
-        lastw[(size_t)i * T + k] = id;
+        if (i == k + 1 && i < T) {
+          // STEP(c), c = k + 1: solve of (c, k) + the diagonal tile's last update (group [g0, c)) + leaf(c)
+          const int c = i, g0 = group_start(c);
+          Deps pre;
+          if (c - g0 >= 2) pre = Deps{Dep{add(PT_PRED, c, c, g0, c - 1, 0, 0, {trsm[at(c, c - 2)]}), 2}};
+          const int id = add(PT_STEP, c, c, g0, c, pre.empty() ? 0 : PF_ACC_IN, 0, {leafof[k], lastw[at(c, k)], lastw[at(c, c)], pre});
+          trsm[at(c, k)] = lastw[at(c, k)] = Deps{Dep{id, 1}};
+          leafof[c] = lastw[at(c, c)] = Deps{Dep{id, 2}};
+        } else {
+          const int q = (i == k + 2 && i < T) ? 0 : queue_of(i, k, false);      // solve of (k + 2, k): second critical chain
+          const int id = add(PT_TRSM, i, k, k, k + 1, 0, q, {leafof[k], lastw[at(i, k)]});
+          trsm[at(i, k)] = lastw[at(i, k)] = Deps{Dep{id, 2}};
+        }
       }
       if (k + 1 < pend)                                  // next column block of the inner panel: K = 128
         for (int i = k + 1; i < TR; ++i) upd(i, k + 1, k, k + 1, false);
@@ -345,12 +645,18 @@ static int pp_build(int64_t n, int64_t e, PPlan& P) {
     }
   }
   const int nt = (int)P.tasks.size();
-  std::vector<int> cnt(nt, 0);
-  for (int t = 0; t < nt; ++t) for (int d : preds[t]) ++cnt[d];
+  // successor lists: phase-1 successors first
+  std::vector<int> c1(nt, 0), c2(nt, 0);
+  for (int t = 0; t < nt; ++t) for (const Dep& d : preds[t]) ++(d.phase == 1 ? c1 : c2)[d.id];
   int off = 0;
-  for (int t = 0; t < nt; ++t) { P.tasks[t].succ_begin = off; off += cnt[t]; P.tasks[t].succ_end = P.tasks[t].succ_begin; }
+  std::vector<int> f1(nt), f2(nt);
+  for (int t = 0; t < nt; ++t) {
+    P.tasks[t].succ_begin = off; f1[t] = off; off += c1[t];
+    P.tasks[t].succ_mid = off; f2[t] = off; off += c2[t];
+    P.tasks[t].succ_end = off;
+  }
   P.succ.assign((size_t)off, -1);
-  for (int t = 0; t < nt; ++t) for (int d : preds[t]) P.succ[(size_t)P.tasks[d].succ_end++] = t;
+  for (int t = 0; t < nt; ++t) for (const Dep& d : preds[t]) P.succ[(size_t)(d.phase == 1 ? f1 : f2)[d.id]++] = t;
   P.dep0.resize(nt);
   for (int t = 0; t < nt; ++t) {
     P.dep0[t] = P.tasks[t].ndeps;
@@ -382,7 +688,8 @@ struct PDevPlan {
 };
 static std::mutex g_pp_mutex;
 static std::map<std::tuple<int, int64_t, int64_t>, PDevPlan*> g_pp_plans;                 // (device, n, e)
-static std::map<std::tuple<hipStream_t, int64_t, int64_t>, int*> g_pp_runtime;            // one runtime area per caller stream and shape
+struct PRuntime { int* rt = nullptr; double* scratch = nullptr; };
+static std::map<std::tuple<hipStream_t, int64_t, int64_t>, PRuntime> g_pp_runtime;      // one runtime area (+ scratch tiles) per caller stream and shape
 
 #ifdef GPN_DEBUG_SWITCHES
 static thread_local int g_pp_chain_wgs = 0, g_pp_grid = 0;
@@ -400,7 +707,7 @@ int potrf_persistent(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda
   int dev = 0;
   GPN_HIP_CHECK(hipGetDevice(&dev));
   PDevPlan* dp = nullptr;
-  int* rt = nullptr;
+  PRuntime rt;
   {
     std::lock_guard<std::mutex> lock(g_pp_mutex);
     auto it = g_pp_plans.find(std::make_tuple(dev, n, e));
@@ -425,18 +732,19 @@ int potrf_persistent(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda
     }
     dp = it->second;
     if (rit == g_pp_runtime.end()) {
-      int* r = nullptr;
-      GPN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&r), (size_t)dp->plan.rt_ints * sizeof(int)));
+      PRuntime r;
+      GPN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&r.rt), (size_t)dp->plan.rt_ints * sizeof(int)));
+      GPN_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&r.scratch), (size_t)dp->plan.T * PP_SCR_SLOT * sizeof(double)));
       rit = g_pp_runtime.emplace(std::make_tuple(s, n, e), r).first;
     }
     rt = rit->second;
   }
   const PPlan& P = dp->plan;
-  GPN_HIP_CHECK(hipMemcpyAsync(rt, dp->d_image, (size_t)P.rt_ints * sizeof(int), hipMemcpyDeviceToDevice, s));
+  GPN_HIP_CHECK(hipMemcpyAsync(rt.rt, dp->d_image, (size_t)P.rt_ints * sizeof(int), hipMemcpyDeviceToDevice, s));
   PArgs a;
   a.A = A; a.lda = lda; a.winv = winv; a.info = info;
   a.T = P.T; a.e = (int)e;
-  a.tasks = dp->d_tasks; a.succ = dp->d_succ; a.rt = rt;
+  a.tasks = dp->d_tasks; a.succ = dp->d_succ; a.rt = rt.rt; a.scratch = rt.scratch;
   a.ntasks = (int)P.tasks.size();
   a.off_dep = P.off_dep;
   for (int q = 0; q < PP_NQ; ++q) a.off_slots[q] = P.off_slots[q];
@@ -461,7 +769,7 @@ int potrf_persistent(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda
 void potrf_persistent_release(hipStream_t s) {
   std::lock_guard<std::mutex> lock(g_pp_mutex);
   for (auto it = g_pp_runtime.begin(); it != g_pp_runtime.end();) {
-    if (!s || std::get<0>(it->first) == s) { (void)hipFree(it->second); it = g_pp_runtime.erase(it); }
+    if (!s || std::get<0>(it->first) == s) { (void)hipFree(it->second.rt); (void)hipFree(it->second.scratch); it = g_pp_runtime.erase(it); }
     else ++it;
   }
 }
@@ -485,24 +793,25 @@ extern "C" int gpn_potrf_lower_persistent(void* stream, double* A, int64_t n, in
 extern "C" int gpn_potrf_persistent_supported(int64_t n, int64_t e) { return pp_supported(n, e) ? 1 : 0; }
 
 // The task graph of gpn_potrf_lower_persistent for an n x n factorisation with e extra rows, for inspection (tests replay it on
-// the host): counts5 = {tasks, successor entries, tasks of queue 0, 1, 2}; tasks8 (8 ints per task: type, queue, i, j, k0, k1,
-// predecessors, first successor) and succ are filled when given (capacities in entries).  Returns 0, GPN_E_UNSUPPORTED for a
-// size the persistent driver does not take, -2 / -3 for a buffer that is too small.
-extern "C" int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts5, int32_t* tasks8, int64_t cap_tasks, int32_t* succ,
+// the host): counts6 = {tasks, successor entries, tasks of queue 0, 1, 2, 3}; tasks12 (12 ints per task: type, queue, i, j, k0, k1,
+// predecessors, flags, succ_begin, succ_mid, succ_end, 0) and succ are filled when given (capacities in entries).  Returns 0,
+// GPN_E_UNSUPPORTED for a size the persistent driver does not take, -2 / -3 for a buffer that is too small.
+extern "C" int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts6, int32_t* tasks12, int64_t cap_tasks, int32_t* succ,
                                          int64_t cap_succ) {
   PPlan P;
   const int rc = pp_build(n, e, P);
   if (rc != GPN_OK) return rc;
-  if (counts5) {
-    counts5[0] = (int64_t)P.tasks.size(); counts5[1] = (int64_t)P.succ.size();
-    for (int q = 0; q < PP_NQ; ++q) counts5[2 + q] = P.qcount[q];
+  if (counts6) {
+    counts6[0] = (int64_t)P.tasks.size(); counts6[1] = (int64_t)P.succ.size();
+    for (int q = 0; q < PP_NQ; ++q) counts6[2 + q] = P.qcount[q];
   }
-  if (tasks8) {
+  if (tasks12) {
     if (cap_tasks < (int64_t)P.tasks.size()) return -2;
     for (size_t t = 0; t < P.tasks.size(); ++t) {
       const PTask& k = P.tasks[t];
-      int32_t* o = tasks8 + 8 * t;
-      o[0] = k.type; o[1] = k.queue; o[2] = k.i; o[3] = k.j; o[4] = k.k0; o[5] = k.k1; o[6] = k.ndeps; o[7] = k.succ_begin;
+      int32_t* o = tasks12 + 12 * t;
+      o[0] = k.type; o[1] = k.queue; o[2] = k.i; o[3] = k.j; o[4] = k.k0; o[5] = k.k1; o[6] = k.ndeps; o[7] = k.flags;
+      o[8] = k.succ_begin; o[9] = k.succ_mid; o[10] = k.succ_end; o[11] = 0;
     }
   }
   if (succ) {

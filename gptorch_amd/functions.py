@@ -6,6 +6,7 @@ the native library and DIFFERENTIABLE like the torch ops the reference wraps:
   trtrs(b, a, lower=True)           functions.py:71-76
   lt_log_determinant(L)             functions.py:61-68
   cholesky_inverse(L, upper=False)  functions.py:50-54
+  inverse(x)                        functions.py:57-58
   jit_op(op, x)                     functions.py:20-43
 
 Each is one autograd node: the forward is the native factorisation / solve, the backward a
@@ -197,3 +198,17 @@ class _CholInverse(torch.autograd.Function):
 def cholesky_inverse(x: torch.Tensor, upper=False) -> torch.Tensor:
     """(L L^T)^-1 from the Cholesky factor, or (U^T U)^-1 from an upper one (functions.py:50-54)."""
     return _CholInverse.apply(x, bool(upper))
+
+
+def inverse(x: torch.Tensor) -> torch.Tensor:
+    """x^-1 through the jitter ladder (functions.py:57-58: `jit_op(torch.inverse, x)`).  The reference's callers invert
+    covariance matrices; natively that is the Cholesky route -- `cholesky` (which climbs the ladder of functions.py:20-43 on
+    the device-side info word, adding the same jitter to the diagonal that the reference would add before retrying
+    torch.inverse) followed by `cholesky_inverse` -- two autograd nodes, no LU.  A matrix that is not symmetric has no
+    native path: NotImplementedError (there is no CPU fallback in this package)."""
+    if x.dim() != 2 or x.shape[0] != x.shape[1]:
+        raise ValueError("inverse expects a square matrix")
+    if not torch.equal(x.detach(), x.detach().t()):
+        raise NotImplementedError("gptorch_amd.functions.inverse: symmetric positive definite matrices only "
+                                  "(native Cholesky route; the reference's torch.inverse is a general LU)")
+    return cholesky_inverse(cholesky(x))

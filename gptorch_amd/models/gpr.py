@@ -137,6 +137,16 @@ _LANES = {}          # device -> two HIP streams shared by every batched call (s
 # by (device, batch, n, dy) only, two groups of equal count / N / dy but different kernel kind or ARD shared one buffer and
 # the first group read the second group's results) -- least recently used first out, bounded in entries and bytes;
 # release_batch_buffers() drops them all.
+# scipy methods whose `minimize` holds a module-wide lock while it runs (one restart at a time whatever we do)
+_SCIPY_SERIAL_METHODS = ("COBYLA",)
+_MULTI_START_STALL_S = 2.0       # a round of the scipy multi-start stops waiting for silent restarts after this long
+_MULTI_START_JOIN_S = 10.0
+
+
+class _MultiStartAborted(RuntimeError):
+    """raised inside a restart's objective when the multi-start search it belongs to has ended (interrupt, error)."""
+
+
 _BATCH_BUFFERS = collections.OrderedDict()    # (group key, batch) -> holder dict {"fb": _ops.FactorBatch}
 BATCH_BUFFER_MAX_ENTRIES = 4
 BATCH_BUFFER_MAX_BYTES = 48 << 30
@@ -167,6 +177,15 @@ def _stacked_values(params):
     return torch.stack([p.transform() for p in params])
 
 
+def _place_all(models):
+    """settings.auto_device: CPU-constructed models move to the GPU (once) BEFORE they are grouped -- the grouping looks at
+    m.X.is_cuda, and a model that is still on the CPU would silently fall out of every lock-step group."""
+    for m in models:
+        place = getattr(m, "_auto_place", None)
+        if place is not None:
+            place()
+
+
 def _group_key(m):
     k = m._stationary()
     return (k._kind, tuple(m.X.shape), m.Y.shape[1], int(k.length_scales.numel()), m.X.device)
@@ -188,7 +207,32 @@ def _lockstep_groups(models, for_grad=False):
         if for_grad and any(getattr(p, "prior", None) is not None for p in m.parameters()):
             continue
         groups.setdefault(_group_key(m), []).append(i)
-    return [(key, g) for key, g in groups.items() if len(g) >= 2]
+    out = []
+    for key, g in groups.items():
+        # a lock-step group holds B factor buffers AND (with gradients) a backward workspace of two more N x N matrices per model at
+        # once: groups that would not fit the device's free memory are split into chunks that do (singletons fall to the sequential path)
+        cap = _lockstep_capacity(key, models[g[0]].X.device)
+        for at in range(0, len(g), cap):
+            chunk = g[at:at + cap]
+            if len(chunk) >= 2:
+                out.append((key, chunk))
+    return out
+
+
+LOCKSTEP_MEMORY_FRACTION = 0.7   # of the device's free memory (+ what the lock-step cache already holds) a group may take
+
+
+def _lockstep_capacity(key, device):
+    """how many models of this group key fit one lock-step call: 3 padded N x N matrices per model (factor + the backward's two)."""
+    n = int(key[1][0])
+    ld = -(-n // 128) * 128 + 128
+    per_model = 3 * 8 * (ld + 16) * ld
+    try:
+        free, _total = torch.cuda.mem_get_info(device)
+    except Exception:
+        return 1 << 30
+    held = sum(v["fb"].nbytes() for v in _BATCH_BUFFERS.values() if "fb" in v)
+    return max(2, int(LOCKSTEP_MEMORY_FRACTION * (free + held)) // per_model)
 
 
 def _expression_groups(models):
@@ -246,6 +290,7 @@ def batched_log_likelihood(models, streams=None):
     over the given streams (the current stream itself gives back-to-back execution)."""
     if streams is not None:
         return _batched_on_streams(models, streams)
+    _place_all(models)
     out = [None] * len(models)
     with torch.no_grad():
         pending = []
@@ -303,6 +348,7 @@ def batched_loss_and_grad(models):
     BIT-IDENTICAL to its own `loss(); backward()`; a model whose factorisation fails is replayed alone through the jitter
     ladder; parameters with priors add their model's own log_prior() (model.py:158-197); sizes that refine the quadratic
     form refine it per model.  Composite / dense-K kernels and singletons take the sequential path."""
+    _place_all(models)
     out = [None] * len(models)
     for key, g in _lockstep_groups(models):
         ms = [models[i] for i in g]
@@ -371,19 +417,30 @@ def _multi_start_scipy(models, method, max_iter, verbose):
     import numpy as np
     from scipy.optimize import minimize
     B = len(models)
+    if method in _SCIPY_SERIAL_METHODS:
+        # scipy runs these under a module-wide lock (COBYLA: scipy.optimize._cobyla_py._module_lock): a second restart's
+        # `minimize` cannot even start while the first one sits in its objective, so the restarts cannot post requests together.
+        # One after the other through each model's own optimize() -- what the reference does (base.py:298-320).
+        return [m.optimize(method=method, max_iter=max_iter, verbose=verbose) for m in models]
     cond = threading.Condition()
     pending, answers = {}, {}
     done = [False] * B
     results = [None] * B
+    state = {"abort": None}
     x0 = [m._get_param_array() for m in models]
 
     def make_fun(i):
         def fun(x):
             with cond:
+                if state["abort"] is not None:
+                    raise _MultiStartAborted(state["abort"])
                 pending[i] = np.array(x, dtype=np.float64, copy=True)
                 cond.notify_all()
-                while i not in answers:
+                while i not in answers and state["abort"] is None:
                     cond.wait()
+                if i not in answers:
+                    pending.pop(i, None)
+                    raise _MultiStartAborted(state["abort"])
                 ans = answers.pop(i)
             if isinstance(ans, BaseException):
                 raise ans
@@ -404,70 +461,93 @@ def _multi_start_scipy(models, method, max_iter, verbose):
     threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(B)]
     for t in threads:
         t.start()
-    while True:
-        with cond:
-            while True:
-                active = [i for i in range(B) if not done[i]]
-                if not active or all(i in pending for i in active):
+    try:
+        while True:
+            with cond:
+                stalled = False
+                while True:
+                    active = [i for i in range(B) if not done[i]]
+                    if not active or all(i in pending for i in active):
+                        break
+                    # a restart that neither finishes nor posts (a method that serialises inside scipy, a callback that blocks):
+                    # after the stall time-out the round covers whoever HAS posted -- never a dead wait
+                    if not cond.wait(timeout=_MULTI_START_STALL_S) and pending:
+                        stalled = True
+                        break
+                if not active:
                     break
-                cond.wait()
-            if not active:
-                break
-            batch = {i: pending.pop(i) for i in active}
-        idx = sorted(batch)
-        out = {}
-        try:
-            # Model._loss_and_grad (model.py:123-133) for all requests of the round at once.  The requested vectors travel to the
-            # device as ONE copy and every parameter becomes a slice of it (model.py:66-76 makes one tensor per parameter: 3 small
-            # copies per model and round); the gradients come back as ONE copy.
-            dev = models[idx[0]].X.device
-            flat = torch.as_tensor(np.concatenate([batch[i] for i in idx]), dtype=torch.float64).to(dev)
-            at = 0
-            for i in idx:
-                for p in models[i].parameters():
-                    if p.requires_grad:
-                        nxt = at + p.numel()
-                        p.data = flat[at:nxt].reshape(p.shape)
-                        at = nxt
-                    p.grad = None                    # (a fresh gradient: what zeroing + accumulating gives)
-            losses = batched_loss_and_grad([models[i] for i in idx])
-            trainable = [[p for p in models[i].parameters() if p.requires_grad] for i in idx]
-            allg = torch.cat([p.grad.reshape(-1) for ps in trainable for p in ps] + [l.reshape(-1) for l in losses]).cpu().numpy()
-            lvals = allg[len(allg) - len(idx):]
-            at = 0
-            for k, i in enumerate(idx):
-                cnt = sum(p.numel() for p in trainable[k])
-                grad = np.array(allg[at:at + cnt])
-                at += cnt
-                value = float(lvals[k])
-                print("loss: %s" % value)
-                finite = np.isfinite(grad)
-                if np.all(finite):
-                    out[i] = (float(value), grad.astype(np.float64))
-                else:
-                    print("Warning: inf or nan in gradient: replacing with zeros")
-                    out[i] = (value, np.where(finite, grad, 0.0).astype(np.float64))
-        except BaseException:
-            # one request of the round failed (e.g. the jitter ladder ran out for one model): evaluate them one by one so
-            # that only the restart it belongs to sees the exception
+                batch = {i: pending.pop(i) for i in (active if not stalled else sorted(pending))}
+            idx = sorted(batch)
             out = {}
-            for i in idx:
-                try:
-                    out[i] = models[i]._loss_and_grad(batch[i])
-                except BaseException as exc:
-                    out[i] = exc
+            try:
+                # Model._loss_and_grad (model.py:123-133) for all requests of the round at once.  The requested vectors travel to
+                # the device as ONE copy and every parameter becomes a slice of it (model.py:66-76 makes one tensor per parameter:
+                # 3 small copies per model and round); the gradients come back as ONE copy.
+                dev = models[idx[0]].X.device
+                flat = torch.as_tensor(np.concatenate([batch[i] for i in idx]), dtype=torch.float64).to(dev)
+                at = 0
+                for i in idx:
+                    for p in models[i].parameters():
+                        if p.requires_grad:
+                            nxt = at + p.numel()
+                            p.data = flat[at:nxt].reshape(p.shape)
+                            at = nxt
+                        p.grad = None                    # (a fresh gradient: what zeroing + accumulating gives)
+                losses = batched_loss_and_grad([models[i] for i in idx])
+                trainable = [[p for p in models[i].parameters() if p.requires_grad] for i in idx]
+                allg = torch.cat([p.grad.reshape(-1) for ps in trainable for p in ps] + [l.reshape(-1) for l in losses]).cpu().numpy()
+                lvals = allg[len(allg) - len(idx):]
+                at = 0
+                staged = {}
+                for k, i in enumerate(idx):
+                    cnt = sum(p.numel() for p in trainable[k])
+                    staged[i] = (float(lvals[k]), np.array(allg[at:at + cnt]))
+                    at += cnt
+                for i in idx:                            # (nothing is printed before the whole round has its values)
+                    value, grad = staged[i]
+                    print("loss: %s" % value)
+                    finite = np.isfinite(grad)
+                    if np.all(finite):
+                        out[i] = (value, grad.astype(np.float64))
+                    else:
+                        print("Warning: inf or nan in gradient: replacing with zeros")
+                        out[i] = (value, np.where(finite, grad, 0.0).astype(np.float64))
+            except Exception:
+                # one request of the round failed (e.g. the jitter ladder ran out for one model): evaluate them one by one so
+                # that only the restart it belongs to sees the exception.  (KeyboardInterrupt / SystemExit are not caught here:
+                # they end the whole search through the `finally` below.)
+                out = {}
+                for i in idx:
+                    try:
+                        out[i] = models[i]._loss_and_grad(batch[i])
+                    except Exception as exc:
+                        out[i] = exc
+            with cond:
+                answers.update(out)
+                cond.notify_all()
+    except BaseException as exc:
         with cond:
-            answers.update(out)
+            state["abort"] = exc
+        raise
+    finally:
+        # whatever ended the collecting loop, no worker stays behind waiting for an answer: every pending and every future
+        # request of a restart that is still running is answered with _MultiStartAborted, its `minimize` unwinds, its thread ends
+        with cond:
+            if state["abort"] is None and not all(done):
+                state["abort"] = RuntimeError("multi-start search ended early")
             cond.notify_all()
-    for t in threads:
-        t.join()
+        for t in threads:
+            t.join(timeout=_MULTI_START_JOIN_S)
     for r in results:
         if isinstance(r, BaseException):
             raise r
     return results
 
 
-def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, learning_rate=None, stacked=True):
+STACKED_MAX_N = 2048      # multi_start_optimize(stacked=None): stacked parameter tensors below this many rows, one optimiser per model from it on
+
+
+def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, learning_rate=None, stacked=None):
     """GPModel.optimize (gptorch/models/base.py:111-296) for several INDEPENDENT restarts at once: every iteration is ONE
     lock-step loss + backward over each group of equally shaped models (see batched_loss_and_grad) and ONE optimiser step
     on the group's STACKED raw parameters -- the torch optimisers the reference offers are elementwise (all but LBFGS), so
@@ -478,6 +558,8 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
     stacked=False: no stacked parameter tensors at all -- every model keeps its own optimiser and only the evaluation is shared:
     trajectories BIT-IDENTICAL to each model's own optimize(), at one optimiser step per model and iteration of host work
     (C1 x 64: 6 ms per iteration instead of 1; immaterial from N = 2048 on).
+    stacked=None (the default): the bitwise mode wherever it is free -- groups of models with at least STACKED_MAX_N (2048) rows
+    keep one optimiser per model, smaller ones are stacked.
     Returns (losses [len(models), max_iter] numpy, seconds).  The models' Params hold the final values afterwards.
 
     Stacked groups: as batched_loss_and_grad's stationary groups, and additionally every model of the group trains the same
@@ -493,16 +575,22 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
     import time
     import numpy as np
     from .base import _TORCH_DEFAULT_LR, _SCIPY_METHODS
+    _place_all(models)
     if method in _SCIPY_METHODS:
         print("Scipy.optimize.minimize...")
         tic = time.time()
-        return _multi_start_scipy(models, method, max_iter, verbose), time.time() - tic
+        try:
+            return _multi_start_scipy(models, method, max_iter, verbose), time.time() - tic
+        finally:
+            release_batch_buffers()
     if learning_rate is None and method in _TORCH_DEFAULT_LR:
         learning_rate = _TORCH_DEFAULT_LR[method]
     losses = np.zeros((len(models), max_iter))
     done = [False] * len(models)
     tic = time.time()
-    groups = _lockstep_groups(models, for_grad=True) if (stacked and method in _TORCH_DEFAULT_LR and method != "LBFGS") else []
+    groups = _lockstep_groups(models, for_grad=True) if (stacked is not False and method in _TORCH_DEFAULT_LR and method != "LBFGS") else []
+    if stacked is None:
+        groups = [(key, g) for key, g in groups if key[1][0] < STACKED_MAX_N]      # key[1] = X's shape
     for key, g in groups:
         ms = [models[i] for i in g]
         B = len(ms)
@@ -570,6 +658,7 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
             res = m.optimize(method=method, max_iter=max_iter, verbose=verbose, learning_rate=learning_rate)
             if isinstance(res, tuple):
                 losses[i, :len(res[0])] = res[0]
+    release_batch_buffers()          # the search is over: its lock-step buffers (B factors + backward workspaces) go back to the allocator
     return losses, time.time() - tic
 
 

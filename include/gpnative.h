@@ -120,11 +120,14 @@ int gpn_potrf_lower_persistent(void* stream, double* A, int64_t n, int64_t e, in
                                double* winv, int32_t* info);
 int gpn_potrf_persistent_supported(int64_t n, int64_t e);
 /* The task graph of gpn_potrf_lower_persistent, for inspection (tests replay it on the host in random valid orders):
- * counts5 = {tasks, successor entries, tasks of queue 0 (chain), 1, 2}; tasks8 (8 ints per task: type 0 leaf / 1 solve /
- * 2 update, queue, tile row i, tile column j, K range [k0, k1) in 128-column blocks, predecessor count, index of the first
- * successor -- the successors of task t are succ[tasks8[8 t + 7] .. tasks8[8 (t + 1) + 7]), of the last task up to counts5[1])
- * and succ are filled when given (capacities in entries).  Tasks are listed in a valid sequential order. */
-int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts5, int32_t* tasks8, int64_t cap_tasks, int32_t* succ,
+ * counts6 = {tasks, successor entries, tasks of queue 0 (the critical chains), 1, 2, 3}; tasks12 = 12 ints per task:
+ * type (0 leaf, 1 tile solve, 2 tile update, 3 chain step = solve of (c, c-1) + last update of (c, c) + leaf(c), 4 the
+ * diagonal tile's partial sums), queue, tile row i, tile column j, K range [k0, k1) in 128-column blocks, predecessor count,
+ * flags (1: raw sums to scratch instead of the update, 2: continue from the scratch sums), succ_begin, succ_mid, succ_end, 0 --
+ * the successors succ[succ_begin .. succ_mid) are released when a step's solved tile is out, succ[succ_mid .. succ_end) at the
+ * end of the task.  succ and tasks12 are filled when given (capacities in entries).  Tasks are listed in a valid sequential
+ * order. */
+int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts6, int32_t* tasks12, int64_t cap_tasks, int32_t* succ,
                               int64_t cap_succ);
 
 /* `batch` factorisations of identical shape in LOCK STEP: problem b at A + b*sA (a factor buffer each: sA >=

@@ -410,6 +410,54 @@ def test_mesh_plan_is_consistent(p):
                 assert max(link.values()) <= count // q + stages + 1
 
 
+@pytest.mark.parametrize("p", [2, 4, 8])
+def test_mesh_plan_matches_under_untagged_in_order_semantics(p):
+    """RCCL's point-to-point operations carry NO tag: between an ordered pair (a -> b) the k-th ncclSend that a issues
+    matches the k-th ncclRecv that b issues, in issue order, and a grouped call (ncclGroupStart/End) completes only when
+    all of its operations have their partner IN THE SAME group on the other side.  gloo matches by tag, so the gloo runs
+    cannot show that the schedule is valid there.  Checked statically, for every root, both forms (direct fan-out and
+    scatter + all-gather) and ragged counts: per stage and per ordered pair, the SEQUENCE of (offset, length) that a sends
+    to b is exactly the sequence b receives from a -- same number, same order, same sizes --; no member posts an operation
+    in a stage in which its partner posts none (that group would never complete); and the C restatement the adapter
+    executes (gpn_mesh_plan) has the same property."""
+    import ctypes
+    from gptorch_amd import _native
+    try:
+        rccl = _native.rccl_lib()
+    except Exception:
+        rccl = None
+    members = list(range(p))
+
+    def check(plans, tag):
+        nstage = max(len(pl) for pl in plans.values())
+        for t in range(nstage):
+            out = {}          # (a, b) -> what a sends to b in this stage, in issue order
+            inn = {}          # (a, b) -> what b receives from a in this stage, in issue order
+            for m in members:
+                for kind, peer, off, ln in (plans[m][t] if t < len(plans[m]) else []):
+                    (out if kind == "send" else inn).setdefault((m, peer) if kind == "send" else (peer, m), []).append((off, ln))
+            assert set(out) == set(inn), (tag, t, "an operation without a partner in the same group")
+            for pair in out:
+                assert out[pair] == inn[pair], (tag, t, pair, "send and receive sequences differ: untagged matching would pair the wrong pieces")
+
+    for root in members:
+        for count, stages, direct in [(5, 4, 0), (97, 4, 0), (1000, 3, 0), (1000, 4, 4096), (4099, 4, 0), (1 << 20, 4, 0), (64, 64, 0)]:
+            plans = {m: gdist.mesh_plan(members, root, m, count, stages, direct) for m in members}
+            check(plans, ("python", p, root, count, stages, direct))
+            if rccl is not None:
+                cplans = {}
+                for me in members:
+                    n = rccl.gpn_mesh_plan(p, root, me, count, stages, direct, None, 0)
+                    buf = (ctypes.c_int64 * (5 * max(1, n)))()
+                    assert rccl.gpn_mesh_plan(p, root, me, count, stages, direct, buf, n) == n
+                    st = {}
+                    for k in range(n):
+                        t, kind, peer, off, ln = buf[5 * k:5 * k + 5]
+                        st.setdefault(int(t), []).append(("send" if kind == 0 else "recv", int(peer), int(off), int(ln)))
+                    cplans[me] = [st.get(t, []) for t in range((max(st) + 1) if st else 0)]
+                check(cplans, ("c", p, root, count, stages, direct))
+
+
 def _mesh_worker(rank, world, port, n, tile, dy, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -1417,8 +1417,8 @@ def test_gpr_with_composite_kernels(device, idx):
 @pytest.mark.parametrize("n,d,dy,kind,ard", [(300, 70, 1, "Rbf", False), (400, 100, 2, "Matern52", True)])
 def test_more_than_64_input_dimensions(device, n, d, dy, kind, ard):
     """D > 64: the hyper-parameter sweeps switch to the variant that stages 16 coordinates at a
-    time (LML mode via loss().backward(), dense-G mode via Kernel.K autograd); points gradients
-    are the documented limit."""
+    time (LML mode via loss().backward(), dense-G mode via Kernel.K autograd); so do the gradients
+    w.r.t. the points."""
     x, y = rng.make_regression(n, d, dy, seed=4)
     ls = (0.7 * np.sqrt(d) * (0.5 + rng.uniform(9, d))) if ard else 0.7 * np.sqrt(d)
     m = GPR(x, y, KERN[kind](d, variance=1.2, length_scales=ls, ARD=ard), likelihood=likelihoods.Gaussian(variance=0.05))
@@ -1442,9 +1442,22 @@ def test_more_than_64_input_dimensions(device, n, d, dy, kind, ard):
     (orc.kernel_K(kind, torch.tensor(x), torch.tensor(x[:50]), rv.exp(), rl.exp()) * torch.tensor(wn)).sum().backward()
     assert (k.variance.grad.cpu() - rv.grad).abs().max().item() < 1e-10
     assert (k.length_scales.grad.cpu() - rl.grad).abs().max().item() < 1e-10
+    # gradients w.r.t. the POINTS beyond 64 dimensions (round 6: gpn_kernel_grad_x2's chunked kernel; util.py:73-88 through
+    # kernels.py:149-222 has no limit): both arguments of K(X, X2), and K(X) itself
     Xg = torch.tensor(x, device=device, requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        k.K(Xg).sum().backward()
+    X2g = torch.tensor(x[:50] + 0.1, device=device, requires_grad=True)
+    (k.K(Xg, X2g) * torch.tensor(wn, device=device)).sum().backward()
+    Xo = torch.tensor(x, requires_grad=True)
+    X2o = torch.tensor(x[:50] + 0.1, requires_grad=True)
+    (orc.kernel_K(kind, Xo, X2o, rv.detach().exp(), rl.detach().exp()) * torch.tensor(wn)).sum().backward()
+    assert (Xg.grad.cpu() - Xo.grad).abs().max().item() < 1e-10 * max(1.0, Xo.grad.abs().max().item())
+    assert (X2g.grad.cpu() - X2o.grad).abs().max().item() < 1e-10 * max(1.0, X2o.grad.abs().max().item())
+    ws = rng.normal(29, (n, n))
+    Xs = torch.tensor(x, device=device, requires_grad=True)
+    (k.K(Xs) * torch.tensor(ws, device=device)).sum().backward()
+    Xso = torch.tensor(x, requires_grad=True)
+    (orc.kernel_K(kind, Xso, None, rv.detach().exp(), rl.detach().exp()) * torch.tensor(ws)).sum().backward()
+    assert (Xs.grad.cpu() - Xso.grad).abs().max().item() < 1e-9 * max(1.0, Xso.grad.abs().max().item())
 
 
 def test_repeated_predictions_switch_to_the_explicit_inverse(device):

@@ -349,3 +349,110 @@ def test_bench_self_launch_reports_a_dead_child(tmp_path):
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["value"] is None and d["n_gpus"] == 2 and d["scaling"] == "strong" and "without a result line" in d["error"]
+
+
+def _two_models(x, y):
+    return [GPR(x, y, kernels.Rbf(2, ARD=True)), GPR(x, y, kernels.Rbf(2, variance=1.3, length_scales=0.8, ARD=True))]
+
+
+def _run_with_deadline(fn, seconds):
+    """fn() in a helper thread: (finished in time, result or exception)."""
+    import threading
+    box = {}
+
+    def target():
+        try:
+            box["result"] = fn()
+        except BaseException as exc:              # noqa: BLE001 -- reported to the caller
+            box["error"] = exc
+    t = threading.Thread(target=target, daemon=True)
+    t.start()
+    t.join(seconds)
+    return not t.is_alive(), box
+
+
+@pytest.mark.parametrize("method", base_mod._SCIPY_METHODS)
+def test_multi_start_scipy_never_hangs(oracle_backed, method):
+    """round-5 advisor finding: multi_start_optimize(method="COBYLA") hung forever -- scipy runs COBYLA under a module-wide lock,
+    so the second restart's thread never reached its objective and the collecting loop waited for it.  Every scipy method the
+    reference lists (base.py:203-215) now either returns one result per restart or raises (the Hessian-based ones do, as in the
+    reference) within seconds, and leaves no worker thread behind."""
+    import threading
+    from gptorch_amd.models import multi_start_optimize
+    _, x, y = oracle_backed
+    models = _two_models(x, y)
+    before = set(threading.enumerate())
+    with quiet():
+        finished, box = _run_with_deadline(lambda: multi_start_optimize(models, method=method, max_iter=2), 120)
+    assert finished, "multi_start_optimize(method=%r) did not come back" % method
+    if "result" in box:
+        results, seconds = box["result"]
+        assert len(results) == 2 and all(hasattr(r, "x") for r in results)
+    else:
+        assert isinstance(box["error"], Exception)
+    leftovers = [t for t in threading.enumerate() if t not in before and t.is_alive()]
+    for t in leftovers:
+        t.join(15)
+    assert not [t for t in leftovers if t.is_alive()]
+
+
+def test_multi_start_scipy_is_interruptible(oracle_backed, monkeypatch):
+    """an exception that is not an evaluation failure (KeyboardInterrupt) ends the search: it propagates to the caller, every
+    restart's `minimize` unwinds through _MultiStartAborted and no thread is left waiting for an answer."""
+    import threading
+    from gptorch_amd.models import gpr as gpr_mod
+    _, x, y = oracle_backed
+    models = _two_models(x, y)
+    real = gpr_mod.batched_loss_and_grad
+    calls = {"n": 0}
+
+    def flaky(ms):
+        calls["n"] += 1
+        if calls["n"] == 2:
+            raise KeyboardInterrupt()
+        return real(ms)
+    monkeypatch.setattr(gpr_mod, "batched_loss_and_grad", flaky)
+    before = set(threading.enumerate())
+    with quiet():
+        finished, box = _run_with_deadline(lambda: gpr_mod.multi_start_optimize(models, method="L-BFGS-B", max_iter=5), 120)
+    assert finished
+    assert isinstance(box.get("error"), KeyboardInterrupt)
+    leftovers = [t for t in threading.enumerate() if t not in before and t.is_alive()]
+    for t in leftovers:
+        t.join(15)
+    assert not [t for t in leftovers if t.is_alive()]
+
+
+def test_multi_start_scipy_round_does_not_wait_for_a_silent_restart(oracle_backed, monkeypatch):
+    """the collecting loop's stall time-out: a restart that neither posts a request nor finishes (here: its objective blocks on
+    a lock held elsewhere for a while) does not stop the others from being served."""
+    import threading
+    import time
+    from gptorch_amd.models import gpr as gpr_mod
+    _, x, y = oracle_backed
+    models = _two_models(x, y)
+    monkeypatch.setattr(gpr_mod, "_MULTI_START_STALL_S", 0.2)
+    gate = threading.Event()
+    real_get = GPR._get_param_array
+
+    served = []
+    real = gpr_mod.batched_loss_and_grad
+
+    def spy(ms):
+        served.append(len(ms))
+        if len(served) == 3:
+            gate.set()                       # from now on the slow restart may post too
+        return real(ms)
+    monkeypatch.setattr(gpr_mod, "batched_loss_and_grad", spy)
+    import scipy.optimize
+    real_min = scipy.optimize.minimize
+
+    def slow_minimize(fun, x0, **kw):
+        if np.allclose(x0, real_get(models[1])):
+            gate.wait(30)                    # the second restart sits here while the first is served alone
+        return real_min(fun=fun, x0=x0, **kw)
+    monkeypatch.setattr(scipy.optimize, "minimize", slow_minimize)
+    with quiet():
+        finished, box = _run_with_deadline(lambda: gpr_mod.multi_start_optimize(models, method="L-BFGS-B", max_iter=3), 120)
+    assert finished and "result" in box, box.get("error")
+    assert served[0] == 1, "the first round served the one restart that had posted"

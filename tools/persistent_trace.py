@@ -10,10 +10,10 @@ n = int(sys.argv[1]); R = int(sys.argv[2]) if len(sys.argv) > 2 else 0; dy = int
 dev = torch.device("cuda:0")
 lib = _native.debug_begin()
 st, ptr = _ops._stream(dev), _ops._ptr
-counts = (ctypes.c_int64 * 5)()
+counts = (ctypes.c_int64 * 6)()
 assert lib.gpn_potrf_persistent_plan(n, dy, counts, None, 0, None, 0) == 0
 nt, ns = counts[0], counts[1]
-tasks = np.zeros((nt, 8), dtype=np.int32); succ = np.zeros(ns, dtype=np.int32)
+tasks = np.zeros((nt, 12), dtype=np.int32); succ = np.zeros(ns, dtype=np.int32)
 lib.gpn_potrf_persistent_plan(n, dy, counts, tasks.ctypes.data, nt, succ.ctypes.data, ns)
 x, y = rng.make_regression(n, 8, dy, seed=0)
 X, Y = torch.as_tensor(x).to(dev), torch.as_tensor(y).to(dev)
@@ -35,22 +35,22 @@ t0 = tr[:, 1].min()
 us = lambda v: (v - t0) / 100.0
 pop0, pop1, run, end, rel = (us(tr[:, k]) for k in range(5))
 wg = tr[:, 5] & 0xffffffff; chain = tr[:, 5] >> 32
-print("n %d: %d tasks (queues %d / %d / %d), span %.1f us, info %d" % (n, nt, counts[2], counts[3], counts[4], rel.max(), int(f.info.item())))
-names = {0: "LEAF", 1: "TRSM", 2: "UPD"}
-for ty in (0, 1, 2):
+print("n %d: %d tasks (queues %d / %d / %d / %d), span %.1f us, info %d" % (n, nt, counts[2], counts[3], counts[4], counts[5], rel.max(), int(f.info.item())))
+names = {0: "LEAF", 1: "TRSM", 2: "UPD", 3: "STEP", 4: "PRED"}
+for ty in (0, 3, 4, 1, 2):
     m = tasks[:, 0] == ty
-    for q in (0, 1, 2):
+    for q in (0, 1, 2, 3):
         mm = m & (tasks[:, 1] == q)
         if not mm.any(): continue
-        Ks = sorted(set((tasks[mm, 5] - tasks[mm, 4]).tolist())) if ty == 2 else [0]
+        Ks = sorted(set((tasks[mm, 5] - tasks[mm, 4] + 1000 * tasks[mm, 7]).tolist())) if ty in (2, 3, 4) else [0]
         for K in Ks:
-            m3 = mm & ((tasks[:, 5] - tasks[:, 4]) == K) if ty == 2 else mm
-            print("  %-4s q%d K=%4d: %5d tasks  run %7.1f us avg (min %6.1f max %7.1f)  acquire %4.1f  release %4.1f  wait-in-pop %7.1f" % (
-                names[ty], q, K * 128, m3.sum(), (end - run)[m3].mean(), (end - run)[m3].min(), (end - run)[m3].max(),
+            m3 = mm & ((tasks[:, 5] - tasks[:, 4] + 1000 * tasks[:, 7]) == K) if ty in (2, 3, 4) else mm
+            print("  %-4s q%d K=%6d: %5d tasks  run %7.1f us avg (min %6.1f max %7.1f)  acquire %4.1f  release %4.1f  wait-in-pop %7.1f" % (
+                names[ty], q, (K % 1000) * 128 + 100000 * (K // 1000), m3.sum(), (end - run)[m3].mean(), (end - run)[m3].min(), (end - run)[m3].max(),
                 (run - pop1)[m3].mean(), (rel - end)[m3].mean(), (pop1 - pop0)[m3].mean()))
 # the critical chain: leaf k -> solve (k+1, k) -> last update of (k+1, k+1) -> leaf k+1
 T = n // 128
-leaf = {int(tasks[t, 2]): t for t in range(nt) if tasks[t, 0] == 0}
+leaf = {int(tasks[t, 2]): t for t in range(nt) if tasks[t, 0] in (0, 3)}
 print("  chain: leaf k: [popped .. released]; then when leaf k+1 was popped")
 for k in list(range(0, min(T - 1, 12))) + list(range(max(12, T - 4), T - 1)):
     a, b = leaf[k], leaf[k + 1]
