@@ -263,6 +263,30 @@ REFINE_MIN_N = 12288
 JITTER_TRIES = 10  # functions.py:21 max_tries
 
 
+# ---- evaluations without a host read-back (hipGraph capture of an optimiser step: models/base.py _optimize_captured) --------
+# While a DeferredInfo is active, lml_forward enqueues ONE attempt (no jitter), leaves the factorisation's `info` word on the
+# device and ORs "info != 0" into the holder's flag instead of reading it back: nothing in the evaluation synchronises the host,
+# so evaluation + closed-form backward + optimiser step capture into one graph.  The caller looks at the flag every so many
+# replays and repeats a chunk that saw a failure through the ordinary path (jitter ladder of functions.py:20-43).
+_DEFERRED = []
+
+
+class DeferredInfo:
+    def __init__(self, device):
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def __enter__(self):
+        _DEFERRED.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _DEFERRED.pop()
+        return False
+
+    def note(self, info):
+        torch.maximum(self.flag, (info != 0).to(torch.int32), out=self.flag)
+
+
 def _ladder(attempt, tries=None):
     """functions.py:20-43: plain try, then +10^(-max_tries+i) I for i = 0..max_tries-1 (max_tries = 10 by default), then
     RuntimeError("Max tries exceeded.").  `attempt(jitter)` -> info."""
@@ -433,6 +457,27 @@ def lml_forward(kind, X, R, variance, length_scales, noise, factor=None, refine=
     do_refine = (n >= refine_min_n()) if refine is None else bool(refine)
     import os
     save_k = os.environ.get("GPN_REFINE_SAVED_K", "0") == "1"
+    if _DEFERRED:
+        # one attempt, no read-back (see DeferredInfo): the caller inspects the flag later
+        save_k = False
+        _no_sync = _DEFERRED[-1]
+        f.generation += 1
+        f._winv_full = None
+        if do_refine and f._refine_work is None:
+            f._refine_work = torch.empty(max(1, int(lib.gpn_lml_refine_work_bytes(n, e)) // 8), dtype=torch.float64, device=X.device)
+        st = lib.gpn_lml_forward(_stream(X.device), KINDS[kind], _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e,
+                                 _ptr(var), _ptr(ls), ls.numel(), _ptr(nz0), _ptr(f.A), f.ld, _ptr(f.winv),
+                                 _ptr(f.info), _ptr(out))
+        _native.check(st, "gpn_lml_forward")
+        if do_refine:
+            st = lib.gpn_lml_refine(_stream(X.device), KINDS[kind], _ptr(Xc), n, Xc.shape[1], _ptr(Rc), None, e,
+                                    _ptr(var), _ptr(ls), ls.numel(), _ptr(nz0), _ptr(f.A), f.ld, _ptr(f.winv),
+                                    _ptr(f._refine_work), _ptr(out))
+            _native.check(st, "gpn_lml_refine")
+        _no_sync.note(f.info)
+        f.jitter_rung = -1
+        f.refined = do_refine
+        return f, out
     f.jitter_rung = _ladder(attempt)
     f.refined = do_refine
     return f, out

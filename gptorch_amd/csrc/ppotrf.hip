@@ -47,8 +47,8 @@ namespace gpn {
 
 enum { PT_LEAF = 0, PT_TRSM = 1, PT_UPD = 2, PT_STEP = 3, PT_PRED = 4, PT_SUB = 5 };
 // UPD: PF_ACC_OUT = raw sums to the column's scratch tile (PRE2); SUB / STEP: PF_ACC_IN = continue from the scratch sums;
-// SUB: PF_HALF1 = rows 64 .. 127 of the tile (else rows 0 .. 63)
-enum { PF_ACC_OUT = 1, PF_ACC_IN = 2, PF_HALF1 = 4 };
+// SUB / TRSM: PF_HALF0 / PF_HALF1 = rows 0 .. 63 / 64 .. 127 of the tile only (neither: the whole tile -- the extra-rows tile)
+enum { PF_ACC_OUT = 1, PF_ACC_IN = 2, PF_HALF1 = 4, PF_HALF0 = 8 };
 struct PTask {                 // 32 bytes
   int16_t type, queue;
   int16_t i, j, k0, k1;        // tile row / column (TRSM, LEAF, STEP: j = the column block); K range in column blocks [k0, k1)
@@ -60,8 +60,12 @@ struct PTask {                 // 32 bytes
 static_assert(sizeof(PTask) == 32, "PTask layout");
 
 // runtime words (ints): control, then per queue a head and a tail on lines of their own
-constexpr int PP_NQ = 4;
-constexpr int RT_TICKET = 0, RT_COMPLETED = 1, RT_DONE = 2, RT_ABORT = 3, RT_Q0 = 32, RT_QSTRIDE = 64, RT_FIXED = RT_Q0 + PP_NQ * RT_QSTRIDE;
+constexpr int PP_MAXQ = 64;    // queue 0: the chains' tasks; 1 + 2 p, 2 + 2 p: tasks whose OUTPUT column lies in outer panel p (near / far rows)
+constexpr int PP_BAND = 3;     // solves / short updates of tile rows at most this far below their column go to the chain queue
+// runtime words (ints): control, then per queue a head and a tail on lines of their own, then (read-only) per queue its task
+// count and the offset of its slots
+constexpr int RT_TICKET = 0, RT_COMPLETED = 1, RT_DONE = 2, RT_ABORT = 3, RT_EPOCH = 64, RT_Q0 = 128, RT_QSTRIDE = 64;      // (RT_EPOCH on a line of its own)
+constexpr int RT_QINFO = RT_Q0 + PP_MAXQ * RT_QSTRIDE, RT_FIXED = RT_QINFO + 2 * PP_MAXQ;
 // scratch per column block: the diagonal tile's 36 lower 16 x 16 blocks (raw sums, [block][r][lane]) + one 128 x 128 tile
 constexpr int64_t PP_SCR_DIAG = 36 * 256, PP_SCR_SUB = LEAF * LEAF, PP_SCR_SLOT = PP_SCR_DIAG + PP_SCR_SUB;
 
@@ -77,7 +81,7 @@ struct PArgs {
   double* scratch;             // PP_SCR_SLOT doubles per column block
   int ntasks;
   int off_dep;
-  int off_slots[PP_NQ];
+  int nq;                      // queues in use
   int R;                       // chain workgroups
   int spin_limit;
   unsigned long long* trace;   // tools' build: 4 stamps (100 MHz clock) + ticket per task, or NULL
@@ -86,42 +90,85 @@ struct PArgs {
 __device__ __forceinline__ int pp_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pp_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// thread 0: the next task of this workgroup's queues, -1 when the factorisation is over (or aborted)
-__device__ __forceinline__ int pp_pop(const PArgs& a, const bool chain) {
+// thread 0: one task of queue q if it has any (-1: empty; -2: aborted)
+__device__ __forceinline__ int pp_take(const PArgs& a, const int q, int h, const int t) {
   int* rt = a.rt;
-  const int order[4] = {chain ? 0 : 2, chain ? 1 : 3, chain ? -1 : 1, chain ? -1 : 0};
+  int* head = rt + RT_Q0 + RT_QSTRIDE * q;
+  while (h < t) {
+    int expect = h;
+    if (__hip_atomic_compare_exchange_strong(head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      const int* slot = rt + rt[RT_QINFO + 2 * q + 1] + h;
+      int task, s2 = 0;
+      while ((task = pp_ld(slot)) < 0) {               // the producer bumped the tail and is about to fill the slot
+        if (++s2 > a.spin_limit) { pp_st(rt + RT_ABORT, 3); return -2; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      return task;
+    }
+    h = expect;                                        // somebody else took it
+  }
+  return -1;
+}
+
+// thread 0: the next task for this workgroup, -1 when the factorisation is over (or aborted).
+// EARLIEST NEED FIRST.  Queue 0 holds the chains' tasks (steps, the tiles right below the diagonal): chain workgroups look there
+// first, the others last.  Every other task sits in the queue of the outer panel its OUTPUT TILE ROW lies in: the chain needs row
+// i complete when it reaches column i, and a task on row i reads nothing of the rows below it -- so rows are served top down,
+// `qmin` = the first queue that still has tasks to hand out (its head has not reached its task count yet).  With queues by task
+// KIND, or by the output COLUMN's panel, long outer-panel tiles of far rows (or the short tasks of far rows) were served before
+// what the next steps were waiting for, and every outer panel ended with the chain waiting for milliseconds
+// (profiles/r6_persistent_trace_*.txt).
+__device__ __forceinline__ int pp_pop(const PArgs& a, const bool chain, int& qmin) {
+  int* rt = a.rt;
+  const int nq = a.nq;
   for (int spins = 0;; ++spins) {
+    // the push epoch BEFORE the scan: an idle workgroup then watches this ONE word instead of sweeping every queue's head and
+    // tail (170 idle workgroups sweeping 17 queues slowed every running task by 1.3-2 x: MI355X_MICROARCH.md, polling-cost)
+    const int epoch = pp_ld(rt + RT_EPOCH);
+    if (chain) {
+      const int t = pp_take(a, 0, pp_ld(rt + RT_Q0), pp_ld(rt + RT_Q0 + 32));
+      if (t != -1) return t < 0 ? -1 : t;
+    }
+    while (qmin < nq && pp_ld(rt + RT_Q0 + RT_QSTRIDE * qmin) >= rt[RT_QINFO + 2 * qmin]) ++qmin;
+    for (int base = qmin; base < nq; base += 8) {
+      int hh[8], tt[8];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int q = order[o];
-      if (q < 0) continue;
-      int* head = rt + RT_Q0 + RT_QSTRIDE * q;
-      int* tail = head + 32;
-      int h = pp_ld(head);
-      const int t = pp_ld(tail);
-      while (h < t) {
-        int expect = h;
-        if (__hip_atomic_compare_exchange_strong(head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          const int* slot = rt + a.off_slots[q] + h;
-          int task, s2 = 0;
-          while ((task = pp_ld(slot)) < 0) {           // the producer bumped the tail and is about to fill the slot
-            if (++s2 > a.spin_limit) { pp_st(rt + RT_ABORT, 3); return -1; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          return task;
+      for (int o = 0; o < 8; ++o) {                     // eight heads and tails in flight at once
+        const int q = base + o;
+        hh[o] = tt[o] = 0;
+        if (q < nq) {
+          hh[o] = pp_ld(rt + RT_Q0 + RT_QSTRIDE * q);
+          tt[o] = pp_ld(rt + RT_Q0 + RT_QSTRIDE * q + 32);
         }
-        h = expect;                                    // somebody else took it
+      }
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        if (hh[o] < tt[o]) {
+          const int t = pp_take(a, base + o, hh[o], tt[o]);
+          if (t != -1) return t < 0 ? -1 : t;
+        }
       }
     }
+    if (!chain) {
+      const int t = pp_take(a, 0, pp_ld(rt + RT_Q0), pp_ld(rt + RT_Q0 + 32));
+      if (t != -1) return t < 0 ? -1 : t;
+    }
+    // nothing anywhere: sleep until somebody pushes (or the factorisation ends)
+    for (int idle = 0;; ++idle) {
+      if (pp_ld(rt + RT_EPOCH) != epoch) break;
+      if ((idle & 15) == 15 && (pp_ld(rt + RT_DONE) | pp_ld(rt + RT_ABORT))) return -1;
+      if (idle > a.spin_limit) { pp_st(rt + RT_ABORT, 2); return -1; }
+      if (idle < 8) __builtin_amdgcn_s_sleep(8);
+      else __builtin_amdgcn_s_sleep(32);
+    }
     if (pp_ld(rt + RT_DONE) | pp_ld(rt + RT_ABORT)) return -1;
-    if (spins > a.spin_limit) { pp_st(rt + RT_ABORT, 2); return -1; }
-    __builtin_amdgcn_s_sleep(4);
   }
 }
 
-// wave 0, after the workgroup's stores have drained: release the successors
+// one wave, after the workgroup's stores have drained: release the successors succ[sbegin .. send); last: the task is complete
 __device__ __forceinline__ void pp_notify(const PArgs& a, const int sbegin, const int send, const bool last, const int lane) {
   int* rt = a.rt;
+  bool pushed = false;
   for (int base = sbegin; base < send; base += 64) {
     const int idx = base + lane;
     int s = -1, q = -1;
@@ -132,25 +179,32 @@ __device__ __forceinline__ void pp_notify(const PArgs& a, const int sbegin, cons
       ready = old == 1;
       if (ready) q = a.tasks[s].queue;
     }
-#pragma unroll
-    for (int qq = 0; qq < PP_NQ; ++qq) {
+    // the ready ones, queue by queue (usually one or two queues): one tail bump per queue, then every lane fills its slot
+    unsigned long long todo = __ballot(ready);
+    while (todo) {
+      const int first = __ffsll((long long)todo) - 1;
+      const int qq = __shfl(q, first, 64);
       const bool mine = ready && q == qq;
       const unsigned long long m = __ballot(mine);
-      if (m == 0) continue;
       const int cnt = __popcll(m);
-      const int leader = __ffsll((long long)m) - 1;
       int basei = 0;
-      if (lane == leader) basei = __hip_atomic_fetch_add(rt + RT_Q0 + RT_QSTRIDE * qq + 32, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      basei = __shfl(basei, leader, 64);
+      if (lane == first) basei = __hip_atomic_fetch_add(rt + RT_Q0 + RT_QSTRIDE * qq + 32, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      basei = __shfl(basei, first, 64);
       if (mine) {
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        pp_st(rt + a.off_slots[qq] + basei + rank, s);
+        pp_st(rt + rt[RT_QINFO + 2 * qq + 1] + basei + rank, s);
       }
+      todo &= ~m;
+      pushed = true;
     }
   }
+  if (pushed && lane == 0) __hip_atomic_fetch_add(rt + RT_EPOCH, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (last && lane == 0) {
     const int c = __hip_atomic_fetch_add(rt + RT_COMPLETED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (c == a.ntasks - 1) pp_st(rt + RT_DONE, 1);
+    if (c == a.ntasks - 1) {
+      pp_st(rt + RT_DONE, 1);
+      __hip_atomic_fetch_add(rt + RT_EPOCH, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // wake the sleepers
+    }
   }
 }
 
@@ -315,38 +369,31 @@ __device__ __forceinline__ void pp_pred(const PArgs& a, const PTask& tk, const i
   }
 }
 
-// SUB: the LAST 128-column block (k1 - 1) of the update of tile (i, j) -- the tile below the next diagonal block, which the next
-// step's solve waits for -- for 64 of its rows:  C -= (sums so far) + X(i, k1-1) X(j, k1-1)^T.  Two such tasks share the tile, on
-// two compute units: the update sits on the second critical chain (solve of (c+1, c-1) -> this -> next step) and the generic
-// 128 x 128 tile task took 37-43 us there against a window of ~32.  K = 128 is the whole problem (colpanel.hip's scheme): the
-// left operand's 64 rows are parked in LDS with all loads in flight at once, a wave keeps its 16 columns of the right operand
-// in registers; sums, K order and epilogue are gemm_tile.h's for the same entries (accumulators from zero or from the
-// scratch sums, 8-k groups in order, C = fma(1, C, -sums)).
+// SUB: the update of 64 rows of tile (i, j) by the K group [k0, k1) of one or two 128-column blocks -- every update that is not
+// an outer panel's: next-column (K = 128), trapezoid (K = 256), and the last block of the column's last update for the tile
+// below the next diagonal block (PF_ACC_IN: the earlier blocks' sums come from scratch).  Half tiles on two compute units:
+// these updates and the solves between them form a chain PER TILE ROW through the columns of an outer panel (solve (i,k) ->
+// update (i,k+1) -> solve (i,k+1) -> ...), which as whole-tile tasks through the generic contraction took ~65 us per column
+// against the diagonal chain's ~55 -- every outer panel ended with the steps waiting for the rows (profiles/r6_persistent_*).
+// K is the whole problem (colpanel.hip's scheme): the left operand's 64 rows are parked in LDS with all loads in flight at once,
+// a wave keeps its 16 columns of the right operand in registers; sums, K order and epilogue are gemm_tile.h's for the same
+// entries (accumulators from zero or from the scratch sums, 8-k groups in order, C = fma(1, C, -sums)).
 __device__ __forceinline__ void pp_sub(const PArgs& a, const PTask& tk, const int tid) {
   extern __shared__ __attribute__((aligned(16))) char pp_lds[];
   const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = (tk.flags & PF_HALF1) ? 1 : 0;
-  const int kb = tk.k1 - 1;
-  const double* Ai = a.A + ((int64_t)tk.i * LEAF + 64 * h) * a.lda + (int64_t)kb * LEAF;     // X(i, kb), rows 64 h ..
-  const double* Bj = a.A + (int64_t)tk.j * LEAF * a.lda + (int64_t)kb * LEAF;               // X(j, kb)
+  const int rows = tk.i < a.T ? 64 : a.e;                  // (the extra-rows tile: one task, its e rows)
+  const bool diag = tk.i == tk.j;
+  const double* Ai = a.A + ((int64_t)tk.i * LEAF + 64 * h) * a.lda;                          // row panel of the output rows
+  const double* Bj = a.A + (int64_t)tk.j * LEAF * a.lda;                                     // row panel of the output columns
   double* C = a.A + ((int64_t)tk.i * LEAF + 64 * h) * a.lda + (int64_t)tk.j * LEAF;
   constexpr int PER = (64 * 64 + L16_THREADS - 1) / L16_THREADS;                              // 6
-  pd2 v[PER];
-#pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int idx = tid + u * L16_THREADS;
-    v[u] = idx < 64 * 64 ? *reinterpret_cast<const pd2*>(Ai + (int64_t)(idx >> 6) * a.lda + (idx & 63) * 2) : pd2{0.0, 0.0};
-  }
   const bool mm = wave < 8;
   const int ct = wave & 7;
-  pd2 b[16];
   pd4 acc[4];
   double cold[4][4];
   if (mm) {
-    const double* bsrc = Bj + (int64_t)(ct * 16 + lr) * a.lda + 2 * lq;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) b[j] = *reinterpret_cast<const pd2*>(bsrc + 8 * j);
     if (tk.flags & PF_ACC_IN) {
       // gemm_tile.h's dump of the 128 x 128 tile (8 waves of 32 x 64): row tile I, column tile ct -> wave (I / 2) * 2 + ct / 4
       const double* scr = a.scratch + (int64_t)tk.j * PP_SCR_SLOT + PP_SCR_DIAG;
@@ -362,38 +409,68 @@ __device__ __forceinline__ void pp_sub(const PArgs& a, const PTask& tk, const in
       for (int i = 0; i < 4; ++i) acc[i] = pd4{0.0, 0.0, 0.0, 0.0};
     }
   }
+  // one 128-column block; last_c: the group's last block -- the old tile is requested behind its operands (the staging registers
+  // are free again by then) and needed only after its MFMAs
+  auto block = [&](const int kb, auto last_c) {
+    constexpr bool last = decltype(last_c)::value;
+    pd2 v[PER];
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int idx = tid + u * L16_THREADS;
-    if (idx < 64 * 64) *reinterpret_cast<pd2*>(pp_lds + (idx >> 6) * PP_LDS_ROW + (idx & 63) * 16) = v[u];
-  }
-  __syncthreads();
-  if (mm) {
-    // the old tile: requested here (the staging registers are free again), needed behind the MFMAs
+    for (int u = 0; u < PER; ++u) {
+      const int idx = tid + u * L16_THREADS;
+      const int row = idx >> 6;
+      v[u] = (idx < 64 * 64 && row < rows) ? *reinterpret_cast<const pd2*>(Ai + (int64_t)row * a.lda + (int64_t)kb * LEAF + (idx & 63) * 2) : pd2{0.0, 0.0};
+    }
+    pd2 b[16];
+    if (mm) {
+      const double* bsrc = Bj + (int64_t)(ct * 16 + lr) * a.lda + (int64_t)kb * LEAF + 2 * lq;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 16; ++j) b[j] = *reinterpret_cast<const pd2*>(bsrc + 8 * j);
+    }
+    if (kb > tk.k0) __syncthreads();                       // every wave is done with the previous block's rows
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cold[i][r] = C[(int64_t)(i * 16 + lq + 4 * r) * a.lda + ct * 16 + lr];
+    for (int u = 0; u < PER; ++u) {
+      const int idx = tid + u * L16_THREADS;
+      if (idx < 64 * 64) *reinterpret_cast<pd2*>(pp_lds + (idx >> 6) * PP_LDS_ROW + (idx & 63) * 16) = v[u];
+    }
+    __syncthreads();
+    if (mm) {
+      if constexpr (last) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const pd2 av = *reinterpret_cast<const pd2*>(pp_lds + (i * 16 + lr) * PP_LDS_ROW + (4 * j + lq) * 16);
-        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b[j].x, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b[j].y, acc[i], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) {
+            const int row = i * 16 + lq + 4 * r;
+            cold[i][r] = row < rows ? C[(int64_t)row * a.lda + ct * 16 + lr] : 0.0;
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const pd2 av = *reinterpret_cast<const pd2*>(pp_lds + (i * 16 + lr) * PP_LDS_ROW + (4 * j + lq) * 16);
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b[j].x, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b[j].y, acc[i], 0, 0, 0);
+        }
       }
     }
+  };
+#pragma unroll 1
+  for (int kb = tk.k0; kb < tk.k1 - 1; ++kb) block(kb, std::false_type{});
+  block(tk.k1 - 1, std::true_type{});
+  if (mm) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        __hip_atomic_store(C + (int64_t)(i * 16 + lq + 4 * r) * a.lda + ct * 16 + lr, fma(1.0, cold[i][r], -1.0 * acc[i][r]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lq + 4 * r, col = ct * 16 + lr;
+        if (row < rows && (!diag || col <= 64 * h + row))
+          __hip_atomic_store(C + (int64_t)row * a.lda + col, fma(1.0, cold[i][r], -1.0 * acc[i][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
   }
 }
 
 // STEP(c) up to the leaf: solve of tile (c, c-1), release of its readers, the diagonal tile's last update
-__device__ __forceinline__ void pp_step(const PArgs& a, const PTask& tk, const int tid) {
+__device__ __forceinline__ void pp_step(const PArgs& a, const PTask& tk, const int task_index, const int tid) {
   extern __shared__ __attribute__((aligned(16))) char pp_lds[];
   const int lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -403,7 +480,10 @@ __device__ __forceinline__ void pp_step(const PArgs& a, const PTask& tk, const i
   double* Ccc = a.A + (int64_t)c * LEAF * (a.lda + 1);
   pp_trsm_tile<true>(a.A + (int64_t)c * LEAF * a.lda + (int64_t)(c - 1) * LEAF, a.lda, LEAF, a.winv + (int64_t)(c - 1) * LEAF * LEAF, tid);
   // X(c, c-1) is out (stores drained, barrier passed): an idle wave releases its readers while the matrix waves go on
-  if (wave == 8) pp_notify(a, tk.succ_begin, tk.succ_mid, false, lane);
+  if (wave == 8) {
+    pp_notify(a, tk.succ_begin, tk.succ_mid, false, lane);
+    if (a.trace && lane == 0) a.trace[8 * (size_t)task_index + 6] = __builtin_amdgcn_s_memrealtime();      // phase 1 released
+  }
   // the sums so far: PRED(c)'s over the earlier blocks of the group (the builder makes one whenever the group has any), or zero
   pd4 dacc[PP_DQ];
   if ((tk.flags & PF_ACC_IN) && wave < 8) {
@@ -454,10 +534,11 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
   __syncthreads();
   const bool chain = s_role != 0;
   unsigned long long t_pop0 = 0, t_pop1 = 0, t_run = 0;
+  int qmin = 1;
   for (;;) {
     if (tid == 0) {
       if (a.trace) t_pop0 = __builtin_amdgcn_s_memrealtime();
-      const int t = pp_pop(a, chain);
+      const int t = pp_pop(a, chain, qmin);
       s_task = t;
       if (a.trace) t_pop1 = __builtin_amdgcn_s_memrealtime();
       if (t >= 0) {
@@ -474,9 +555,10 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
     int tid_it = tid;
     asm volatile("" : "+v"(tid_it));
     const PTask tk = a.tasks[task];
-    const int rows_i = tk.i < a.T ? LEAF : a.e;
+    const int half = (tk.flags & PF_HALF1) ? 1 : 0;
+    const int rows_i = tk.i < a.T ? ((tk.flags & (PF_HALF0 | PF_HALF1)) ? 64 : LEAF) : a.e;
     if (tk.type == PT_LEAF || tk.type == PT_STEP) {
-      if (tk.type == PT_STEP) pp_step(a, tk, tid_it);
+      if (tk.type == PT_STEP) pp_step(a, tk, task, tid_it);
       Leaf16Args la;
       la.A = a.A + (int64_t)tk.i * LEAF * (a.lda + 1);
       la.lda = a.lda;
@@ -487,7 +569,8 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
       la.sA = la.sW = la.sInfo = 0;
       leaf16_body<false, true>(la, nullptr, 0, tid_it);
     } else if (tk.type == PT_TRSM) {
-      pp_trsm_tile<false>(a.A + (int64_t)tk.i * LEAF * a.lda + (int64_t)tk.j * LEAF, a.lda, rows_i, a.winv + (int64_t)tk.j * LEAF * LEAF, tid_it);
+      pp_trsm_tile<false>(a.A + ((int64_t)tk.i * LEAF + 64 * half) * a.lda + (int64_t)tk.j * LEAF, a.lda, rows_i,
+                          a.winv + (int64_t)tk.j * LEAF * LEAF, tid_it);
     } else if (tk.type == PT_PRED) {
       pp_pred(a, tk, tid_it);
     } else if (tk.type == PT_SUB) {
@@ -519,7 +602,7 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
     if (a.trace && tid == 0) t_end = __builtin_amdgcn_s_memrealtime();
     if (wave == 0) pp_notify(a, tk.succ_mid, tk.succ_end, true, lane);
     if (a.trace && tid == 0) {
-      unsigned long long* o = a.trace + 6 * (size_t)task;
+      unsigned long long* o = a.trace + 8 * (size_t)task;
       o[0] = t_pop0; o[1] = t_pop1; o[2] = t_run; o[3] = t_end; o[4] = __builtin_amdgcn_s_memrealtime();
       o[5] = ((unsigned long long)(chain ? 1 : 0) << 32) | (unsigned)blockIdx.x;
     }
@@ -535,9 +618,10 @@ struct PPlan {
   std::vector<PTask> tasks;
   std::vector<int> succ;
   std::vector<int> dep0;
-  std::vector<int> initial[PP_NQ];
-  int qcount[PP_NQ] = {0, 0, 0, 0};
-  int off_dep = 0, off_slots[PP_NQ] = {0, 0, 0, 0}, rt_ints = 0;
+  int nq = 0;
+  std::vector<int> initial[PP_MAXQ];
+  int qcount[PP_MAXQ] = {};
+  int off_dep = 0, off_slots[PP_MAXQ] = {}, rt_ints = 0;
 };
 
 static bool pp_supported(int64_t n, int64_t e) {
@@ -581,11 +665,16 @@ static int pp_build(int64_t n, int64_t e, PPlan& P) {
     preds.push_back(d);
     return (int)P.tasks.size() - 1;
   };
-  // queue of an ordinary task: 1 = inside one outer panel's diagonal triangle (not a top-level update), 2 = row panel at most
-  // one outer panel below the column panel, 3 = the bulk
-  auto queue_of = [&](int i, int j, bool top) {
-    const int pi = panel(i), pj = panel(j);
-    return (!top && pi == pj) ? 1 : (pi - pj <= 1 ? 2 : 3);
+  // queue of an ordinary task: by the outer panel its output tile ROW lies in (pp_pop: earliest need first) -- the chain needs
+  // tile row i complete when it reaches column i, and what a task on row i reads from other rows are rows ABOVE i --; the
+  // extra-rows tile last.  The band of PP_BAND tile rows below the diagonal feeds the chains within a few steps: the chain queue.
+  const int NP = (T + OW - 1) / OW;
+  P.nq = 1 + NP + 1;
+  if (P.nq > PP_MAXQ) return GPN_E_UNSUPPORTED;
+  auto queue_of = [&](int i, int j, int kl, bool top) {
+    (void)kl;
+    if (!top && i - j <= PP_BAND && i < T) return 0;
+    return 1 + (i < T ? i / OW : NP);
   };
   // start of the K group whose update is the LAST one of column c's tiles (it ends at column c - 1)
   auto group_start = [&](int c) { return c % PW != 0 ? c - 1 : (c % OW != 0 ? c - PW : c - OW); };
@@ -599,13 +688,26 @@ static int pp_build(int64_t n, int64_t e, PPlan& P) {
       Deps pre;
       if (k1 - k0 >= 2) pre = Deps{Dep{add(PT_UPD, i, j, k0, kl, PF_ACC_OUT, 0, {trsm[at(i, kl - 1)], trsm[at(j, kl - 1)]}), 2}};
       const int fl = pre.empty() ? 0 : PF_ACC_IN;
-      const int h0 = add(PT_SUB, i, j, kl, k1, fl, 0, {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)], pre});
+      const int h0 = add(PT_SUB, i, j, kl, k1, fl | PF_HALF0, 0, {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)], pre});
       const int h1 = add(PT_SUB, i, j, kl, k1, fl | PF_HALF1, 0, {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)], pre});
       lastw[at(i, j)] = Deps{Dep{h0, 2}, Dep{h1, 2}};
       return;
     }
-    const int id = add(PT_UPD, i, j, k0, k1, 0, queue_of(i, j, top), {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)]});
-    lastw[at(i, j)] = Deps{Dep{id, 2}};
+    if (top) {                                           // an outer panel's update: the generic 128 x 128 tile task
+      const int id = add(PT_UPD, i, j, k0, k1, 0, queue_of(i, j, kl, top), {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)]});
+      lastw[at(i, j)] = Deps{Dep{id, 2}};
+      return;
+    }
+    // next-column update / trapezoid: two half-tile tasks (one for the extra-rows tile)
+    const int q = queue_of(i, j, kl, false);
+    if (i < T) {
+      const int h0 = add(PT_SUB, i, j, k0, k1, PF_HALF0, q, {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)]});
+      const int h1 = add(PT_SUB, i, j, k0, k1, PF_HALF1, q, {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)]});
+      lastw[at(i, j)] = Deps{Dep{h0, 2}, Dep{h1, 2}};
+    } else {
+      const int id = add(PT_SUB, i, j, k0, k1, 0, q, {trsm[at(i, kl)], trsm[at(j, kl)], lastw[at(i, j)]});
+      lastw[at(i, j)] = Deps{Dep{id, 2}};
+    }
   };
   for (int p0 = 0; p0 < T; p0 += PW) {
     const int pend = std::min(p0 + PW, T);
@@ -625,9 +727,15 @@ static int pp_build(int64_t n, int64_t e, PPlan& P) {
           trsm[at(c, k)] = lastw[at(c, k)] = Deps{Dep{id, 1}};
           leafof[c] = lastw[at(c, c)] = Deps{Dep{id, 2}};
         } else {
-          const int q = (i == k + 2 && i < T) ? 0 : queue_of(i, k, false);      // solve of (k + 2, k): second critical chain
-          const int id = add(PT_TRSM, i, k, k, k + 1, 0, q, {leafof[k], lastw[at(i, k)]});
-          trsm[at(i, k)] = lastw[at(i, k)] = Deps{Dep{id, 2}};
+          const int q = queue_of(i, k, k, false);
+          if (i < T) {                                   // two half-tile solves (rows are independent)
+            const int h0 = add(PT_TRSM, i, k, k, k + 1, PF_HALF0, q, {leafof[k], lastw[at(i, k)]});
+            const int h1 = add(PT_TRSM, i, k, k, k + 1, PF_HALF1, q, {leafof[k], lastw[at(i, k)]});
+            trsm[at(i, k)] = lastw[at(i, k)] = Deps{Dep{h0, 2}, Dep{h1, 2}};
+          } else {
+            const int id = add(PT_TRSM, i, k, k, k + 1, 0, q, {leafof[k], lastw[at(i, k)]});
+            trsm[at(i, k)] = lastw[at(i, k)] = Deps{Dep{id, 2}};
+          }
         }
       }
       if (k + 1 < pend)                                  // next column block of the inner panel: K = 128
@@ -665,7 +773,7 @@ static int pp_build(int64_t n, int64_t e, PPlan& P) {
   }
   P.off_dep = RT_FIXED;
   int o = P.off_dep + ((nt + 31) & ~31);
-  for (int q = 0; q < PP_NQ; ++q) { P.off_slots[q] = o; o += (P.qcount[q] + 31) & ~31; }
+  for (int q = 0; q < P.nq; ++q) { P.off_slots[q] = o; o += (P.qcount[q] + 31) & ~31; }
   P.rt_ints = o;
   return GPN_OK;
 }
@@ -673,10 +781,12 @@ static int pp_build(int64_t n, int64_t e, PPlan& P) {
 static void pp_image(const PPlan& P, std::vector<int>& img) {
   img.assign((size_t)P.rt_ints, 0);
   for (size_t t = 0; t < P.dep0.size(); ++t) img[(size_t)P.off_dep + t] = P.dep0[t];
-  for (int q = 0; q < PP_NQ; ++q) {
+  for (int q = 0; q < P.nq; ++q) {
     for (int s = 0; s < ((P.qcount[q] + 31) & ~31); ++s) img[(size_t)P.off_slots[q] + s] = -1;
     for (size_t s = 0; s < P.initial[q].size(); ++s) img[(size_t)P.off_slots[q] + s] = P.initial[q][s];
     img[RT_Q0 + RT_QSTRIDE * q + 32] = (int)P.initial[q].size();     // tail
+    img[RT_QINFO + 2 * q] = P.qcount[q];
+    img[RT_QINFO + 2 * q + 1] = P.off_slots[q];
   }
 }
 
@@ -747,11 +857,11 @@ int potrf_persistent(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda
   a.tasks = dp->d_tasks; a.succ = dp->d_succ; a.rt = rt.rt; a.scratch = rt.scratch;
   a.ntasks = (int)P.tasks.size();
   a.off_dep = P.off_dep;
-  for (int q = 0; q < PP_NQ; ++q) a.off_slots[q] = P.off_slots[q];
+  a.nq = P.nq;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 2) cus = 256;
   const int grid = g_pp_grid > 0 ? g_pp_grid : cus;
-  a.R = std::min(grid - 1, g_pp_chain_wgs > 0 ? g_pp_chain_wgs : 12);
+  a.R = std::min(grid - 1, g_pp_chain_wgs > 0 ? g_pp_chain_wgs : 16);
   a.spin_limit = 1 << 22;
   a.trace = g_pp_trace;
   static std::atomic<int> attr_done{0};
@@ -793,17 +903,18 @@ extern "C" int gpn_potrf_lower_persistent(void* stream, double* A, int64_t n, in
 extern "C" int gpn_potrf_persistent_supported(int64_t n, int64_t e) { return pp_supported(n, e) ? 1 : 0; }
 
 // The task graph of gpn_potrf_lower_persistent for an n x n factorisation with e extra rows, for inspection (tests replay it on
-// the host): counts6 = {tasks, successor entries, tasks of queue 0, 1, 2, 3}; tasks12 (12 ints per task: type, queue, i, j, k0, k1,
-// predecessors, flags, succ_begin, succ_mid, succ_end, 0) and succ are filled when given (capacities in entries).  Returns 0,
-// GPN_E_UNSUPPORTED for a size the persistent driver does not take, -2 / -3 for a buffer that is too small.
-extern "C" int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts6, int32_t* tasks12, int64_t cap_tasks, int32_t* succ,
+// the host): counts (3 + 64 entries) = {tasks, successor entries, queues in use, tasks of queue 0, 1, ...}; tasks12 (12 ints per
+// task: type, queue, i, j, k0, k1, predecessors, flags, succ_begin, succ_mid, succ_end, 0) and succ are filled when given
+// (capacities in entries).  Returns 0, GPN_E_UNSUPPORTED for a size the persistent driver does not take, -2 / -3 for a buffer
+// that is too small.
+extern "C" int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts, int32_t* tasks12, int64_t cap_tasks, int32_t* succ,
                                          int64_t cap_succ) {
   PPlan P;
   const int rc = pp_build(n, e, P);
   if (rc != GPN_OK) return rc;
-  if (counts6) {
-    counts6[0] = (int64_t)P.tasks.size(); counts6[1] = (int64_t)P.succ.size();
-    for (int q = 0; q < PP_NQ; ++q) counts6[2 + q] = P.qcount[q];
+  if (counts) {
+    counts[0] = (int64_t)P.tasks.size(); counts[1] = (int64_t)P.succ.size(); counts[2] = P.nq;
+    for (int q = 0; q < PP_MAXQ; ++q) counts[3 + q] = q < P.nq ? P.qcount[q] : 0;
   }
   if (tasks12) {
     if (cap_tasks < (int64_t)P.tasks.size()) return -2;
@@ -823,7 +934,7 @@ extern "C" int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts6,
 
 #ifdef GPN_DEBUG_SWITCHES
 extern "C" int gpn_debug_set_persistent(int chain_wgs, int grid) { g_pp_chain_wgs = chain_wgs; g_pp_grid = grid; return GPN_OK; }
-// device buffer of 6 x 8 bytes per task (gpn_potrf_persistent_plan's count): per task the 100 MHz stamps {pop begins, task popped,
+// device buffer of 8 x 8 bytes per task (gpn_potrf_persistent_plan's count): per task the 100 MHz stamps {pop begins, task popped,
 // acquire done, stores drained, successors released} and (chain role << 32 | workgroup); NULL switches the trace off
 extern "C" int gpn_debug_persistent_trace(unsigned long long* buf) { g_pp_trace = buf; return GPN_OK; }
 #endif

@@ -111,10 +111,17 @@ class GPModel(Model):
             return o.Rprop(parameters, lr=lr, etas=(0.5, 1.2), step_sizes=(1e-06, 50))
         return None
 
-    def optimize(self, method="Adam", max_iter=2000, verbose=True, learning_rate=None):
+    def optimize(self, method="Adam", max_iter=2000, verbose=True, learning_rate=None, capture=False):
         """Minimise loss() over the trainable parameters; returns (losses, seconds)
-        for torch optimisers, the scipy result for scipy methods (base.py:111-296)."""
+        for torch optimisers, the scipy result for scipy methods (base.py:111-296).
+        capture=True (GPR over a native stationary kernel on the GPU, torch optimisers but LBFGS): the body of the reference's
+        loop -- zero_grad(); loss(); backward(); step() (base.py:260-269) -- is captured into ONE hipGraph and replayed per
+        iteration; the losses stay on the device and come back once at the end (the reference's `loss.item()` is a host
+        synchronisation per iteration).  Same returned array, same printed lines (printed after the loop).  Anything else falls
+        back to the ordinary loop."""
         self._auto_place()
+        if capture and self._can_capture(method):
+            return self._optimize_captured(method, max_iter, verbose, learning_rate)
         parameters = [p for p in self.parameters() if p.requires_grad]
         if learning_rate is None and method in _TORCH_DEFAULT_LR:
             learning_rate = _TORCH_DEFAULT_LR[method]
@@ -157,6 +164,110 @@ class GPModel(Model):
             print("Optimization terminated by reaching the maximum iterations")
         else:
             print("Optimization terminated by getting below the tolerant error")
+        return losses, t
+
+    # ---- the optimiser step as one hipGraph replay (round 6) ---------------------------------------------------------------
+    CAPTURE_WARMUP = 3          # eager iterations before the capture (torch's recipe: lazily created optimiser state, caches)
+    CAPTURE_CHUNK = 25          # replays between two looks at the "a factorisation failed" flag
+
+    def _can_capture(self, method):
+        from .. import _ops
+        stationary = getattr(self, "_stationary", None)
+        if method not in _TORCH_DEFAULT_LR or method == "LBFGS" or not self.X.is_cuda or stationary is None or stationary() is None:
+            return False
+        if type(self).log_likelihood.__qualname__ != "GPR.log_likelihood":      # VFE / DistGPR / user subclasses: their own path
+            return False
+        return True
+
+    def _optimize_captured(self, method, max_iter, verbose, learning_rate):
+        """see optimize(capture=True).  Numerics: the optimiser is built with capturable=True and its step counters in fp64
+        (torch creates them in the DEFAULT dtype, fp32, which would round the bias corrections to 1e-7): the trajectory
+        agrees with the ordinary loop's to rounding (device pow instead of the host's for beta ** step), not bit for bit.
+        A replay whose factorisation reports info != 0 cannot climb the jitter ladder inside the graph: the flag is read every
+        CAPTURE_CHUNK replays, and a chunk that saw one is rolled back (parameters, optimiser state) and repeated eagerly."""
+        import inspect
+        from .. import _ops
+        dev = self.X.device
+        parameters = [p for p in self.parameters() if p.requires_grad]
+        if learning_rate is None:
+            learning_rate = _TORCH_DEFAULT_LR[method]
+        prev_dtype = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            self.optimizer = self._make_optimizer(method, parameters, learning_rate)
+            if "capturable" in inspect.signature(type(self.optimizer).__init__).parameters:
+                for g in self.optimizer.param_groups:
+                    g["capturable"] = True
+            losses_dev = torch.zeros(max(1, max_iter), dtype=torch.float64, device=dev)
+            counter = torch.zeros(1, dtype=torch.long, device=dev)
+            tic = time()
+            print("{}: Start optimizing via {}".format(self.__class__.__name__, method))
+
+            def eager_step(idx):
+                self.optimizer.zero_grad(set_to_none=True)
+                loss = self.loss()
+                loss.backward()
+                self.optimizer.step()
+                losses_dev[idx] = loss.detach().reshape(())
+
+            done = 0
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                while done < min(self.CAPTURE_WARMUP, max_iter):
+                    eager_step(done)
+                    done += 1
+            torch.cuda.current_stream(dev).wait_stream(side)
+            if done < max_iter:
+                counter.fill_(done)
+                self.optimizer.zero_grad(set_to_none=True)
+                deferred = _ops.DeferredInfo(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph), deferred:
+                    loss = self.loss()
+                    loss.backward()
+                    self.optimizer.step()
+                    losses_dev.index_copy_(0, counter, loss.detach().reshape(1))
+                    counter.add_(1)
+                # (the capture itself executed nothing: iteration `done` is the first replay)
+
+                def snapshot():
+                    return ([p.detach().clone() for p in parameters],
+                            [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.optimizer.state[p].items()} for p in parameters])
+
+                def restore(snap):
+                    with torch.no_grad():
+                        for p, v in zip(parameters, snap[0]):
+                            p.copy_(v)
+                        for p, st in zip(parameters, snap[1]):
+                            for k, v in st.items():
+                                if torch.is_tensor(v):
+                                    self.optimizer.state[p][k].copy_(v)     # IN PLACE: the graph holds these addresses
+                                else:
+                                    self.optimizer.state[p][k] = v
+
+                while done < max_iter:
+                    chunk = min(self.CAPTURE_CHUNK, max_iter - done)
+                    snap = snapshot()
+                    deferred.flag.zero_()
+                    for _ in range(chunk):
+                        graph.replay()
+                    if int(deferred.flag.item()) != 0:            # ONE read-back per chunk
+                        restore(snap)
+                        for k in range(chunk):
+                            eager_step(done + k)
+                        counter.fill_(done + chunk)
+                    done += chunk
+            losses = losses_dev[:max_iter].cpu().numpy().astype(np.float64)
+        finally:
+            torch.set_default_dtype(prev_dtype)
+        for idx in range(max_iter):
+            if verbose or idx % 20 == 0:
+                print("Iter: %d\tLoss: %s" % (idx, losses[idx]))
+        t = time() - tic
+        print("Optimization time taken: %s s" % t)
+        print("Optimization method: %s" % str(self.optimizer))
+        print("Optimization terminated by reaching the maximum iterations")
         return losses, t
 
     def _optimize_scipy(self, method="L-BFGS-B", tol=None, callback=None, maxiter=1000, disp=True):

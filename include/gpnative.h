@@ -120,14 +120,15 @@ int gpn_potrf_lower_persistent(void* stream, double* A, int64_t n, int64_t e, in
                                double* winv, int32_t* info);
 int gpn_potrf_persistent_supported(int64_t n, int64_t e);
 /* The task graph of gpn_potrf_lower_persistent, for inspection (tests replay it on the host in random valid orders):
- * counts6 = {tasks, successor entries, tasks of queue 0 (the critical chains), 1, 2, 3}; tasks12 = 12 ints per task:
+ * counts (3 + 64 entries) = {tasks, successor entries, queues in use, tasks of queue 0 (the critical chains), 1, ...: queue
+ * 1 + p = tasks whose output tile row lies in outer panel p; the extra-rows tile last}; tasks12 = 12 ints per task:
  * type (0 leaf, 1 tile solve, 2 tile update, 3 chain step = solve of (c, c-1) + last update of (c, c) + leaf(c), 4 the
- * diagonal tile's partial sums), queue, tile row i, tile column j, K range [k0, k1) in 128-column blocks, predecessor count,
- * flags (1: raw sums to scratch instead of the update, 2: continue from the scratch sums), succ_begin, succ_mid, succ_end, 0 --
+ * diagonal tile's partial sums, 5 = 64 rows of the last block of the update of tile (c+1, c)), queue, tile row i, tile column j, K range [k0, k1) in 128-column blocks, predecessor count,
+ * flags (1: raw sums to scratch instead of the update, 2: continue from the scratch sums, 4: rows 64 .. 127), succ_begin, succ_mid, succ_end, 0 --
  * the successors succ[succ_begin .. succ_mid) are released when a step's solved tile is out, succ[succ_mid .. succ_end) at the
  * end of the task.  succ and tasks12 are filled when given (capacities in entries).  Tasks are listed in a valid sequential
  * order. */
-int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts6, int32_t* tasks12, int64_t cap_tasks, int32_t* succ,
+int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts, int32_t* tasks12, int64_t cap_tasks, int32_t* succ,
                               int64_t cap_succ);
 
 /* `batch` factorisations of identical shape in LOCK STEP: problem b at A + b*sA (a factor buffer each: sA >=

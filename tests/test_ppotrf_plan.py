@@ -10,12 +10,12 @@ import pytest
 from gptorch_amd import _native
 
 LEAF, TRSM, UPD, STEP, PRED, SUB = 0, 1, 2, 3, 4, 5
-ACC_OUT, ACC_IN, HALF1 = 1, 2, 4
+ACC_OUT, ACC_IN, HALF1, HALF0 = 1, 2, 4, 8
 
 
 def _plan(n, e):
     lib = _native.lib()
-    counts = (ctypes.c_int64 * 6)()
+    counts = (ctypes.c_int64 * 67)()
     rc = lib.gpn_potrf_persistent_plan(n, e, counts, None, 0, None, 0)
     assert rc == 0, rc
     nt, ns = counts[0], counts[1]
@@ -43,8 +43,8 @@ def test_graph_shape(n, e):
     nt = counts[0]
     T = n // 128
     TR = T + (1 if e else 0)
-    assert sum(counts[2:6]) == nt
-    assert (tasks[:, 6] <= 5).all() and (tasks[:, 6] >= 0).all()
+    assert sum(counts[3:3 + counts[2]]) == nt and counts[2] == 2 + (T + 7) // 8
+    assert (tasks[:, 6] <= 8).all() and (tasks[:, 6] >= 0).all()
     # predecessor counts agree with the successor lists, and the listed order is a valid sequential order
     indeg = np.zeros(nt, dtype=np.int64)
     pos = 0
@@ -60,8 +60,11 @@ def test_graph_shape(n, e):
     assert pos == len(succ)
     assert (indeg == tasks[:, 6]).all()
     assert (tasks[:, 0] == LEAF).sum() == 1 and (tasks[:, 0] == STEP).sum() == T - 1
-    # every off-diagonal tile below the diagonal is solved exactly once: by a solve task or by the step of its row
-    assert (tasks[:, 0] == TRSM).sum() + (T - 1) == sum(TR - 1 - k for k in range(T))
+    # every off-diagonal tile below the diagonal is solved exactly once: by two half-tile solves (one for the extra-rows tile) or
+    # by the step of its row
+    halves = ((tasks[:, 0] == TRSM) & ((tasks[:, 7] & (HALF0 | HALF1)) != 0)).sum()
+    whole = ((tasks[:, 0] == TRSM) & ((tasks[:, 7] & (HALF0 | HALF1)) == 0)).sum()
+    assert halves // 2 + whole + (T - 1) == sum(TR - 1 - k for k in range(T)) and halves % 2 == 0
     ready = np.nonzero(tasks[:, 6] == 0)[0]
     assert list(ready) == [0] and tasks[0, 0] == LEAF
     # the scratch tiles are written once before they are read
@@ -116,7 +119,10 @@ def test_replay_in_random_valid_order(n, e, seed):
         if ty == LEAF:
             leaf(i)
         elif ty == TRSM:
-            A[rows(i), cols(j)] = A[rows(i), cols(j)] @ W[j].T
+            half = slice(64, 128) if fl & HALF1 else (slice(0, 64) if fl & HALF0 else slice(None))
+            blk = A[rows(i), cols(j)]
+            blk[half] = blk[half] @ W[j].T
+            A[rows(i), cols(j)] = blk
         elif ty == PRED:
             scr_d[i] = A[rows(i), ks] @ A[rows(i), ks].T
         elif ty == UPD:
@@ -128,12 +134,15 @@ def test_replay_in_random_valid_order(n, e, seed):
                 if i == j:
                     acc = np.tril(acc)
                 A[rows(i), cols(j)] -= acc
-        elif ty == SUB:                           # 64 rows of the tile below the next diagonal block: the group's last block
-            half = slice(64, 128) if fl & HALF1 else slice(0, 64)
-            last = slice((k1 - 1) * 128, k1 * 128)
-            acc = A[rows(i), last][half] @ A[rows(j), last].T
+        elif ty == SUB:                           # 64 rows of a tile (all rows of the extra-rows tile): a short-K update
+            half = slice(64, 128) if fl & HALF1 else (slice(0, 64) if fl & HALF0 else slice(None))
+            acc = A[rows(i), ks][half] @ A[rows(j), ks].T
             if fl & ACC_IN:
+                assert k1 - k0 == 1
                 acc = acc + scr_s[j][half]
+            if i == j:
+                r0 = 64 if fl & HALF1 else 0
+                acc = np.tril(acc, k=r0)
             blk = A[rows(i), cols(j)]
             blk[half] -= acc
             A[rows(i), cols(j)] = blk

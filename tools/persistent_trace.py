@@ -10,7 +10,7 @@ n = int(sys.argv[1]); R = int(sys.argv[2]) if len(sys.argv) > 2 else 0; dy = int
 dev = torch.device("cuda:0")
 lib = _native.debug_begin()
 st, ptr = _ops._stream(dev), _ops._ptr
-counts = (ctypes.c_int64 * 6)()
+counts = (ctypes.c_int64 * 67)()
 assert lib.gpn_potrf_persistent_plan(n, dy, counts, None, 0, None, 0) == 0
 nt, ns = counts[0], counts[1]
 tasks = np.zeros((nt, 12), dtype=np.int32); succ = np.zeros(ns, dtype=np.int32)
@@ -23,28 +23,28 @@ _ops.kernel_matrix("Rbf", X, None, one(1.0), one(float(np.sqrt(8))), noise=one(1
 f.pack_rhs(Y)
 saved = f.A.clone()
 lib.gpn_debug_set_persistent(R, 0)
-trace = torch.zeros(nt * 6, dtype=torch.int64, device=dev)
+trace = torch.zeros(nt * 8, dtype=torch.int64, device=dev)
 for rep in range(3):
     f.A.copy_(saved); f.info.zero_()
     lib.gpn_debug_persistent_trace(trace.data_ptr() if rep == 2 else None)
     assert lib.gpn_potrf_lower_persistent(st, ptr(f.A), n, dy, f.ld, ptr(f.winv), ptr(f.info)) == 0
 torch.cuda.synchronize()
 lib.gpn_debug_persistent_trace(None)
-tr = trace.cpu().numpy().reshape(nt, 6).astype(np.int64)
+tr = trace.cpu().numpy().reshape(nt, 8).astype(np.int64)
 t0 = tr[:, 1].min()
 us = lambda v: (v - t0) / 100.0
 pop0, pop1, run, end, rel = (us(tr[:, k]) for k in range(5))
 wg = tr[:, 5] & 0xffffffff; chain = tr[:, 5] >> 32
-print("n %d: %d tasks (queues %d / %d / %d / %d), span %.1f us, info %d" % (n, nt, counts[2], counts[3], counts[4], counts[5], rel.max(), int(f.info.item())))
-names = {0: "LEAF", 1: "TRSM", 2: "UPD", 3: "STEP", 4: "PRED"}
-for ty in (0, 3, 4, 1, 2):
+print("n %d: %d tasks (queues %s), span %.1f us, info %d" % (n, nt, " / ".join(str(c) for c in counts[3:3 + counts[2]]), rel.max(), int(f.info.item())))
+names = {0: "LEAF", 1: "TRSM", 2: "UPD", 3: "STEP", 4: "PRED", 5: "SUB"}
+for ty in (0, 3, 4, 5, 1, 2):
     m = tasks[:, 0] == ty
-    for q in (0, 1, 2, 3):
+    for q in range(int(counts[2])):
         mm = m & (tasks[:, 1] == q)
         if not mm.any(): continue
-        Ks = sorted(set((tasks[mm, 5] - tasks[mm, 4] + 1000 * tasks[mm, 7]).tolist())) if ty in (2, 3, 4) else [0]
+        Ks = sorted(set((tasks[mm, 5] - tasks[mm, 4] + 1000 * tasks[mm, 7]).tolist())) if ty in (2, 3, 4, 5) else [0]
         for K in Ks:
-            m3 = mm & ((tasks[:, 5] - tasks[:, 4] + 1000 * tasks[:, 7]) == K) if ty in (2, 3, 4) else mm
+            m3 = mm & ((tasks[:, 5] - tasks[:, 4] + 1000 * tasks[:, 7]) == K) if ty in (2, 3, 4, 5) else mm
             print("  %-4s q%d K=%6d: %5d tasks  run %7.1f us avg (min %6.1f max %7.1f)  acquire %4.1f  release %4.1f  wait-in-pop %7.1f" % (
                 names[ty], q, (K % 1000) * 128 + 100000 * (K // 1000), m3.sum(), (end - run)[m3].mean(), (end - run)[m3].min(), (end - run)[m3].max(),
                 (run - pop1)[m3].mean(), (rel - end)[m3].mean(), (pop1 - pop0)[m3].mean()))
@@ -58,6 +58,30 @@ for k in list(range(0, min(T - 1, 12))) + list(range(max(12, T - 4), T - 1)):
         k, run[a], end[a], rel[a], pop1[b], pop1[b] - rel[a], rel[b] - rel[a]))
 steps = np.array([rel[leaf[k + 1]] - rel[leaf[k]] for k in range(T - 1)])
 print("  chain step: mean %.1f us, median %.1f, max %.1f; sum %.1f of span %.1f" % (steps.mean(), np.median(steps), steps.max(), steps.sum(), rel.max()))
+# ---- critical paths behind the largest waits of the chain
+ph1 = np.where(tr[:, 6] > 0, us(tr[:, 6]), rel)
+preds = [[] for _ in range(nt)]
+for t in range(nt):
+    b, m, e_ = tasks[t, 8:11]
+    for s_ in succ[b:m]: preds[s_].append((t, 1))
+    for s_ in succ[m:e_]: preds[s_].append((t, 2))
+def when(t, phase): return ph1[t] if (phase == 1 and tasks[t, 0] == 3) else rel[t]
+def label(t):
+    ty, q, i, j, k0, k1, nd, fl = tasks[t, :8]
+    return "%-4s(%2d,%2d) K=%4d fl%d q%d" % (names[ty], i, j, (k1 - k0) * 128, fl, q)
+steps_t = [leaf[k] for k in range(1, T)]
+gaps = sorted(((pop1[t] - max(when(p, ph) for p, ph in preds[t]) if preds[t] else 0.0, t) for t in steps_t), reverse=True)
+waits = sorted(((pop1[leaf[k + 1]] - rel[leaf[k]], k) for k in range(T - 1)), reverse=True)[:int(os.environ.get('PP_PATHS', '3'))]
+for wgap, k in waits:
+    t = leaf[k + 1]
+    print("  --- step %d waited %.1f us after step %d's end; critical path backwards:" % (k + 1, wgap, k))
+    for depth in range(int(os.environ.get('PP_DEPTH', '9'))):
+        if not preds[t]: break
+        p, ph = max(preds[t], key=lambda pp: when(pp[0], pp[1]))
+        ready = when(p, ph)
+        print("      %s ready %.1f popped %.1f (queue %.1f) run %.1f..%.1f released %.1f   <- %s (ph %d) at %.1f" % (
+            label(t), max(when(x, y) for x, y in preds[t]), pop1[t], pop1[t] - max(when(x, y) for x, y in preds[t]), run[t], end[t], rel[t], label(p), ph, ready))
+        t = p
 for role in (1, 0):
     m = chain == role
     wgs = np.unique(wg[m])
