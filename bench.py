@@ -242,7 +242,7 @@ def usable_cpus():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(w, x, y, full=True, full_timeout=900.0, budget=260.0):
+def cpu_baseline(w, x, y, full=True, full_timeout=900.0, budget=90.0):
     """the CPU oracle (oracle/gp_oracle.py: the reference's op sequence on the same ATen / MKL kernels, kind "port") on
     this box's host cores, SURVEY 8(d).
       1. an 8192-row sample of the SAME data / kernel / hyper-parameters at several thread counts (a few seconds each):
@@ -648,9 +648,69 @@ def run_single(args, device):
                             "loss_first_restart0": float(losses[0, 0]), "loss_last_restart0": float(losses[0, -1]),
                             "gradients": "bit-identical per model to loss().backward() (tests/test_gpu_lockstep_fit.py)"}
                 return run
+            def fit_captured(key, iters):
+                # round 6: ONE model, the reference's loop (base.py:260-269) with the optimiser step as one hipGraph replay
+                # (GPModel.optimize(capture=True)) against the ordinary loop (one host read-back of the loss per iteration)
+                def run():
+                    import contextlib
+                    ww = WORKLOADS[key]
+                    res = {}
+                    for cap in (False, True):
+                        m_ = build_model(ww, 0, device)[0]
+                        with contextlib.redirect_stdout(sys.stderr):
+                            m_.optimize(method="Adam", max_iter=8, verbose=False, learning_rate=0.01, capture=cap)
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            losses, _ = m_.optimize(method="Adam", max_iter=iters, verbose=False, learning_rate=0.01, capture=cap)
+                            torch.cuda.synchronize()
+                            res[cap] = ((time.perf_counter() - t0) / iters * 1e3, float(losses[-1]))
+                    return {"config": "%s -> one model, %d Adam steps (lr 0.01): the step as one hipGraph replay" % (ww["name"].replace(" LML eval", ""), iters),
+                            "ms_per_step_captured": res[True][0], "ms_per_step_ordinary_loop": res[False][0], "speedup": res[False][0] / res[True][0],
+                            "final_loss_captured": res[True][1], "final_loss_ordinary_loop": res[False][1]}
+                return run
+
+            def persistent(key):
+                # round 6: gpn_potrf_lower as ONE persistent dataflow launch (csrc/ppotrf.hip) against the launch-based driver on the
+                # same matrix: built as asked, bit-identical, SLOWER -- it is not what log_likelihood() runs
+                def run():
+                    from gptorch_amd import _ops
+                    ww = WORKLOADS[key]
+                    mdl = build_model(ww, 0, device)[0]
+                    k = mdl.kernel
+                    f = _ops.Factor(ww["n"], ww["dy"], device)
+                    _ops.kernel_matrix(k._kind, mdl.X, None, k.variance.transform(), k.length_scales.transform(),
+                                       noise=mdl.likelihood.variance.transform(), out=f.A, ldk=f.ld, lower=True)
+                    f.pack_rhs(mdl.Y)
+                    saved = f.A.clone()
+                    st = _ops._stream(device)
+
+                    def one(fn):
+                        ts, snap = [], None
+                        for rep in range(6):
+                            f.A.copy_(saved)
+                            f.info.zero_()
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            rc = fn(st, _ops._ptr(f.A), f.n, f.e, f.ld, _ops._ptr(f.winv), _ops._ptr(f.info))
+                            e1.record()
+                            torch.cuda.synchronize()
+                            if rc != 0:
+                                raise RuntimeError("status %d" % rc)
+                            if rep >= 2:
+                                ts.append(e0.elapsed_time(e1))
+                        snap = (torch.tril(f.A[:f.n, :f.n]).clone(), f.A[f.n:f.n + f.e, :f.n].clone(), f.winv.clone(), int(f.info.item()))
+                        return float(np.median(ts)), snap
+                    t_l, a = one(lib.gpn_potrf_lower)
+                    t_p, b = one(lib.gpn_potrf_lower_persistent)
+                    same = all(torch.equal(u, v) for u, v in zip(a[:3], b[:3])) and a[3] == b[3]
+                    return {"config": "%s: the factorisation alone, launch-based driver vs ONE persistent dataflow launch" % ww["name"].replace(" LML eval", ""),
+                            "ms_launch_based": t_l, "ms_persistent": t_p, "bit_identical": bool(same), "shipped_driver": "launch-based"}
+                return run
             leg("c2_batched", lockstep("c2", 8))
             leg("c1_batched", lockstep("c1", 64))
+            leg("c2_persistent_factorisation", persistent("c2"))
             if not args.no_fit:
+                leg("c1_fit_captured", fit_captured("c1", 100))
                 leg("c2_fit_batched", fit_lockstep("c2", 8, 50, 1, 10))
                 leg("c1_fit_batched", fit_lockstep("c1", 64, 50, 4, 50))
             leg("c2_concurrent_restarts", restarts)
@@ -1148,7 +1208,7 @@ def main():
     ap.add_argument("--no-fit", action="store_true", help="skip the 50-Adam-step fit leg (c3_adam50: about 30 s)")
     ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline from the 8192-row sample only (extrapolated), "
                     "skipping the full-size CPU evaluation (about 2-4 minutes at C3)")
-    ap.add_argument("--cpu-baseline-budget", type=float, default=260.0,
+    ap.add_argument("--cpu-baseline-budget", type=float, default=90.0,
                     help="seconds the full-size CPU leg may take (1 warm-up + up to 3 timed evaluations; fewer timed ones if "
                          "3 would overrun it; 0 = always 3)")
     ap.add_argument("--no-extras", action="store_true", help="headline + rooflines only (profiling runs)")

@@ -176,14 +176,11 @@ SIGNATURES.update(PROFILE_SIGNATURES)
 DEBUG_SIGNATURES = {
     "gpn_debug_set_gemm_variant": (c_int, [c_int]),
     "gpn_debug_set_potrf_variant": (c_int, [c_int]),
+    "gpn_debug_set_outer_width": (c_int, [c_int, c_int]),
+    "gpn_debug_set_extra_rows": (c_int, [c_int]),
+    "gpn_debug_set_thin_tiles": (c_int, [c_int]),
     "gpn_debug_masked_stream": (c_int, [ctypes.POINTER(ctypes.c_uint32), c_int, ctypes.POINTER(c_void_p)]),
-    "gpn_debug_leaf_timing": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "gpn_debug_leaf16_timing": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_debug_set_backsub_persistent": (c_int, [c_int]),
-    "gpn_debug_set_inner_left": (c_int, [c_int]),
-    "gpn_debug_set_split_assembly": (c_int, [c_int]),
-    "gpn_debug_set_tri_big": (c_int, [c_int, c_int]),
-    "gpn_debug_set_outer_lookahead": (c_int, [c_int, c_int, c_int, c_int]),
     "gpn_debug_set_persistent": (c_int, [c_int, c_int]),
     "gpn_debug_persistent_trace": (c_int, [c_void_p]),
 }

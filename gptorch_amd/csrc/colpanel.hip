@@ -140,186 +140,6 @@ __global__ __launch_bounds__(256, 2) void colpanel_kernel(ColPanelArgs p) {
     }
 }
 
-// ---- both column passes of a chain step in ONE launch (A/B, tools' build only: measured SLOWER, potrf.hip g_fused_colstep) --
-#ifdef GPN_DEBUG_SWITCHES
-// Step k of the chain solves all m rows below diagonal block k (X = B W_k^T, in place) and then updates the next column
-// block by them (C -= X X_top^T, X_top = the first 128 solved rows).  As two launches the second re-reads X from HBM and
-// pays its own ramp (13.5 us at C2 for 0.27 GFLOP through the generic contraction); here a workgroup keeps its 32 x 128
-// X tile in LDS and goes straight on to its rows of C.  The only thing it needs from OTHER workgroups is X_top: the four
-// workgroups that own those rows (blockIdx.x < 4: dispatched first) store their tiles with agent-scope stores, drain them
-// and count themselves in on a device counter; every workgroup polls that counter after its own solve (by then the four
-// are done or about to be), then reads X_top with agent-scope loads (MI355X_MICROARCH.md "Valid forms": sc1 payload, sc1
-// flag, no fence needed; tools/handoff_bench.hip measured the pattern).  The poll is bounded: a counter that never
-// arrives sets info = GPN_INFO_INTERNAL instead of hanging the queue.  Same fragment maps and k order as the two kernels
-// above, so X is bit-identical to colpanel_kernel<0>'s.
-struct ColStepArgs {
-  double* B;            // [m, 128] rows below the diagonal block, columns of block k (solved in place)
-  const double* W;      // W_k
-  double* C;            // [m, 128] the same rows, columns of block k+1
-  int64_t lda;
-  int m;
-  int* flag;            // one zeroed counter per problem of the batch
-  int32_t* info;        // per problem
-  int64_t sA, sW;
-};
-
-__global__ __launch_bounds__(256, 2) void colstep_kernel(ColStepArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[CP_ROWS * CP_LDS_ROW];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r0 = blockIdx.x * CP_ROWS;
-  const int lr = lane & 15, lq = lane >> 4;
-  const bool top = blockIdx.x < LEAF / CP_ROWS;          // my rows are rows of X_top
-  double* B = p.B + (int64_t)blockIdx.y * p.sA;
-  double* C = p.C + (int64_t)blockIdx.y * p.sA;
-  const double* W = p.W + (int64_t)blockIdx.y * p.sW;
-  int* flag = p.flag + blockIdx.y;
-  const int64_t lda = p.lda;
-
-  // ---- A tile and old C tile: all loads in flight at once
-  d2 areg[8];
-  {
-    const int row = tid >> 3, seg0 = tid & 7;
-    const bool ok = r0 + row < p.m;
-    const double* src = B + (int64_t)(r0 + row) * lda + seg0 * 2;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) areg[i] = ok ? *reinterpret_cast<const d2*>(src + i * 16) : d2{0.0, 0.0};
-  }
-  const int cu[2] = {2 * wave, 2 * wave + 1};            // update: my two 16-column tiles of C
-  d4 accu[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + i * 16 + lq + 4 * r;
-        accu[i][c][r] = row < p.m ? C[(int64_t)row * lda + cu[c] * 16 + lr] : 0.0;
-      }
-  // ---- solve: B fragments of W_k for the column tiles {w, 7 - w}
-  const int cs[2] = {wave, 7 - wave};
-  d2 b[2][16];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const double* src = W + (int64_t)(cs[c] * 16 + lr) * CP_K + 2 * lq;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) b[c][j] = (8 * j <= cs[c] * 16 + 15) ? *reinterpret_cast<const d2*>(src + 8 * j) : d2{0.0, 0.0};
-  }
-  {
-    const int row = tid >> 3, seg0 = tid & 7;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<d2*>(lds + row * CP_LDS_ROW + (seg0 + 8 * i) * 16) = areg[i];
-  }
-  __syncthreads();
-  d4 accs[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) accs[i][c] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    d2 a[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const d2*>(lds + (i * 16 + lr) * CP_LDS_ROW + (4 * j + lq) * 16);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      if (8 * j > cs[c] * 16 + 15) continue;             // W[col][k] = 0 for k > col
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        accs[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[c][j].x, accs[i][c], 0, 0, 0);
-        accs[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[c][j].y, accs[i][c], 0, 0, 0);
-      }
-    }
-  }
-  __syncthreads();                                       // every wave is done with the A tile: X takes its place
-  // ---- X: in place to the matrix (agent scope for the rows of X_top), and to LDS as the update's left operand
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int lrow = i * 16 + lq + 4 * r, col = cs[c] * 16 + lr;
-        double* dst = B + (int64_t)(r0 + lrow) * lda + col;
-        if (r0 + lrow < p.m) {
-          if (top) __hip_atomic_store(dst, accs[i][c][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *dst = accs[i][c][r];
-        }
-        *reinterpret_cast<double*>(lds + lrow * CP_LDS_ROW + col * 8) = accs[i][c][r];
-      }
-  if (top) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my rows of X_top have left this wave
-  __syncthreads();
-  if (tid == 0) {
-    if (top) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int need = min(LEAF / CP_ROWS, (int)gridDim.x);
-    int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 22)) {                         // (seconds: a lost counter, not a slow producer)
-        if (p.info) atomicCAS(p.info + blockIdx.y, 0, GPN_INFO_INTERNAL);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- update: B fragments = -X_top rows {2w, 2w+1} tiles (agent-scope loads: written by other workgroups of this launch)
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const double* src = B + (int64_t)(cu[c] * 16 + lr) * lda + 2 * lq;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const double x = __hip_atomic_load(src + 8 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double y = __hip_atomic_load(src + 8 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      b[c][j] = d2{-x, -y};
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    d2 a[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const d2*>(lds + (i * 16 + lr) * CP_LDS_ROW + (4 * j + lq) * 16);
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        accu[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[c][j].x, accu[i][c], 0, 0, 0);
-        accu[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[c][j].y, accu[i][c], 0, 0, 0);
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + i * 16 + lq + 4 * r;
-        if (row < p.m) C[(int64_t)row * lda + cu[c] * 16 + lr] = accu[i][c][r];
-      }
-}
-
-// one chain step's two column passes in one launch: B [m, 128] <- B W^T in place, C [m, 128] -= X X_top^T with X_top = the
-// first 128 rows of the result (m >= 128); flag: `batch` zeroed ints; everything inside one matrix (leading dimension lda)
-int colstep(hipStream_t s, int64_t m, double* B, const double* W, double* C, int64_t lda, int* flag, int32_t* info, int batch,
-            int64_t sA, int64_t sW) {
-  if (m < LEAF || batch <= 0) return GPN_E_UNSUPPORTED;
-  ColStepArgs a;
-  a.B = B; a.W = W; a.C = C; a.lda = lda; a.m = (int)m; a.flag = flag; a.info = info; a.sA = sA; a.sW = sW;
-  const dim3 grid((unsigned)((m + CP_ROWS - 1) / CP_ROWS), (unsigned)batch);
-  int rec = -1;
-  if (profile_on()) rec = profile_begin(s, 3.0 * batch * (double)m * LEAF * CP_K, PROF_GEMM_SOLVE);
-  hipLaunchKernelGGL(colstep_kernel, grid, dim3(256), 0, s, a);
-  if (rec >= 0) profile_end(s, rec);
-  GPN_LAUNCH_CHECK();
-  return GPN_OK;
-}
-
-#endif
-
-// C[m, nb] = A[m, 128] B[nb, 128]^T (mode 0, B lower triangular, C may be A) or C -= A B^T (mode 1); nb <= 128; `batch`
-// problems at constant strides in one launch;
-// operands 16-byte aligned with even leading dimensions; mode 0 reads only the first nb of A's 128 K columns (the padding
-// columns of a ragged last block may hold anything).
 int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B, int64_t ldb,
              double* C, int64_t ldc, int batch, int64_t sA, int64_t sB, int64_t sC) {
   if (m <= 0 || nb <= 0 || batch <= 0) return GPN_OK;

@@ -39,31 +39,20 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), ((BM / WM) * (BN / WN) 
   gemm_nt_tile<BM, BN, WM, WN, DMA, NS, BLOW, PIPE>(p, (int)blockIdx.x, (int)gridDim.x, false);
 }
 
-// PERSISTENT form (round 6: the bulk of an outer panel's trailing update underneath the next panel's chain, potrf.hip): the
-// `total` tiles of a lower-tile launch are walked by gridDim.x workgroups, workgroup b taking the tiles b, b + gridDim.x, ...
-// of the grouped order (the tiles in flight at any time are a contiguous run of that order: the same operand-panel sharing as
-// the ordinary dispatch).  With one such workgroup per compute unit (LDS padding) and one workgroup fewer than the chip has
-// compute units, ONE COMPUTE UNIT STAYS EMPTY for as long as the launch runs -- the 128 x 128 leaf, which needs an empty
-// compute unit, is never queued behind a resident tile -- and the registers and LDS the workgroup leaves on its own compute
-// unit take the chain's column passes.  Same tile code, same per-entry summation order: bit-identical to the ordinary launch.
-template <int BM, int BN, int WM, int WN, bool DMA, int NS = 2, bool BLOW = false, bool PIPE = false>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), ((BM / WM) * (BN / WN) > 8 ? 1 : 2)) void gemm_nt_persistent_kernel(GemmArgs p, int total) {
-  for (int q = (int)blockIdx.x; q < total; q += (int)gridDim.x) {
-    gemm_nt_tile<BM, BN, WM, WN, DMA, NS, BLOW, PIPE>(p, q, total, true);
-    __syncthreads();               // every wave is done reading the LDS stages before the next tile's first DMA lands in them
-  }
-}
-
-// A/B switches exist only in the tools' build (libgpnative_dbg.so, -DGPN_DEBUG_SWITCHES): per calling thread, so two
-// threads of one process can hold different variants and a setter never races another thread's launches.  The product
-// library is compiled with the defaults as constants and exports no setter.
+// Switches: constants in the product library; in the tools' build (libgpnative_dbg.so, -DGPN_DEBUG_SWITCHES) per-thread variables
+// behind gpn_debug_set_gemm_variant / gpn_debug_set_thin_tiles at the end of this file -- forcing one tile shape for a launch
+// is how tests/test_gpu_gemm.py holds every shape against the reference product (and against each other: bit-identical).
 #ifdef GPN_DEBUG_SWITCHES
-static thread_local int g_thin_tiles = 1;    // (A/B of the thin-tile path; reaches the kernels through GemmArgs)
-static thread_local int g_smem_pad = 0;      // debug: extra dynamic LDS per workgroup (KiB) to lower the occupancy
+static thread_local int g_gemm_variant = 0;  // 0 = the shipped dispatch, 1 = register staging, 3..11 = forced tile shapes
+static thread_local int g_thin_tiles = 1;    // the thin-tile path (reaches the kernels through GemmArgs)
+static thread_local int g_smem_pad = 0;      // extra dynamic LDS per workgroup (KiB): lowers the occupancy
 #else
+static constexpr int g_gemm_variant = 0;
 static constexpr int g_thin_tiles = 1;
 static constexpr int g_smem_pad = 0;
 #endif
+static constexpr int g_group_h = 8;
+static constexpr int g_big_tile_min_trapezoid = 4096;   // trapezoid launches (nested panels): 128 x 128 tiles from this many of them
 
 // workgroups of a staircase launch with b x b tiles
 static int64_t stair_tiles(int64_t M, int64_t N, int st_blk, int st_step, int st_diag, int64_t b) {
@@ -84,11 +73,9 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   if (a.lower == 3 && (BM != BN || a.st_blk % BN || a.st_step % BM)) return GPN_E_UNSUPPORTED;
   const int grid = (a.lower == 3   ? (int)stair_tiles(a.M, a.N, a.st_blk, a.st_step, a.st_diag, BM)
                     : a.lower == 2 ? (a.mt - a.nt) * a.nt + a.nt * (a.nt + 1) / 2
-                    : a.lower == 4 ? 4 * a.q_cnt
-                    : a.lower == 5 ? a.mt * (a.mt + 1)
-                    : a.lower      ? (a.q_cnt > 0 ? a.q_cnt : a.mt * (a.mt + 1) / 2) : a.mt * a.nt) * std::max(1, a.batch);
+                    : a.lower      ? a.mt * (a.mt + 1) / 2 : a.mt * a.nt) * std::max(1, a.batch);
   if (grid <= 0) return GPN_OK;
-  const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + (g_smem_pad + a.lds_pad_kb) * 1024;
+  const int smem = ((BM + BN) / 16) * 2 * 1024 * NS + g_smem_pad * 1024;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN, DMA, NS, BLOW, PIPE>;
   static std::atomic<int> attr_set{-1};      // per template instance: the largest size asked for so far (the attribute is a maximum)
   if (attr_set.load(std::memory_order_acquire) < smem) {
@@ -102,10 +89,8 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
     // executed flops: tiles actually computed x 2*BM*BN*K
     const double tiles = (a.lower == 3   ? (double)stair_tiles(a.M, a.N, a.st_blk, a.st_step, a.st_diag, BM)
                           : a.lower == 2 ? (double)(a.mt - a.nt) * a.nt + 0.5 * a.nt * (a.nt + 1.0)
-                          : a.lower == 4 ? 4.0 * a.q_cnt
-                          : a.lower == 5 ? (double)a.mt * (a.mt + 1.0)
-                          : a.lower      ? (a.q_cnt > 0 ? (double)a.q_cnt : 0.5 * a.mt * (a.mt + 1.0)) : (double)a.mt * a.nt) * std::max(1, a.batch);
-    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : ((a.lower == 1 || a.lower == 4 || a.lower == 5) ? PROF_GEMM_SYRK : PROF_GEMM));
+                          : a.lower      ? 0.5 * a.mt * (a.mt + 1.0) : (double)a.mt * a.nt) * std::max(1, a.batch);
+    const int cls = inplace ? PROF_GEMM_SOLVE : (a.tri ? PROF_GEMM_TRI : (a.lower == 1 ? PROF_GEMM_SYRK : PROF_GEMM));
     rec = profile_begin(s, tiles * 2.0 * BM * BN * (double)a.K, cls);
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (BM / WM) * (BN / WN)), smem, s, a);
@@ -114,67 +99,17 @@ static int launch(hipStream_t s, const GemmArgs& a0, int inplace = 0) {
   return GPN_OK;
 }
 
-#ifdef GPN_DEBUG_SWITCHES
-static thread_local int g_gemm_variant = 0;  // 0 = LDS-DMA staging, 1 = register staging, 3..6 = forced tile shapes (debug/A-B)
-static thread_local int g_group_h = 0;       // 0 = from GPN_GEMM_GROUP_H at first use (default 8): A/B of the grouped tile order's L2 reuse
-static thread_local int g_big_tile_min_trapezoid = 4096;   // trapezoid launches (nested panels): 128x128 tiles from this many of them
-static thread_local int g_split_tail = 0;    // 1 = the partial last round of a big lower-tile launch as quarter tiles (measured neutral: off)
-static thread_local int g_tri_big_k = 0, g_tri_big_tiles = 0;   // A/B: K-clipped launches of a lock-step batch on 128x128 tiles from this K / tile count
-#else
-static constexpr int g_gemm_variant = 0;
-static constexpr int g_big_tile_min_trapezoid = 4096;
-static constexpr int g_group_h = 8;
-static constexpr int g_split_tail = 0;
-static constexpr int g_tri_big_k = 0, g_tri_big_tiles = 0;
-#endif
-
 struct Stair { int blk = 0, step = 0, diag = 0; };
 struct Outer { int count = 0; int64_t sA = 0, sB = 0, sC = 0; };     // second batch level (count == 0: none)
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair(), int lds_pad_kb = 0, Outer ob = Outer());
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair(), Outer ob = Outer());
 
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
-            double beta, double* C, int64_t ldc, int lower, int tri, int inplace, int lds_pad_kb) {
-  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, 1, 0, 0, 0, Stair(), lds_pad_kb);
-}
-
-int gemm_nt_lower_persistent(hipStream_t s, int64_t M, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
-                             int64_t ldb, double beta, double* C, int64_t ldc, int nwg, int lds_pad_kb) {
-  if (M <= 0) return GPN_OK;
-  if (K <= 0 || (K % 16) || nwg < 1) return GPN_E_UNSUPPORTED;
-  GemmArgs a;
-  a.batch = 1; a.sA = a.sB = a.sC = 0;
-  a.inner = 0; a.sA2 = a.sB2 = a.sC2 = 0;
-  a.acc_in = nullptr; a.acc_out = nullptr;
-  a.A = A; a.B = B; a.C = C;
-  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.M = (int)M; a.N = (int)M; a.K = (int)K;
-  a.mt = a.nt = (int)((M + 127) / 128);
-  a.lower = 1;
-  a.st_blk = a.st_step = a.st_diag = 0;
-  a.q_off = a.q_cnt = a.q_mt = 0;
-  a.lds_pad_kb = lds_pad_kb;
-  a.group_h = 8;
-  a.thin = g_thin_tiles;
-  a.tri = 0;
-  a.alpha = alpha; a.beta = beta;
-  const int total = a.mt * (a.mt + 1) / 2;
-  const int grid = std::min(nwg, total);
-  const int smem = (128 + 128) / 16 * 2 * 1024 * 2 + lds_pad_kb * 1024;
-  auto kern = gemm_nt_persistent_kernel<128, 128, 32, 64, true, 2, false, true>;
-  static std::atomic<int> attr_set{-1};
-  if (attr_set.load(std::memory_order_acquire) < smem) {
-    GPN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set.store(smem, std::memory_order_release);
-  }
-  const int rec = profile_on() ? profile_begin(s, (double)total * 2.0 * 128 * 128 * (double)K, PROF_GEMM_SYRK) : -1;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a, total);
-  if (rec >= 0) profile_end(s, rec);
-  GPN_LAUNCH_CHECK();
-  return GPN_OK;
+            double beta, double* C, int64_t ldc, int lower, int tri, int inplace) {
+  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, 1, 0, 0, 0);
 }
 
 int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
@@ -198,7 +133,7 @@ int gemm_nt_strided2(hipStream_t s, int64_t M, int64_t N, int64_t K, double alph
   if (outer <= 1) return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, 0, inner, sA, sB, sC);
   Outer ob;
   ob.count = outer; ob.sA = sA2; ob.sB = sB2; ob.sC = sC2;
-  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, 0, inner, sA, sB, sC, Stair(), 0, ob);
+  return gemm_nt_impl(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, 0, inner, sA, sB, sC, Stair(), ob);
 }
 
 int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_t K, double alpha,
@@ -212,7 +147,7 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st, int lds_pad_kb, Outer ob) {
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st, Outer ob) {
   if (M <= 0 || N <= 0 || batch <= 0) return GPN_OK;
   GemmArgs a;
   a.batch = batch; a.sA = sA; a.sB = sB; a.sC = sC;
@@ -228,11 +163,6 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   a.mt = a.nt = 0;
   a.lower = lower;
   a.st_blk = st.blk; a.st_step = st.step; a.st_diag = st.diag;
-  a.q_off = a.q_cnt = a.q_mt = 0;
-  a.lds_pad_kb = lds_pad_kb;
-#ifdef GPN_DEBUG_SWITCHES
-  if (g_group_h == 0) { const char* e = getenv("GPN_GEMM_GROUP_H"); g_group_h = e ? atoi(e) : 8; if (g_group_h < 1 || g_group_h > 64) g_group_h = 8; }
-#endif
   a.group_h = g_group_h;
   a.thin = g_thin_tiles;
   a.tri = tri;
@@ -254,8 +184,7 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   // K-clipped launches (tri != 0) have uneven tiles, so the finer grain wins longer.  U U^T (lower):
   // N = 8192 3.02 (64) vs 3.12 ms (128), N = 12288 10.3 vs 9.8, N = 16384 25.3 vs 22.7; the
   // triangular inversion's rectangular products stay on 64x64 tiles up to N = 16384 (28.0 vs 29.2 ms).
-  const bool tri_big_ab = g_tri_big_k > 0 && batch > 1 && K >= g_tri_big_k && t128 >= g_tri_big_tiles && M > 64 && N > 64;
-  const bool small = tri ? !((K >= 8192 && t128 >= (lower ? 4096 : 8192) && M > 64 && N > 64) || tri_big_ab)
+  const bool small = tri ? !(K >= 8192 && t128 >= (lower ? 4096 : 8192) && M > 64 && N > 64)
                          : !(K >= 512 && t128 >= (lower == 2 ? g_big_tile_min_trapezoid : 4096) && M > 64 && N > 64);
   if (inplace) {
     // C aliases A (panel solve against an inverted leaf block): one column tile must cover
@@ -273,17 +202,6 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   if (g_gemm_variant == 9) return launch<128, 128, 64, 32, true, 2, false, true>(s, a);   // 8 waves x (64x32), pipelined
   if (g_gemm_variant == 10) return launch<128, 128, 64, 32, true, 2, false, false>(s, a); // 8 waves x (64x32), plain loop
   if (g_gemm_variant == 11) return launch<128, 128, 32, 64, true, 2, false, true>(s, a);  // 8 waves x (32x64), pipelined
-#ifdef GPN_DEBUG_SWITCHES
-  // round-3 review item 8: a 256 x 128 macro tile (16 waves of 32 x 64, ONE workgroup / CU, 96 KB LDS: 25 % fewer operand
-  // bytes per flop from L2) against the 128 x 128 tile, both with the plain K loop (the pipelined loop needs whole LDS-DMA
-  // pieces per MFMA group: 3 pieces per wave here)
-  if (g_gemm_variant == 12) return launch<128, 128, 32, 64, true, 2, false, false>(s, a);
-  if (g_gemm_variant == 13) {
-    if (a.lower == 1 && !a.tri && a.batch == 1) a.lower = 5;
-    else if (a.lower) return GPN_E_UNSUPPORTED;
-    return launch<256, 128, 32, 64, true, 2, false, false>(s, a);
-  }
-#endif
   // skinny products (a handful of rows against a long K, e.g. alpha^T U^T): latency-bound per
   // K-step, so the deep ring and 4x more workgroups pay (131 vs 448 us at 1 x 8192 x 8192)
   // 21: A/B of whole workloads (tools/workload_ab.py): the shipped dispatch with the 4-wave 128x128 kernel
@@ -297,23 +215,6 @@ static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double a
   if (std_path) {
     if (small) return launch<64, 64, 32, 32, true, 2, false, true>(s, a);
     if (g_gemm_variant == 21) return launch<128, 128, 64, 64, true, 2, false, true>(s, a);
-    // Partial last round of a lower-tile launch: the 128 x 128 kernel has 512 slots (2 workgroups / CU), so t128 mod 512
-    // tiles keep the chip for one whole tile time (0.44 ms at K = 2048) however few they are.  When their 64 x 64 quarters
-    // fit ONE round of the small kernel's 1280 slots they go out as a second launch of quarter tiles instead (0.27 ms);
-    // every entry keeps its summation order (bit-identical).  C3's ten big trailing updates all qualify (mt a multiple of
-    // 16 => t128 mod 512 in 48 .. 248).  Measured NEUTRAL on whole evaluations (C3 186.05 vs 186.28 ms, C4 1363.9 vs 1363.0:
-    // the big kernel's last round is not synchronous, tiles are dealt to slots as they free up), so it is OFF in the product
-    // and kept behind g_split_tail (tools' build, gemm variant bit 7) with its test.
-    const int64_t rem = t128 % 512;
-    if (g_split_tail && lower == 1 && batch == 1 && rem > 0 && 4 * rem <= 1280) {
-      GemmArgs big = a;
-      big.q_cnt = (int)(t128 - rem);
-      int rc = launch<128, 128, 32, 64, true, 2, false, true>(s, big);
-      if (rc != GPN_OK) return rc;
-      GemmArgs q = a;
-      q.lower = 4; q.q_off = (int)(t128 - rem); q.q_cnt = (int)rem; q.q_mt = (int)((M + 127) / 128);
-      return launch<64, 64, 32, 32, true, 2, false, true>(s, q);
-    }
     return launch<128, 128, 32, 64, true, 2, false, true>(s, a);
   }
   return small ? launch<64, 64, 32, 32, false>(s, a) : launch<128, 128, 64, 64, false>(s, a);
@@ -342,12 +243,10 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
 }
 
 #ifdef GPN_DEBUG_SWITCHES
+// (libgpnative_dbg.so only; the calling thread's launches)
 extern "C" int gpn_debug_set_thin_tiles(int on) { gpn::g_thin_tiles = on; return GPN_OK; }
-extern "C" int gpn_debug_set_tri_big(int k, int tiles) { gpn::g_tri_big_k = k; gpn::g_tri_big_tiles = tiles; return GPN_OK; }
-extern "C" int gpn_debug_set_big_tile_min_trapezoid(int t) { gpn::g_big_tile_min_trapezoid = t; return GPN_OK; }
-extern "C" int gpn_debug_set_gemm_variant(int v) {     // (libgpnative_dbg.so only; the calling thread's launches)
-  gpn::g_gemm_variant = v & 0x7f;
-  gpn::g_split_tail = (v & 0x80) ? 1 : 0;   // bit 7: quarter-tile launch for the partial last round of big lower-tile launches
+extern "C" int gpn_debug_set_gemm_variant(int v) {
+  gpn::g_gemm_variant = v & 0x7f;     // forced tile shape (see gemm_nt_impl)
   gpn::g_smem_pad = v >> 8;           // bits 8..: KiB of LDS padding per workgroup
   return GPN_OK;
 }

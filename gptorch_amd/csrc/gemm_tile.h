@@ -16,12 +16,8 @@ struct GemmArgs {
   int64_t lda, ldb, ldc;
   int M, N, K;
   int mt, nt;       // tile counts
-  int lower;        // 0 full, 1 lower-tile square, 2 trapezoid, 3 staircase (st_* below), 4 quarters of the last big tiles (q_*)
-  // lower == 4: this launch computes, as BM x BN = 64 x 64 quarter tiles, the 128 x 128 tiles q_off .. q_off + q_cnt - 1 of a
-  // lower-tile launch with q_mt tile rows (its partial last round: gemm_nt_impl); block b = quarter (b & 3) of tile q_off + b/4
-  int q_off, q_cnt, q_mt;
-  int lds_pad_kb;   // extra dynamic LDS per workgroup: caps the workgroups per CU of a launch that shares the chip (look-ahead)
-  int group_h;      // tile rows per group of the grouped tile order (8; A/B of the L2 reuse: tools' build)
+  int lower;        // 0 full, 1 lower-tile square, 2 trapezoid, 3 staircase (st_* below)
+  int group_h;      // tile rows per group of the grouped tile order (8)
   int thin;         // 1: tiles with at most 16 rows of the matrix skip the MFMAs of their empty blocks (0: A/B, tools' build)
   // staircase: C is M x (nb * st_blk); column block b (st_blk columns) only has the rows from b * st_step on, and with
   // st_diag its first st_blk x st_blk square is lower-only -- the local tile columns of one block-cyclic trailing update
@@ -176,24 +172,6 @@ __device__ __forceinline__ void gemm_nt_tile(GemmArgs p, int bid, int nwg, const
     } else {
       tile_of_block_lower(q - rect, nwg - rect, p.nt, true, ti, tj, p.group_h);
     }
-  } else if (p.lower == 4) {
-    // quarters of the big tiles of a partial last round: the four quarters of one parent are consecutive logical ids,
-    // i.e. on one XCD (they share the parent's operand panels)
-    const int idx = xcd_remap(bid, nwg);
-    int pi, pj;
-    lower_tile_of_index(p.q_off + (idx >> 2), p.q_mt, pi, pj, p.group_h);
-    ti = 2 * pi + ((idx >> 1) & 1);
-    tj = 2 * pj + (idx & 1);
-    if (tj > ti || ti >= p.mt) return;        // the upper-right quarter of a diagonal parent; a ragged parent's empty half
-  } else if (p.lower == 5) {
-    // (A/B: 2:1 macro tiles) lower-tile square with BM = 2 BN: the two column halves of the BM x BM parent tiles of the
-    // grouped lower order, consecutive logical ids (one XCD: they share the parent's row panel)
-    const int idx = xcd_remap(bid, nwg);
-    int pi, pj;
-    lower_tile_of_index(idx >> 1, p.mt, pi, pj, p.group_h);
-    ti = pi;
-    tj = 2 * pj + (idx & 1);
-    if (tj * BN >= p.N) return;
   } else if (p.lower) tile_of_block_lower(bid, nwg, p.mt, spread, ti, tj, p.group_h);
   else tile_of_block(bid, nwg, p.mt, p.nt, spread, ti, tj, p.group_h);
 
@@ -488,7 +466,7 @@ __device__ __forceinline__ void gemm_nt_tile(GemmArgs p, int bid, int nwg, const
 
   // epilogue: reg r of lane l is C[(l>>4) + 4r][l&15] of its 16x16 tile
   const int crow = lane >> 4, ccol = lane & 15;
-  const bool diag_tile = p.lower == 3 ? stair_diag_tile : p.lower == 5 ? (ti == (tj >> 1)) : (p.lower && (ti == tj));     // (lower == 4 included)
+  const bool diag_tile = p.lower == 3 ? stair_diag_tile : (p.lower && (ti == tj));
   // beta != 0: ALL loads of one row of 16x16 tiles are issued before the first use (one HBM
   // round trip per TN*4 elements); element-by-element load -> fma -> store serialises 16+ round
   // trips per tile, which is most of the run time of a K = 128 update

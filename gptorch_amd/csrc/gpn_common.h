@@ -27,12 +27,7 @@ void set_hip_error(hipError_t e, const char* where);
 // the factorisation drivers (no argument validation).
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
-            double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0, int lds_pad_kb = 0);
-
-// lower-tile C[M, M] = alpha A B^T + beta C (K a multiple of 16) as ONE persistent launch of at most `nwg` 128 x 128-tile
-// workgroups with `lds_pad_kb` KiB of LDS padding each (gemm_f64.hip gemm_nt_persistent_kernel); bit-identical to gemm_nt(lower = 1)
-int gemm_nt_lower_persistent(hipStream_t s, int64_t M, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
-                             int64_t ldb, double beta, double* C, int64_t ldc, int nwg, int lds_pad_kb);
+            double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0);
 
 // gpn_potrf_lower as one persistent launch (ppotrf.hip); GPN_E_UNSUPPORTED = not this size / not under this capture
 int potrf_persistent(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda, double* winv, int32_t* info);
@@ -49,18 +44,10 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
 int colpanel(hipStream_t s, int mode, int64_t m, int64_t nb, const double* A, int64_t lda, const double* B, int64_t ldb,
              double* C, int64_t ldc, int batch = 1, int64_t sA = 0, int64_t sB = 0, int64_t sC = 0);
 
-// both column passes of a chain step in one launch (colpanel.hip colstep_kernel; tools' build): B <- B W^T in place, C -= X X_top^T
-int colstep(hipStream_t s, int64_t m, double* B, const double* W, double* C, int64_t lda, int* flag, int32_t* info, int batch,
-            int64_t sA, int64_t sW);
 // the 128 x 128 factor leaf, second generation (leaf16.hip): `batch` independent leaves in one launch, problem b at
 // A + b sA, winv + b sW, info + b sInfo
 int leaf16(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* winv, int32_t* info, int batch, int64_t sA,
            int64_t sW, int64_t sInfo);
-// one chain step as one launch (leaf16.hip): the next leaf (diagonal block at Anext) next to the column work of this step
-int chain_step(hipStream_t s, double* Anext, int64_t lda, int col0, double* Wnext, int32_t* info, double* B, const double* W,
-               const double* Xtop, double* C, int64_t m, int batch, int64_t sA, int64_t sW, int64_t sInfo);
-int leaf16_timing(hipStream_t s, double* A, int64_t lda, double* winv, int32_t* info, unsigned long long* diag72);
-
 // `batch` problems of identical shape at constant strides (elements) in one launch
 int gemm_nt_batched(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                     const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
@@ -94,16 +81,6 @@ int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, in
 // K(X) + noise I (lower tiles) into A and into Ksave (kmat.hip; gpn_lml_forward_saving)
 int assemble_lower_saving(hipStream_t s, int kind, const double* X, int64_t n, int d, const double* variance, const double* length_scales,
                           int nls, const double* noise, double* A, double* Ksave, int64_t lda);
-// one part of K(X) + noise I, lower tiles (kmat.hip): part 1 = the first `cols` columns, 2 = the rest
-int assemble_lower_part(hipStream_t s, int kind, const double* X, int64_t n, int d, const double* variance, const double* length_scales,
-                        int nls, const double* noise, double* A, int64_t lda, int part, int64_t cols);
-// the factorisation of gpn_potrf_lower with the columns from `split` on still being written on a side stream (potrf.hip):
-// split_columns = how many leading columns the driver needs before its first top-level trailing update (0: no split at this size);
-// side = the stream for that work and the event to record on it when it is done
-int64_t potrf_split_columns(int64_t n);
-int potrf_side_stream(hipStream_t s, hipStream_t* side, hipEvent_t* go, hipEvent_t* done);
-int potrf_lower_after(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda, double* winv, int32_t* info, hipEvent_t rest_ready);
-
 // K(X_b) + noise_b I (lower tiles) + right-hand sides + info words of `batch` models (kmat.hip; gpn_lml_forward_batched)
 int assemble_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d, const double* Y, int64_t sY,
                      const double* M, int64_t sM, int dy, const double* variance, const double* length_scales, int nls,

@@ -26,7 +26,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int GT = 64;     // tile edge
 constexpr int GDC = 16;    // coordinates per staged chunk
-constexpr int GMAXD = 64;  // max input dimension supported by the register accumulators
+constexpr int GMAXD = 64;  // gpn_kernel_grad_x2: up to this input dimension one accumulator per coordinate in registers, the chunked kernel above it
 
 struct GradArgs {
   const double* X;
@@ -680,7 +680,7 @@ template <int KIND>
 static int launch_x2(hipStream_t s, const GradX2Args& a, dim3 grid) {
   if (a.d <= 16) hipLaunchKernelGGL((grad_x2_kernel<KIND, 16>), grid, dim3(256), 0, s, a);
   else if (a.d <= 32) hipLaunchKernelGGL((grad_x2_kernel<KIND, 32>), grid, dim3(256), 0, s, a);
-  else if (a.d <= 64) hipLaunchKernelGGL((grad_x2_kernel<KIND, 64>), grid, dim3(256), 0, s, a);
+  else if (a.d <= GMAXD) hipLaunchKernelGGL((grad_x2_kernel<KIND, 64>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((grad_x2_chunked_kernel<KIND>), dim3(grid.x, grid.y, (unsigned)((a.d + GDC - 1) / GDC)), dim3(256), 0, s, a);
   GPN_LAUNCH_CHECK();
   return GPN_OK;

@@ -32,11 +32,6 @@ struct KmatArgs {
   int n, m, d, nls;
   int symmetric, lower, vec_ok;
   int64_t sX, sK;     // strided batch (gridDim.z problems): points and output at these strides, hyper-parameters consecutive
-  // lower launches in two parts (gpn_lml_forward at large N: the second part is assembled on a side stream underneath the first
-  // outer panel's chain): part 0 = every tile on / below the diagonal; part 1 = the tiles of the first `tc` tile COLUMNS (the
-  // triangle of the first tc tile rows, then the tc-wide rectangle of the rows below); part 2 = the triangle of the tile rows /
-  // columns from tc on
-  int part = 0, tc = 0;
   // gpn_lml_forward_saving: every entry is also stored here (same leading dimension) -- a pristine copy of Kyy for the refinement
   // step's residual pass, which otherwise re-computes every entry (the factorisation overwrites K in place)
   double* K2 = nullptr;
@@ -59,19 +54,11 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   if (p.lower) {
     // only the tiles on/below the diagonal are launched (row-major over the triangle): no
     // empty workgroups, equal work for every XCD
-    int q = blockIdx.x;
-    const int tri = p.tc * (p.tc + 1) / 2;
-    if (p.part == 1 && q >= tri) {           // the rectangle below the first tc tile rows
-      q -= tri;
-      ti = p.tc + q / p.tc;
-      tj = q - (ti - p.tc) * p.tc;
-    } else {
-      ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
-      while (ti * (ti + 1) / 2 > q) --ti;
-      while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
-      tj = q - ti * (ti + 1) / 2;
-      if (p.part == 2) { ti += p.tc; tj += p.tc; }
-    }
+    const int q = blockIdx.x;
+    ti = (int)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > q) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= q) ++ti;
+    tj = q - ti * (ti + 1) / 2;
   } else {
     tj = blockIdx.x;
     ti = blockIdx.y;
@@ -190,38 +177,6 @@ __global__ void pack_rhs_kernel(const double* Y, const double* M, int64_t n, int
 int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
                   int32_t* info) {
   hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((lde + 255) / 256)), dim3(256), 0, s, Y, M, n, dy, E, lde, 1, info);
-  GPN_LAUNCH_CHECK();
-  return GPN_OK;
-}
-
-// K(X) + noise I, lower tiles, ONE PART of it (KmatArgs.part: 1 = the first `cols` columns, 2 = the rest; cols a multiple of the
-// 64-wide tile): the two launches together write exactly what gpn_kernel_matrix(..., GPN_LOWER) writes, entry for entry
-int assemble_lower_part(hipStream_t s, int kind, const double* X, int64_t n, int d, const double* variance, const double* length_scales,
-                        int nls, const double* noise, double* A, int64_t lda, int part, int64_t cols) {
-  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
-  if ((part != 1 && part != 2) || cols <= 0 || cols % KT || cols >= n) return GPN_E_UNSUPPORTED;
-  KmatArgs a;
-  a.X = X; a.X2 = X;
-  a.variance = variance; a.ls = length_scales; a.noise = noise;
-  a.K = A; a.ldk = lda;
-  a.n = (int)n; a.m = (int)n; a.d = d; a.nls = nls;
-  a.symmetric = 1; a.lower = 1;
-  a.vec_ok = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-  a.sX = 0; a.sK = 0;
-  a.part = part; a.tc = (int)(cols / KT);
-  const int64_t tm = (n + KT - 1) / KT, tc = a.tc;
-  const int64_t tiles = part == 1 ? tc * (tc + 1) / 2 + (tm - tc) * tc : (tm - tc) * (tm - tc + 1) / 2;
-  const dim3 grid((unsigned)tiles);
-  int rec = -1;
-  if (profile_on()) rec = profile_begin(s, 8.0 * ((double)tiles * KT * KT + (part == 1 ? (double)n * d : 0.0)), PROF_KMAT);
-  switch (kind) {
-    case GPN_RBF: hipLaunchKernelGGL(kmat_kernel<GPN_RBF>, grid, dim3(256), 0, s, a); break;
-    case GPN_MATERN52: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN52>, grid, dim3(256), 0, s, a); break;
-    case GPN_MATERN32: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN32>, grid, dim3(256), 0, s, a); break;
-    case GPN_EXP: hipLaunchKernelGGL(kmat_kernel<GPN_EXP>, grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL(kmat_kernel<GPN_PERIODIC>, grid, dim3(256), 0, s, a); break;
-  }
-  if (rec >= 0) profile_end(s, rec);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

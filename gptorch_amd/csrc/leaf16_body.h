@@ -42,32 +42,14 @@ struct Leaf16Args {
   int64_t sA, sW, sInfo;              // per-workgroup strides (elements): blockIdx.x-th problem of a batch
 };
 
-// DIAG build: a timeline -- stamp[(wave * 8 + k) * 8 + ev] = s_memtime when the wave ISSUED past event ev of block k.  The
-// stamps go to LDS (one ds_write by lane 0; copied to `diag` at the end of the kernel) and tie nothing: a stamp that waits
-// for the value it brackets, or stores to global memory, perturbs the tile waves' loop by hundreds of cycles per tile.
-#define L16_TL(k, ev, tie)                                                                                   \
-  if constexpr (DIAG) {                                                                                      \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                              \
-    if (lane == 0) stampbuf[(wave * 8 + (k)) * 8 + (ev)] = t_;                                               \
-  }
-#define L16_TU(k, j, tie)
-
 // WT: every global store is an agent-scope write-through (`sc1`) store -- the leaf as a task of the persistent factorisation
 // (ppotrf.hip), whose results other workgroups of the same launch read (MI355X_MICROARCH.md "Valid forms").
-template <bool DIAG, bool WT = false>
-__device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long long* diag, const int prob, const int tid_in = -1) {
+template <bool WT = false>
+__device__ __forceinline__ void leaf16_body(const Leaf16Args& p, const int prob, const int tid_in = -1) {
   auto gst = [](double* q, double v) {
     if constexpr (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *q = v;
   };
-  [[maybe_unused]] int tie0 = 0;      // (placeholder argument of the stamp macros)
-  __shared__ unsigned long long stampbuf[DIAG ? 12 * 8 * 8 : 1];
-  if constexpr (DIAG) {
-    for (int idx = threadIdx.x; idx < 12 * 8 * 8; idx += L16_THREADS) stampbuf[idx] = 0;
-    __syncthreads();
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();
-    if ((threadIdx.x & 63) == 0) stampbuf[((threadIdx.x >> 6) * 8 + 0) * 8 + 6] = t_;      // kernel entry
-  }
   double* A = p.A + (int64_t)prob * p.sA;
   double* winv = p.winv + (int64_t)prob * p.sW;
   int32_t* info = p.info ? p.info + (int64_t)prob * p.sInfo : nullptr;
@@ -144,7 +126,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
     constexpr int w = decltype(wconst)::value;
     // slot J (J <= w): A tile (w, J); slot J + 1 (J >= w): identity tile (8 + w, J).  Transposed storage.
     d4 acc[9];
-    L16_TL(1, 6, tie0)
     {
       // One memory round trip, COALESCED and 16 bytes per lane: a tile is fetched row-major by two instructions (lane l:
       // row (l >> 3) + 8 i, columns 2 (l & 7), + 1 -- 8 consecutive lanes = 128 consecutive bytes), only the tiles on and left
@@ -168,7 +149,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
           if (q <= w) ld[q][i2] = *reinterpret_cast<const d2*>(rowp + 16 * q);      // (uniform branch, no use inside)
         }
       }
-      L16_TL(2, 6, tie0)
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
         if (q < 8 && q < w) {                                         // A tile left of the diagonal (uniform branch)
@@ -206,7 +186,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
         }
       }
     }
-    L16_TL(3, 6, acc[0])
     auto dump = [&](double* dst, const d4& t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) dst[r * 64 + lane] = t[r];
@@ -215,7 +194,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
     // flags, not by a barrier: the pivot wave starts when row 0's ONE tile is in, not when row 7's eight are
     if (w == 0) { dump(Raw + (0 * 2 + 1) * 256, acc[0]); publish_flag(&rawflag[0], 1); }
     if (w == 1) { dump(Raw + (1 * 2 + 0) * 256, acc[0]); dump(Raw + (1 * 2 + 1) * 256, acc[1]); publish_flag(&rawflag[1], 1); }
-    L16_TL(4, 6, tie0)
 
     // T(i,j) -= X(i,k) X(j,k)^T:  xa = X(j,k) fragments, nx = -X(i,k) (own registers)
     auto update = [&](d4& t, const d4& xa, const d4& nx) {
@@ -235,9 +213,7 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
     bool ok = true;                                                   // false: a failure somewhere -- no more global stores
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      L16_TL(k, 0, tie0)
       ok = ok && wait_flag(&wready, k);                               // W_k and L_k are out
-      L16_TL(k, 1, tie0)
       if (!ok) break;                                                 // uniform
       d4 wf;
 #pragma unroll
@@ -253,14 +229,12 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
           for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[r], acc[q][r], x, 0, 0, 0);
         }
       }
-      L16_TL(k, 2, x)
       double* myx = xslot(w > 0 ? w : 1, k < w ? k : 0);              // (only used when apart)
       if (apart) {
         dump(myx, x);
         publish_flag(&xready[w], k + 1);                              // X(w, k) is out
       }
       const d4 nx = d4{-x[0], -x[1], -x[2], -x[3]};
-      L16_TL(k, 3, tie0)
       if (k < 7) {
         // ---- updates with panel k, BEFORE this panel's global stores (the stores are fire-and-forget, the next blocks wait
         // for these tiles).  The A operand X(j, k) of the NEXT tile is requested between the first and the second MFMA of
@@ -304,7 +278,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
           }
         }
       }
-      L16_TL(k, 4, tie0)
       // ---- this panel's final tiles to global memory
       if (!ok) break;
       if (apart) {
@@ -332,7 +305,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
           }
         }
       }
-      L16_TL(k, 5, tie0)
     }
   };
   if (tilewave) {
@@ -367,9 +339,7 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
   } else {
     // ======================================= pivot wave =======================================
     __builtin_amdgcn_s_setprio(3);
-    L16_TL(4, 6, tie0)
     wait_flag(&rawflag[0], 0);                                        // D(0,0) is out (a failure leaves through the loop below)
-    L16_TL(5, 6, tie0)
     double a[16];
     const int myrow = lane & 31;
     // block 0: D(0,0) as dumped by wave 0 (transposed storage of a symmetric tile) -> one row per lane
@@ -386,7 +356,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
     }
 #pragma unroll 1
     for (int k = 0; k < 8; ++k) {
-      L16_TL(k, 0, a[0])
       // ---- 16 pivots, one row per lane; lanes 16..31 carry the identity rows.  Per pivot J only the NEXT column is updated
       // at once (readlane broadcast: it feeds the next pivot); the columns after it take pivot J's rank-1 update one pivot
       // LATER, from an LDS broadcast of the column (one ds_write_b64 + uniform ds_read_b128s issued here, consumed during
@@ -418,7 +387,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
         }
         lprev = l;
       }
-      L16_TL(k, 1, a[15])
       // a failed pivot (d <= 0 or NaN) turns everything after it into NaN, a[15] of row 15 included
       {
         const double last = bcast(a[15], 15);
@@ -438,7 +406,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
 #pragma unroll
         for (int c = 0; c < 16; ++c) dst[c] = a[c];
       }
-      L16_TL(k, 2, tie0)
       // (after a failed pivot nothing is announced: the waiters see failflag in their spin and leave without storing)
       if (__hip_atomic_load(&failflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
       // ONE LDS round trip between two blocks: the raw tiles for block k + 1 were published a panel ago, so they are read
@@ -467,7 +434,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
           dacc[r] = Raw[(par * 2 + 1) * 256 + r * 64 + lane];
         }
       }
-      L16_TL(k, 3, tie0)
       // ---- next diagonal block from the raw tiles:  X = A(k+1,k) W_k^T,  D(k+1) -= X X^T
       {
         d4 x = d4{0.0, 0.0, 0.0, 0.0};
@@ -475,7 +441,6 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
         for (int r = 0; r < 4; ++r) x = __builtin_amdgcn_mfma_f64_16x16x4f64(wf[r], ar[r], x, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[r], x[r], dacc, 0, 0, 0);
-        L16_TL(k, 4, dacc)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Drow[lc * RS + g + 4 * r] = dacc[r];
         L16_WAVE_FENCE();
@@ -483,17 +448,9 @@ __device__ __forceinline__ void leaf16_body(const Leaf16Args& p, unsigned long l
         for (int c = 0; c < 16; ++c) a[c] = Drow[myrow * RS + c];
         L16_WAVE_FENCE();
       }
-      L16_TL(k, 5, a[0])
     }
   }
-  if constexpr (DIAG) {
-    L16_TL(0, 7, tie0)                                                 // end of the wave's work
-    if (lane == 0) stampbuf[(wave * 8 + 1) * 8 + 7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);   // HW_ID
-  }
   __syncthreads();
-  if constexpr (DIAG) {
-    for (int idx = tid; idx < 12 * 8 * 8; idx += L16_THREADS) diag[idx] = stampbuf[idx];
-  }
   if (failflag) {
     if (tid == 0 && info) {
       if constexpr (WT) {          // another workgroup of the same launch may have reported before: first report wins, atomically

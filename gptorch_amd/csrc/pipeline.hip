@@ -110,28 +110,6 @@ extern "C" int gpn_lml_forward(void* stream, int kind, const double* X, int64_t 
   if (!info) return -16;
   if (!out3) return -17;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int64_t split = (n > 0 && X && variance && length_scales && kind >= GPN_RBF && kind <= GPN_PERIODIC && d > 0 && (nls == 1 || nls == d))
-                            ? potrf_split_columns(n) : 0;
-  if (split > 0) {
-    // large N: only the columns of the first top-level panel are assembled here; the rest of the matrix is written on a side
-    // stream underneath that panel's chain and joined before its trailing update (potrf.hip).  Entry for entry the same matrix.
-    hipStream_t side;
-    hipEvent_t go, done;
-    int rc = potrf_side_stream(s, &side, &go, &done);
-    if (rc != GPN_OK) return rc;
-    GPN_HIP_CHECK(hipEventRecord(go, s));                       // whatever used the buffer before is ordered before both parts
-    GPN_HIP_CHECK(hipStreamWaitEvent(side, go, 0));
-    rc = assemble_lower_part(s, kind, X, n, d, variance, length_scales, nls, noise, A, lda, 1, split);
-    if (rc != GPN_OK) return rc;
-    rc = pack_rhs_full(s, Y, M, n, dy, A + n * lda, lda, info);
-    if (rc != GPN_OK) return rc;
-    rc = assemble_lower_part(side, kind, X, n, d, variance, length_scales, nls, noise, A, lda, 2, split);
-    GPN_HIP_CHECK(hipEventRecord(done, side));                  // (recorded also on an error exit: nothing stays unjoined)
-    if (rc != GPN_OK) { (void)hipStreamWaitEvent(s, done, 0); return rc; }
-    rc = potrf_lower_after(s, A, n, dy, lda, winv, info, done);
-    if (rc != GPN_OK) return rc;
-    return gpn_lml_reduce(stream, A, n, dy, lda, out3);
-  }
   int rc = gpn_kernel_matrix(stream, kind, X, n, nullptr, n, d, variance, length_scales, nls, noise, GPN_LOWER, A, lda);
   if (rc != GPN_OK) return rc;
   // (Y - M)^T into the extra rows; the corner right of them (it accumulates -alpha alpha^T during

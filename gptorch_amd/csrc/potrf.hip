@@ -2,9 +2,9 @@
 // solves built on it.  Replaces torch.cholesky / torch.triangular_solve under
 // functions.cholesky / functions.trtrs (functions.py:46-47, 71-76).
 //
-// Two host drivers over the same kernels: the flat panel driver with look-ahead on an auxiliary
+// Two host drivers over the same kernels: the nested-panel driver with in-panel look-ahead on an auxiliary
 // stream (potrf_lookahead, the default for the factorisation) and recursive blocking down to a
-// 128x128 leaf (used for small n, the right-solves and as the A/B reference):
+// 128x128 leaf (used for small n, the right-solves and as the cross-check in the tests):
 //   potrf(A):  A11 = potrf(A11);  A21 <- A21 * L11^-T;  A22 -= A21 A21^T;  potrf(A22)
 //   trsm(B,L): B1 <- B1 * L11^-T; B2 -= B1 * L21^T;     B2 <- B2 * L22^-T
 // Every flop outside the 128x128 leaves is an "NT" fp64-MFMA contraction
@@ -31,47 +31,20 @@
 namespace gpn {
 
 // ---------------------------------------------------------------------------------
-// Leaf: one workgroup (576 threads, 9 waves) factors a 128x128 diagonal block AND
-// forms its inverse:  L = chol(A[0:kb,0:kb]) in place,  W = L^-1 -> winv (128x128,
-// ld 128, zero outside the kb x kb lower triangle).  Rows/cols >= kb act as identity.
-// FACTOR=false: A already holds a lower-triangular L; only W is formed (blockIdx.x
-// selects the diagonal block).
-//
-// Right-looking, blocked by 8 columns, on the stacked matrix [A ; I] (256 x 128): the
-// identity rows are "extra rows" exactly as in the outer algorithm, so they come out as
-// I * L^-T = W^T and the inverse needs no pass of its own.  The whole trailing matrix
-// lives in REGISTERS as 16x16 MFMA accumulator tiles.
-//
-// Roles.  Waves 0..7 are TILE waves: wave w owns A-part tile row w (tiles (w,J), J <= w) and
-// identity-part tile row w (tiles (8+w,J), J >= w) -- always 9 tiles, in static slots
-// (slot J for the A tile of column J, slot J+1 for the identity tile of column J).  Wave 8 is
-// the PIVOT wave.  Per block of 8 pivots (panel p), with look-ahead:
-//   A  tile waves: rank-8 update with panel p of tile column `jact` only (the column the next
-//      panel lives in), then publish the next raw 8-column panel to LDS
-//   B  pivot wave: 8x8 diagonal block of panel p+1, one row per lane, broadcasts through
-//      v_readlane only (no LDS / barrier on the serial pivot chain: rsq + 2 Newton per pivot)
-//      tile waves: the rest of the rank-8 update with panel p (2 MFMAs per live tile)
-//   C  waves 0..3, one thread per row: forward substitution of panel p+1 against L8;
-//      waves 4..7, one thread per row: panel p's final values (L rows / W^T rows) LDS -> global
-// 3 barriers per 8 pivots; the panel buffer is double-buffered.
+// The first-generation 128 x 128 leaf (rounds 1-3; the factorisation's leaf is leaf16.hip since round 4).  What is left of it is its
+// FACTOR = false form -- the inverse of a GIVEN lower-triangular block, gpn_trtri_diag -- on the same machinery: blocked
+// elimination by 8 columns on the stacked matrix [L ; I] (256 x 128), whose identity rows come out as I L^-T = W^T; the trailing
+// matrix lives in registers as 16 x 16 MFMA accumulator tiles (waves 0..7 own one tile row of each part, wave 8 inverts the
+// 8 x 8 diagonal blocks); 3 barriers per 8 pivots, double-buffered panel.  (FACTOR = true -- Cholesky of the block on the same
+// scheme, with its pipelined pivot wave and the stamped diagnostic build -- is in the history: rounds 1-3, LAB.md 8.)
 // ---------------------------------------------------------------------------------
 constexpr int XPS = 9;                 // padded row of the panel buffer (doubles)
 constexpr int LEAF_THREADS = 576;
 
-#define GPN_STAMP(k)                                                            \
-  if constexpr (DIAG) {                                                         \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                 \
-    acc_t[k] += t_ - last_t;                                                    \
-    last_t = t_;                                                                \
-  }
-
-template <bool FACTOR, bool DIAG = false, bool PIPE = false>
+template <bool FACTOR>
 __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int64_t lda, int kb_, int col0_,
-                                                                  double* winv_, int32_t* info, int n_total,
-                                                                  unsigned long long* diag = nullptr) {
+                                                                  double* winv_, int32_t* info, int n_total) {
   typedef double d4 __attribute__((ext_vector_type(4)));
-  unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_t = 0;
-  if constexpr (DIAG) last_t = __builtin_amdgcn_s_memtime();
   int kb = kb_, col0 = col0_;
   double* winv = winv_;
   if constexpr (!FACTOR) {
@@ -85,10 +58,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   // parity of the panel they belong to (the pivot wave runs ahead of the tile waves in PIPE mode)
   __shared__ double Dg2[2][64];         // L8 (row-major 8x8), for the output rows
   __shared__ double Ds2[2][64];         // L8 scaled by 1/diag (diagonal slot: 1/diag), for the row solves
-  __shared__ double Rn2[2][64];         // PIPE: rows of the panel after next x columns of the next panel (raw)
-  __shared__ double Dn2[2][64];         // PIPE: 8x8 diagonal block of the panel after next (raw)
-  __shared__ int tb_count;              // PIPE: arrivals at the tile waves' software barrier
-  __shared__ double Xs[64];             // PIPE: pivot-wave scratch (its 8 solved rows)
   __shared__ int failflag;
 
   const int tid = threadIdx.x;
@@ -97,7 +66,7 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   const bool tilewave = wave < 8;
   const int w = wave & 7;
   const int lr = lane >> 4, lc = lane & 15;      // D-layout: rows lr + 4r, column lc
-  if (tid == 0) { failflag = 0; tb_count = 0; }
+  if (tid == 0) failflag = 0;
   if (!tilewave) __builtin_amdgcn_s_setprio(3);   // the pivot chain must not queue behind tile-wave VALU work
 
   // slot J (J = 0..7): A tile (w, J), used when J <= w; slot J+1: identity tile (8+w, J), used
@@ -135,35 +104,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
         if (J >= w) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) xp[(128 + 16 * w + lr + 4 * r) * XPS + (lc & 7)] = acc[J + 1][r];
-        }
-      }
-    }
-  };
-
-  // PIPE: what the pivot wave needs to advance the diagonal block of the panel starting at row
-  // rn0 by itself: Rn = rows rn0..rn0+7 x columns rn0-8..rn0-1, Dn = rows x columns rn0..rn0+7,
-  // both as the tile registers hold them now (one tile wave owns all of them)
-  auto publish_extra = [&](int rn0) {
-    const int wr = rn0 >> 4;
-    if (w != wr) return;                       // wave-uniform
-    const int rh = rn0 & 8;
-    const int J1 = (rn0 - 8) >> 4, h1 = ((rn0 - 8) >> 3) & 1, hd = (rn0 >> 3) & 1;
-    double* Rn = Rn2[(rn0 >> 3) & 1];
-    double* Dn = Dn2[(rn0 >> 3) & 1];
-#pragma unroll
-    for (int J = 0; J < 8; ++J) {
-      if (J == J1 && (lc >> 3) == h1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row16 = lr + 4 * r;
-          if ((row16 & 8) == rh) Rn[(row16 & 7) * 8 + (lc & 7)] = acc[J][r];
-        }
-      }
-      if (J == wr && (lc >> 3) == hd) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row16 = lr + 4 * r;
-          if ((row16 & 8) == rh) Dn[(row16 & 7) * 8 + (lc & 7)] = acc[J][r];
         }
       }
     }
@@ -275,36 +215,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     if (lane == 0 && fail && failflag == 0) failflag = fail;     // keep the FIRST failing column
   };
 
-  // PIPE (pivot wave): advance the NEXT diagonal block past the 8 pivots just taken, from the raw
-  // blocks the tile waves published:  X = Rn L8^-T,  D' = Dn - X X^T.
-  auto catch_up = [&](int c0) -> double {        // c0: first column of the block just factored
-    const double* Ds = Ds2[(c0 >> 3) & 1];
-    const double* Rn = Rn2[((c0 >> 3) + 1) & 1];
-    const double* Dn = Dn2[((c0 >> 3) + 1) & 1];
-    // lanes 0..7: one row of Rn each, forward substitution against the L8 this wave has just
-    // written to Ds (same right-looking order as solve_rows: 8 dependent FMAs); then all 64
-    // lanes take their element of D' = Dn - X X^T with X read back from LDS
-    const int pi = lane >> 3, pc = lane & 7;
-    if (lane < 8) {
-      double x[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) x[c] = Rn[lane * 8 + c] * Ds[c * 8 + c];
-#pragma unroll
-      for (int k2 = 0; k2 < 7; ++k2) {
-#pragma unroll
-        for (int c = k2 + 1; c < 8; ++c) x[c] = fma(-x[k2], Ds[c * 8 + k2], x[c]);
-      }
-#pragma unroll
-      for (int c = 0; c < 8; ++c) Xs[lane * 8 + c] = x[c];
-    }
-    const double* xi = Xs + pi * 8;
-    const double* xc = Xs + pc * 8;
-    double d = Dn[lane];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) d = fma(-xi[k], xc[k], d);
-    return d;
-  };
-
   // P2 (threads 0..255 = waves 0..3): forward substitution of one panel row against L8;
   // the solved row goes back to LDS (the pivot wave streams it to global one phase later)
   auto solve_rows = [&](double* xp, int c0) {
@@ -361,15 +271,11 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
 
   // ---- prologue: panel 0 ------------------------------------------------------------------
   double a_main = 0.0, wt = 0.0;              // pivot wave: its 8x8 block / carried L8^-T
-  if (tilewave) {
-    publish(Xp[0], 0, 0);
-    if constexpr (PIPE) publish_extra(8);
-  }
+  if (tilewave) publish(Xp[0], 0, 0);
   __syncthreads();
   if (!tilewave) {
     a_main = Xp[0][(lane >> 3) * XPS + (lane & 7)];
     pivot_block(a_main, 0, wt);
-    if constexpr (PIPE) a_main = catch_up(0);
   }
   __syncthreads();
   if (!failflag) solve_rows(Xp[0], 0);
@@ -377,81 +283,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
 
   // ---- main loop --------------------------------------------------------------------------
   int done = 0;
-  if constexpr (PIPE) {
-    const bool prologue_ok = !failflag;          // read between barriers: the same for every wave
-    if (prologue_ok) {
-    // Two phases per panel.  X: the pivot wave factors the NEXT diagonal block straight from its
-    // registers (it advanced that block itself, see catch_up) while the tile waves apply the
-    // current panel's rank-8 update, publish the next raw panel and store the current one.
-    // Y: row solves of the next panel || the pivot wave advances the block after next.
-    // The two roles run SEPARATE loops with the same barrier sequence: in one loop the loop
-    // invariants of both roles (LDS addresses, lane predicates) are live together and the
-    // 168-VGPR budget of a 9-wave workgroup spills.
-    if (tilewave) {
-      // software barrier of the 8 tile waves (monotonic arrival counter in LDS): the second
-      // hand-over of an iteration (solved panel -> next update) does not involve the pivot wave,
-      // and a hardware barrier there would stall its pivot chain for ~900 cycles per block.
-      // The spin is bounded: on a lost arrival the leaf reports failure instead of hanging.
-      int epoch = 0;
-      auto tile_barrier = [&]() {
-        ++epoch;
-        // LDS only: the LDS unit serves one wave's operations in order, so "my panel writes, then
-        // my arrival" needs no fence; a release/acquire pair would also wait for the panel's
-        // GLOBAL stores (s_waitcnt vmcnt(0), ~1 us) that nobody in this kernel reads back.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(&tb_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        int spins = 0;
-        while (__hip_atomic_load(&tb_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 8 * epoch) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1 << 22)) { failflag = LEAF + 1; break; }
-        }
-        asm volatile("" ::: "memory");
-      };
-      // (failflag is only examined right after the hardware barrier, where both roles see the
-      //  same value: the pivot wave runs ahead and may raise it at any time)
-      for (int kb8 = 0; kb8 < 16; ++kb8) {
-        const int c0 = kb8 * 8;
-        const int J0 = kb8 >> 1;
-        const int jact = (c0 + 8) >> 4;
-        const int halfn = (kb8 + 1) & 1;
-        const bool has1 = kb8 < 15, has2 = kb8 < 14;
-        double* cur = Xp[kb8 & 1];
-        double* nxt = Xp[(kb8 + 1) & 1];
-        GPN_STAMP(0)
-        if (has1) {
-          update(cur, jact, 7, J0);              // nobody waits for the publish any more: one pass
-          publish(nxt, jact, halfn);
-          if (has2) publish_extra(c0 + 16);
-        }
-        GPN_STAMP(1)
-        if (!has1) { store_panel(cur, c0); break; }
-        GPN_STAMP(2)
-        __syncthreads();                         // all 9 waves: L8(next) and the raw blocks are out
-        GPN_STAMP(3)
-        if (failflag) break;                     // uniform
-        solve_rows(nxt, c0 + 8);                 // waves 0..3
-        store_panel(cur, c0);                    // waves 4..7 (idle in this phase otherwise)
-        GPN_STAMP(4)
-        tile_barrier();
-        GPN_STAMP(5)
-      }
-    } else {
-      for (int kb8 = 0; kb8 < 16; ++kb8) {
-        const int c0 = kb8 * 8;
-        const bool has1 = kb8 < 15, has2 = kb8 < 14;
-        GPN_STAMP(0)
-        if (has1) pivot_block(a_main, c0 + 8, wt);
-        if (!has1) break;
-        GPN_STAMP(2)
-        __syncthreads();
-        GPN_STAMP(3)
-        if (failflag) break;
-        if (has2) a_main = catch_up(c0 + 8);
-        GPN_STAMP(4)
-      }
-    }
-    }
-  } else {
   for (int kb8 = 0; kb8 < 16 && !failflag; ++kb8) {
     const int c0 = kb8 * 8;
     const int J0 = kb8 >> 1;
@@ -459,7 +290,6 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     const int halfn = (kb8 + 1) & 1;
     double* cur = Xp[kb8 & 1];
     double* nxt = Xp[(kb8 + 1) & 1];
-    GPN_STAMP(0)
     // A
     if (tilewave) {
       if (kb8 < 15) {
@@ -469,35 +299,20 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
     }
     done = kb8 + 1;
     if (kb8 == 15) break;
-    GPN_STAMP(1)
     __syncthreads();
-    GPN_STAMP(2)
     // B
     if (tilewave) update(cur, jact + 1, 7, J0);
     else { a_main = nxt[(c0 + 8 + (lane >> 3)) * XPS + (lane & 7)]; pivot_block(a_main, c0 + 8, wt); }
-    GPN_STAMP(3)
     __syncthreads();
-    GPN_STAMP(4)
     if (failflag) break;                     // uniform
     // C
     solve_rows(nxt, c0 + 8);
     store_panel(cur, c0);
-    GPN_STAMP(5)
     __syncthreads();
-    GPN_STAMP(6)
   }
-  }
-  if constexpr (DIAG) {
-    GPN_STAMP(7)
-    if (lane == 0) for (int k = 0; k < 8; ++k) diag[wave * 8 + k] = acc_t[k];
-  }
-  if (!PIPE && !failflag) store_panel(Xp[1], 120);     // last panel (kb8 = 15 lives in buffer 1)
+  if (!failflag) store_panel(Xp[1], 120);     // last panel (kb8 = 15 lives in buffer 1)
   __syncthreads();
   if (failflag) {
-    // failflag == LEAF + 1: the software barrier of the tile waves lost an arrival (bounded spin
-    // ran out) -- an internal failure, NOT a statement about the matrix: reported as the negative
-    // status GPN_INFO_INTERNAL, which overrides any pivot index and which the shell raises on
-    // instead of climbing the jitter ladder.
     if (tid == 0 && info) {
       if (failflag > LEAF) *info = GPN_INFO_INTERNAL;
       else if (*info == 0) *info = col0 + failflag;
@@ -508,17 +323,24 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   (void)done;
 }
 
-// (A/B switches: libgpnative_dbg.so only, per calling thread -- see gemm_f64.hip)
+// Switches: constants in the product library; in the tools' build (libgpnative_dbg.so, -DGPN_DEBUG_SWITCHES) per-thread
+// variables behind the gpn_debug_set_* entry points at the end of this file -- other PARAMETRISATIONS of the shipped driver
+// (plain recursion, panel widths and nesting, left- / right-looking in-panel updates, the extra rows' kernel), which
+// tests/test_gpu_parity.py::test_factorisation_drivers_agree holds against each other.  The schedules that were built, measured
+// and dropped (look-ahead over panels in three forms incl. round 6's persistent bulk, look-ahead inside the outer panel, the
+// fused chain step, both column passes in one launch, left-looking inner panels, split assembly) are in the history and in
+// LAB.md 8 / 10 / 11 / 12 with their same-box logs under profiles/.
 #ifdef GPN_DEBUG_SWITCHES
 #define GPN_SWITCH static thread_local int
 #else
 #define GPN_SWITCH static constexpr int
 #endif
-GPN_SWITCH g_leaf_pipe = 1;          // 1 = two-phase leaf (pivot wave advances its own block); 0 = three-phase
-GPN_SWITCH g_leaf_gen = 2;           // 2 = 16-pivot-block leaf (leaf16.hip, round 4); 1 = the first-generation leaf above
-// bit 0: every in-place solve against an inverted leaf block (the chain's and the right-solve recursion's) through
-// colpanel.hip; bit 1: the chain's next-column update too (measured slower: DESIGN 8-1f); 0 = the generic contraction
-GPN_SWITCH g_chain_kernel = 1;
+GPN_SWITCH g_potrf_variant = 0;      // 0 = nested panels with in-panel look-ahead (default), 1 = plain recursion
+GPN_SWITCH g_panel_width = 0;        // inner panel width, 0 = by size
+GPN_SWITCH g_outer_width = 0;        // outer panel width: 0 = by size, -1 = one level
+GPN_SWITCH g_outer_width2 = 0;       // a third level
+GPN_SWITCH g_aux_left_looking = -1;  // in-panel updates beyond the next column block: -1 = by size, 0 right- / 1 left-looking
+GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row of the lower-tile launch
 
 struct Ctx {
   hipStream_t s;
@@ -535,16 +357,12 @@ struct Ctx {
   // A + b sA, winv + b sW, info + b; every launch of the drivers below covers all of them
   int batch = 1;
   int64_t sA = 0, sW = 0;
-  // gpn_lml_forward at large N: the columns right of the first top-level panel are still being assembled on a side stream;
-  // the first top-level trailing update waits for this event (nullptr: nothing pending)
-  hipEvent_t rest_ready = nullptr;
 };
 
 // the drivers' contraction / column-pass launches, batched when the context is
 static inline int cgemm(const Ctx& c, hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
-                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0,
-                        int lds_pad_kb = 0) {
-  if (c.batch == 1) return gemm_nt(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, lds_pad_kb);
+                        const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int lower, int tri = 0, int inplace = 0) {
+  if (c.batch == 1) return gemm_nt(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace);
   return gemm_nt_strided(s, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower, tri, inplace, c.batch, c.sA, c.sA, c.sA);
 }
 // mode 0: B = an inverted leaf block of winv; mode 1: everything inside the factor buffers
@@ -554,20 +372,10 @@ static inline int ccolpanel(const Ctx& c, hipStream_t s, int mode, int64_t m, in
 }
 
 // one factor leaf (or `batch` of them at constant strides) on stream s
+// one factor leaf (or `batch` of them at constant strides) on stream s
 static int launch_leaf(hipStream_t s, double* A, int64_t lda, int kb, int col0, double* W, int32_t* info, int batch = 1,
                        int64_t sA = 0, int64_t sW = 0, int64_t sInfo = 0) {
-  if (g_leaf_gen == 2) return leaf16(s, A, lda, kb, col0, W, info, batch, sA, sW, sInfo);
-  for (int b = 0; b < batch; ++b) {
-    double* Ab = A + b * sA;
-    double* Wb = W + b * sW;
-    int32_t* ib = info + b * sInfo;
-    if (g_leaf_pipe)
-      hipLaunchKernelGGL((potrf_leaf_kernel<true, false, true>), dim3(1), dim3(LEAF_THREADS), 0, s, Ab, lda, kb, col0, Wb, ib, 0, nullptr);
-    else
-      hipLaunchKernelGGL((potrf_leaf_kernel<true, false>), dim3(1), dim3(LEAF_THREADS), 0, s, Ab, lda, kb, col0, Wb, ib, 0, nullptr);
-  }
-  GPN_LAUNCH_CHECK();
-  return GPN_OK;
+  return leaf16(s, A, lda, kb, col0, W, info, batch, sA, sW, sInfo);
 }
 
 static inline int64_t split_point(int64_t n) {
@@ -584,9 +392,7 @@ static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L,
   if (kb <= LEAF) {
     const double* W = winv + (diag0 / LEAF) * (LEAF * LEAF);
     // in place: one LEAF-wide column tile per row block (see file header)
-    if (g_chain_kernel & 1) c.rc = ccolpanel(c, c.s, 0, m, kb, B, ldb, W, LEAF, B, ldb);
-    else if (c.batch == 1) c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
-    else c.rc = gemm_nt_strided(c.s, m, kb, LEAF, 1.0, B, ldb, W, LEAF, 0.0, B, ldb, 0, GPN_TRI_B_LOWER, 1, c.batch, c.sA, c.sW, c.sA);
+    c.rc = ccolpanel(c, c.s, 0, m, kb, B, ldb, W, LEAF, B, ldb);
     return;
   }
   const int64_t h = split_point(kb);
@@ -623,7 +429,7 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
 
 // ---- flat right-looking driver with look-ahead -------------------------------------------
 // The recursion above runs every launch of the factorisation back to back on one stream, and
-// most of them are latency-bound (one leaf = one workgroup for ~47 us; panel solves and small
+// most of them are latency-bound (one leaf = one workgroup for ~19 us; panel solves and small
 // updates of ~9 us each).  This driver shortens that serial chain.  Panels of PW columns; inside
 // a panel, per LEAF-wide column block k:
 //     main stream : leaf(k) -> solve ALL rows below against W_k (one in-place launch)
@@ -637,22 +443,14 @@ static void potrf_rec(Ctx& c, double* A, int64_t n, int64_t e, int64_t col0) {
 // square receives finite garbage from the rectangular updates: nothing reads it (the leaf
 // masks j > i on load, every other consumer uses blocks strictly below the diagonal blocks
 // or winv).
-constexpr int64_t AUX_FLAGS = 1 << 18;           // counters per stream (steps x problems of one factorisation)
 struct Aux {
-  hipStream_t s1 = nullptr;
-  hipStream_t s2 = nullptr;                     // look-ahead over panels (A/B): the bulk of a trailing update
-  hipEvent_t chain_done = nullptr, bulk_done = nullptr;
+  hipStream_t s1 = nullptr;                     // (one aux stream only: HIP multiplexes streams onto a few hardware queues)
   hipEvent_t solve[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t rest[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t extra_go = nullptr, extra_done = nullptr;
-  int* flags = nullptr;                         // zeroed counters of the fused column steps (colpanel.hip colstep): one per step and problem
-  hipEvent_t trap_go = nullptr, trap_done = nullptr;     // the part of an inner panel's update beyond the next inner panel (second aux stream)   // the extra rows' share of an outer panel's trailing update (aux stream)
-  hipStream_t s_asm = nullptr;                   // gpn_lml_forward: assembly of the columns right of the first top-level panel
-  hipEvent_t asm_go = nullptr, asm_done = nullptr;
+  hipEvent_t extra_go = nullptr, extra_done = nullptr;     // the extra rows' share of an outer panel's trailing update (aux stream)
 };
 static std::mutex g_aux_mutex;
 static std::unordered_map<hipStream_t, Aux> g_aux;
-GPN_SWITCH g_potrf_variant = 0;     // 0 = look-ahead panels (default), 1 = plain recursion
 
 static Aux* aux_for(hipStream_t s) {
   std::lock_guard<std::mutex> lock(g_aux_mutex);
@@ -662,28 +460,12 @@ static Aux* aux_for(hipStream_t s) {
   int least = 0, greatest = 0;     // aux work is off the critical path: lowest priority
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
   if (hipStreamCreateWithPriority(&a.s1, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-  // (the second helper stream: the persistent bulk of an outer panel's trailing update, underneath the next panel's chain)
-  if (hipStreamCreateWithPriority(&a.s2, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.chain_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.bulk_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-#ifdef GPN_DEBUG_SWITCHES
-  if (hipEventCreateWithFlags(&a.trap_go, hipEventDisableTiming) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.trap_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-#endif
-  if (hipStreamCreateWithPriority(&a.s_asm, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.asm_go, hipEventDisableTiming) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.asm_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.extra_go, hipEventDisableTiming) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&a.extra_done, hipEventDisableTiming) != hipSuccess) return nullptr;
-#ifdef GPN_DEBUG_SWITCHES
-  if (hipMalloc(reinterpret_cast<void**>(&a.flags), AUX_FLAGS * sizeof(int)) != hipSuccess) return nullptr;
-#endif
   for (int i = 0; i < 4; ++i) {
     if (hipEventCreateWithFlags(&a.solve[i], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.rest[i], hipEventDisableTiming) != hipSuccess) return nullptr;
   }
-  // (one aux stream only: HIP multiplexes streams onto a few hardware queues -- 4 by default --
-  //  and streams that share a queue serialise)
   return &g_aux.emplace(s, a).first->second;
 }
 
@@ -748,64 +530,6 @@ static int extra_rows_update(hipStream_t s, const double* P, double* R, int64_t 
   return GPN_OK;
 }
 
-GPN_SWITCH g_panel_width = 0;        // 0 = by size; debug override
-// A/B (tools' build): an inner panel's update beyond the next inner panel on the second aux stream, underneath that panel's
-// chain.  Measured neutral (C3 181.4 -> 180.8 ms, N = 16384 28.63 -> 28.77, C2 5.37 -> 5.56): the chain's kernels slow down
-// by what the overlap saves, and each fork / join costs ~25 us.  Off.
-GPN_SWITCH g_inner_lookahead = 0;
-// A/B (tools' build): chain steps as [solve of the 128 rows under the diagonal block] [next diagonal block's update] [ONE launch:
-// the next leaf next to the solve + next-column update of all rows below] (leaf16.hip chain_step).  Correct (same LML to 1e-14,
-// lock-step batches bit-identical) and SLOWER: C3 180.8 -> 185.1 ms, N = 16384 28.7 -> 28.9, C2 x 8 26.5 -> 27.1 ms.  Timeline
-// (profiles/r4_fused_step_timeline.txt): the two four-workgroup launches cost 8 + 13 us, and the fused launch 66-80 us at
-// m = 30 k (one 768-thread workgroup per CU, three dependent memory round trips per 32-row tile, nothing to overlap them
-// with) against 20 + 18 + 15 us for leaf, solve and update as separate launches.  Off.
-GPN_SWITCH g_fused_steps = 0;
-// A/B (tools' build): the two column passes of a chain step in ONE launch (colpanel.hip colstep_kernel: X tile kept in LDS,
-// X_top handed between workgroups through agent-scope stores + a device counter).  Correct and bit-identical across batch
-// sizes, and SLOWER than the two launches: C2 5.36 -> 5.53 ms, C3 180.1 -> 183.8, N = 2048 0.61 -> 0.67 (an acquire fence +
-// plain loads instead of agent-scope loads: the same) -- a workgroup's solve, hand-off wait, operand reload and update run
-// one after the other with two workgroups per CU to hide them, where two launches each fill the chip.  Off.
-GPN_SWITCH g_fused_colstep = 0;
-GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row of the lower-tile launch (A/B)
-// look-ahead over PANELS (A/B, tools' build only): after panel p only the strip of the trailing update that panel p+1 lives in
-// runs on the caller's stream; the rest goes to a second lowest-priority stream, capped to g_bulk_pad KiB of extra LDS per
-// workgroup (= fewer workgroups per CU, so that the chain's kernels always find room), underneath panel p+1's chain
-GPN_SWITCH g_panel_lookahead = 0;
-GPN_SWITCH g_bulk_pad = 32;
-GPN_SWITCH g_aux_left_looking = -1;  // -1 = by size; 0 / 1 = forced (A/B)
-// ---- look-ahead over OUTER panels with a PERSISTENT bulk (round 6) ----------------------------------------------------------
-// After outer panel o only the columns the NEXT outer panel lives in (the "strip", a trapezoid launch) are updated on the
-// caller's stream; the rest of the lower-tile K = outer-width update goes to the second helper stream as ONE persistent
-// launch (gemm_f64.hip gemm_nt_persistent_kernel): one 128 x 128-tile workgroup per compute unit on all compute units BUT
-// ONE, underneath the next panel's chain.  Every earlier look-ahead (LAB.md 8-1c, 10-10) failed on DISPATCH -- the leaf
-// needs an empty compute unit and found none while tiles of an ordinary launch kept arriving (priorities order dispatch,
-// nothing is pre-empted) -- and an ordinary launch capped to one workgroup per compute unit still refilled every compute
-// unit it emptied.  A persistent grid of (compute units - 1) workgroups that cannot share a compute unit (LDS padding)
-// leaves one compute unit empty for as long as it runs: the leaf starts at once, and the column passes and short-K updates of
-// the chain move in beside the bulk's workgroups (each leaves 256 of 512 vector registers per SIMD and ~76 KB of LDS).
-// Every entry keeps its K grouping and summation order: the factor is bit-identical to the plain schedule.
-GPN_SWITCH g_outer_lookahead = -1;   // -1 = by size; 0 / 1 = forced (A/B)
-GPN_SWITCH g_la_strip_extra = 0;     // extra 128-column blocks in the strip beyond the next outer panel (A/B: balance)
-GPN_SWITCH g_la_nwg = 0;             // persistent workgroups (0 = compute units - 1)
-GPN_SWITCH g_la_pad_kb = 20;         // LDS padding of the persistent workgroups: 64 + 20 KB > half a compute unit's 160 KB
-static inline bool outer_lookahead_by_size(int64_t n) { (void)n; return false; }   // measured slower (see above): off
-static int device_cus() {
-  static std::atomic<int> cus{0};
-  int v = cus.load(std::memory_order_acquire);
-  if (v == 0) {
-    int dev = 0, count = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&count, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || count <= 1)
-      count = 256;
-    cus.store(count, std::memory_order_release);
-    v = count;
-  }
-  return v;
-}
-// Left-looking formation of the INNER panels (round 5): after an inner panel, instead of the K = inner-width trapezoid over all
-// remaining columns of the outer panel, ONLY the next inner panel's columns are updated -- by every solved column of the outer
-// panel so far (K = 1, 2, 3 ... inner widths): the same flops in launches with two to three times the K (the 64 x 64 tile ran the
-// K = 512 trapezoids at 48 TFLOP/s, L2 -> LDS bound) and each block of the outer panel read and written once.
-GPN_SWITCH g_inner_left = -1;        // -1 = by size; 0 / 1 = forced (A/B)
 // Same-box sweeps (r1z, tools/potrf_ab.py): panel width 1024 / 1536 / 2048 -> C2 7.10 / 7.00 / 7.01 ms,
 // N = 16384 31.9 (1536) vs 32.2 (2048), C3 201.5 / 200.0 / 201.1, C4 1492 / 1473 / 1472; with the
 // left-looking aux update (below) the large sizes prefer 2048: C3 198.1, C4 1454 ms.
@@ -817,7 +541,7 @@ static inline bool large_problem(int64_t n) { return n >= 24576; }
 // with K = w[1] -- the lower-tile launch bench.py prices.  The inner width prices the chain's K = 128 work (HBM-bound
 // column passes), the outer width the C-tile traffic of the big updates: with one level C2 wanted 256-column panels
 // for the first and paid 11.5 GB of C traffic per evaluation for it (K = 256 updates of the whole trailing matrix).
-// Same-box sweeps, ms per evaluation (tools/outer_ab.py, Rbf D = 8, inner:outer):
+// Same-box sweeps, ms per evaluation (round 4, Rbf D = 8, inner:outer):
 //   N = 2048:  256 0.606 | 256:512 0.615 | 256:1024 0.621
 //   N = 4096:  256 1.529 | 256:512 1.518 | 256:1024 1.535 | 256:2048 1.558      (x 8 in lock step: 4.89 | 4.68 | 4.65 | 4.69)
 //   N = 8192:  256 5.52 | 256:512 5.33 | 256:1024 5.34 | 256:2048 5.43 | 512:1024 5.58 | 128:1024 5.40
@@ -827,11 +551,7 @@ static inline bool large_problem(int64_t n) { return n >= 24576; }
 //   N = 24576: 2048 83.99 | 1024 83.9 | 512:2048 82.2 | 256:2048 81.7 | 256:1024 82.7
 //   N = 32768: 2048 184.6 | 512:2048 182.3 | 256:2048 182.7 | 256:1024 184.3 | 512:1024 184.4 | 1024:2048 184.2
 //              (a third level -- 256:1024:2048, 256:512:2048, 256:1024:4096, 512:2048:8192 -- is within 0.3 ms of 512:2048)
-// (Single level, round 4 after the leaf rewrite: N = 8192 256 5.68 | 512 5.74 | 1024 5.85 | 1536 6.03 | 2048 6.19;
-//  C3 1536 188.4 | 2048 188.6-188.9 | 2560 189.9.)
 struct PanelLevels { int n = 1; int64_t w[3] = {0, 0, 0}; };
-GPN_SWITCH g_outer_width = 0;        // 0 = by size, -1 = one level; > 0: debug overrides (tools' build)
-GPN_SWITCH g_outer_width2 = 0;
 static inline int64_t panel_width(int64_t n) {            // inner panels
   if (g_panel_width) return g_panel_width;
   return n < 20480 ? 256 : 512;
@@ -847,24 +567,15 @@ static inline PanelLevels panel_levels(int64_t n) {
   return L;
 }
 
-static inline bool inner_left_by_size(int64_t n) { (void)n; return false; }
-
 static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
   Aux* ax = aux_for(c.s);
   if (!ax) { c.rc = GPN_E_HIP; return; }
   const PanelLevels lev = panel_levels(n);
   const int64_t lda = c.lda, PW = lev.w[0];
   const bool left_looking = g_aux_left_looking < 0 ? large_problem(n) : g_aux_left_looking != 0;
-  const bool inner_left = lev.n >= 2 && (g_inner_left < 0 ? inner_left_by_size(n) : g_inner_left != 0);
-  const bool lookahead = lev.n >= 2 && c.batch == 1 && ax->s2 && !c.rest_ready && (g_outer_lookahead < 0 ? outer_lookahead_by_size(n) : g_outer_lookahead != 0);
   auto hip_ok = [&](hipError_t err) { if (err != hipSuccess && c.rc == GPN_OK) { set_hip_error(err, "potrf_lookahead"); c.rc = GPN_E_HIP; } };
   int step = 0, rest_idx = 0;
-  int64_t leaf_done = -1;                          // the diagonal block a fused step has already factored
-  const int64_t nsteps = (n + LEAF - 1) / LEAF;
-  const bool colsteps = g_fused_colstep != 0 && (g_chain_kernel & 1) && nsteps * c.batch <= AUX_FLAGS;
-  if (colsteps) hip_ok(hipMemsetAsync(ax->flags, 0, (size_t)(nsteps * c.batch) * sizeof(int), c.s));
-  const bool fused_steps = g_fused_steps != 0;
-  bool rest_pending = false, bulk_pending = false, extra_pending = false, trap_pending = false;
+  bool rest_pending = false, extra_pending = false;
   for (int64_t p0 = 0; p0 < n && c.rc == GPN_OK; p0 += PW) {
     const int64_t pw = std::min(PW, n - p0), pend = p0 + pw;
     if (extra_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->extra_done, 0)); extra_pending = false; }   // the extra rows of this panel's columns
@@ -873,72 +584,16 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       const int64_t c1 = k0 + kb;                 // first row/column after this block
       double* Akk = A + k0 * lda + k0;
       const double* Wk = c.winv + (k0 / LEAF) * (LEAF * LEAF);
-      if (leaf_done != k0) {
+      {
         const int rec = profile_on() ? profile_begin(c.s, c.batch * 2.0 * LEAF * LEAF * LEAF / 3.0, PROF_LEAF) : -1;
-        { const int lrc = launch_leaf(c.s, Akk, lda, (int)kb, (int)k0, const_cast<double*>(Wk), c.info, c.batch, c.sA, c.sW, 1); if (c.rc == GPN_OK) c.rc = lrc; }
+        const int lrc = launch_leaf(c.s, Akk, lda, (int)kb, (int)k0, const_cast<double*>(Wk), c.info, c.batch, c.sA, c.sW, 1);
+        if (c.rc == GPN_OK) c.rc = lrc;
         if (rec >= 0) profile_end(c.s, rec);
       }
       const int64_t m = n + e - c1;                // rows below (incl. the extra rows)
       if (m <= 0 || c.rc != GPN_OK) continue;
       double* B = A + c1 * lda + k0;               // [m, kb] <- B W_k^T   (in place)
-#ifdef GPN_DEBUG_SWITCHES
-      if (fused_steps && kb == LEAF && c1 + LEAF <= pend && m > LEAF && g_leaf_gen == 2 && (g_chain_kernel & 1)) {
-        // ---- the step as three launches: the 128 rows under the diagonal block (solve, next diagonal block), then ONE
-        // launch with leaf(k+1) next to the solve + next-column update of all rows below (leaf16.hip chain_step)
-        const int64_t c2 = c1 + LEAF;
-        c.rc = ccolpanel(c, c.s, 0, LEAF, LEAF, B, lda, Wk, LEAF, B, lda);
-        if (rest_pending) {                        // column block c1 was last written on the aux stream
-          hip_ok(hipStreamWaitEvent(c.s, ax->rest[rest_idx], 0));
-          rest_pending = false;
-        }
-        if (c.rc == GPN_OK) c.rc = ccolpanel(c, c.s, 1, LEAF, LEAF, B, lda, B, lda, A + c1 * lda + c1, lda);
-        if (c.rc == GPN_OK) {
-          const int rec = profile_on() ? profile_begin(c.s, c.batch * (2.0 * LEAF * LEAF * LEAF / 3.0 + 3.0 * (m - LEAF) * LEAF * LEAF), PROF_GEMM_SOLVE) : -1;
-          c.rc = chain_step(c.s, A + c1 * lda + c1, lda, (int)c1, c.winv + (c1 / LEAF) * (LEAF * LEAF), c.info, A + c2 * lda + k0, Wk, B,
-                            A + c2 * lda + c1, m - LEAF, c.batch, c.sA, c.sW, 1);
-          if (rec >= 0) profile_end(c.s, rec);
-        }
-        leaf_done = c1;
-        if (c.rc != GPN_OK) continue;
-        const bool fork = c2 < pend;
-        if (fork) hip_ok(hipEventRecord(ax->solve[step & 3], c.s));
-        if (fork) {
-          hip_ok(hipStreamWaitEvent(ax->s1, ax->solve[step & 3], 0));
-          const int64_t m2 = n + e - c2;
-          if (!left_looking) {
-            c.rc = cgemm(c, ax->s1, m2, pend - c2, kb, -1.0, A + c2 * lda + k0, lda, A + c2 * lda + k0, lda, 1.0,
-                           A + c2 * lda + c2, lda, 0);
-          } else {
-            const int64_t nb2 = std::min<int64_t>(LEAF, pend - c2);
-            c.rc = cgemm(c, ax->s1, m2, nb2, c1 - p0, -1.0, A + c2 * lda + p0, lda, A + c2 * lda + p0, lda, 1.0,
-                           A + c2 * lda + c2, lda, 0);
-          }
-          rest_idx = step & 3;
-          hip_ok(hipEventRecord(ax->rest[rest_idx], ax->s1));
-          rest_pending = true;
-        }
-        continue;
-      }
-#else
-      (void)fused_steps;
-#endif
-      // both column passes in one launch (full blocks; the rows of X_top are matrix rows: c1 + 128 <= pend <= n)
-#ifdef GPN_DEBUG_SWITCHES
-      const bool onepass = colsteps && kb == LEAF && c1 + LEAF <= pend && m >= LEAF;
-#else
-      const bool onepass = false;
-#endif
-      if (onepass) {
-        if (rest_pending) {                        // column block c1 was last written on the aux stream
-          hip_ok(hipStreamWaitEvent(c.s, ax->rest[rest_idx], 0));
-          rest_pending = false;
-        }
-#ifdef GPN_DEBUG_SWITCHES
-        c.rc = colstep(c.s, m, B, Wk, A + c1 * lda + c1, lda, ax->flags + (k0 / LEAF) * c.batch, c.info, c.batch, c.sA, c.sW);
-#endif
-      } else if (g_chain_kernel & 1) c.rc = ccolpanel(c, c.s, 0, m, kb, B, lda, Wk, LEAF, B, lda);
-      else if (c.batch == 1) c.rc = gemm_nt(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, /*inplace=*/1);
-      else c.rc = gemm_nt_strided(c.s, m, kb, LEAF, 1.0, B, lda, Wk, LEAF, 0.0, B, lda, 0, GPN_TRI_B_LOWER, 1, c.batch, c.sA, c.sW, c.sA);
+      c.rc = ccolpanel(c, c.s, 0, m, kb, B, lda, Wk, LEAF, B, lda);
       if (c.rc != GPN_OK || c1 >= pend) continue;  // last block of the panel: nothing left inside it
       const int64_t nb1 = std::min<int64_t>(LEAF, pend - c1);
       const int64_t c2 = c1 + nb1;
@@ -951,10 +606,7 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       // The aux work is forked AFTER it: launched together, the 1000+ workgroups of the rest
       // update crowd this small launch out (16 us instead of 7); behind it they overlap with
       // the next leaf + solve instead.
-      if (c.rc == GPN_OK && !onepass) {
-        if ((g_chain_kernel & 2) && kb == LEAF) c.rc = ccolpanel(c, c.s, 1, m, nb1, B, lda, B, lda, A + c1 * lda + c1, lda);
-        else c.rc = cgemm(c, c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
-      }
+      c.rc = cgemm(c, c.s, m, nb1, kb, -1.0, B, lda, B, lda, 1.0, A + c1 * lda + c1, lda, 0);
       if (fork) hip_ok(hipEventRecord(ax->solve[step & 3], c.s));
       if (fork && c.rc == GPN_OK) {                // the rest of the panel on the aux stream
         hip_ok(hipStreamWaitEvent(ax->s1, ax->solve[step & 3], 0));
@@ -983,120 +635,42 @@ static void potrf_lookahead(Ctx& c, double* A, int64_t n, int64_t e) {
       hip_ok(hipStreamWaitEvent(c.s, ax->rest[rest_idx], 0));
       rest_pending = false;
     }
-    const int64_t m = n + e - pend;
-    const int64_t pw2 = std::min(PW, n - pend);    // width of the next panel
-    if (g_panel_lookahead && lev.n == 1 && ax->s2 && pend + pw2 < n) {     // (A/B of the one-level schedule only)
-      // ---- look-ahead: strip now, bulk on the second stream underneath the next panel's chain
-      double* P = A + pend * lda + p0;
-      const int64_t kp = round_up(pw, 16);
-      if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }   // it wrote these columns
-      hip_ok(hipEventRecord(ax->chain_done, c.s));                                  // panel p is solved
-      // strip: rows >= pend x the next panel's columns (lower-only inside its top square)
-      c.rc = cgemm(c, c.s, m, pw2, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
-      if (c.rc != GPN_OK) break;
-      hip_ok(hipStreamWaitEvent(ax->s2, ax->chain_done, 0));
-      double* P2 = P + pw2 * lda;                  // rows >= pend + pw2 of the solved panel
-      double* C2 = A + (pend + pw2) * lda + pend + pw2;
-      const int64_t m2 = m - pw2;
-      if (c.corner || e == 0) {
-        c.rc = cgemm(c, ax->s2, m2, m2, kp, -1.0, P2, lda, P2, lda, 1.0, C2, lda, 1, 0, 0, g_bulk_pad);
-      } else {
-        const int64_t ms = m2 - e;
-        c.rc = cgemm(c, ax->s2, ms, ms, kp, -1.0, P2, lda, P2, lda, 1.0, C2, lda, 1, 0, 0, g_bulk_pad);
-        if (c.rc == GPN_OK)
-          c.rc = cgemm(c, ax->s2, e, ms, kp, -1.0, P2 + ms * lda, lda, P2, lda, 1.0, C2 + ms * lda, lda, 0, 0, 0, g_bulk_pad);
-      }
-      hip_ok(hipEventRecord(ax->bulk_done, ax->s2));
-      bulk_pending = true;
-      continue;
-    }
-    if (bulk_pending && lev.n == 1) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }
-    if (trap_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->trap_done, 0)); trap_pending = false; }   // it wrote the columns updated next
     if (pend >= n) break;
+    const int64_t m = n + e - pend;
     int l = 0;                                     // the widest level that ends here
     while (l + 1 < lev.n && pend % lev.w[l + 1] == 0) ++l;
     const int64_t o0 = l == 0 ? p0 : pend - lev.w[l];
+    double* P = A + pend * lda + o0;               // [m, pend - o0] the solved panel below the diagonal square
+    const int64_t kp = round_up(pend - o0, 16);
     if (l + 1 < lev.n) {
       // below the top level: the columns up to the end of the panel one level up only (all rows below incl. the extra
       // ones; lower-only in the top square)
       const int64_t oend = std::min(n, (pend / lev.w[l + 1] + 1) * lev.w[l + 1]);
-      if (l == 0 && inner_left) {
-        // left-looking: the next inner panel's columns only, by all solved columns of the enclosing outer panel
-        const int64_t ostart = (pend / lev.w[1]) * lev.w[1];
-        const int64_t nc1 = std::min(PW, oend - pend);
-        double* Pl = A + pend * lda + ostart;
-        c.rc = cgemm(c, c.s, m, nc1, round_up(pend - ostart, 16), -1.0, Pl, lda, Pl, lda, 1.0, A + pend * lda + pend, lda, 2);
-        continue;
-      }
-      double* P = A + pend * lda + o0;
-      const int64_t kp = round_up(pend - o0, 16), ncols = oend - pend;
-      const bool ahead = l == 0 && ncols > PW && g_inner_lookahead != 0 && ax->s2;
-      if (!ahead) {
-        c.rc = cgemm(c, c.s, m, ncols, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
-      } else {
-        // look-ahead inside the outer panel: the next inner panel's columns here, the columns beyond them on the second
-        // aux stream underneath that panel's chain (joined before the next update of those columns is launched)
-        hip_ok(hipEventRecord(ax->trap_go, c.s));
-        hip_ok(hipStreamWaitEvent(ax->s2, ax->trap_go, 0));
-        c.rc = cgemm(c, c.s, m, PW, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
-        if (c.rc == GPN_OK)
-          c.rc = cgemm(c, ax->s2, m - PW, ncols - PW, kp, -1.0, P + PW * lda, lda, P + PW * lda, lda, 1.0,
-                       A + (pend + PW) * lda + pend + PW, lda, 2);
-        hip_ok(hipEventRecord(ax->trap_done, ax->s2));
-        trap_pending = true;
-      }
-    } else {
-      if (c.rest_ready) {                          // the columns right of this panel were assembled on a side stream
-        hip_ok(hipStreamWaitEvent(c.s, c.rest_ready, 0));
-        c.rest_ready = nullptr;
-      }
-      double* P = A + pend * lda + o0;             // [m, pend - o0] solved (outer) panel below the diagonal square
-      const int64_t kp = round_up(pend - o0, 16);
-      if (bulk_pending) { hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0)); bulk_pending = false; }   // the previous bulk wrote these columns
-      // look-ahead over outer panels: strip here, persistent bulk on the second helper stream (see g_outer_lookahead)
-      const int64_t W1 = lev.w[lev.n - 1];
-      const int64_t S = std::min(n - pend, W1 + (int64_t)g_la_strip_extra * LEAF);     // the next outer panel's columns (+ A/B extra)
-      const bool la = lookahead && (c.corner || e == 0) && pend + S < n && (pend + S) % LEAF == 0 && (kp % 16) == 0;
-      if (la) {
-        c.rc = cgemm(c, c.s, m, S, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
-        if (c.rc != GPN_OK) break;
-        hip_ok(hipEventRecord(ax->chain_done, c.s));
-        hip_ok(hipStreamWaitEvent(ax->s2, ax->chain_done, 0));
-        const int64_t m2 = m - S;                  // rows / columns from pend + S on (incl. the extra rows: corner form)
-        const int nwg = g_la_nwg > 0 ? g_la_nwg : device_cus() - 1;
-        c.rc = gemm_nt_lower_persistent(ax->s2, m2, kp, -1.0, P + S * lda, lda, P + S * lda, lda, 1.0, A + (pend + S) * lda + pend + S, lda, nwg,
-                                        g_la_pad_kb);
-        hip_ok(hipEventRecord(ax->bulk_done, ax->s2));
-        bulk_pending = true;
-        continue;
-      }
+      c.rc = cgemm(c, c.s, m, oend - pend, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 2);
+    } else if (e > 0 && e <= XR_MAXE && g_extra_rows_kernel && n >= XR_MIN_N && (lda & 1) == 0 && (o0 & 1) == 0) {
+      // matrix rows: lower-tile square here; the few extra rows: dot products on the aux stream underneath it
       // (the fork / join is ~25 us per outer panel: C2 5.36 -> 5.53 ms with it, x 8 in lock step neutral, C3 182.4 -> 181.3;
       //  against the THIN tile row of gemm_f64.hip that the extra rows are otherwise: N = 16384 28.42 vs 28.14 ms, C3 178.9 vs
       //  180.2, C4 1329.7 vs 1333 -- on from XR_MIN_N rows)
-      if (e > 0 && e <= XR_MAXE && g_extra_rows_kernel && n >= XR_MIN_N && (lda & 1) == 0 && (o0 & 1) == 0) {
-        // matrix rows: lower-tile square here; the few extra rows: dot products on the aux stream underneath it
-        const int64_t ms = n - pend;
-        hip_ok(hipEventRecord(ax->extra_go, c.s));
-        hip_ok(hipStreamWaitEvent(ax->s1, ax->extra_go, 0));
-        c.rc = cgemm(c, c.s, ms, ms, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
-        if (c.rc == GPN_OK) c.rc = extra_rows_update(ax->s1, P, A + n * lda + pend, lda, ms, kp, e, c.batch, c.sA);
-        hip_ok(hipEventRecord(ax->extra_done, ax->s1));
-        extra_pending = true;
-      } else if (c.corner || e == 0) {
-        c.rc = cgemm(c, c.s, m, m, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
-      } else {
-        const int64_t ms = n - pend;               // matrix rows / columns left; the e extra rows: rectangular
-        c.rc = cgemm(c, c.s, ms, ms, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
-        if (c.rc == GPN_OK)
-          c.rc = cgemm(c, c.s, e, ms, kp, -1.0, P + ms * lda, lda, P, lda, 1.0, A + n * lda + pend, lda, 0);
-      }
+      const int64_t ms = n - pend;
+      hip_ok(hipEventRecord(ax->extra_go, c.s));
+      hip_ok(hipStreamWaitEvent(ax->s1, ax->extra_go, 0));
+      c.rc = cgemm(c, c.s, ms, ms, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+      if (c.rc == GPN_OK) c.rc = extra_rows_update(ax->s1, P, A + n * lda + pend, lda, ms, kp, e, c.batch, c.sA);
+      hip_ok(hipEventRecord(ax->extra_done, ax->s1));
+      extra_pending = true;
+    } else if (c.corner || e == 0) {
+      c.rc = cgemm(c, c.s, m, m, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+    } else {
+      const int64_t ms = n - pend;                 // matrix rows / columns left; the e extra rows: rectangular
+      c.rc = cgemm(c, c.s, ms, ms, kp, -1.0, P, lda, P, lda, 1.0, A + pend * lda + pend, lda, 1);
+      if (c.rc == GPN_OK)
+        c.rc = cgemm(c, c.s, e, ms, kp, -1.0, P + ms * lda, lda, P, lda, 1.0, A + n * lda + pend, lda, 0);
     }
   }
-  if (bulk_pending) hip_ok(hipStreamWaitEvent(c.s, ax->bulk_done, 0));
-  if (trap_pending) hip_ok(hipStreamWaitEvent(c.s, ax->trap_done, 0));
   if (extra_pending) hip_ok(hipStreamWaitEvent(c.s, ax->extra_done, 0));     // (error exits: nothing of this call stays in flight unordered)
-  if (c.rest_ready) { hip_ok(hipStreamWaitEvent(c.s, c.rest_ready, 0)); c.rest_ready = nullptr; }
 }
+
 
 // U_ii <- W_ii^T for every LEAF x LEAF diagonal block
 __global__ __launch_bounds__(256) void diag_transpose_kernel(const double* winv, double* U, int64_t ldu, int n, int64_t sW = 0,
@@ -1283,36 +857,6 @@ extern "C" int gpn_potrf_lower(void* stream, double* A, int64_t n, int64_t e, in
   return c.rc;
 }
 
-// ---- assembly of the trailing columns underneath the first top-level panel (gpn_lml_forward, pipeline.hip) -------------------
-// The first top-level panel's chain (leaves, HBM-bound column passes, K = 128 ... 512 updates) leaves most of the chip's vector
-// ALUs idle for 2-3 ms at N = 32768, and the K assembly of everything RIGHT of that panel (88 % of the matrix, VALU-bound) is not
-// needed before the panel's trailing update: it runs on a third stream underneath the chain.
-// Measured NEUTRAL (tools/split_asm_ab.py, same box, two passes: C3 179.88 / 180.07 -> 180.01 / 180.15 ms, N = 20480 49.96 / 49.85 ->
-// 49.79 / 49.89, N = 24000 76.03 / 76.01 -> 75.91 / 76.11; factors bit-identical): the chain's kernels slow down by what the
-// overlap saves, like every other overlap tried on this chain (LAB.md 8, 10-10).  OFF in the product; kept as a tools'-build A/B.
-GPN_SWITCH g_split_assembly = 0;     // 1 = split (A/B, tools' build)
-int64_t gpn::potrf_split_columns(int64_t n) {
-  if (!g_split_assembly || g_potrf_variant == 1 || n < XR_MIN_N) return 0;
-  const PanelLevels L = panel_levels(n);
-  const int64_t w = L.w[L.n - 1];
-  return (L.n >= 2 && w % 64 == 0 && w < n) ? w : 0;
-}
-int gpn::potrf_side_stream(hipStream_t s, hipStream_t* side, hipEvent_t* go, hipEvent_t* done) {
-  Aux* ax = aux_for(s);
-  if (!ax) return GPN_E_HIP;
-  *side = ax->s_asm; *go = ax->asm_go; *done = ax->asm_done;
-  return GPN_OK;
-}
-int gpn::potrf_lower_after(hipStream_t s, double* A, int64_t n, int64_t e, int64_t lda, double* winv, int32_t* info, hipEvent_t rest_ready) {
-  Ctx c{s, lda, winv, info, GPN_OK};
-  c.rest_ready = rest_ready;
-  potrf_lookahead(c, A, n, e);
-  return c.rc;
-}
-#ifdef GPN_DEBUG_SWITCHES
-extern "C" int gpn_debug_set_split_assembly(int v) { g_split_assembly = v; return GPN_OK; }
-#endif
-
 // panel width of the look-ahead driver for an n x n factorisation (what bench.py needs to count the
 // algorithmic flops of the SYRK trailing updates: one lower-tile K = width contraction per panel)
 extern "C" int64_t gpn_potrf_panel_width(int64_t n) {
@@ -1338,14 +882,8 @@ extern "C" int gpn_release_stream(void* stream) {
   std::lock_guard<std::mutex> lock(g_aux_mutex);
   auto drop = [](Aux& a) {
     if (a.s1) { (void)hipStreamSynchronize(a.s1); (void)hipStreamDestroy(a.s1); }
-    if (a.s2) { (void)hipStreamSynchronize(a.s2); (void)hipStreamDestroy(a.s2); }
-    if (a.chain_done) (void)hipEventDestroy(a.chain_done);
-    if (a.bulk_done) (void)hipEventDestroy(a.bulk_done);
     if (a.extra_go) (void)hipEventDestroy(a.extra_go);
     if (a.extra_done) (void)hipEventDestroy(a.extra_done);
-    if (a.flags) (void)hipFree(a.flags);
-    if (a.trap_go) (void)hipEventDestroy(a.trap_go);
-    if (a.trap_done) (void)hipEventDestroy(a.trap_done);
     for (int i = 0; i < 4; ++i) {
       if (a.solve[i]) (void)hipEventDestroy(a.solve[i]);
       if (a.rest[i]) (void)hipEventDestroy(a.rest[i]);
@@ -1384,43 +922,15 @@ extern "C" int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t
 }
 
 #ifdef GPN_DEBUG_SWITCHES
+// (tools' build only: the calling thread's driver parametrisation -- see the switches at the top of the drivers)
 extern "C" int gpn_debug_set_potrf_variant(int v) {
-  g_potrf_variant = v & 1;           // bit 0: plain recursion; bit 2: three-phase leaf; bits 8..: panel width / 128
-  g_leaf_pipe = ((v >> 2) & 1) ? 0 : 1;
-  g_leaf_gen = ((v >> 1) & 1) ? 1 : 2;                                   // bit 1: the first-generation leaf
+  g_potrf_variant = v & 1;           // bit 0: plain recursion; bits 8..: inner panel width / 128
   g_panel_width = ((v >> 8) & 0xff) * LEAF;
   g_aux_left_looking = ((v >> 3) & 1) ? 1 : (((v >> 5) & 1) ? 0 : -1);   // bit 3: force left-looking aux update, bit 5: force right-looking
-  g_panel_lookahead = (v >> 4) & 1;                                      // bit 4: look-ahead over panels (bulk of the trailing update on a second stream)
-  g_bulk_pad = (v >> 16) ? (v >> 16) : 32;                               // bits 16..: its LDS padding in KiB (occupancy cap)
-  g_chain_kernel = 1 ^ ((v >> 6) & 3);                                   // bit 6: the chain's solve through the generic contraction; bit 7: its next-column update through colpanel.hip
   return GPN_OK;
 }
-extern "C" int gpn_debug_set_fused_colstep(int v) { g_fused_colstep = v; return GPN_OK; }
-extern "C" int gpn_debug_set_fused_steps(int v) { g_fused_steps = v; return GPN_OK; }
 extern "C" int gpn_debug_set_extra_rows(int on) { g_extra_rows_kernel = on; return GPN_OK; }
-extern "C" int gpn_debug_set_inner_lookahead(int v) { g_inner_lookahead = v; return GPN_OK; }
-extern "C" int gpn_debug_set_inner_left(int v) { g_inner_left = v; return GPN_OK; }
 extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; }
-// mode: -1 by size, 0 off, 1 on; strip_extra: 128-column blocks added to the strip; nwg: persistent workgroups (0 = CUs - 1); pad_kb: their LDS padding
-extern "C" int gpn_debug_set_outer_lookahead(int mode, int strip_extra, int nwg, int pad_kb) {
-  g_outer_lookahead = mode; g_la_strip_extra = strip_extra; g_la_nwg = nwg; g_la_pad_kb = pad_kb < 0 ? 20 : pad_kb;
-  return GPN_OK;
-}
-
-// diagnostic build of the leaf with s_memtime stamps (not part of the public header):
-// diag[wave*8 + k] = cycles summed over the pivot blocks in segment k
-// (0 loop top, 1 phase A, 2 barrier, 3 phase B, 4 barrier, 5 phase C, 6 barrier, 7 tail)
-extern "C" int gpn_debug_leaf_timing(void* stream, double* A, int64_t lda, double* winv, int32_t* info,
-                                     unsigned long long* diag72) {
-  hipLaunchKernelGGL((potrf_leaf_kernel<true, true, true>), dim3(1), dim3(LEAF_THREADS), 0, static_cast<hipStream_t>(stream),
-                     A, lda, LEAF, 0, winv, info, 0, diag72);
-  GPN_LAUNCH_CHECK();
-  return GPN_OK;
-}
-extern "C" int gpn_debug_leaf16_timing(void* stream, double* A, int64_t lda, double* winv, int32_t* info,
-                                       unsigned long long* diag72) {
-  return leaf16_timing(static_cast<hipStream_t>(stream), A, lda, winv, info, diag72);
-}
 #endif
 
 extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t ldl, double* winv, int32_t* info) {
@@ -1430,8 +940,8 @@ extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t 
   if (!winv) return -5;
   if (n == 0) return GPN_OK;
   const unsigned nb = (unsigned)((n + LEAF - 1) / LEAF);
-  hipLaunchKernelGGL((potrf_leaf_kernel<false, false>), dim3(nb), dim3(LEAF_THREADS), 0, static_cast<hipStream_t>(stream),
-                     const_cast<double*>(L), ldl, 0, 0, winv, info, (int)n, nullptr);
+  hipLaunchKernelGGL((potrf_leaf_kernel<false>), dim3(nb), dim3(LEAF_THREADS), 0, static_cast<hipStream_t>(stream),
+                     const_cast<double*>(L), ldl, 0, 0, winv, info, (int)n);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }
@@ -1457,14 +967,7 @@ extern "C" int gpn_trsm_right_lt(void* stream, const double* L, int64_t n, int64
 // gpr.py:104-106) its <= 512-wide levels are ~190 latency-bound launches -- 2.3 ms at N = 8192 for 6.9e10 flops (33
 // TFLOP/s).  With the inverses of the BIGB x BIGB diagonal blocks formed once per factor (n BIGB^2 / 3 flops), the same
 // solve is n / BIGB steps of two large contractions:  X_k = B_k W_k^T  (K-clipped),  B_rest -= X_k L(rest, k)^T.
-#ifdef GPN_DEBUG_SWITCHES
-// (GPN_BIGB: A/B of the block size in the TOOLS' build only -- the product library's block is the 1024 the header documents: a
-// stray environment variable must not change the gpn_block_inverse layout or the summation order of predict / VFE results)
-static int64_t bigb_env() { const char* e = getenv("GPN_BIGB"); const int64_t v = e ? atoll(e) : 0; return (v >= 256 && v % 128 == 0) ? v : 1024; }
-static const int64_t BIGB = bigb_env();
-#else
-static constexpr int64_t BIGB = 1024;
-#endif
+static constexpr int64_t BIGB = 1024;      // (the block of gpn_block_inverse: part of the documented layout)
 
 extern "C" int64_t gpn_block_inverse_bytes(int64_t n) {
   if (n <= 0) return 0;

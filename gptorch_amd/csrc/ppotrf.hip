@@ -121,7 +121,7 @@ __device__ __forceinline__ int pp_take(const PArgs& a, const int q, int h, const
 __device__ __forceinline__ int pp_pop(const PArgs& a, const bool chain, int& qmin) {
   int* rt = a.rt;
   const int nq = a.nq;
-  for (int spins = 0;; ++spins) {
+  for (;;) {
     // the push epoch BEFORE the scan: an idle workgroup then watches this ONE word instead of sweeping every queue's head and
     // tail (170 idle workgroups sweeping 17 queues slowed every running task by 1.3-2 x: MI355X_MICROARCH.md, polling-cost)
     const int epoch = pp_ld(rt + RT_EPOCH);
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
       la.winv = a.winv + (int64_t)tk.i * LEAF * LEAF;
       la.info = a.info;
       la.sA = la.sW = la.sInfo = 0;
-      leaf16_body<false, true>(la, nullptr, 0, tid_it);
+      leaf16_body<true>(la, 0, tid_it);
     } else if (tk.type == PT_TRSM) {
       pp_trsm_tile<false>(a.A + ((int64_t)tk.i * LEAF + 64 * half) * a.lda + (int64_t)tk.j * LEAF, a.lda, rows_i,
                           a.winv + (int64_t)tk.j * LEAF * LEAF, tid_it);
@@ -584,8 +584,7 @@ __global__ __launch_bounds__(L16_THREADS) void ppotrf_kernel(PArgs a) {
       g.M = rows_i; g.N = LEAF; g.K = (tk.k1 - tk.k0) * LEAF;
       g.mt = g.nt = 1;
       g.lower = tk.i == tk.j ? 1 : 0;
-      g.q_off = g.q_cnt = g.q_mt = 0;
-      g.lds_pad_kb = 0; g.group_h = 8; g.thin = 1;
+      g.group_h = 8; g.thin = 1;
       g.st_blk = g.st_step = g.st_diag = 0;
       g.tri = 0;
       g.alpha = -1.0; g.beta = 1.0;
@@ -647,7 +646,6 @@ static int pp_build(int64_t n, int64_t e, PPlan& P) {
   std::vector<Deps> trsm((size_t)TR * T);                // who solved tile (i, k)
   std::vector<Deps> leafof((size_t)T);
   std::vector<Deps> preds;
-  auto panel = [&](int t) { return t < T ? t / OW : (1 << 20); };
   auto add = [&](int type, int i, int j, int k0, int k1, int flags, int queue, std::initializer_list<Deps> deps) {
     PTask t{};
     t.type = (int16_t)type; t.i = (int16_t)i; t.j = (int16_t)j; t.k0 = (int16_t)k0; t.k1 = (int16_t)k1;

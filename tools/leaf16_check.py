@@ -36,8 +36,7 @@ def run(lib, m):
 
 ok = True
 with _native.debug_library() as lib:
-    for gen in (2, 1):
-        lib.gpn_debug_set_potrf_variant(0 if gen == 2 else 2)
+    for gen in (2,):
         for n in (128, 127, 113, 100, 64, 33, 17, 16, 15, 1):
             for cond in (1e2, 1e8):
                 m = spd(n, cond)
@@ -73,15 +72,13 @@ with _native.debug_library() as lib:
         print("gen %d NaN entry -> info %d" % (gen, int(f.info.item())))
         ok &= int(f.info.item()) > 0
     # determinism
-    lib.gpn_debug_set_potrf_variant(0)
     m = spd(128, 1e6)
     f1, f2 = run(lib, m), run(lib, m)
     same = torch.equal(f1.A, f2.A) and torch.equal(f1.winv, f2.winv)
     ok &= same
     print("bitwise repeatable:", same)
     # timing, back to back
-    for gen in (2, 1, 2, 1):
-        lib.gpn_debug_set_potrf_variant(0 if gen == 2 else 2)
+    for gen in (2, 2):
         R = 400
         m = spd(128, 1e3)
         fs = []
@@ -97,36 +94,5 @@ with _native.debug_library() as lib:
         e1.record()
         torch.cuda.synchronize()
         print("gen %d leaf: %.2f us per launch back to back" % (gen, e0.elapsed_time(e1) * 1e3 / R))
-    # timeline (DIAG build): diag[wave][k][ev]
-    m = spd(128, 1e3)
-    f = _ops.Factor(128, 0, dev)
-    diag = torch.zeros(12 * 8 * 8 + 8 * 9 * 4 * 64 + 12 * 8 * 8, dtype=torch.int64, device=dev)
-    for it in range(3):
-        f.A[:128, :128] = m
-        f.info.zero_()
-        diag.zero_()
-        torch.cuda.synchronize()
-        lib.gpn_debug_leaf16_timing(_stream(dev), _ptr(f.A), f.ld, _ptr(f.winv), _ptr(f.info), _ptr(diag))
-        torch.cuda.synchronize()
-    d = diag[:768].cpu().numpy().reshape(12, 8, 8)
-    hwid = d[:, 1, 7].copy()
-    d[:, 1, 7] = 0
-    t0 = d[d > 0].min()
-    rel = np.where(d > 0, d - t0, -1)
-    print("kernel entry per wave:", [int(rel[w, 0, 6]) for w in range(12)])
-    print("prologue per wave [roles set, loads issued, tiles in registers, zero-fill + raw dumps issued]:")
-    print(rel[:, 1:5, 6])
-    print("pivot wave: at P / past P:", int(rel[0, 4, 6]), int(rel[0, 5, 6]))
-    print("HW_ID simd per wave:", [(int(hwid[w]) >> 4) & 3 for w in range(12)])
-    print("end of work per wave (cycles):", [int(rel[w, 0, 7]) for w in range(12)])
-    print("pivot wave (0): per block k: [top, pivots done, published, B(k) passed, catch-up MFMAs done, next block in registers]")
-    print(rel[0, :, :6])
-    rowof = {3: 7, 7: 0, 1: 5, 5: 3, 9: 1, 2: 6, 6: 4, 10: 2}
-    print("compact: per tile ROW (wave), per panel: [W_k seen | solve done | updates done]")
-    for w in sorted(rowof, key=lambda q: rowof[q]):
-        print("  row %d (wave %2d, simd %d):" % (rowof[w], w, (int(hwid[w]) >> 4) & 3), " ".join("[%5d %5d %5d]" % (rel[w, k, 1], rel[w, k, 2], rel[w, k, 5]) for k in range(8)))
-    for w in (3, 7, 1, 5, 9):
-        print("tile wave %d: per panel k: [at B(k), B(k) passed, solve done, stores/dump issued, T(k) passed, update done]" % w)
-        print(rel[w, :, :6])
 print("LEAF16 CHECK", "OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
