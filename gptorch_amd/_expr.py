@@ -92,6 +92,18 @@ class Program:
         return out
 
 
+def flat_grad(prog, per_instance):
+    """per-instance gradient vectors (_sweeps) -> ONE flat vector [ntheta] in packing order (instances of one leaf add up)."""
+    flat = torch.zeros(prog.ntheta, dtype=torch.float64, device=per_instance[0].device)
+    for i, li in enumerate(prog.instances):
+        var_off, nvar, ls_off, nls = prog.offsets[li]
+        g = per_instance[i]
+        flat[var_off:var_off + nvar] += g[:nvar]
+        if nls:
+            flat[ls_off:ls_off + nls] += g[nvar:nvar + nls]
+    return flat
+
+
 def _leaf_type(k):
     from . import kernels
     if isinstance(k, kernels.Stationary):

@@ -104,6 +104,8 @@ SIGNATURES.update({
     "gpn_lml_refine_dense": (c_int, [c_void_p, c_void_p, c_int64, c_double, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpn_lml_refine_expr": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p, c_int64, c_int,
                                     c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "gpn_refine_resid_part_expr": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p, c_int64, c_int,
+                                           c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "gpn_kernel_matrix_expr": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p,
                                        c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64]),
     "gpn_kernel_expr_grad_work_bytes": (c_int64, [c_int64, c_int64, c_int, c_int]),

@@ -813,6 +813,40 @@ extern "C" int gpn_refine_resid_part(void* stream, int kind, const double* X, in
   return GPN_OK;
 }
 
+// gpn_refine_resid_part for a covariance EXPRESSION (gpn_expr_term program, kexpr.hip): the share of the lower 64 x 64 tiles
+// q0 <= q < q1 in Kyy a, Kyy re-computed from the points -- what a rank of the block-cyclic drivers contributes when the model's
+// kernel is a Sum / Product tree (DistGPR over the reference's example model Linear + Rbf + Constant, examples/regression_1d.py:34-53).
+// work: gpn_refine_resid_part_work_bytes(dy, q1 - q0); ka [dy][round_up(n, 128)][2].
+extern "C" int gpn_refine_resid_part_expr(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                                          const double* theta, const double* X, int64_t n, int d, const double* noise,
+                                          const double* a, int dy, int64_t q0, int64_t q1, double* work, double* ka) {
+  if (!terms || !group_start) return -2;
+  if (!theta) return -6;
+  if (!X) return -7;
+  if (n <= 0) return -8;
+  if (d <= 0) return -9;
+  if (!noise) return -10;
+  if (!a) return -11;
+  if (dy <= 0) return -12;
+  const int64_t ntile = (n + RT - 1) / RT, ntri = ntile * (ntile + 1) / 2;
+  if (q0 < 0 || q1 < q0 || q1 > ntri) return -13;
+  if (!work) return -15;
+  if (!ka) return -16;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t lds = round_up(n, LEAF);
+  const int64_t cnt = q1 - q0;
+  double* prow = work;
+  double* pcol = work + cnt * dy * RT * 2;
+  if (cnt > 0) {
+    const int rc = expr_resid(s, terms, nterms, group_start, ngroups, theta, X, n, d, noise, a, dy, lds, q0, cnt, prow, pcol);
+    if (rc != GPN_OK) return rc;
+  }
+  hipLaunchKernelGGL(refine_gather_kernel, dim3((unsigned)ntile, (unsigned)dy), dim3(256), 0, s, prow, pcol, (int)ntile, dy, lds, n, ka,
+                     q0, q1);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
 extern "C" int gpn_refine_finish(void* stream, const double* Y, const double* M, const double* a, const double* ka, int64_t n, int dy,
                                  double* out3) {
   if (!Y) return -2;

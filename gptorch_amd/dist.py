@@ -188,9 +188,19 @@ class NativeTileOps:
     def zeros(self, rows, cols):
         return torch.zeros(rows, cols, dtype=torch.float64, device=self.device)
 
+    # `kind`: the name of a native stationary kernel (hyper-parameters: variance [1], ls [1 | d]) or an _expr.Program -- a Sum /
+    # Product tree over native leaves (round 6: the reference's example model Linear + Rbf + Constant,
+    # examples/regression_1d.py:34-53, on the grid), whose packed constrained parameters travel in `variance` (ls: empty)
     def kernel_block(self, kind, Xi, Xj, variance, ls, out):
         """out[:ri, :rj] <- K(Xi, Xj) (rectangular; out is a view with a leading dimension)."""
+        if not isinstance(kind, str):
+            from . import _expr
+            _expr.kernel_matrix(kind, _ops._c(variance.detach()), Xi, Xj, out=out, ldk=out.stride(0))
+            return
         _ops.kernel_matrix(kind, Xi, Xj, variance, ls, out=out, ldk=out.stride(0))
+
+    def kernel_param_count(self, kind, variance, ls):
+        return int(variance.numel()) if not isinstance(kind, str) else 1 + int(ls.numel())
 
     def winv_numel(self, n):
         return int(_ops._native.lib().gpn_winv_bytes(n)) // 8
@@ -226,6 +236,10 @@ class NativeTileOps:
 
     def kernel_grad(self, kind, Xi, Xj, variance, ls, G):
         """-> tensor [1 + nls]: sum G * dK(Xi, Xj)/d(variance, length_scales) (gpn_kernel_grad)."""
+        if not isinstance(kind, str):
+            from . import _expr
+            outs, _ = _expr._sweeps(kind, _ops._c(variance.detach()), Xi, Xj, G, G.stride(0))
+            return _expr.flat_grad(kind, outs)
         from . import _backward
         gv, gl = _backward.kernel_backward(kind, Xi, Xj, variance, ls, G)
         return torch.cat([gv, gl])
@@ -290,6 +304,13 @@ class NativeTileOps:
         dy, lds = a.shape
         ka = torch.empty(dy, lds, 2, dtype=torch.float64, device=X.device)
         work = torch.empty(max(1, int(lib.gpn_refine_resid_part_work_bytes(dy, q1 - q0)) // 8), dtype=torch.float64, device=X.device)
+        if not isinstance(kind, str):
+            theta, nz = _ops._c(variance.detach()), _ops._c(noise.detach()).reshape(-1)[:1].contiguous()
+            st = lib.gpn_refine_resid_part_expr(_ops._stream(X.device), kind.terms, len(kind.instances), kind.gstart, kind.ngroups, _ops._ptr(theta),
+                                                _ops._ptr(_ops._c(X)), n, d, _ops._ptr(nz), _ops._ptr(a), dy, q0, q1, _ops._ptr(work), _ops._ptr(ka))
+            _ops._native.check(st, "gpn_refine_resid_part_expr")
+            ka[:, n:].zero_()
+            return ka
         var, l, nz = _ops._c(variance.detach()), _ops._c(ls.detach()), _ops._c(noise.detach())
         st = lib.gpn_refine_resid_part(_ops._stream(X.device), _ops.KINDS[kind], _ops._ptr(_ops._c(X)), n, d, _ops._ptr(var), _ops._ptr(l),
                                        l.numel(), _ops._ptr(nz), _ops._ptr(a), dy, q0, q1, _ops._ptr(work), _ops._ptr(ka))
@@ -761,7 +782,8 @@ class BlockCyclicGP:
         all-reduced."""
         assert self.with_inverse, "factor with with_inverse=True first"
         ops, nt, T, dy, dev = self.ops, self.nt, self.T, self.dy, self.X.device
-        nls = length_scales.numel()
+        count = getattr(ops, "kernel_param_count", None)
+        nls = (count(self.kind, variance, length_scales) if count else 1 + length_scales.numel()) - 1      # kernel parameters - 1
         A = self.A
         ncr = self.cidx.numel()
         # alpha^T [dy, n], replicated
@@ -850,8 +872,12 @@ class BlockCyclicGP:
         if self.comm:
             dist.all_reduce(mean, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
-        if diag:
+        if diag and isinstance(self.kind, str):
             var = variance.reshape(()) - out                   # Kdiag = variance (kernels.py:174-179)
+        elif diag:                                             # an expression: its own diagonal at the test points
+            kss = ops.zeros(ns, ns)
+            ops.kernel_block(self.kind, x_new, x_new, variance, length_scales, kss)
+            var = kss.diagonal() - out
         else:
             kss = ops.zeros(ns, ns)
             ops.kernel_block(self.kind, x_new, x_new, variance, length_scales, kss)
@@ -871,7 +897,8 @@ class BlockCyclicGP:
     def log_likelihood(self, variance, length_scales, noise, resid, max_tries=10):
         """assemble + factor with the jitter ladder of functions.py:20-43 (decided on the
         all-reduced info, so every rank takes the same branch)."""
-        refine = self.refine if self.refine is not None else self.n >= _ops.refine_min_n(grid=True)
+        refine = self.refine if self.refine is not None else \
+            self.n >= min(_ops.refine_min_n(grid=True), _ops.refine_min_n(expression=not isinstance(self.kind, str)))
         refine = refine and (self.comm or self.world == 1)        # (a phantom rank of tools/dist_phantom_profile.py has no peers to ask)
         self.refined = False
         self.assemble(variance, length_scales, noise, resid)

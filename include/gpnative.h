@@ -365,6 +365,14 @@ int gpn_lml_refine_expr(void* stream, const gpn_expr_term* terms, int nterms, co
 int gpn_lml_refine_dense(void* stream, const double* K, int64_t ldk, double diag_add, int64_t n, const double* Y, const double* M, int dy,
                          const double* A, int64_t lda, const double* winv, double* work, double* out3);
 
+/* gpn_refine_resid_part for a covariance expression (gpn_expr_term program): the share of the lower 64 x 64 tiles q0 <= q < q1 in
+ * Kyy a with Kyy re-computed from the points in double-double -- a rank's contribution to the block-cyclic refinement step when
+ * the model's kernel is a Sum / Product tree (DistGPR over the reference's example model, examples/regression_1d.py:34-53).
+ * work: gpn_refine_resid_part_work_bytes(dy, q1 - q0) bytes; ka [dy][round_up(n, 128)][2] (hi, lo). */
+int gpn_refine_resid_part_expr(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                               const double* theta, const double* X, int64_t n, int d, const double* noise,
+                               const double* a, int dy, int64_t q0, int64_t q1, double* work, double* ka);
+
 /* The same refinement step in pieces, for a factor that is spread over several GPUs (gptorch_amd/dist.py
  * BlockCyclicGP._refine: 2-D block-cyclic tiles; the exchange between the pieces is the caller's).  Vectors are
  * [dy][ld] row-major, one right-hand side per row.

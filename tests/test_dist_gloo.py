@@ -21,8 +21,35 @@ class CpuTileOps:
     def zeros(self, rows, cols):
         return torch.zeros(rows, cols, dtype=torch.float64)
 
+    @staticmethod
+    def _expr_K(prog, theta, Xi, Xj):
+        """a covariance expression (gptorch_amd._expr.Program: sum over groups of products of leaves) from the oracle's
+        primitives (kernels.py:286-306 Sum / Product, 238-265 Linear, 94-105 Constant); theta: the packed constrained parameters"""
+        from gptorch_amd import _native
+        kinds = {v: k for k, v in __import__("gptorch_amd._ops", fromlist=["KINDS"]).KINDS.items()}
+        total = None
+        for g in range(prog.ngroups):
+            prod = None
+            for i in range(prog.gstart[g], prog.gstart[g + 1]):
+                t = prog.terms[i]
+                var = theta[t.var_off:t.var_off + t.nvar]
+                if t.type == _native.TERM_STATIONARY:
+                    k = orc.kernel_K(kinds[t.kind], Xi, Xj, var, theta[t.ls_off:t.ls_off + t.nls])
+                elif t.type == _native.TERM_LINEAR:
+                    k = orc.linear_K(Xi, Xj, var)
+                elif t.type == _native.TERM_CONSTANT:
+                    k = var.reshape(()) * torch.ones(Xi.shape[0], Xj.shape[0], dtype=torch.float64)
+                else:
+                    raise NotImplementedError("White leaves are not taken by the grid")
+                prod = k if prod is None else prod * k
+            total = prod if total is None else total + prod
+        return total
+
+    def kernel_param_count(self, kind, variance, ls):
+        return int(variance.numel()) if not isinstance(kind, str) else 1 + int(ls.numel())
+
     def kernel_block(self, kind, Xi, Xj, variance, ls, out):
-        K = orc.kernel_K(kind, Xi, Xj, variance, ls)
+        K = orc.kernel_K(kind, Xi, Xj, variance, ls) if isinstance(kind, str) else self._expr_K(kind, variance, Xi, Xj)
         out[:K.shape[0], :K.shape[1]] = K
 
     def winv_numel(self, n):
@@ -59,6 +86,9 @@ class CpuTileOps:
     def kernel_grad(self, kind, Xi, Xj, variance, ls, G):
         with torch.enable_grad():          # (called from inside an autograd.Function's forward by DistGPR)
             v = variance.detach().clone().requires_grad_(True)
+            if not isinstance(kind, str):
+                (self._expr_K(kind, v, Xi, Xj) * G.detach()).sum().backward()
+                return v.grad
             l = ls.detach().clone().requires_grad_(True)
             (orc.kernel_K(kind, Xi, Xj, v, l) * G.detach()).sum().backward()
         return torch.cat([v.grad, l.grad])
@@ -85,7 +115,8 @@ class CpuTileOps:
 
     def resid_part(self, kind, X, variance, ls, noise, a, q0, q1):
         n = X.shape[0]
-        K = orc.kernel_K(kind, X, X, variance, ls) + noise * torch.eye(n, dtype=torch.float64)
+        K = (orc.kernel_K(kind, X, X, variance, ls) if isinstance(kind, str) else self._expr_K(kind, variance, X, X)) \
+            + noise * torch.eye(n, dtype=torch.float64)
         mask = torch.zeros(n, n, dtype=torch.bool)
         for q in range(q0, q1):                       # lower 64 x 64 tiles, row-major; each with its mirror
             ti = int(((8 * q + 1) ** 0.5 - 1) / 2)
@@ -369,6 +400,78 @@ def test_dist_gpr_model_matches_oracle(tmp_path, world):
         ref2 = o2.log_likelihood().item()
     assert abs(float(z["lml_other"]) - ref2) < 1e-9 * abs(ref2) and float(z["lml_other_again"]) == float(z["lml_other"])
     assert str(z["mismatch"]) == "X and Y must have same # data."           # gpr.py:56-57
+
+
+def _dist_composite_worker(rank, world, port, name, refine, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if refine:
+        os.environ["GPN_REFINE_MIN_N"] = "256"
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gptorch_amd import kernels, likelihoods
+        from gptorch_amd.models import DistGPR
+        n, d, dy = 400, 3, 2
+        x, y = rng.make_regression(n, d, dy, seed=0)
+        if name == "rbf_plus_linear":
+            kern = kernels.Rbf(3, variance=1.2, length_scales=1.5) + kernels.Linear(3, variance=np.array([0.3, 0.5, 0.7]))
+        elif name == "m32_times_rbf":
+            kern = kernels.Matern32(3, variance=0.9, length_scales=2.0) * kernels.Rbf(3, variance=1.1, length_scales=np.array([1.0, 2.0, 3.0]), ARD=True)
+        else:                                   # the reference's example model (examples/regression_1d.py:34-53)
+            kern = kernels.Linear(3) + kernels.Rbf(3, variance=0.7, length_scales=1.4) + kernels.Constant(3, variance=0.4)
+        m = DistGPR(x, y, kern, likelihood=likelihoods.Gaussian(variance=0.05), tile=128, tile_ops=CpuTileOps())
+        loss = m.loss()
+        loss.backward()
+        grads = {nm: p.grad.numpy().copy() for nm, p in m.named_parameters() if p.grad is not None}
+        xs = rng.normal(71, (16, d))
+        mu, var = m.predict_f(xs)
+        _, cov = m.predict_f(xs, diag=False)
+        refined = bool(m._eng().refined)
+        if rank == 0:
+            np.savez(out_path, loss=loss.item(), mu=mu, var=var, cov=cov, refined=refined, names=np.array(sorted(grads)),
+                     **{"g_" + k.replace(".", "_"): v for k, v in grads.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name,refine", [(2, "rbf_plus_linear", False), (4, "m32_times_rbf", False), (2, "m32_times_rbf", True),
+                                               (4, "example_model", False)])
+def test_dist_gpr_over_composite_kernels(tmp_path, world, name, refine):
+    """DistGPR over Sum / Product trees (round 6; the reference's example model Linear + Rbf + Constant,
+    /root/reference/examples/regression_1d.py:34-53, could not use the grid): loss, every raw-parameter gradient and the
+    predictions against the REFERENCE's values for the composite cases (tests/golden/composite_cases.json), on 2 and 4
+    ranks, also with the block-cyclic refinement step forced on; the example model against the oracle's primitives."""
+    import contextlib, io
+    from tests._util import load_json
+    out = str(tmp_path / "c.npz")
+    with contextlib.redirect_stdout(io.StringIO()):
+        mp.spawn(_dist_composite_worker, args=(world, _free_port(), name, refine, out), nprocs=world, join=True)
+    z = np.load(out)
+    assert bool(z["refined"]) == refine
+    if name != "example_model":
+        case = [c for c in load_json("composite_cases.json") if c["name"] == name][0]
+        assert abs(float(z["loss"]) - case["loss"]) < 1e-9 * max(1.0, abs(case["loss"]))
+        assert sorted(case["grads"]) == sorted(str(s) for s in z["names"])
+        for nm, r in case["grads"].items():
+            r = np.asarray(r)
+            got = z["g_" + nm.replace(".", "_")]
+            assert np.abs(got.reshape(r.shape) - r).max() < 1e-8 * max(1.0, np.abs(r).max()), nm
+        assert np.abs(z["mu"] - np.asarray(case["mean"])).max() < 1e-9
+        assert np.abs(z["var"] - np.asarray(case["var"])).max() < 1e-9
+        assert np.abs(z["cov"] - np.asarray(case["cov"])).max() < 1e-9
+    else:
+        n, d, dy = 400, 3, 2
+        x, y = rng.make_regression(n, d, dy, seed=0)
+        xt, yt = torch.tensor(x), torch.tensor(y)
+        one = lambda v: torch.tensor([v], dtype=torch.float64)
+        K = lambda a, b: orc.linear_K(a, b, torch.ones(3, dtype=torch.float64)) + orc.kernel_K("Rbf", a, b, one(0.7), one(1.4)) + 0.4
+        Kyy = K(xt, xt) + 0.05 * torch.eye(n, dtype=torch.float64)
+        assert abs(float(z["loss"]) + orc.dense_lml(Kyy, yt).item()) < 1e-9 * abs(float(z["loss"]))
+        xs = torch.tensor(rng.normal(71, (16, d)))
+        mu, cov = orc.dense_predict(Kyy, K(xt, xs), K(xs, xs), yt, diag=False)
+        assert np.abs(z["mu"] - mu.numpy()).max() < 1e-9 and np.abs(z["cov"] - cov.numpy()).max() < 1e-9
+        assert np.abs(z["var"] - cov.diagonal().numpy()[:, None]).max() < 1e-9
 
 
 # ------------------------------------------------------------------------------------------------------------

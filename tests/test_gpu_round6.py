@@ -240,3 +240,65 @@ def test_multi_start_default_is_bitwise_from_2048_rows(device):
         assert np.array_equal(losses[b], l)
         for p, q in zip(ms[b].parameters(), ps):
             assert torch.equal(p.detach(), q)
+
+
+# ---- DistGPR over composite kernels (native tile operations) ----------------------------------------------------------------
+def test_dist_gpr_example_model_native_tiles(device):
+    """the reference's example model (examples/regression_1d.py:34-53: Linear + Rbf + Constant) at BASELINE configs[1]'s size on the
+    block-cyclic engine with the product's native tile operations (1 x 1 grid in this process; tiles of 2048: gpn_kernel_matrix_expr
+    per tile block, gpn_kernel_expr_grad per leaf and tile block, gpn_refine_resid_part_expr above the composite refinement
+    threshold): loss within north_star's 1e-8, gradients and predictions against the REFERENCE (tests/golden/composite_big_case.json)."""
+    from gptorch_amd.models import DistGPR
+    case = load_json("composite_big_case.json")
+    d = case["d"]
+    x, y = rng.make_regression(case["n"], d, case["dy"], seed=0)
+    k = kernels.Linear(d, variance=0.3) + kernels.Rbf(d, variance=1.2, length_scales=float(np.sqrt(d))) + kernels.Constant(d, variance=0.4)
+    m = DistGPR(x, y, k, likelihood=likelihoods.Gaussian(variance=case["noise"]), tile=2048)
+    m.cuda()
+    loss = m.loss()
+    assert m._eng().refined, "N = 8192 is above the composite kernels' refinement threshold"
+    assert abs(loss.item() - case["loss"]) < 1e-8, (loss.item(), case["loss"])
+    loss.backward()
+    got = {n: p.grad.cpu().numpy() for n, p in m.named_parameters() if p.grad is not None}
+    assert sorted(got) == sorted(case["grads"])
+    for n, r in case["grads"].items():
+        r = np.asarray(r)
+        assert np.abs(got[n].reshape(r.shape) - r).max() < 1e-8 * max(1.0, np.abs(r).max()), (n, got[n], r)
+    xs = rng.normal(case["seed_xs"], (16, d))
+    mu, var = m.predict_f(xs)
+    assert np.max(np.abs(mu - np.asarray(case["mean"]))) < 1e-8
+    assert np.max(np.abs(var - np.asarray(case["var"]))) < 1e-8
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_dist_gpr_composite_cases_native_tiles(device, idx):
+    """the reference's composite cases (Rbf + Linear, Matern32 x Rbf-ARD; tests/golden/composite_cases.json) through DistGPR's native
+    tile operations with several tiles per side (tile 128 on 400 rows): loss, gradients, predictions diag and full."""
+    from gptorch_amd.models import DistGPR
+    case = load_json("composite_cases.json")[idx]
+    x, y = rng.make_regression(case["n"], case["d"], case["dy"], seed=0)
+    if case["name"] == "rbf_plus_linear":
+        kern = kernels.Rbf(3, variance=1.2, length_scales=1.5) + kernels.Linear(3, variance=np.array([0.3, 0.5, 0.7]))
+    else:
+        kern = kernels.Matern32(3, variance=0.9, length_scales=2.0) * kernels.Rbf(3, variance=1.1, length_scales=np.array([1.0, 2.0, 3.0]), ARD=True)
+    m = DistGPR(x, y, kern, likelihood=likelihoods.Gaussian(variance=case["noise"]), tile=128)
+    m.cuda()
+    loss = m.loss()
+    assert abs(loss.item() - case["loss"]) < 1e-9 * max(1.0, abs(case["loss"]))
+    loss.backward()
+    for n, r in case["grads"].items():
+        r = np.asarray(r)
+        g = dict(m.named_parameters())[n].grad.cpu().numpy()
+        assert np.abs(g.reshape(r.shape) - r).max() < 1e-8 * max(1.0, np.abs(r).max()), n
+    xs = rng.normal(case["seed_xs"], (16, case["d"]))
+    mu, var = m.predict_f(xs)
+    _, cov = m.predict_f(xs, diag=False)
+    assert np.abs(mu - np.asarray(case["mean"])).max() < 1e-8 and np.abs(var - np.asarray(case["var"])).max() < 1e-8
+    assert np.abs(cov - np.asarray(case["cov"])).max() < 1e-8
+
+
+def test_dist_gpr_rejects_what_the_grid_cannot_assemble(device):
+    from gptorch_amd.models import DistGPR
+    x, y = rng.make_regression(100, 3, 1, seed=0)
+    with pytest.raises(NotImplementedError):
+        DistGPR(x, y, kernels.Matern52(3) + kernels.White(3, variance=0.05))
