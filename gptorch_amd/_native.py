@@ -45,6 +45,18 @@ SIGNATURES = {
                                   c_void_p, c_int64, c_double, c_void_p, c_int64, c_int64, c_int]),
     "gpn_gemm_nt_batched": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64,
                                     c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64, c_int, c_int, c_int]),
+    "gpn_gemm_nt_batched_scaled": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                           c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64, c_int, c_int, c_int]),
+    "gpn_kernel_matrix_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
+                                          c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int64]),
+    "gpn_trsm_right_lt_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                          c_void_p, c_int64, c_int64, c_int64, c_int]),
+    "gpn_trtri_upper_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                        c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int]),
+    "gpn_kernel_grad_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
+                                        c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "gpn_kernel_grad_x2_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
+                                           c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_void_p]),
     "gpn_trtri_upper": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64]),
     "gpn_trtri_upper_ws": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
     "gpn_grad_work_bytes": (c_int64, [c_int64, c_int64, c_int, c_int]),

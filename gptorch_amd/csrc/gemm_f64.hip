@@ -104,7 +104,8 @@ struct Outer { int count = 0; int64_t sA = 0, sB = 0, sC = 0; };     // second b
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair(), Outer ob = Outer());
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st = Stair(), Outer ob = Outer(),
+                        const double* alpha_dev = nullptr);
 
 int gemm_nt(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb,
@@ -147,9 +148,10 @@ int gemm_nt_stair(hipStream_t s, int64_t M, int64_t nblocks, int64_t blk, int64_
 static int gemm_nt_impl(hipStream_t s, int64_t M, int64_t N, int64_t K, double alpha,
                         const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int lower, int tri, int inplace,
-                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st, Outer ob) {
+                        int batch, int64_t sA, int64_t sB, int64_t sC, Stair st, Outer ob, const double* alpha_dev) {
   if (M <= 0 || N <= 0 || batch <= 0) return GPN_OK;
   GemmArgs a;
+  a.alpha_dev = alpha_dev;
   a.batch = batch; a.sA = sA; a.sB = sB; a.sC = sC;
   a.inner = 0; a.sA2 = a.sB2 = a.sC2 = 0;
   a.acc_in = nullptr; a.acc_out = nullptr;
@@ -268,6 +270,29 @@ extern "C" int gpn_gemm_nt_batched(void* stream, int64_t M, int64_t N, int64_t K
   if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GPN_E_ALIGN;
   return gpn::gemm_nt_impl(static_cast<hipStream_t>(stream), M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
                            lower ? 1 : 0, tri, 0, batch, sA, sB, sC);
+}
+
+// gpn_gemm_nt_batched with one scale per problem, read from device memory: C_z = alphas[z] A_z B_z^T + beta C_z.  Per problem
+// bit-identical to gpn_gemm_nt(alpha = alphas[z]) -- lock-step sparse models scale by their own 1 / noise variance
+// (sparse_gpr.py:131-135 divides by sigma per model).
+extern "C" int gpn_gemm_nt_batched_scaled(void* stream, int64_t M, int64_t N, int64_t K, const double* alphas,
+                                          const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
+                                          double beta, double* C, int64_t ldc, int64_t sC, int lower, int tri, int batch) {
+  if (M < 0) return -2;
+  if (N < 0) return -3;
+  if (K <= 0 || (K % 16) != 0) return -4;
+  if (!alphas) return -5;
+  if (batch < 1) return -18;
+  if (M == 0 || N == 0) return GPN_OK;
+  if (!A) return -6;
+  if (!B) return -9;
+  if (!C) return -13;
+  if (lower && M != N) return -16;
+  if (tri < 0 || tri > 15) return -17;
+  if ((lda % 2) || (ldb % 2) || (sA % 2) || (sB % 2)) return GPN_E_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GPN_E_ALIGN;
+  return gpn::gemm_nt_impl(static_cast<hipStream_t>(stream), M, N, K, 0.0, A, lda, B, ldb, beta, C, ldc,
+                           lower ? 1 : 0, tri, 0, batch, sA, sB, sC, gpn::Stair(), gpn::Outer(), alphas);
 }
 
 extern "C" int gpn_gemm_nt(void* stream, int64_t M, int64_t N, int64_t K, double alpha,

@@ -36,6 +36,9 @@ struct GemmArgs {
   // element ((wave * TM + i) * TN + j) * 4 + r of lane l at [...] * 64 + l.  NULL: off.  (Ordinary launches never read them.)
   const double* acc_in;
   double* acc_out;
+  // strided batch only: problem z scales its product by alpha_dev[z] (device memory) instead of `alpha` -- lock-step models whose
+  // scale is a hyper-parameter of the model (the sparse bound's 1 / noise variance).  NULL: off.
+  const double* alpha_dev = nullptr;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -130,6 +133,9 @@ __device__ __forceinline__ void gemm_nt_tile(GemmArgs p, int bid, int nwg, const
     } else {
       p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC;
     }
+    if (p.alpha_dev) p.alpha = p.alpha_dev[z];
+  } else if (p.alpha_dev) {
+    p.alpha = p.alpha_dev[0];
   }
   int diag_off = 0;       // lower launches: the entry (row, col) is on or below ITS diagonal iff col + diag_off <= row
   bool stair_diag_tile = false;

@@ -43,12 +43,13 @@ struct GradArgs {
   // lock-step batch (gridDim.y models, gpn_lml_grad_batched): model z reads X + z sX, variance[z], ls + z nls, G + z sG,
   // at + z sAt and writes partial + z sPartial
   int64_t sX = 0, sG = 0, sAt = 0, sPartial = 0;
+  int64_t sX2 = -1;     // stride of the second point set (-1: sX -- the symmetric case)
 };
 
 __device__ __forceinline__ void select_model(GradArgs& p) {
   if (gridDim.y > 1) {
     const int64_t z = blockIdx.y;
-    p.X += z * p.sX; p.X2 += z * p.sX; p.variance += z; p.ls += z * p.nls;
+    p.X2 += z * (p.sX2 < 0 ? p.sX : p.sX2); p.X += z * p.sX; p.variance += z; p.ls += z * p.nls;
     p.G += z * p.sG; p.at += z * p.sAt; p.partial += z * p.sPartial;
   }
 }
@@ -507,6 +508,10 @@ struct GradX2Args {
   int64_t ldg;
   double* partial;   // [slabs, m, d]
   int n, m, d, nls, slab_rows;
+  // lock-step batch (gridDim.z models; the register kernel only): model z reads X + z sX, X2 + z sX2, variance[z], ls + z nls,
+  // G + z sG and writes partial + z sPartial
+  int batch = 1;
+  int64_t sX = 0, sX2 = 0, sG = 0, sPartial = 0;
 };
 
 template <int KIND, int DMAX>
@@ -518,6 +523,10 @@ __global__ __launch_bounds__(256) void grad_x2_kernel(GradX2Args p) {
   const int j0 = blockIdx.x * GT, col = j0 + lane;
   const int r_begin = blockIdx.y * p.slab_rows;
   const int r_end = min(p.n, r_begin + p.slab_rows);
+  if (p.batch > 1) {
+    const int64_t zb = blockIdx.z;
+    p.X += zb * p.sX; p.X2 += zb * p.sX2; p.variance += zb; p.ls += zb * p.nls; p.G += zb * p.sG; p.partial += zb * p.sPartial;
+  }
   const double var = p.variance[0];
 
   __shared__ double inv_ell[DMAX];
@@ -660,9 +669,11 @@ __global__ __launch_bounds__(256) void grad_x2_chunked_kernel(GradX2Args p) {
 }
 
 __global__ __launch_bounds__(256) void grad_x2_reduce_kernel(const double* partial, int slabs, int64_t md, double scale,
-                                                             int accumulate, double* out) {
+                                                             int accumulate, double* out, int64_t sPartial = 0) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= md) return;
+  partial += (int64_t)blockIdx.y * sPartial;        // gridDim.y models of a lock-step batch, outputs back to back
+  out += (int64_t)blockIdx.y * md;
   double s = 0.0;
   for (int b = 0; b < slabs; ++b) s += partial[(int64_t)b * md + k];
   out[k] = (accumulate ? out[k] : 0.0) + scale * s;
@@ -678,6 +689,7 @@ static int x2_slabs(int64_t n, int64_t m) {
 
 template <int KIND>
 static int launch_x2(hipStream_t s, const GradX2Args& a, dim3 grid) {
+  if (a.batch > 1 && a.d > GMAXD) return GPN_E_UNSUPPORTED;     // (the chunked kernel's gridDim.z = coordinate blocks)
   if (a.d <= 16) hipLaunchKernelGGL((grad_x2_kernel<KIND, 16>), grid, dim3(256), 0, s, a);
   else if (a.d <= 32) hipLaunchKernelGGL((grad_x2_kernel<KIND, 32>), grid, dim3(256), 0, s, a);
   else if (a.d <= GMAXD) hipLaunchKernelGGL((grad_x2_kernel<KIND, 64>), grid, dim3(256), 0, s, a);
@@ -851,6 +863,103 @@ extern "C" int gpn_kernel_grad(void* stream, int kind, const double* X, int64_t 
   const int rc = dispatch_kind<false>(s, kind, a, nblocks);
   if (rc != GPN_OK) return rc;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(1 + nls)), dim3(256), 0, s, work, nblocks, a.nout, out, (int64_t)0, 0);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// gpn_kernel_grad for `batch` models in ONE sweep launch (gridDim.y) + one reduction launch: model b reads X + b sX (0: shared
+// points), X2 + b sX2, variance[b], length_scales + b nls, G + b sG and writes out + b (1 + nls).  work: batch *
+// gpn_grad_work_bytes(n, m, nls, 0).  Per model bit-identical to gpn_kernel_grad.  (Lock-step sparse models: the sweeps against
+// dF/dKuu and dF/dKuf of sparse_gpr.py:126-129 for every restart at once.)
+extern "C" int gpn_kernel_grad_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n,
+                                       const double* X2, int64_t sX2, int64_t m, int d,
+                                       const double* variance, const double* length_scales, int nls,
+                                       const double* G, int64_t ldg, int64_t sG, double* work, double* out) {
+  if (batch < 1 || batch > 65535) return -3;
+  if (!X) return -4;
+  if (n <= 0) return -6;
+  const bool symmetric = (X2 == nullptr);
+  if (symmetric) m = n;
+  if (m <= 0) return -9;
+  if (d <= 0) return -10;
+  if (!variance) return -11;
+  if (!length_scales) return -12;
+  if (nls != 1 && nls != d) return -13;
+  if (!G) return -14;
+  if (ldg < m) return -15;
+  if (!work) return -17;
+  if (!out) return -18;
+  GradArgs a;
+  a.X = X; a.X2 = symmetric ? X : X2; a.variance = variance; a.ls = length_scales;
+  a.G = G; a.ldg = ldg; a.at = nullptr; a.ldat = 0; a.partial = work;
+  a.n = (int)n; a.m = (int)m; a.d = d; a.nls = nls; a.dy = 0; a.nout = 2 + nls;
+  a.tiles_m = (int)((n + GT - 1) / GT);
+  a.tiles_n = (int)((m + GT - 1) / GT);
+  const int64_t nblocks = (int64_t)a.tiles_m * a.tiles_n;
+  a.sX = sX; a.sX2 = symmetric ? sX : sX2; a.sG = sG; a.sAt = 0; a.sPartial = nblocks * a.nout;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rc = dispatch_kind<false>(s, kind, a, nblocks, batch);
+  if (rc != GPN_OK) return rc;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(1 + nls), (unsigned)batch), dim3(256), 0, s, work, nblocks, a.nout, out,
+                     a.sPartial, 1 + nls);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// gpn_kernel_grad_x2 for `batch` models: out + b m d (+)= scale * ...; work: batch * gpn_grad_x2_work_bytes(n, m, d).  Up to 64
+// input dimensions ONE launch over all models (+ one reduction launch), above that model by model; per model bit-identical to
+// gpn_kernel_grad_x2.
+extern "C" int gpn_kernel_grad_x2_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n,
+                                          const double* X2, int64_t sX2, int64_t m, int d,
+                                          const double* variance, const double* length_scales, int nls,
+                                          const double* G, int64_t ldg, int64_t sG, double scale, int accumulate,
+                                          double* work, double* out) {
+  if (batch < 1 || batch > 65535) return -3;
+  if (!X) return -4;
+  if (n <= 0) return -6;
+  if (!X2) return -7;
+  if (m <= 0) return -9;
+  if (d <= 0 || d > 65535 * GDC) return -10;
+  if (!variance) return -11;
+  if (!length_scales) return -12;
+  if (nls != 1 && nls != d) return -13;
+  if (!G) return -14;
+  if (ldg < m) return -15;
+  if (!work) return -19;
+  if (!out) return -20;
+  const int64_t md = m * (int64_t)d;
+  const int64_t one = gpn_grad_x2_work_bytes(n, m, d) / (int64_t)sizeof(double);
+  if (batch == 1 || d > GMAXD) {
+    for (int z = 0; z < batch; ++z) {
+      const int rc = gpn_kernel_grad_x2(stream, kind, X + z * sX, n, X2 + z * sX2, m, d, variance + z, length_scales + (int64_t)z * nls, nls,
+                                        G + z * sG, ldg, scale, accumulate, work + z * one, out + z * md);
+      if (rc != GPN_OK) return rc;
+    }
+    return GPN_OK;
+  }
+  GradX2Args a;
+  a.X = X; a.X2 = X2; a.variance = variance; a.ls = length_scales; a.G = G; a.ldg = ldg; a.partial = work;
+  a.n = (int)n; a.m = (int)m; a.d = d; a.nls = nls;
+  const int slabs = x2_slabs(n, m);
+  const int64_t row_tiles = (n + GT - 1) / GT;
+  a.slab_rows = (int)((row_tiles + slabs - 1) / slabs) * GT;
+  const int used = (int)((n + a.slab_rows - 1) / a.slab_rows);
+  a.batch = batch; a.sX = sX; a.sX2 = sX2; a.sG = sG; a.sPartial = one;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((m + GT - 1) / GT), (unsigned)used, (unsigned)batch);
+  int rc;
+  switch (kind) {
+    case GPN_RBF: rc = launch_x2<GPN_RBF>(s, a, grid); break;
+    case GPN_MATERN52: rc = launch_x2<GPN_MATERN52>(s, a, grid); break;
+    case GPN_MATERN32: rc = launch_x2<GPN_MATERN32>(s, a, grid); break;
+    case GPN_EXP: rc = launch_x2<GPN_EXP>(s, a, grid); break;
+    case GPN_PERIODIC: rc = launch_x2<GPN_PERIODIC>(s, a, grid); break;
+    case GPN_SQDIST: rc = launch_x2<GPN_SQDIST>(s, a, grid); break;
+    default: return -2;
+  }
+  if (rc != GPN_OK) return rc;
+  hipLaunchKernelGGL(grad_x2_reduce_kernel, dim3((unsigned)((md + 255) / 256), (unsigned)batch), dim3(256), 0, s, work, used, md, scale,
+                     accumulate, out, one);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

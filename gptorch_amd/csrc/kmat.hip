@@ -32,6 +32,7 @@ struct KmatArgs {
   int n, m, d, nls;
   int symmetric, lower, vec_ok;
   int64_t sX, sK;     // strided batch (gridDim.z problems): points and output at these strides, hyper-parameters consecutive
+  int64_t sX2 = -1;   // ... of the second point set (-1: the first set's stride -- the symmetric case)
   // gpn_lml_forward_saving: every entry is also stored here (same leading dimension) -- a pristine copy of Kyy for the refinement
   // step's residual pass, which otherwise re-computes every entry (the factorisation overwrites K in place)
   double* K2 = nullptr;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   __shared__ double inv_ell[DC];
   if (gridDim.z > 1) {                       // problem z of a strided batch (gpn_lml_forward_batched)
     const int z = blockIdx.z;
-    p.X += z * p.sX; p.X2 += z * p.sX; p.K += z * p.sK;
+    p.X2 += z * (p.sX2 < 0 ? p.sX : p.sX2); p.X += z * p.sX; p.K += z * p.sK;
     if (p.K2) p.K2 += z * p.sK;
     p.variance += z; p.ls += z * p.nls;
     if (p.noise) p.noise += z;
@@ -284,6 +285,59 @@ extern "C" int gpn_kernel_matrix(void* stream, int kind, const double* X, int64_
     case GPN_EXP: hipLaunchKernelGGL(kmat_kernel<GPN_EXP>, grid, dim3(256), 0, s, a); break;
     case GPN_PERIODIC: hipLaunchKernelGGL(kmat_kernel<GPN_PERIODIC>, grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(kmat_kernel<GPN_SQDIST>, grid, dim3(256), 0, s, a); break;
+  }
+  if (rec >= 0) profile_end(s, rec);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// gpn_kernel_matrix for `batch` models in ONE launch (gridDim.z): model b reads X + b sX (sX = 0: shared points), X2 + b sX2,
+// variance[b], length_scales + b nls, noise[b] and writes K + b sK.  Per model the same kernel, entry by entry: bit-identical to
+// gpn_kernel_matrix.  (Lock-step sparse models: K(Z_b) and K(x, Z_b), sparse_gpr.py:126-129, for every restart at once.)
+extern "C" int gpn_kernel_matrix_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n,
+                                         const double* X2, int64_t sX2, int64_t m, int d,
+                                         const double* variance, const double* length_scales, int nls, const double* noise,
+                                         int uplo, double* K, int64_t ldk, int64_t sK) {
+  using namespace gpn;
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
+  if (batch < 1 || batch > 65535) return -3;
+  if (!X) return -4;
+  if (n < 0) return -6;
+  const bool symmetric = (X2 == nullptr);
+  if (symmetric) m = n;
+  if (m < 0) return -9;
+  if (d <= 0) return -10;
+  if (!variance) return -11;
+  if (!length_scales) return -12;
+  if (nls != 1 && nls != d) return -13;
+  if (uplo != GPN_FULL && uplo != GPN_LOWER) return -15;
+  if (uplo == GPN_LOWER && !symmetric) return -15;
+  if (!K) return -16;
+  if (ldk < m) return -17;
+  if (batch > 1 && sK < (n - 1) * ldk + m) return -18;
+  if (n == 0 || m == 0) return GPN_OK;
+  KmatArgs a;
+  a.X = X; a.X2 = symmetric ? X : X2;
+  a.variance = variance; a.ls = length_scales; a.noise = noise;
+  a.K = K; a.ldk = ldk;
+  a.n = (int)n; a.m = (int)m; a.d = d; a.nls = nls;
+  a.symmetric = symmetric; a.lower = (uplo == GPN_LOWER);
+  a.vec_ok = ((ldk & 1) == 0) && ((reinterpret_cast<uintptr_t>(K) & 15) == 0) && ((sK & 1) == 0);
+  a.sX = sX; a.sK = sK; a.sX2 = symmetric ? sX : sX2;
+  const unsigned tn = (unsigned)((m + KT - 1) / KT), tm = (unsigned)((n + KT - 1) / KT);
+  if (!a.lower && tm > 65535) return GPN_E_UNSUPPORTED;
+  dim3 grid = a.lower ? dim3(tm * (tm + 1) / 2, 1, (unsigned)batch) : dim3(tn, tm, (unsigned)batch);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rec = -1;
+  if (profile_on())
+    rec = profile_begin(s, batch * (a.lower ? 8.0 * (0.5 * n * (n + 1.0) + (double)n * d) : 8.0 * ((double)n * m + (double)(n + (symmetric ? 0 : m)) * d)),
+                        PROF_KMAT);
+  switch (kind) {
+    case GPN_RBF: hipLaunchKernelGGL(kmat_kernel<GPN_RBF>, grid, dim3(256), 0, s, a); break;
+    case GPN_MATERN52: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN52>, grid, dim3(256), 0, s, a); break;
+    case GPN_MATERN32: hipLaunchKernelGGL(kmat_kernel<GPN_MATERN32>, grid, dim3(256), 0, s, a); break;
+    case GPN_EXP: hipLaunchKernelGGL(kmat_kernel<GPN_EXP>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(kmat_kernel<GPN_PERIODIC>, grid, dim3(256), 0, s, a); break;
   }
   if (rec >= 0) profile_end(s, rec);
   GPN_LAUNCH_CHECK();

@@ -357,6 +357,9 @@ struct Ctx {
   // A + b sA, winv + b sW, info + b; every launch of the drivers below covers all of them
   int batch = 1;
   int64_t sA = 0, sW = 0;
+  // right-solves of a batch whose right-hand sides live OUTSIDE the factor buffers (gpn_trsm_right_lt_batched): their stride
+  // (-1: inside the factor buffers, sA)
+  int64_t sRhs = -1;
 };
 
 // the drivers' contraction / column-pass launches, batched when the context is
@@ -389,16 +392,18 @@ static inline int64_t split_point(int64_t n) {
 static void trsm_rec(Ctx& c, double* B, int64_t m, int64_t ldb, const double* L, int64_t ldl,
                      int64_t kb, int64_t diag0, const double* winv) {
   if (c.rc != GPN_OK || m <= 0 || kb <= 0) return;
+  const int64_t sB = c.sRhs >= 0 ? c.sRhs : c.sA;
   if (kb <= LEAF) {
     const double* W = winv + (diag0 / LEAF) * (LEAF * LEAF);
     // in place: one LEAF-wide column tile per row block (see file header)
-    c.rc = ccolpanel(c, c.s, 0, m, kb, B, ldb, W, LEAF, B, ldb);
+    c.rc = colpanel(c.s, 0, m, kb, B, ldb, W, LEAF, B, ldb, c.batch, sB, c.sW, sB);
     return;
   }
   const int64_t h = split_point(kb);
   trsm_rec(c, B, m, ldb, L, ldl, h, diag0, winv);
   if (c.rc != GPN_OK) return;
-  c.rc = cgemm(c, c.s, m, kb - h, h, -1.0, B, ldb, L + h * ldl, ldl, 1.0, B + h, ldb, 0);
+  c.rc = c.batch == 1 ? gemm_nt(c.s, m, kb - h, h, -1.0, B, ldb, L + h * ldl, ldl, 1.0, B + h, ldb, 0, 0, 0)
+                      : gemm_nt_strided(c.s, m, kb - h, h, -1.0, B, ldb, L + h * ldl, ldl, 1.0, B + h, ldb, 0, 0, 0, c.batch, sB, c.sA, sB);
   trsm_rec(c, B + h, m, ldb, L + h * ldl + h, ldl, kb - h, diag0 + h, winv);
 }
 
@@ -962,6 +967,29 @@ extern "C" int gpn_trsm_right_lt(void* stream, const double* L, int64_t n, int64
   return c.rc;
 }
 
+// gpn_trsm_right_lt for `batch` factors of one shape in lock step: problem b solves against L + b sL / winv + b sW in place on
+// B + b sB.  The same recursion, every launch once over all problems: per problem bit-identical to gpn_trsm_right_lt.
+extern "C" int gpn_trsm_right_lt_batched(void* stream, const double* L, int64_t n, int64_t ldl, int64_t sL, const double* winv, int64_t sW,
+                                         double* B, int64_t m, int64_t ldb, int64_t sB, int batch) {
+  if (!L) return -2;
+  if (n < 0) return -3;
+  if (ldl < round_up(n, LEAF) || (ldl % LEAF) != 0) return -4;
+  if (batch < 1) return -12;
+  if (batch > 1 && (sL < n * ldl || (sL & 1))) return -5;
+  if (!winv) return -6;
+  if (batch > 1 && sW < gpn_winv_bytes(n) / (int64_t)sizeof(double)) return -7;
+  if (!B) return -8;
+  if (m < 0) return -9;
+  if (ldb < round_up(n, LEAF) || (ldb % LEAF) != 0) return -10;
+  if (batch > 1 && (sB < m * ldb || (sB & 1))) return -11;
+  if ((reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(B) & 15)) return GPN_E_ALIGN;
+  if (n == 0 || m == 0) return GPN_OK;
+  Ctx c{static_cast<hipStream_t>(stream), ldl, const_cast<double*>(winv), nullptr, GPN_OK};
+  c.batch = batch; c.sA = sL; c.sW = sW; c.sRhs = sB;
+  trsm_rec(c, B, m, ldb, L, ldl, n, 0, winv);
+  return c.rc;
+}
+
 // ---- right-solves against BIG inverted diagonal blocks -----------------------------------------------------------------
 // gpn_trsm_right_lt walks the recursion down to the 128-wide leaf inverses: at m = 1024 right-hand sides (GPR._predict,
 // gpr.py:104-106) its <= 512-wide levels are ~190 latency-bound launches -- 2.3 ms at N = 8192 for 6.9e10 flops (33
@@ -1163,6 +1191,45 @@ extern "C" int gpn_trtri_upper(void* stream, const double* L, int64_t n, int64_t
   Ctx c{s, ldl, const_cast<double*>(winv), nullptr, GPN_OK};
   trtri_rec(c, L, ldl, U, ldu, n, 0);
   return c.rc;
+}
+
+// U_b = L_b^-T for `batch` factors of one shape: gpn_trtri_upper_ws's schedule with every launch once over all problems
+// (n > 256; up to there gpn_trtri_upper problem by problem -- a handful of launches each).  U and S zero-initialised by the
+// caller; per problem bit-identical to the single-problem entry points.
+extern "C" int gpn_trtri_upper_batched(void* stream, const double* L, int64_t n, int64_t ldl, int64_t sL, const double* winv, int64_t sW,
+                                       double* U, int64_t ldu, int64_t sU, double* S, int64_t lds, int64_t sS, int batch) {
+  if (!L) return -2;
+  if (n < 0) return -3;
+  if (ldl < round_up(n, LEAF) || (ldl % LEAF) != 0) return -4;
+  if (batch < 1) return -14;
+  if (batch > 1 && (sL < n * ldl || (sL & 1))) return -5;
+  if (!winv) return -6;
+  if (batch > 1 && sW < gpn_winv_bytes(n) / (int64_t)sizeof(double)) return -7;
+  if (!U) return -8;
+  if (ldu < round_up(n, LEAF) || (ldu % LEAF) != 0) return -9;
+  if (batch > 1 && (sU < n * ldu || (sU & 1))) return -10;
+  if ((reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(U) & 15)) return GPN_E_ALIGN;
+  if (n == 0) return GPN_OK;
+  if (n <= 2 * LEAF) {
+    for (int z = 0; z < batch; ++z) {
+      const int rc = gpn_trtri_upper(stream, L + z * sL, n, ldl, winv + z * sW, U + z * sU, ldu);
+      if (rc != GPN_OK) return rc;
+    }
+    return GPN_OK;
+  }
+  if (!S) return -11;
+  if (lds < round_up(n, LEAF) || (lds % LEAF) != 0) return -12;
+  if (batch > 1 && (sS < n * lds || (sS & 1))) return -13;
+  if (reinterpret_cast<uintptr_t>(S) & 15) return GPN_E_ALIGN;
+  // (the transposes put equal nodes x models into gridDim.z: chunks of models that fit)
+  const int64_t max_models = std::max<int64_t>(1, 65535 / std::max<int64_t>(1, n / 256 + 1));
+  for (int z0 = 0; z0 < batch; z0 += (int)max_models) {
+    const int nb = (int)std::min<int64_t>(max_models, batch - z0);
+    const int rc = trtri_upper_ws_batched(static_cast<hipStream_t>(stream), L + z0 * sL, n, ldl, sL, winv + z0 * sW, sW, U + z0 * sU, ldu, sU,
+                                          S + z0 * sS, lds, sS, nb);
+    if (rc != GPN_OK) return rc;
+  }
+  return GPN_OK;
 }
 
 extern "C" int gpn_lml_reduce(void* stream, const double* A, int64_t n, int64_t e, int64_t lda, double* out3) {

@@ -254,6 +254,58 @@ def _expression_groups(models):
     return [(key, g, progs) for key, (g, progs) in groups.items() if len(g) >= 2]
 
 
+def _vfe_groups(models):
+    """[(key, indices)] of the VFE models (sparse_gpr.py:108-153) that can share one lock-step evaluation
+    (_vfe_lockstep.BatchedVFEBound): one native stationary kind, equal (N, D, dy, M, ARD), on one device, in the single-chunk regime
+    (_vfe_lockstep.supported); split into chunks that fit the device's free memory."""
+    from . import _vfe_lockstep
+    from .sparse_gpr import VFE
+    groups = {}
+    for i, m in enumerate(models):
+        if not isinstance(m, VFE) or type(m).log_likelihood is not VFE.log_likelihood or type(m)._bound is not VFE._bound:
+            continue
+        k = m._native_kernel()
+        if k is None or not m.X.is_cuda or not _vfe_lockstep.supported(m.X.shape[0], m.Z.shape[0]):
+            continue
+        key = ("vfe", k._kind, tuple(m.X.shape), m.Y.shape[1], int(k.length_scales.numel()), tuple(m.Z.shape), m.X.device)
+        groups.setdefault(key, []).append(i)
+    out = []
+    for key, g in groups.items():
+        try:
+            free, _total = torch.cuda.mem_get_info(key[-1])
+            cap = max(2, int(LOCKSTEP_MEMORY_FRACTION * free) // _vfe_lockstep.per_model_bytes(key[2][0], key[5][0], key[3]))
+        except Exception:
+            cap = 1 << 30
+        for at in range(0, len(g), cap):
+            chunk = g[at:at + cap]
+            if len(chunk) >= 2:
+                out.append((key, chunk))
+    return out
+
+
+def _vfe_group_bound(ms, key, differentiable):
+    """the lock-step bounds [B] of one _vfe_groups group (autograd-connected to every model's Params when differentiable)"""
+    from . import _vfe_lockstep
+    B = len(ms)
+    m0 = ms[0]
+    same_x = all(m.X.data_ptr() == m0.X.data_ptr() for m in ms)
+    same_y = same_x and all(m.Y.data_ptr() == m0.Y.data_ptr() for m in ms)
+    X = m0.X if same_x else torch.stack([m.X for m in ms])
+    Y = m0.Y if same_y else torch.stack([m.Y for m in ms])               # sparse_gpr.py:125 quirk: err = Y (Zero mean only)
+    plists = ([m.kernel.variance for m in ms], [m.kernel.length_scales for m in ms], [m.likelihood.variance for m in ms])
+    stacks = []
+    for plist in plists:
+        t0 = _shared_transform(plist)
+        if not differentiable:
+            stacks.append(_stacked_values(plist))
+        elif t0 is not None:
+            stacks.append(t0(torch.stack(list(plist))))
+        else:
+            stacks.append(torch.stack([p.transform() for p in plist]))
+    Z = torch.stack([m.Z for m in ms]) if differentiable else torch.stack([m.Z.data for m in ms])
+    return _vfe_lockstep.BatchedVFEBound.apply(stacks[0].reshape(B), stacks[1].reshape(B, -1), stacks[2].reshape(B), Z, key[1], X, Y)
+
+
 def _group_data(ms, differentiable=False):
     """(X, R) of a lock-step group: shared [n, d] / [n, dy] when every model holds the same tensors (restarts on one data
     set), else stacked [B, ...].  differentiable: R keeps the autograd graph of trainable mean functions."""
@@ -320,6 +372,10 @@ def batched_log_likelihood(models, streams=None):
             lml = _expr.BatchedExprLogLik.apply(X, R, nz, progs, _batch_holder((key, len(ms))), *flat)
             for b, i in enumerate(g):
                 out[i] = lml[b:b + 1].clone()
+        for key, g in _vfe_groups(models):
+            elbo = _vfe_group_bound([models[i] for i in g], key, differentiable=False)
+            for b, i in enumerate(g):
+                out[i] = elbo[b].clone()                                     # (VFE.log_likelihood returns a 0-dim tensor)
         for i, m in enumerate(models):
             if out[i] is None:
                 out[i] = m.log_likelihood()
@@ -394,6 +450,20 @@ def batched_loss_and_grad(models):
         ld = loss.detach()
         for b, i in enumerate(g):
             out[i] = ld[b:b + 1]
+    for key, g in _vfe_groups(models):
+        # sparse models of one shape (sparse_gpr.py:108-153 in a multi-start search over inducing points / hyper-parameters)
+        ms = [models[i] for i in g]
+        elbo = _vfe_group_bound(ms, key, differentiable=True)
+        # Model.loss (model.py:158-197): -(bound + log prior), model by model as the sequential code forms it
+        if any(getattr(p, "prior", None) is not None for m in ms for p in m.parameters()):
+            loss = torch.stack([-(elbo[b] + m.log_prior()) for b, m in enumerate(ms)])
+        else:
+            loss = -(elbo + 0.0)
+        if loss.requires_grad:
+            loss.sum().backward()
+        ld = loss.detach()
+        for b, i in enumerate(g):
+            out[i] = ld[b]
     for i, m in enumerate(models):
         if out[i] is None:
             loss = m.loss()
@@ -630,7 +700,7 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
     rest = [i for i in range(len(models)) if not done[i]]
     rest_models = [models[i] for i in rest]
     if method in _TORCH_DEFAULT_LR and method != "LBFGS" and len(rest) >= 2 and \
-            (_lockstep_groups(rest_models) or _expression_groups(rest_models)):
+            (_lockstep_groups(rest_models) or _expression_groups(rest_models) or _vfe_groups(rest_models)):
         # What cannot share a stacked parameter tensor (composite kernels, priors, trainable mean functions, mixed frozen
         # parameters) still shares the EVALUATION: every model keeps its own optimiser over its own parameters -- exactly the
         # objects and tensor layouts of its own optimize(), so its trajectory is bit-identical -- and each iteration is one

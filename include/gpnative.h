@@ -208,6 +208,40 @@ int gpn_gemm_nt_batched(void* stream, int64_t M, int64_t N, int64_t K, double al
                         const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
                         double beta, double* C, int64_t ldc, int64_t sC, int lower, int tri, int batch);
 
+/* gpn_gemm_nt_batched with one scale per problem, read from DEVICE memory: C_z = alphas[z] A_z B_z^T + beta C_z; per problem
+ * bit-identical to gpn_gemm_nt(alpha = alphas[z]).  Lock-step sparse models scale by their own 1 / noise variance
+ * (sparse_gpr.py:131-135 divides by sigma per model). */
+int gpn_gemm_nt_batched_scaled(void* stream, int64_t M, int64_t N, int64_t K, const double* alphas,
+                               const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
+                               double beta, double* C, int64_t ldc, int64_t sC, int lower, int tri, int batch);
+
+/* ---- lock-step forms of the single-purpose entry points (round 6) -------------
+ * `batch` models of one shape, every launch once over all of them: model b at pointer + b * stride (strides in doubles;
+ * sX = 0: shared points), hyper-parameters consecutive (variance[b], length_scales + b nls, noise[b]).  Each is per model
+ * BIT-IDENTICAL to its single-model entry point.  They carry the sparse bound (sparse_gpr.py:108-153) of B restarts in lock
+ * step -- K(Z_b), K(x, Z_b), the right-solve against chol K(Z_b), L_b^-T, the sweeps against dF/dKuu and dF/dKuf -- where the
+ * reference runs one model per optimiser step (models/base.py:260-269). */
+int gpn_kernel_matrix_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n,
+                              const double* X2, int64_t sX2, int64_t m, int d,
+                              const double* variance, const double* length_scales, int nls, const double* noise,
+                              int uplo, double* K, int64_t ldk, int64_t sK);
+int gpn_trsm_right_lt_batched(void* stream, const double* L, int64_t n, int64_t ldl, int64_t sL, const double* winv, int64_t sW,
+                              double* B, int64_t m, int64_t ldb, int64_t sB, int batch);
+/* U, S zero-initialised by the caller (S may be NULL up to n = 256) */
+int gpn_trtri_upper_batched(void* stream, const double* L, int64_t n, int64_t ldl, int64_t sL, const double* winv, int64_t sW,
+                            double* U, int64_t ldu, int64_t sU, double* S, int64_t lds, int64_t sS, int batch);
+/* out [batch, 1 + nls]; work: batch * gpn_grad_work_bytes(n, m, nls, 0) */
+int gpn_kernel_grad_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n,
+                            const double* X2, int64_t sX2, int64_t m, int d,
+                            const double* variance, const double* length_scales, int nls,
+                            const double* G, int64_t ldg, int64_t sG, double* work, double* out);
+/* out [batch, m, d]; work: batch * gpn_grad_x2_work_bytes(n, m, d) */
+int gpn_kernel_grad_x2_batched(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n,
+                               const double* X2, int64_t sX2, int64_t m, int d,
+                               const double* variance, const double* length_scales, int nls,
+                               const double* G, int64_t ldg, int64_t sG, double scale, int accumulate,
+                               double* work, double* out);
+
 /* ---- backward of the LML (closed form) ---------------------
  * U <- L^-T (upper triangular, row-major) into a ZERO-INITIALISED buffer of
  * gpn_factor_rows(n,0) x ldu (ldu = gpn_factor_ld(n,0)); L/winv from gpn_potrf_lower.
