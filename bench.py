@@ -706,6 +706,49 @@ def run_single(args, device):
                     return {"config": "%s: the factorisation alone, launch-based driver vs ONE persistent dataflow launch" % ww["name"].replace(" LML eval", ""),
                             "ms_launch_based": t_l, "ms_persistent": t_p, "bit_identical": bool(same), "shipped_driver": "launch-based"}
                 return run
+            def vfe_lockstep(n, m, d, B):
+                # round 6: B sparse (VFE) restarts of one shape, `loss(); backward()` in LOCK STEP (batched_loss_and_grad ->
+                # models/_vfe_lockstep.py) against the reference's order, one model after the other (base.py:260-269 over
+                # sparse_gpr.py:108-153); every bound and gradient bit-identical to the model's own
+                def run():
+                    from gptorch_amd import kernels, likelihoods, mean_functions, rng
+                    from gptorch_amd.models import VFE, batched_loss_and_grad
+                    g = np.random.default_rng(0)
+                    xv, yv = rng.make_regression(n, d, 1, seed=0)
+                    ms_ = []
+                    for b in range(B):
+                        v = VFE(xv, yv, kernels.Rbf(d, variance=1.0 + 0.01 * b, length_scales=0.5 * float(np.sqrt(d)) * (1.0 + 0.02 * b)),
+                                inducing_points=xv[g.choice(n, m, replace=False)], likelihood=likelihoods.Gaussian(variance=0.05),
+                                mean_function=mean_functions.Zero(1))
+                        v.cuda()
+                        if ms_:
+                            v.X, v.Y = ms_[0].X, ms_[0].Y
+                        ms_.append(v)
+
+                    def seq():
+                        out = []
+                        for v in ms_:
+                            v.zero_grad()
+                            l_ = v.loss()
+                            l_.backward()
+                            out.append(l_.detach())
+                        return out
+
+                    def lock():
+                        for v in ms_:
+                            v.zero_grad()
+                        return batched_loss_and_grad(ms_)
+                    t_s, a = timed(seq, 5, 2)
+                    ga = [[p_.grad.clone() for p_ in v.parameters()] for v in ms_]
+                    t_l, b_ = timed(lock, 5, 2)
+                    same = all(torch.equal(u, w) for u, w in zip(a, b_)) and \
+                        all(torch.equal(u, p_.grad) for gs, v in zip(ga, ms_) for u, p_ in zip(gs, v.parameters()))
+                    return {"config": "VFE + Rbf, N=%d M=%d D=%d: %d restarts, loss(); backward() in lock step" % (n, m, d, B),
+                            "batch": B, "ms_lock_step": t_l * 1e3, "ms_one_after_the_other": t_s * 1e3, "speedup": t_s / t_l,
+                            "bit_identical_to_sequential": bool(same)}
+                return run
+            leg("vfe_lockstep_n512", vfe_lockstep(512, 64, 2, 64))
+            leg("vfe_lockstep_n8192", vfe_lockstep(8192, 512, 8, 8))
             leg("c2_batched", lockstep("c2", 8))
             leg("c1_batched", lockstep("c1", 64))
             leg("c2_persistent_factorisation", persistent("c2"))

@@ -57,6 +57,7 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gpn_kernel_grad_x2_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
                                            c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_void_p]),
+    "gpn_dot2d_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int]),
     "gpn_trtri_upper": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64]),
     "gpn_trtri_upper_ws": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
     "gpn_grad_work_bytes": (c_int64, [c_int64, c_int64, c_int, c_int]),

@@ -560,6 +560,30 @@ def row_sumsq(A, rows, cols):
     return out
 
 
+def dot2d_raw(x, ldx, sx, y, ldy, sy, rows, cols, batch, device):
+    """out[z] = <x_z, y_z> over a rows x cols view (gpn_dot2d_batched; x, y: pointers, y None: the plain sum) -> [batch]."""
+    out = torch.empty(batch, dtype=torch.float64, device=device)
+    st = _native.lib().gpn_dot2d_batched(_stream(device), x, ldx, sx, y, ldy, sy, rows, cols, _ptr(out), batch)
+    _native.check(st, "gpn_dot2d_batched")
+    return out
+
+
+def dot2d(x, y=None):
+    """sum(x * y) (y None: sum(x)) of 2-D fp64 device tensors with unit inner stride, as a 0-dim tensor: ONE launch with a fixed
+    summation order (the scalar sums of the sparse bound, sparse_gpr.py:139-151; their lock-step form is the same kernel)."""
+    _req(x, y)
+    x = x if x.stride(1) == 1 else x.contiguous()
+    if y is not None:
+        y = y if y.stride(1) == 1 else y.contiguous()
+    return dot2d_raw(_ptr(x), x.stride(0), 0, _ptr(y), 0 if y is None else y.stride(0), 0, x.shape[0], x.shape[1], 1, x.device)[0]
+
+
+def diag_sum(A, m):
+    """sum of the first m diagonal entries of a row-major matrix (0-dim tensor; see dot2d)."""
+    _req(A)
+    return dot2d_raw(_ptr(A), A.stride(0) + 1, 0, None, 0, 0, m, 1, 1, A.device)[0]
+
+
 def padded_like_factor(f, m):
     """zeroed [round_up(m,128), f.ld] buffer for right-hand sides of solve_right_lt."""
     return zeros(round_up(max(m, 1), LEAF), f.ld, f.device)

@@ -807,6 +807,31 @@ __global__ void transpose_batched_kernel(const double* src, int64_t n, int64_t l
   }
 }
 
+// out[z] = sum_{i < rows, j < cols} x_z[i ldx + j] * y_z[i ldy + j]  (y == NULL: the plain sum of x), problem z at x + z sx,
+// y + z sy.  One workgroup per problem; thread t adds the entries t, t + 256, ... of the row-major index order, then a fixed
+// tree: the value does not depend on how many problems share the launch.
+__global__ __launch_bounds__(256) void dot2d_kernel(const double* x, int64_t ldx, int64_t sx, const double* y, int64_t ldy, int64_t sy,
+                                                    int64_t rows, int64_t cols, double* out) {
+  __shared__ double red[256];
+  x += (int64_t)blockIdx.x * sx;
+  if (y) y += (int64_t)blockIdx.x * sy;
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  const int64_t total = rows * cols;
+  for (int64_t k = tid; k < total; k += 256) {
+    const int64_t i = k / cols, j = k - i * cols;
+    const double a = x[i * ldx + j];
+    s += y ? a * y[i * ldy + j] : a;
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) out[blockIdx.x] = red[0];
+}
+
 __global__ void copy_matrix_kernel(const double* src, int64_t rows, int64_t cols, int64_t lds,
                                    double* dst, int64_t ldd, int tril) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1308,6 +1333,22 @@ extern "C" int gpn_copy_matrix(void* stream, const double* src, int64_t rows, in
   if (rows == 0 || cols == 0) return GPN_OK;
   dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535));
   hipLaunchKernelGGL(copy_matrix_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), src, rows, cols, lds, dst, ldd, tril);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// The small scalar sums of the sparse bound (sparse_gpr.py:139-151: tr(AA^T), |err|^2, ...) for `batch` models in one launch,
+// each value independent of the batch size (see dot2d_kernel): out[z] = <x_z, y_z> over a rows x cols view (y NULL: sum of x).
+extern "C" int gpn_dot2d_batched(void* stream, const double* x, int64_t ldx, int64_t sx, const double* y, int64_t ldy, int64_t sy,
+                                 int64_t rows, int64_t cols, double* out, int batch) {
+  if (!x) return -2;
+  if (rows < 0) return -8;
+  if (cols < 0) return -9;
+  if (ldx < 0 || ldy < 0) return -3;
+  if (!out) return -10;
+  if (batch < 1) return -11;
+  hipLaunchKernelGGL(dot2d_kernel, dim3((unsigned)batch), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, sx, y, ldy, sy, rows, cols,
+                     out);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

@@ -16,8 +16,9 @@ to ~10^4, M up to ~10^3) one model's ~100 launches each leave most of the chip i
 Same kernels per model, same per-entry summation order, and the host-side scalar arithmetic of the sequential code restated
 operation by operation (a tensor divided by a Python float is a multiplication by its reciprocal in PyTorch: the reciprocals
 are formed on the host exactly as there): every model's bound and gradients are BIT-IDENTICAL to its own
-`log_likelihood()` / `loss(); backward()` (tests/test_gpu_vfe_lockstep.py).  A model whose chol K(Z) or chol(B) reports
-info != 0 is replayed alone through the sequential path (jitter ladder of functions.py:20-43) -- forward and backward.
+`log_likelihood()` / `loss(); backward()` (tests/test_gpu_vfe_lockstep.py).  The jitter ladder (functions.py:20-43) runs in lock
+step too: the models whose chol K(Z) (or chol(B)) reports info != 0 climb it together as a sub-batch, rung by rung, and a
+factor that succeeds is copied into its slot -- the same assembly + factorisation per model as the sequential ladder.
 
 Scope: native stationary kinds, the single-chunk regime (N below 32768 rows: no split-K accumulators, no chunk pipelines),
 right-solves by recursion (M < BLOCKED_SOLVE_MIN_M or N < 4 M).  Anything else -- config 5's N = 10^6 / M = 4096 fills the
@@ -31,6 +32,7 @@ from .. import _native, _ops
 from . import sparse_gpr as _sg
 
 _ptr, _stream, round_up = _ops._ptr, _ops._stream, _ops.round_up
+LADDER_CLIMBS = 0  # factorisations that needed the jitter ladder so far (diagnostics: tools/vfe_batched_bench.py)
 
 
 def supported(n, m):
@@ -60,6 +62,45 @@ class _BState:
 
 def _z3(B, rows, cols, dev):
     return _ops.zeros(B * rows, cols, dev).view(B, rows, cols)
+
+
+def _potrf_b(fb):
+    _check(_native.lib().gpn_potrf_lower_batched(_stream(fb.A.device), _ptr(fb.A), fb.n, fb.e, fb.ld, fb.sA, _ptr(fb.winv), fb.sW,
+                                                 _ptr(fb.info), fb.batch), "gpn_potrf_lower_batched")
+
+
+def _climb(fb, fill):
+    """functions.py:20-43 for the factors of a FactorBatch whose first (plain) attempt has been enqueued: the failing problems
+    retry TOGETHER with +10^(-tries+i) I, i = 0 .. tries-1 -- fill(sub, idx, jitter) assembles problems idx into the FactorBatch
+    `sub` -- and every factor that succeeds is copied into its slot of fb.  One read-back of `info` per attempt."""
+    global LADDER_CLIMBS
+
+    def failing(info):
+        if any(v < 0 for v in info):
+            raise _ops.NativeError("factorisation reported the internal status %d (not a property of the matrix)" % min(info))
+        return [j for j, v in enumerate(info) if v != 0]
+
+    bad = failing(fb.info.tolist())
+    if not bad:
+        return
+    LADDER_CLIMBS += len(bad)
+    tries = int(_ops.JITTER_TRIES)
+    A3, W = fb.A.view(fb.batch, fb.rows, fb.ld), fb.winv.view(fb.batch, fb.sW)
+    for i in range(tries):
+        sub = _ops.FactorBatch(len(bad), fb.n, fb.e, fb.A.device)
+        fill(sub, bad, 10.0 ** (-tries + i))
+        _potrf_b(sub)
+        still = set(failing(sub.info.tolist()))
+        S3, SW = sub.A.view(sub.batch, sub.rows, sub.ld), sub.winv.view(sub.batch, sub.sW)
+        for j, b in enumerate(bad):
+            if j not in still:
+                A3[b].copy_(S3[j])
+                W[b].copy_(SW[j])
+        bad = [b for j, b in enumerate(bad) if j in still]
+        if not bad:
+            fb.info.zero_()
+            return
+    raise RuntimeError("Max tries exceeded.")
 
 
 def _gemm_b(A, lda, sA, Bm, ldb, sB, C, ldc, sC, M, N, K, batch, alpha=1.0, alphas=None, beta=0.0, lower=False, tri=0, dev=None):
@@ -100,8 +141,15 @@ def _forward(kind, var, ls, nz, s2, Z, X, Y):
     f_uu = _ops.FactorBatch(B, m, 0, dev)
     _check(lib.gpn_kernel_matrix_batched(stream, k, B, _ptr(Z), m * d, m, None, 0, m, d, _ptr(var), _ptr(ls), nls, None,
                                          _ops.GPN_LOWER, _ptr(f_uu.A), f_uu.ld, f_uu.sA), "gpn_kernel_matrix_batched")
-    _check(lib.gpn_potrf_lower_batched(stream, _ptr(f_uu.A), m, 0, f_uu.ld, f_uu.sA, _ptr(f_uu.winv), f_uu.sW, _ptr(f_uu.info), B),
-           "gpn_potrf_lower_batched")
+    _potrf_b(f_uu)
+
+    def fill_uu(sub, idx, jitter):
+        ix = torch.tensor(idx, device=dev)
+        Zs, vs, lss = Z[ix].contiguous(), var[ix].contiguous(), ls[ix].contiguous()
+        nzs = torch.full((len(idx),), jitter, dtype=torch.float64, device=dev)
+        _check(lib.gpn_kernel_matrix_batched(stream, k, len(idx), _ptr(Zs), m * d, m, None, 0, m, d, _ptr(vs), _ptr(lss), nls, _ptr(nzs),
+                                             _ops.GPN_LOWER, _ptr(sub.A), sub.ld, sub.sA), "gpn_kernel_matrix_batched")
+    _climb(f_uu, fill_uu)
     st.f_uu = f_uu
     # A_b^T = K(x, Z_b) L_b^-T, A_b = its transpose
     nc, mp, pp = round_up(n, _ops.LEAF), round_up(m, 16), round_up(dy, 16)
@@ -128,21 +176,29 @@ def _forward(kind, var, ls, nz, s2, Z, X, Y):
     Aerr = torch.zeros(B, mp, dy, dtype=torch.float64, device=dev)
     _gemm_b(_ptr(A), nc, mp * nc, _ptr(errT), nc, 0 if shared_y else pp * nc, _ptr(Aerr), dy, mp * dy, m, dy, kp, B, dev=dev)
     del A
-    # the scalar sums: the SAME torch reductions on the same shapes as the sequential code, model by model
+    # the scalar sums: the kernel of the sequential code (_ops.dot2d / diag_sum), one launch over the models
+    Yc = Y if Y.stride(-1) == 1 else Y.contiguous()
     if shared_y:
-        yy = Y.pow(2).sum().expand(B)
+        yy = _ops.dot2d(Yc, Yc).expand(B)
     else:
-        yy = torch.stack([Y[b].pow(2).sum() for b in range(B)])
+        yy = _ops.dot2d_raw(_ptr(Yc), Yc.stride(1), Yc.stride(0), _ptr(Yc), Yc.stride(1), Yc.stride(0), n, dy, B, dev)
     st.yy, st.trkff = yy, n * var
     st.AAT, st.Aerr = AAT, Aerr
-    st.tr = torch.stack([AAT[b].diagonal()[:m].sum() for b in range(B)])
+    st.tr = _ops.dot2d_raw(_ptr(AAT), fB.ld + 1, fB.sA, None, 0, 0, m, 1, B, dev)
     # B_b = AAT_b + I = LB LB^T with (A err)^T as extra rows
     A3 = fB.A.view(B, fB.rows, fB.ld)
     A3.copy_(AAT)
     A3.diagonal(dim1=1, dim2=2)[:, :m].add_(1.0)
     A3[:, m:m + dy, :m] = Aerr[:, :m, :].transpose(1, 2)
-    _check(lib.gpn_potrf_lower_batched(stream, _ptr(fB.A), m, dy, fB.ld, fB.sA, _ptr(fB.winv), fB.sW, _ptr(fB.info), B),
-           "gpn_potrf_lower_batched")
+    _potrf_b(fB)
+
+    def fill_B(sub, idx, jitter):
+        ix = torch.tensor(idx, device=dev)
+        S3 = sub.A.view(sub.batch, sub.rows, sub.ld)
+        S3.copy_(AAT[ix])
+        S3.diagonal(dim1=1, dim2=2)[:, :m].add_(1.0 + jitter)
+        S3[:, m:m + dy, :m] = Aerr[ix][:, :m, :].transpose(1, 2)
+    _climb(fB, fill_B)
     _check(lib.gpn_lml_reduce_batched(stream, _ptr(fB.A), m, dy, fB.ld, fB.sA, _ptr(fB.out), B), "gpn_lml_reduce_batched")
     st.fB, st.terms = fB, fB.out
     return st
@@ -258,10 +314,9 @@ def _backward(st, var, ls, Z, X, Y):
 
     t = st.terms
     c2 = t[:, 1] * tab[1]
-    b = beta[:, :m, :p]
-    s_ba = torch.stack([(b[i] * st.Aerr[i, :m]).sum() for i in range(B)])
-    s_bb = torch.stack([(b[i] * b[i]).sum() for i in range(B)])
-    trb = torch.stack([Binv[i].diagonal().sum() for i in range(B)])
+    s_ba = _ops.dot2d_raw(_ptr(beta), pp, mp * pp, _ptr(st.Aerr), p, mp * p, m, p, B, dev)
+    s_bb = _ops.dot2d_raw(_ptr(beta), pp, mp * pp, _ptr(beta), pp, mp * pp, m, p, B, dev)
+    trb = _ops.dot2d_raw(_ptr(Binv), m + 1, m * m, None, 0, 0, m, 1, B, dev)
     quad = s_ba * tab[0] - s_bb                                            # beta^T (B - I) beta
     g_noise = tab[3] * (m - trb) - c2 * tab[0] + (0.5 * quad) * tab[0] - (0.5 * p * st.tr) * tab[0] \
         - tab[4] + (0.5 * (st.yy + p * st.trkff)) * tab[1]
@@ -279,17 +334,6 @@ class BatchedVFEBound(torch.autograd.Function):
         s2 = [float(v) for v in nz.tolist()]                               # (sparse_gpr._VFEBound reads noise.item() per model)
         st = _forward(kind, var, ls, nz, s2, Zc, X, Y)
         elbo = _elbo(st)
-        info = torch.maximum(st.f_uu.info.abs(), st.fB.info.abs()).tolist()        # ONE read-back for the group
-        st.replayed = {}
-        for b, bad in enumerate(info):
-            if bad:
-                # the jitter ladder (functions.py:20-43) is per model: this one alone, through the sequential code
-                asm = _sg._NativeAsm(kind, var[b:b + 1], ls[b])
-                xb = X if X.dim() == 2 else X[b]
-                yb = Y if Y.dim() == 2 else Y[b]
-                one = _sg._vfe_forward(asm, xb, yb, Zc[b], s2[b])
-                elbo[b] = _sg._elbo(one, yb.shape[1], s2[b])
-                st.replayed[b] = (asm, one)
         ctx.st, ctx.X, ctx.Y = st, X, Y
         ctx.save_for_backward(var, ls, Zc)
         ctx.shapes = (variance.shape, length_scales.shape, noise.shape, Z.shape)
@@ -300,12 +344,6 @@ class BatchedVFEBound(torch.autograd.Function):
         var, ls, Zc = ctx.saved_tensors
         st, X, Y = ctx.st, ctx.X, ctx.Y
         g_var, g_ls, g_noise, g_Z = _backward(st, var, ls, Zc, X, Y)
-        for b, (asm, one) in st.replayed.items():
-            xb = X if X.dim() == 2 else X[b]
-            yb = Y if Y.dim() == 2 else Y[b]
-            gn = _sg._vfe_backward(asm, xb, yb, Zc[b], one)
-            gv, gl, gz = asm.tensors()
-            g_var[b], g_ls[b], g_noise[b], g_Z[b] = gv[0], gl.reshape(-1), gn[0], gz
         g = grad_out
         sv, sl, sn, sz = ctx.shapes
         return ((g * g_var).reshape(sv), (g[:, None] * g_ls).reshape(sl), (g * g_noise).reshape(sn),

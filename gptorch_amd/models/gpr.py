@@ -708,8 +708,19 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
         opts = []
         for m in rest_models:
             m._auto_place()
-            m.optimizer = m._make_optimizer(method, [p for p in m.parameters() if p.requires_grad], learning_rate)
-            opts.append(m.optimizer)
+        plist = [p for m in rest_models for p in m.parameters() if p.requires_grad]
+        if len({id(p) for p in plist}) == len(plist):
+            # ONE optimiser object over every model's own parameter tensors: the torch optimisers are elementwise per tensor and
+            # their multi-tensor kernels treat every tensor of the list by itself, so each model's update is what its own
+            # optimiser would do -- bit for bit -- at one step() call per iteration instead of one per model
+            shared = rest_models[0]._make_optimizer(method, plist, learning_rate)
+            for m in rest_models:
+                m.optimizer = shared
+            opts.append(shared)
+        else:                                   # models that share Param objects: every model's own optimiser, as optimize() would
+            for m in rest_models:
+                m.optimizer = m._make_optimizer(method, [p for p in m.parameters() if p.requires_grad], learning_rate)
+                opts.append(m.optimizer)
         print("multi_start_optimize: %d models, one lock-step evaluation per iteration, via %s" % (len(rest), method))
         for idx in range(max_iter):
             for o in opts:

@@ -315,7 +315,7 @@ def _vfe_forward(asm, x, err, Z, s2):
         del parts
     # row shards: one all-reduce of the M-sized sums and of (N, |err|^2)
     scal = torch.tensor([float(n), 0.0, 0.0], dtype=torch.float64, device=dev)
-    scal[1] = err.pow(2).sum()
+    scal[1] = _ops.dot2d(err, err)
     scal[2] = asm.trkff(x)                                                 # tr Kff (sparse_gpr.py:139-141)
     if SHARD_GROUP is not None:
         _all_reduce(AAT)
@@ -323,7 +323,7 @@ def _vfe_forward(asm, x, err, Z, s2):
         _all_reduce(scal)
     st.n_all, st.yy_all, st.trkff = int(round(scal[0].item())), scal[1], scal[2]
     st.Aerr = Aerr[:m]
-    st.tr = AAT.diagonal()[:m].sum()
+    st.tr = _ops.diag_sum(AAT, m)
 
     def attempt(jitter):
         fB.A.copy_(AAT)
@@ -403,8 +403,8 @@ def _vfe_backward(asm, x, err, Z, st):
     n_all = st.n_all
     c2 = st.terms[1] / (s * s)
     b = beta[:m, :p]
-    quad = (b * st.Aerr).sum() / s - (b * b).sum()                         # beta^T (B - I) beta
-    g_noise = (0.5 * p / s) * (m - Binv.diagonal().sum()) - c2 / s + 0.5 * quad / s - 0.5 * p * st.tr / s \
+    quad = _ops.dot2d(b, st.Aerr) / s - _ops.dot2d(b, b)                   # beta^T (B - I) beta
+    g_noise = (0.5 * p / s) * (m - _ops.diag_sum(Binv, m)) - c2 / s + 0.5 * quad / s - 0.5 * p * st.tr / s \
         - 0.5 * p * n_all / s + 0.5 * (st.yy_all + p * st.trkff) / (s * s)
     return g_noise.reshape(1)
 

@@ -612,6 +612,11 @@ int gpn_transpose(void* stream, const double* src, int64_t rows, int64_t cols, i
  * (torch.cholesky returns a zeroed upper triangle) */
 int gpn_copy_matrix(void* stream, const double* src, int64_t rows, int64_t cols, int64_t lds,
                     double* dst, int64_t ldd, int tril);
+/* out[z] = sum_{i < rows, j < cols} x_z[i ldx + j] * y_z[i ldy + j] (y NULL: the plain sum), problem z at x + z sx, y + z sy:
+ * the scalar sums of the sparse bound (sparse_gpr.py:139-151: tr(A A^T), |err|^2 ...) for `batch` models in one launch.  A
+ * fixed summation order per problem: out[z] does not depend on `batch`. */
+int gpn_dot2d_batched(void* stream, const double* x, int64_t ldx, int64_t sx, const double* y, int64_t ldy, int64_t sy,
+                      int64_t rows, int64_t cols, double* out, int batch);
 /* out[r] = sum_c A[r,c]^2  (the (A*A).sum(0) of gpr.py:109-113 in transposed storage) */
 int gpn_row_sumsq(void* stream, const double* A, int64_t rows, int64_t cols, int64_t lda,
                   double* out);

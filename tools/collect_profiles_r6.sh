@@ -8,7 +8,7 @@
 #   3  HBM traffic counters (one --pmc pass each; FETCH / WRITE as MI355X_MICROARCH.md prescribes) -> traffic_c{2,3}.json
 #   4  MFMA-busy of the contraction launches at C3, VALU issue of the HBM-side kernels
 #   5  round 6: the persistent factorisation against the launch-based driver (sizes, per-task trace at C2), the optimiser step
-#      as one graph replay, the lock-step fit timings
+#      as one graph replay, the lock-step fit timings, sparse (VFE) restarts in lock step
 set -u
 TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -53,4 +53,6 @@ PP_PATHS=2 PP_DEPTH=14 python3 tools/persistent_trace.py 8192 16 > $O/persistent
 python3 tools/capture_bench.py 512 1024 2048 4096 8192 --iters 100 > $O/capture_bench.txt 2>&1
 python3 tools/fit_batched_bench.py c2 1 8 --parts > $O/fit_batched_c2.txt 2>&1
 python3 tools/kmat_bench.py c2 c3 c4 > $O/kmat_bench.txt 2>&1
+python3 tools/vfe_batched_bench.py --parts > $O/vfe_batched_bench.txt 2>&1
+python3 tools/vfe_fit_probe.py > $O/vfe_fit_probe.txt 2>&1
 ls -la $O | head -60
