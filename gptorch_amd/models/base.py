@@ -3,6 +3,7 @@ GPModel: data + kernel + likelihood + mean function, the optimiser loop and the
 public predict API -- behaviour of gptorch/models/base.py (the shell around the
 native hot path; no dense arithmetic happens here).
 """
+import os
 from time import time
 
 import numpy as np
@@ -48,6 +49,9 @@ _SCIPY_METHODS = ["CG", "BFGS", "Newton-CG", "Nelder-Mead", "Powell", "L-BFGS-B"
                   "dogleg", "trust-ncg"]                                            # base.py:203-215
 
 
+FOREACH_ON_GPU = os.environ.get("GPTORCH_AMD_FOREACH", "1") != "0"     # _make_optimizer: multi-tensor optimiser kernels for GPU parameters
+
+
 class GPModel(Model):
     def __init__(self, x, y, kernel, likelihood, mean_function, name="gp"):
         super().__init__()
@@ -87,28 +91,32 @@ class GPModel(Model):
         return likelihoods.Gaussian(variance=float(0.001 * y.var()))
 
     def _make_optimizer(self, method, parameters, learning_rate):
-        """The nine torch optimisers with the reference's settings (base.py:144-200)."""
+        """The nine torch optimisers with the reference's settings (base.py:144-200).  On the GPU the multi-tensor ("foreach")
+        implementation is asked for explicitly: PyTorch picks it by itself for plain Parameters only, and would step `Param`
+        tensors (a Parameter subclass, as in the reference) one small launch per tensor and operation."""
         lr = learning_rate
         o = torch.optim
+        parameters = list(parameters)
+        fe = {"foreach": True} if (FOREACH_ON_GPU and parameters and all(p.is_cuda for p in parameters)) else {}
         if method == "SGD":
-            return o.SGD(parameters, lr=lr if lr is not None else 0.01, momentum=0.9)
+            return o.SGD(parameters, lr=lr if lr is not None else 0.01, momentum=0.9, **fe)
         if method == "Adam":
-            return o.Adam(parameters, lr=lr if lr is not None else 0.01)
+            return o.Adam(parameters, lr=lr if lr is not None else 0.01, **fe)
         if method == "LBFGS":
             return o.LBFGS(parameters, lr=1.0 if lr is None else lr, max_iter=5, max_eval=None, tolerance_grad=1e-05,
                            tolerance_change=1e-09, history_size=50, line_search_fn=None)
         if method == "Adadelta":
-            return o.Adadelta(parameters, lr=lr, rho=0.9, eps=1e-06, weight_decay=0.00001)
+            return o.Adadelta(parameters, lr=lr, rho=0.9, eps=1e-06, weight_decay=0.00001, **fe)
         if method == "Adagrad":
-            return o.Adagrad(parameters, lr=lr, lr_decay=0, weight_decay=0)
+            return o.Adagrad(parameters, lr=lr, lr_decay=0, weight_decay=0, **fe)
         if method == "Adamax":
-            return o.Adamax(parameters, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0)
+            return o.Adamax(parameters, lr=lr, betas=(0.9, 0.999), eps=1e-08, weight_decay=0, **fe)
         if method == "ASGD":
-            return o.ASGD(parameters, lr=lr, lambd=0.0001, alpha=0.75, t0=1000000.0, weight_decay=0)
+            return o.ASGD(parameters, lr=lr, lambd=0.0001, alpha=0.75, t0=1000000.0, weight_decay=0, **fe)
         if method == "RMSprop":
-            return o.RMSprop(parameters, lr=lr, alpha=0.99, eps=1e-08, weight_decay=0.00, momentum=0.01, centered=False)
+            return o.RMSprop(parameters, lr=lr, alpha=0.99, eps=1e-08, weight_decay=0.00, momentum=0.01, centered=False, **fe)
         if method == "Rprop":
-            return o.Rprop(parameters, lr=lr, etas=(0.5, 1.2), step_sizes=(1e-06, 50))
+            return o.Rprop(parameters, lr=lr, etas=(0.5, 1.2), step_sizes=(1e-06, 50), **fe)
         return None
 
     def optimize(self, method="Adam", max_iter=2000, verbose=True, learning_rate=None, capture=False):
