@@ -39,18 +39,12 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), ((BM / WM) * (BN / WN) 
   gemm_nt_tile<BM, BN, WM, WN, DMA, NS, BLOW, PIPE>(p, (int)blockIdx.x, (int)gridDim.x, false);
 }
 
-// Switches: constants in the product library; in the tools' build (libgpnative_dbg.so, -DGPN_DEBUG_SWITCHES) per-thread variables
-// behind gpn_debug_set_gemm_variant / gpn_debug_set_thin_tiles at the end of this file -- forcing one tile shape for a launch
-// is how tests/test_gpu_gemm.py holds every shape against the reference product (and against each other: bit-identical).
-#ifdef GPN_DEBUG_SWITCHES
-static thread_local int g_gemm_variant = 0;  // 0 = the shipped dispatch, 1 = register staging, 3..11 = forced tile shapes
-static thread_local int g_thin_tiles = 1;    // the thin-tile path (reaches the kernels through GemmArgs)
-static thread_local int g_smem_pad = 0;      // extra dynamic LDS per workgroup (KiB): lowers the occupancy
-#else
-static constexpr int g_gemm_variant = 0;
-static constexpr int g_thin_tiles = 1;
-static constexpr int g_smem_pad = 0;
-#endif
+// Switches (gpn_common.h: constants in the product library, per-thread variables behind gpn_debug_set_gemm_variant /
+// gpn_debug_set_thin_tiles in the tools' build) -- forcing one tile shape for a launch is how tests/test_gpu_gemm.py holds every
+// shape against the reference product (and against each other: bit-identical).
+GPN_SWITCH int g_gemm_variant = 0;  // 0 = the shipped dispatch, 1 = register staging, 3..11 = forced tile shapes
+GPN_SWITCH int g_thin_tiles = 1;    // the thin-tile path (reaches the kernels through GemmArgs)
+GPN_SWITCH int g_smem_pad = 0;      // extra dynamic LDS per workgroup (KiB): lowers the occupancy
 static constexpr int g_group_h = 8;
 static constexpr int g_big_tile_min_trapezoid = 4096;   // trapezoid launches (nested panels): 128 x 128 tiles from this many of them
 
@@ -244,15 +238,14 @@ extern "C" int gpn_gemm_nt_stair(void* stream, int64_t M, int64_t nblocks, int64
   return gpn::gemm_nt_stair(static_cast<hipStream_t>(stream), M, nblocks, blk, K, alpha, A, lda, B, ldb, beta, C, ldc, step, diag);
 }
 
-#ifdef GPN_DEBUG_SWITCHES
 // (libgpnative_dbg.so only; the calling thread's launches)
+GPN_DEBUG_ONLY(
 extern "C" int gpn_debug_set_thin_tiles(int on) { gpn::g_thin_tiles = on; return GPN_OK; }
 extern "C" int gpn_debug_set_gemm_variant(int v) {
   gpn::g_gemm_variant = v & 0x7f;     // forced tile shape (see gemm_nt_impl)
   gpn::g_smem_pad = v >> 8;           // bits 8..: KiB of LDS padding per workgroup
   return GPN_OK;
-}
-#endif
+})
 
 extern "C" int gpn_gemm_nt_batched(void* stream, int64_t M, int64_t N, int64_t K, double alpha,
                                    const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,

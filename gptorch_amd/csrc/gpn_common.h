@@ -4,6 +4,19 @@
 #include <stdint.h>
 #include "../../include/gpnative.h"
 
+// A/B switches.  In the product library they are compile-time constants; in the tools' build (libgpnative_dbg.so, compiled with
+// -DGPN_DEBUG_SWITCHES by build.sh) they are per-thread variables behind the gpn_debug_* entry points -- other PARAMETRISATIONS of
+// the shipped code (forced tile shapes, panel widths, one launch per block instead of the persistent back-substitution ...)
+// that the cross-check tests hold against each other.  This is the only conditional region: sources declare a switch with
+// GPN_SWITCH and wrap what only the tools' build has in GPN_DEBUG_ONLY(...).
+#ifdef GPN_DEBUG_SWITCHES
+#define GPN_SWITCH static thread_local
+#define GPN_DEBUG_ONLY(...) __VA_ARGS__
+#else
+#define GPN_SWITCH static constexpr
+#define GPN_DEBUG_ONLY(...)
+#endif
+
 namespace gpn {
 
 constexpr int LEAF = 128;  // diagonal leaf block (potrf + inverse in one workgroup) = padding granule of factor buffers

@@ -323,24 +323,19 @@ __global__ __launch_bounds__(LEAF_THREADS) void potrf_leaf_kernel(double* A, int
   (void)done;
 }
 
-// Switches: constants in the product library; in the tools' build (libgpnative_dbg.so, -DGPN_DEBUG_SWITCHES) per-thread
-// variables behind the gpn_debug_set_* entry points at the end of this file -- other PARAMETRISATIONS of the shipped driver
+// Switches (gpn_common.h: constants in the product library, per-thread variables behind the gpn_debug_set_* entry points at the
+// end of this file in the tools' build) -- other PARAMETRISATIONS of the shipped driver
 // (plain recursion, panel widths and nesting, left- / right-looking in-panel updates, the extra rows' kernel), which
 // tests/test_gpu_parity.py::test_factorisation_drivers_agree holds against each other.  The schedules that were built, measured
 // and dropped (look-ahead over panels in three forms incl. round 6's persistent bulk, look-ahead inside the outer panel, the
 // fused chain step, both column passes in one launch, left-looking inner panels, split assembly) are in the history and in
 // LAB.md 8 / 10 / 11 / 12 with their same-box logs under profiles/.
-#ifdef GPN_DEBUG_SWITCHES
-#define GPN_SWITCH static thread_local int
-#else
-#define GPN_SWITCH static constexpr int
-#endif
-GPN_SWITCH g_potrf_variant = 0;      // 0 = nested panels with in-panel look-ahead (default), 1 = plain recursion
-GPN_SWITCH g_panel_width = 0;        // inner panel width, 0 = by size
-GPN_SWITCH g_outer_width = 0;        // outer panel width: 0 = by size, -1 = one level
-GPN_SWITCH g_outer_width2 = 0;       // a third level
-GPN_SWITCH g_aux_left_looking = -1;  // in-panel updates beyond the next column block: -1 = by size, 0 right- / 1 left-looking
-GPN_SWITCH g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row of the lower-tile launch
+GPN_SWITCH int g_potrf_variant = 0;      // 0 = nested panels with in-panel look-ahead (default), 1 = plain recursion
+GPN_SWITCH int g_panel_width = 0;        // inner panel width, 0 = by size
+GPN_SWITCH int g_outer_width = 0;        // outer panel width: 0 = by size, -1 = one level
+GPN_SWITCH int g_outer_width2 = 0;       // a third level
+GPN_SWITCH int g_aux_left_looking = -1;  // in-panel updates beyond the next column block: -1 = by size, 0 right- / 1 left-looking
+GPN_SWITCH int g_extra_rows_kernel = 1;  // 0 = the extra rows as one more tile row of the lower-tile launch
 
 struct Ctx {
   hipStream_t s;
@@ -951,8 +946,8 @@ extern "C" int gpn_potrf_lower_panel(void* stream, double* A, int64_t n, int64_t
   return c.rc;
 }
 
-#ifdef GPN_DEBUG_SWITCHES
 // (tools' build only: the calling thread's driver parametrisation -- see the switches at the top of the drivers)
+GPN_DEBUG_ONLY(
 extern "C" int gpn_debug_set_potrf_variant(int v) {
   g_potrf_variant = v & 1;           // bit 0: plain recursion; bits 8..: inner panel width / 128
   g_panel_width = ((v >> 8) & 0xff) * LEAF;
@@ -960,8 +955,7 @@ extern "C" int gpn_debug_set_potrf_variant(int v) {
   return GPN_OK;
 }
 extern "C" int gpn_debug_set_extra_rows(int on) { g_extra_rows_kernel = on; return GPN_OK; }
-extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; }
-#endif
+extern "C" int gpn_debug_set_outer_width(int w1, int w2) { g_outer_width = w1; g_outer_width2 = w2; return GPN_OK; })
 
 extern "C" int gpn_trtri_diag(void* stream, const double* L, int64_t n, int64_t ldl, double* winv, int32_t* info) {
   if (!L) return -2;

@@ -799,13 +799,9 @@ static std::map<std::tuple<int, int64_t, int64_t>, PDevPlan*> g_pp_plans;       
 struct PRuntime { int* rt = nullptr; double* scratch = nullptr; };
 static std::map<std::tuple<hipStream_t, int64_t, int64_t>, PRuntime> g_pp_runtime;      // one runtime area (+ scratch tiles) per caller stream and shape
 
-#ifdef GPN_DEBUG_SWITCHES
-static thread_local int g_pp_chain_wgs = 0, g_pp_grid = 0;
-static thread_local unsigned long long* g_pp_trace = nullptr;
-#else
-static constexpr int g_pp_chain_wgs = 0, g_pp_grid = 0;
-static constexpr unsigned long long* g_pp_trace = nullptr;
-#endif
+GPN_SWITCH int g_pp_chain_wgs = 0;                       // chain workgroups / grid (0: the defaults); the per-task trace buffer
+GPN_SWITCH int g_pp_grid = 0;
+GPN_SWITCH unsigned long long* g_pp_trace = nullptr;
 
 // gpn_potrf_lower as one persistent launch.  GPN_E_UNSUPPORTED: this size (or a stream under capture that has no plan yet)
 // stays with the launch-based driver.  The plan (task table + successor lists + the pristine runtime image) is built on the
@@ -930,9 +926,8 @@ extern "C" int gpn_potrf_persistent_plan(int64_t n, int64_t e, int64_t* counts, 
   return GPN_OK;
 }
 
-#ifdef GPN_DEBUG_SWITCHES
+GPN_DEBUG_ONLY(
 extern "C" int gpn_debug_set_persistent(int chain_wgs, int grid) { g_pp_chain_wgs = chain_wgs; g_pp_grid = grid; return GPN_OK; }
 // device buffer of 8 x 8 bytes per task (gpn_potrf_persistent_plan's count): per task the 100 MHz stamps {pop begins, task popped,
 // acquire done, stores drained, successors released} and (chain role << 32 | workgroup); NULL switches the trace off
-extern "C" int gpn_debug_persistent_trace(unsigned long long* buf) { g_pp_trace = buf; return GPN_OK; }
-#endif
+extern "C" int gpn_debug_persistent_trace(unsigned long long* buf) { g_pp_trace = buf; return GPN_OK; })

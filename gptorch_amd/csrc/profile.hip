@@ -81,13 +81,12 @@ extern "C" int gpn_profile_collect(double* out3_host) {
   return GPN_OK;
 }
 
-#ifdef GPN_DEBUG_SWITCHES
-// Experimental: a stream restricted to a subset of the 256 CUs (hipExtStreamCreateWithCUMask).
+// Experimental (tools' build): a stream restricted to a subset of the 256 CUs (hipExtStreamCreateWithCUMask).
 // mask_words = 8 x uint32 (bit i = CU i enabled).  Returns the hipStream_t through *out.
+GPN_DEBUG_ONLY(
 extern "C" int gpn_debug_masked_stream(const uint32_t* mask_words, int nwords, void** out) {
   hipStream_t s;
   GPN_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask_words));
   *out = s;
   return GPN_OK;
-}
-#endif
+})

@@ -530,12 +530,7 @@ static int gemv_t_chunks(int64_t rows, int64_t cols) {
   return (int)nchunk;
 }
 
-#ifdef GPN_DEBUG_SWITCHES
-static thread_local int g_backsub_persistent = 1;
-#else
-static constexpr int g_backsub_persistent = 1;
-#endif
-//   // 0 = one launch per 128-column block (backsub_step_kernel; A/B and bit-identity test, tools' build)
+GPN_SWITCH int g_backsub_persistent = 1;   // 0 = one launch per 128-column block (backsub_step_kernel; A/B and bit-identity test, tools' build)
 
 struct RefineLayout { int64_t lds, s, a, partial, norm, prow, pcol, total; int nseg, tiles_per_seg; };
 static RefineLayout refine_layout(int64_t n, int dy) {
@@ -560,9 +555,7 @@ static RefineLayout refine_layout(int64_t n, int dy) {
 
 using namespace gpn;
 
-#ifdef GPN_DEBUG_SWITCHES
-extern "C" int gpn_debug_set_backsub_persistent(int on) { gpn::g_backsub_persistent = on; return GPN_OK; }
-#endif
+GPN_DEBUG_ONLY(extern "C" int gpn_debug_set_backsub_persistent(int on) { gpn::g_backsub_persistent = on; return GPN_OK; })
 
 extern "C" int64_t gpn_lml_refine_work_bytes(int64_t n, int dy) {
   if (n < 0 || dy <= 0) return 0;

@@ -135,6 +135,41 @@ def test_lockstep_vfe_climbs_the_ladder_per_failing_model(device):
             assert torch.equal(a, b)
 
 
+def test_lockstep_vfe_with_priors_and_frozen_parameters(device):
+    """parameters with priors (model.py:158-197: loss = -(bound + log prior), each model's own), frozen inducing points in one model
+    and a frozen kernel variance in another: loss and every gradient that exists bit-identical to loss(); backward(); a scipy
+    multi-start over the same group returns each model's own result"""
+    g = lambda a, b: torch.distributions.Gamma(torch.tensor(a, dtype=torch.float64, device=device), torch.tensor(b, dtype=torch.float64, device=device))
+
+    def fresh():
+        ms = _models(4, 450, 36, 2, 1, "Matern52", seed=11)
+        ms[0].kernel.variance.prior = g(2.0, 1.0)
+        ms[2].likelihood.variance.prior = g(1.5, 10.0)
+        ms[1].Z.requires_grad_(False)
+        ms[3].kernel.variance.requires_grad_(False)
+        return ms
+    a, b = fresh(), fresh()
+    assert len(gpr_mod._vfe_groups(b)) == 1
+    for mdl in a:
+        mdl.zero_grad()
+        mdl.loss().backward()
+    out = batched_loss_and_grad(b)
+    for ma, mb, l1 in zip(a, b, out):
+        assert torch.equal(ma.loss().detach(), l1)
+        for p, q in zip(ma.parameters(), mb.parameters()):
+            assert (p.grad is None) == (q.grad is None)
+            if p.grad is not None:
+                assert torch.equal(p.grad, q.grad)
+    assert b[1].Z.grad is None and b[3].kernel.variance.grad is None
+    assert out[0].item() != (-(b[0].log_likelihood())).item()        # the prior really is in the loss
+    c, d = fresh(), fresh()
+    with contextlib.redirect_stdout(io.StringIO()):
+        own = [mdl.optimize(method="L-BFGS-B", max_iter=6) for mdl in c]
+        res, _ = multi_start_optimize(d, method="L-BFGS-B", max_iter=6)
+    for r0, r1 in zip(own, res):
+        assert np.array_equal(r0.x, r1.x) and r0.fun == r1.fun and r0.nfev == r1.nfev
+
+
 def test_mixed_models_take_their_own_paths(device):
     """VFE groups, a GPR group and a singleton in one call: every loss and gradient as from the model's own loss(); backward()"""
     v1 = _models(2, 400, 32, 2, 1, "Rbf", seed=1)
