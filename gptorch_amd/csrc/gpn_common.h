@@ -83,7 +83,7 @@ int lml_grad_batched(hipStream_t s, int kind, int batch, const double* X, int64_
                      const double* variance, const double* length_scales, int nls,
                      const double* Kinv, int64_t ldk, int64_t sK, const double* at, int64_t ldat, int64_t sAt, int dy,
                      double* work, int64_t sWork, double* out);
-// U_b = L_b^-T of `batch` lock-step models (potrf.hip)
+// U_b = L_b^-T of `batch` lock-step models (trisolve.hip)
 int trtri_upper_ws_batched(hipStream_t s, const double* L, int64_t n, int64_t ldl, int64_t sL, const double* winv, int64_t sW,
                            double* U, int64_t ldu, int64_t sU, double* S, int64_t lds, int64_t sS, int batch);
 
