@@ -601,7 +601,7 @@ def run_single(args, device):
                             "bit_identical_to_sequential": bool(same),
                             "cholesky_frac_of_fp64_peak": B * (n ** 3 / 3.0) / t / 1e12 / PEAK_FP64_MFMA_TFLOPS}
                 return run
-            def fit_lockstep(key, B, iters, seq_models, seq_iters):
+            def fit_lockstep(key, B, iters, seq_models, seq_iters, capture=False):
                 # north_star's GP-fits/sec at small N: B restarts x `iters` Adam steps as ONE lock-step fit (multi_start_optimize:
                 # gpn_lml_forward_batched + gpn_lml_backward_batched + one optimiser step on the stacked raw parameters per
                 # iteration) against the reference's loop, one model and one step at a time (base.py:260-269: GPModel.optimize)
@@ -624,7 +624,7 @@ def run_single(args, device):
                         multi_start_optimize(models, method="Adam", max_iter=2, learning_rate=0.01)      # warm-up: buffers, first launches
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
-                        losses, _ = multi_start_optimize(models, method="Adam", max_iter=iters, learning_rate=0.01)
+                        losses, _ = multi_start_optimize(models, method="Adam", max_iter=iters, learning_rate=0.01, capture=capture)
                         torch.cuda.synchronize()
                         dt = time.perf_counter() - t0
                         del models
@@ -639,7 +639,8 @@ def run_single(args, device):
                         dseq = (time.perf_counter() - t0) / (seq_models * seq_iters)      # seconds per model and step
                     n = float(ww["n"])
                     return {"config": "%s -> %d restarts x %d Adam steps (lr 0.01) as ONE lock-step fit (multi_start_optimize -> "
-                                      "gpn_lml_forward_batched + gpn_lml_backward_batched)" % (ww["name"].replace(" LML eval", ""), B, iters),
+                                      "gpn_lml_forward_batched + gpn_lml_backward_batched)%s" % (ww["name"].replace(" LML eval", ""), B, iters,
+                                                                                                 ", the iteration as one hipGraph replay (capture=True)" if capture else ""),
                             "batch": B, "adam_steps": iters, "s_per_batched_fit": dt, "fits_per_s": B / dt, "ms_per_batched_step": dt / iters * 1e3,
                             "frac_of_fp64_peak_on_N3": B * iters * n ** 3 / dt / 1e12 / PEAK_FP64_MFMA_TFLOPS,
                             "sequential_ms_per_model_step": dseq * 1e3, "sequential_fits_per_s": 1.0 / (iters * dseq),
@@ -739,10 +740,10 @@ def run_single(args, device):
                             v.zero_grad()
                         return batched_loss_and_grad(ms_)
                     t_s, a = timed(seq, 5, 2)
-                    ga = [[p_.grad.clone() for p_ in v.parameters()] for v in ms_]
+                    ga = [[p_.grad.clone() for p_ in v.parameters() if p_.grad is not None] for v in ms_]
                     t_l, b_ = timed(lock, 5, 2)
                     same = all(torch.equal(u, w) for u, w in zip(a, b_)) and \
-                        all(torch.equal(u, p_.grad) for gs, v in zip(ga, ms_) for u, p_ in zip(gs, v.parameters()))
+                        all(torch.equal(u, w) for gs, v in zip(ga, ms_) for u, w in zip(gs, [p_.grad for p_ in v.parameters() if p_.grad is not None]))
                     return {"config": "VFE + Rbf, N=%d M=%d D=%d: %d restarts, loss(); backward() in lock step" % (n, m, d, B),
                             "batch": B, "ms_lock_step": t_l * 1e3, "ms_one_after_the_other": t_s * 1e3, "speedup": t_s / t_l,
                             "bit_identical_to_sequential": bool(same)}
@@ -756,6 +757,7 @@ def run_single(args, device):
                 leg("c1_fit_captured", fit_captured("c1", 100))
                 leg("c2_fit_batched", fit_lockstep("c2", 8, 50, 1, 10))
                 leg("c1_fit_batched", fit_lockstep("c1", 64, 50, 4, 50))
+                leg("c1_fit_batched_captured", fit_lockstep("c1", 64, 200, 2, 20, capture=True))
             leg("c2_concurrent_restarts", restarts)
             held.clear()
             torch.cuda.empty_cache()

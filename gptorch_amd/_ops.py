@@ -747,9 +747,15 @@ class BatchedGPRLogLik(torch.autograd.Function):
                                         refine=X.shape[-2] >= refine_min_n())
         holder["fb"] = fb
         out = terms[:, 2].clone()
-        info = fb.info.cpu()                         # ONE read-back for the batch (the reference: one per model and step)
         replayed = {}
-        for b in (torch.nonzero(info).reshape(-1).tolist() if bool(info.any()) else ()):
+        if _DEFERRED:
+            # under hipGraph capture (multi_start_optimize(capture=True)): nothing may read `info` back -- it is OR-ed into the
+            # capture's device flag, and a chunk of replays that saw a failure is repeated eagerly (through the ladder below)
+            _DEFERRED[-1].note(fb.info.max().reshape(1))
+            info = None
+        else:
+            info = fb.info.cpu()                     # ONE read-back for the batch (the reference: one per model and step)
+        for b in (torch.nonzero(info).reshape(-1).tolist() if (info is not None and bool(info.any())) else ()):
             if int(info[b]) != 0:
                 f, t = lml_forward(kind, X if X.dim() == 2 else X[b], R if R.dim() == 2 else R[b], variance.reshape(batch)[b:b + 1],
                                    length_scales.reshape(batch, -1)[b], noise.reshape(batch)[b:b + 1])

@@ -614,10 +614,76 @@ def _multi_start_scipy(models, method, max_iter, verbose):
     return results
 
 
+def _captured_lockstep_loop(model, method, trainable, learning_rate, step, dev_losses, max_iter):
+    """multi_start_optimize(capture=True) for one stacked group: `step(optimizer, idx)` (zero_grad, transforms, lock-step loss + backward, optimiser
+    step, loss row idx) captured into ONE hipGraph after GPModel.CAPTURE_WARMUP eager steps and replayed; see GPModel._optimize_captured
+    (the single-model form: same warm-up on a side stream, fp64 step counters, device-side loss index, chunked info flag with rollback)."""
+    import inspect
+    dev = dev_losses.device
+    prev_dtype = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        optimizer = model._make_optimizer(method, trainable, learning_rate)
+        if "capturable" in inspect.signature(type(optimizer).__init__).parameters:
+            for g in optimizer.param_groups:
+                g["capturable"] = True
+
+        def eager(idx):
+            step(optimizer, idx, set_to_none=True)
+        counter = torch.zeros(1, dtype=torch.long, device=dev)
+        done = 0
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            while done < min(model.CAPTURE_WARMUP, max_iter):
+                eager(done)
+                done += 1
+        torch.cuda.current_stream(dev).wait_stream(side)
+        if done < max_iter:
+            counter.fill_(done)
+            optimizer.zero_grad(set_to_none=True)
+            deferred = _ops.DeferredInfo(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), deferred:
+                loss = step(optimizer, None, set_to_none=True)
+                dev_losses.index_copy_(0, counter, loss.detach().reshape(1, -1))
+                counter.add_(1)
+
+            def snapshot():
+                return ([p.detach().clone() for p in trainable],
+                        [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in optimizer.state[p].items()} for p in trainable])
+
+            def restore(snap):
+                with torch.no_grad():
+                    for p, v in zip(trainable, snap[0]):
+                        p.copy_(v)
+                    for p, st in zip(trainable, snap[1]):
+                        for k, v in st.items():
+                            if torch.is_tensor(v):
+                                optimizer.state[p][k].copy_(v)          # IN PLACE: the graph holds these addresses
+                            else:
+                                optimizer.state[p][k] = v
+            while done < max_iter:
+                chunk = min(model.CAPTURE_CHUNK, max_iter - done)
+                snap = snapshot()
+                deferred.flag.zero_()
+                for _ in range(chunk):
+                    graph.replay()
+                if int(deferred.flag.item()) != 0:                      # ONE read-back per chunk
+                    restore(snap)
+                    for k in range(chunk):
+                        eager(done + k)
+                    counter.fill_(done + chunk)
+                done += chunk
+    finally:
+        torch.set_default_dtype(prev_dtype)
+    return optimizer
+
+
 STACKED_MAX_N = 2048      # multi_start_optimize(stacked=None): stacked parameter tensors below this many rows, one optimiser per model from it on
 
 
-def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, learning_rate=None, stacked=None):
+def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, learning_rate=None, stacked=None, capture=False):
     """GPModel.optimize (gptorch/models/base.py:111-296) for several INDEPENDENT restarts at once: every iteration is ONE
     lock-step loss + backward over each group of equally shaped models (see batched_loss_and_grad) and ONE optimiser step
     on the group's STACKED raw parameters -- the torch optimisers the reference offers are elementwise (all but LBFGS), so
@@ -630,6 +696,11 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
     (C1 x 64: 6 ms per iteration instead of 1; immaterial from N = 2048 on).
     stacked=None (the default): the bitwise mode wherever it is free -- groups of models with at least STACKED_MAX_N (2048) rows
     keep one optimiser per model, smaller ones are stacked.
+    capture=True: the stacked groups' iteration -- transforms, lock-step evaluation, closed-form backward, the optimiser's
+    `capturable` step, the loss row -- is captured into ONE hipGraph after three eager steps and replayed (GPModel.optimize(
+    capture=True) for B restarts at once: base.py:260-269 without a host round trip per iteration); `info != 0` is OR-ed into a
+    device flag read every 25 replays, and a chunk that saw one is rolled back and repeated eagerly through the jitter ladder.
+    Trajectories agree with the uncaptured stacked loop to rounding (the optimiser's bias corrections are formed on the device).
     Returns (losses [len(models), max_iter] numpy, seconds).  The models' Params hold the final values afterwards.
 
     Stacked groups: as batched_loss_and_grad's stationary groups, and additionally every model of the group trains the same
@@ -675,21 +746,28 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
         trainable = [r for r in raws if r.requires_grad]
         if not trainable:
             continue                     # nothing to optimise in lock step: each model's own optimize() reports as the reference does
-        optimizer = ms[0]._make_optimizer(method, trainable, learning_rate)
         holder = {}
         dev_losses = torch.empty(max_iter, B, dtype=torch.float64, device=X.device)
         print("multi_start_optimize: %d x %s in lock step via %s" % (B, ms[0].__class__.__name__, method))
-        for idx in range(max_iter):
-            optimizer.zero_grad()
+
+        def step(optimizer, idx, set_to_none=False):
+            optimizer.zero_grad(set_to_none=set_to_none)
             var, ls, nz = (t(r) for t, r in zip(transforms, raws))
             lml = _ops.BatchedGPRLogLik.apply(X, R, var.reshape(B), ls.reshape(B, -1), nz.reshape(B), key[0], holder)
             loss = -(lml + 0.0)
-            if trainable:
-                loss.sum().backward()
+            loss.sum().backward()
             optimizer.step()
-            dev_losses[idx] = loss.detach()
-            if verbose:
-                print("Iter: %d\tLoss: %s" % (idx, dev_losses[idx].tolist()))
+            if idx is not None:
+                dev_losses[idx] = loss.detach()
+            return loss
+        if capture:
+            optimizer = _captured_lockstep_loop(ms[0], method, trainable, learning_rate, step, dev_losses, max_iter)
+        else:
+            optimizer = ms[0]._make_optimizer(method, trainable, learning_rate)
+            for idx in range(max_iter):
+                step(optimizer, idx)
+                if verbose:
+                    print("Iter: %d\tLoss: %s" % (idx, dev_losses[idx].tolist()))
         losses[g, :] = dev_losses.t().cpu().numpy()
         with torch.no_grad():
             for pl, r in zip(plists, raws):

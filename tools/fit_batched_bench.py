@@ -3,7 +3,8 @@
 batched_loss_and_grad -> gpn_lml_forward_batched + gpn_lml_backward_batched) against the same restarts stepped one after the
 other by their own optimize().  Usage: fit_batched_bench.py [c2|c1|n=<N>,d=<D>] [B ...] [--steps K] [--parts] [--composite]
 --composite: the reference's example kernel Linear + Rbf + Constant (examples/regression_1d.py:34-53) instead of Rbf: the lock-step
-path of composite kernels (_expr.BatchedExprLogLik), timed through batched_loss_and_grad + one Adam step per model."""
+path of composite kernels (_expr.BatchedExprLogLik), timed through batched_loss_and_grad + one Adam step per model.
+--capture: also the stacked lock-step loop with its iteration as one hipGraph replay (multi_start_optimize(capture=True))."""
 import contextlib, io, os, sys, time
 import numpy as np
 import torch
@@ -95,6 +96,14 @@ for B in Bs:
     print("N %d D %d B %3d: sequential %8.2f ms / step (%.1f %% of peak on N^3) | lock step %8.2f ms / step (%.1f %%)  -> %.2fx; "
           "fits/s of 50 steps: %.3f vs %.3f" % (n, d, B, t_seq * 1e3, 100 * flops / t_seq / PEAK, t_bat * 1e3, 100 * flops / t_bat / PEAK,
                                                  t_seq / t_bat, B / (50 * t_seq), B / (50 * t_bat)), flush=True)
+    if "--capture" in sys.argv and B > 1:
+        it = max(steps, 100)
+        with quiet():
+            multi_start_optimize(ms, method="Adam", max_iter=8, stacked=True, capture=True)
+            t_cap = wall(lambda: multi_start_optimize(ms, method="Adam", max_iter=it, stacked=True, capture=True)) / it
+            t_stk = wall(lambda: multi_start_optimize(ms, method="Adam", max_iter=it, stacked=True)) / it
+        print("    stacked loop, %d iterations: %.3f ms / step | as one hipGraph replay %.3f ms / step (%.2fx); fits/s of 50 steps: %.0f vs %.0f"
+              % (it, t_stk * 1e3, t_cap * 1e3, t_stk / t_cap, B / (50 * t_stk), B / (50 * t_cap)), flush=True)
     if "--parts" in sys.argv and B > 1:
         k = ms[0]._stationary()
         var = torch.stack([m.kernel.variance.transform().reshape(()) for m in ms])
