@@ -748,6 +748,49 @@ def run_single(args, device):
                             "batch": B, "ms_lock_step": t_l * 1e3, "ms_one_after_the_other": t_s * 1e3, "speedup": t_s / t_l,
                             "bit_identical_to_sequential": bool(same)}
                 return run
+            def kfold_lockstep(key, folds):
+                # k-fold cross-validation of one model (equal folds: every fold's training set has N (k-1)/k rows of its OWN): the k
+                # training evaluations `loss(); backward()` in lock step against one after the other (base.py:260-269 per fold)
+                def run():
+                    from gptorch_amd import kernels, likelihoods
+                    from gptorch_amd.models import GPR, batched_loss_and_grad
+                    ww = WORKLOADS[key]
+                    m0 = build_model(ww, 0, device)[0]
+                    n = ww["n"]
+                    per = n // folds
+                    ms_ = []
+                    for f_ in range(folds):
+                        keep = torch.cat([torch.arange(0, f_ * per, device=device), torch.arange((f_ + 1) * per, per * folds, device=device)])
+                        k_ = type(m0.kernel)(ww["d"], variance=ww["variance"], length_scales=ww["length_scales"])
+                        mf = GPR(m0.X[keep].contiguous(), m0.Y[keep].contiguous(), k_, likelihood=likelihoods.Gaussian(variance=ww["noise"]))
+                        mf.cuda()
+                        ms_.append(mf)
+
+                    def seq():
+                        out = []
+                        for v in ms_:
+                            v.zero_grad()
+                            l_ = v.loss()
+                            l_.backward()
+                            out.append(l_.detach())
+                        return out
+
+                    def lock():
+                        for v in ms_:
+                            v.zero_grad()
+                        return batched_loss_and_grad(ms_)
+                    t_s, a = timed(seq, 3, 1)
+                    ga = [[p_.grad.clone() for p_ in v.parameters() if p_.grad is not None] for v in ms_]
+                    t_l, b_ = timed(lock, 3, 1)
+                    same = all(torch.equal(u.reshape(-1), w.reshape(-1)) for u, w in zip(a, b_)) and \
+                        all(torch.equal(u, w) for gs, v in zip(ga, ms_) for u, w in zip(gs, [p_.grad for p_ in v.parameters() if p_.grad is not None]))
+                    nf = float(per * (folds - 1))
+                    return {"config": "%s: %d-fold cross-validation, the %d training evaluations (N = %d rows each, own data) loss(); backward() in lock step"
+                                      % (ww["name"].replace(" LML eval", ""), folds, folds, int(nf)),
+                            "folds": folds, "ms_lock_step": t_l * 1e3, "ms_one_after_the_other": t_s * 1e3, "speedup": t_s / t_l,
+                            "frac_of_fp64_peak_on_N3": folds * nf ** 3 / t_l / 1e12 / PEAK_FP64_MFMA_TFLOPS, "bit_identical_to_sequential": bool(same)}
+                return run
+            leg("c2_kfold_batched", kfold_lockstep("c2", 8))
             leg("vfe_lockstep_n512", vfe_lockstep(512, 64, 2, 64))
             leg("vfe_lockstep_n8192", vfe_lockstep(8192, 512, 8, 8))
             leg("c2_batched", lockstep("c2", 8))
