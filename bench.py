@@ -797,7 +797,7 @@ def run_single(args, device):
             leg("c1_batched", lockstep("c1", 64))
             leg("c2_persistent_factorisation", persistent("c2"))
             if not args.no_fit:
-                leg("c1_fit_captured", fit_captured("c1", 100))
+                leg("c1_fit_captured", fit_captured("c1", 300))
                 leg("c2_fit_batched", fit_lockstep("c2", 8, 50, 1, 10))
                 leg("c1_fit_batched", fit_lockstep("c1", 64, 50, 4, 50))
                 leg("c1_fit_batched_captured", fit_lockstep("c1", 64, 200, 2, 20, capture=True))

@@ -58,6 +58,10 @@ SIGNATURES = {
     "gpn_kernel_grad_x2_batched": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
                                            c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_double, c_int, c_void_p, c_void_p]),
     "gpn_dot2d_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int]),
+    "gpn_lml_forward_ragged": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int,
+                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
+    "gpn_lml_backward_ragged": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "gpn_trtri_upper": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64]),
     "gpn_trtri_upper_ws": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64]),
     "gpn_grad_work_bytes": (c_int64, [c_int64, c_int64, c_int, c_int]),

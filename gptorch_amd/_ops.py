@@ -199,13 +199,15 @@ class FactorBatch:
         return f
 
 
-def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None, refine=False):
+def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None, refine=False, n_of=None):
     """GPR.log_likelihood (gpr.py:47-67) of `batch` models in lock step (gpn_lml_forward_batched): X [n, d] shared or
     [batch, n, d]; R = Y - m(X) [n, dy] shared or [batch, n, dy]; variance [batch], length_scales [batch, nls],
     noise [batch].  -> (FactorBatch, terms [batch, 3]); NO host synchronisation: the caller reads fb.info and
     replays the models whose info != 0 through the sequential path (jitter ladder).
     refine: follow the lock-step factorisation with gpn_lml_refine on every model's factor (what lml_forward does from
-    refine_min_n() rows on: the same call on the same factor, so the refined terms are bit-identical too)."""
+    refine_min_n() rows on: the same call on the same factor, so the refined terms are bit-identical too).
+    n_of (int32 device tensor [batch]): a RAGGED batch (gpn_lml_forward_ragged) -- model b has n_of[b] <= n points, X [batch, n, d] and
+    R [batch, n, dy] are padded to n rows (the padding is not read into any result); no refinement."""
     _req(X, R, variance, length_scales, noise)
     batch = int(variance.numel())
     shared_x, shared_r = X.dim() == 2, R.dim() == 2
@@ -218,6 +220,14 @@ def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None, ref
     Xc, Rc = _c(X.detach()), _c(R.detach())
     var, ls, nz = _c(variance.detach().reshape(batch)), _c(length_scales.detach().reshape(batch, -1)), _c(noise.detach().reshape(batch))
     fb.generation += 1
+    if n_of is not None:
+        if shared_x or shared_r or refine:
+            raise ValueError("ragged batches hold every model's own (padded) data and are not refined")
+        st = _native.lib().gpn_lml_forward_ragged(
+            _stream(X.device), KINDS[kind], batch, _ptr(Xc), n * d, n, _ptr(n_of), d, _ptr(Rc), n * e, e, _ptr(var), _ptr(ls), ls.shape[1],
+            _ptr(nz), _ptr(fb.A), fb.ld, fb.sA, _ptr(fb.winv), fb.sW, _ptr(fb.info), _ptr(fb.out))
+        _native.check(st, "gpn_lml_forward_ragged")
+        return fb, fb.out
     st = _native.lib().gpn_lml_forward_batched(
         _stream(X.device), KINDS[kind], batch, _ptr(Xc), 0 if shared_x else n * d, n, d, _ptr(Rc), 0 if shared_r else n * e,
         None, 0, e, _ptr(var), _ptr(ls), ls.shape[1], _ptr(nz), _ptr(fb.A), fb.ld, fb.sA, _ptr(fb.winv), fb.sW,
@@ -237,7 +247,7 @@ def lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=None, ref
     return fb, fb.out
 
 
-def lml_backward_batched(kind, X, variance, length_scales, fb, need_resid=False):
+def lml_backward_batched(kind, X, variance, length_scales, fb, need_resid=False, n_of=None):
     """the closed-form backward of the `batch` models of an lml_forward_batched call in lock step (gpn_lml_backward_batched):
     -> (grads [batch, 2 + nls] = dLML/d(variance, length_scales, noise) per model w.r.t. the CONSTRAINED values,
         dLML/dR [batch, n, dy] or None).  Per model bit-identical to _backward.lml_backward on that model's factor."""
@@ -252,6 +262,14 @@ def lml_backward_batched(kind, X, variance, length_scales, fb, need_resid=False)
     out = torch.empty(batch, 2 + nls, dtype=torch.float64, device=fb.A.device)
     g_R = torch.empty(batch, n, dy, dtype=torch.float64, device=fb.A.device) if need_resid else None
     Xc = _c(X.detach())
+    if n_of is not None:                              # the backward of a ragged batch (gpn_lml_backward_ragged): no dLML/dR
+        if need_resid or Xc.dim() != 3:
+            raise ValueError("ragged batches: every model's own padded points, zero mean functions")
+        st = lib.gpn_lml_backward_ragged(_stream(fb.A.device), KINDS[kind], batch, _ptr(Xc), n * Xc.shape[-1], n, _ptr(n_of), Xc.shape[-1],
+                                         _ptr(_c(variance.detach().reshape(batch))), _ptr(ls), nls, _ptr(fb.A), fb.ld, fb.sA,
+                                         _ptr(fb.winv), fb.sW, dy, _ptr(fb._backward_work), _ptr(out))
+        _native.check(st, "gpn_lml_backward_ragged")
+        return out, None
     st = lib.gpn_lml_backward_batched(_stream(fb.A.device), KINDS[kind], batch, _ptr(Xc), 0 if Xc.dim() == 2 else n * Xc.shape[-1], n,
                                       Xc.shape[-1], _ptr(_c(variance.detach().reshape(batch))), _ptr(ls), nls, _ptr(fb.A), fb.ld, fb.sA,
                                       _ptr(fb.winv), fb.sW, dy, _ptr(fb._backward_work), _ptr(out), _ptr(g_R))
@@ -741,10 +759,13 @@ class BatchedGPRLogLik(torch.autograd.Function):
     GPRLogLik -- also from refine_min_n() rows on, where every model's quadratic form is refined as GPRLogLik's is."""
 
     @staticmethod
-    def forward(ctx, X, R, variance, length_scales, noise, kind, holder):
+    def forward(ctx, X, R, variance, length_scales, noise, kind, holder, n_of=None):
+        # n_of (int32 device tensor [batch]; `sizes` = the same numbers on the host in holder["sizes"]): a RAGGED group -- X, R padded
+        # to the largest model (lml_forward_batched(n_of=...)): no refinement, no gradient w.r.t. R
         batch = int(variance.numel())
+        sizes = holder.get("sizes") if n_of is not None else None
         fb, terms = lml_forward_batched(kind, X, R, variance, length_scales, noise, fb=holder.get("fb"),
-                                        refine=X.shape[-2] >= refine_min_n())
+                                        refine=n_of is None and X.shape[-2] >= refine_min_n(), n_of=n_of)
         holder["fb"] = fb
         out = terms[:, 2].clone()
         replayed = {}
@@ -757,11 +778,13 @@ class BatchedGPRLogLik(torch.autograd.Function):
             info = fb.info.cpu()                     # ONE read-back for the batch (the reference: one per model and step)
         for b in (torch.nonzero(info).reshape(-1).tolist() if (info is not None and bool(info.any())) else ()):
             if int(info[b]) != 0:
-                f, t = lml_forward(kind, X if X.dim() == 2 else X[b], R if R.dim() == 2 else R[b], variance.reshape(batch)[b:b + 1],
+                nb = X.shape[-2] if sizes is None else sizes[b]
+                f, t = lml_forward(kind, (X if X.dim() == 2 else X[b])[:nb], (R if R.dim() == 2 else R[b])[:nb], variance.reshape(batch)[b:b + 1],
                                    length_scales.reshape(batch, -1)[b], noise.reshape(batch)[b:b + 1])
                 out[b] = t[2]
                 replayed[b] = f
         ctx.kind, ctx.fb, ctx.generation, ctx.replayed = kind, fb, fb.generation, replayed
+        ctx.n_of, ctx.sizes = n_of, sizes
         ctx.save_for_backward(X, R, variance, length_scales, noise)
         return out
 
@@ -773,12 +796,13 @@ class BatchedGPRLogLik(torch.autograd.Function):
         fb = ctx.fb
         if fb.generation != ctx.generation:
             # the shared buffers were refactorised by a later forward: rebuild this node's factors privately
-            fb, _ = lml_forward_batched(ctx.kind, X, R, variance, length_scales, noise)
+            fb, _ = lml_forward_batched(ctx.kind, X, R, variance, length_scales, noise, n_of=ctx.n_of)
         need_r = ctx.needs_input_grad[1]
-        grads, g_R = lml_backward_batched(ctx.kind, X, variance, length_scales, fb, need_resid=need_r)
+        grads, g_R = lml_backward_batched(ctx.kind, X, variance, length_scales, fb, need_resid=need_r, n_of=ctx.n_of)
         nls = grads.shape[1] - 2
         for b, f in ctx.replayed.items():
-            gv, gl, gn, gr = _backward.lml_backward(ctx.kind, X if X.dim() == 2 else X[b], variance.reshape(batch)[b:b + 1],
+            nb = X.shape[-2] if ctx.sizes is None else ctx.sizes[b]
+            gv, gl, gn, gr = _backward.lml_backward(ctx.kind, (X if X.dim() == 2 else X[b])[:nb], variance.reshape(batch)[b:b + 1],
                                                     length_scales.reshape(batch, -1)[b], noise.reshape(batch)[b:b + 1], f)
             grads[b, 0:1], grads[b, 1:1 + nls], grads[b, 1 + nls:] = gv, gl, gn
             if need_r:
@@ -790,7 +814,7 @@ class BatchedGPRLogLik(torch.autograd.Function):
             if R.dim() == 2:
                 g_resid = g_resid.sum(0)
         return (None, g_resid, (go * grads[:, 0]).reshape(variance.shape), (go[:, None] * grads[:, 1:1 + nls]).reshape(length_scales.shape),
-                (go * grads[:, 1 + nls]).reshape(noise.shape), None, None)
+                (go * grads[:, 1 + nls]).reshape(noise.shape), None, None, None)
 
 
 class DenseLogLik(torch.autograd.Function):

@@ -82,11 +82,14 @@ int gemm_nt_strided2(hipStream_t s, int64_t M, int64_t N, int64_t K, double alph
 int lml_grad_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
                      const double* variance, const double* length_scales, int nls,
                      const double* Kinv, int64_t ldk, int64_t sK, const double* at, int64_t ldat, int64_t sAt, int dy,
-                     double* work, int64_t sWork, double* out);
+                     double* work, int64_t sWork, double* out, const int32_t* n_of = nullptr);
 // U_b = L_b^-T of `batch` lock-step models (trisolve.hip)
 int trtri_upper_ws_batched(hipStream_t s, const double* L, int64_t n, int64_t ldl, int64_t sL, const double* winv, int64_t sW,
                            double* U, int64_t ldu, int64_t sU, double* S, int64_t lds, int64_t sS, int batch);
 
+// gpn_lml_reduce_batched with one point count per model (matutil.hip; gpn_lml_forward_ragged)
+int lml_reduce_ragged(hipStream_t s, const double* A, int64_t n, int64_t e, int64_t lda, int64_t sA, double* out3, int batch,
+                      const int32_t* n_of);
 // extra rows <- (Y - M)^T, corner right of them <- 0, *info <- 0 (kmat.hip; used by gpn_lml_forward)
 int pack_rhs_full(hipStream_t s, const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
                   int32_t* info);
@@ -97,7 +100,7 @@ int assemble_lower_saving(hipStream_t s, int kind, const double* X, int64_t n, i
 // K(X_b) + noise_b I (lower tiles) + right-hand sides + info words of `batch` models (kmat.hip; gpn_lml_forward_batched)
 int assemble_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d, const double* Y, int64_t sY,
                      const double* M, int64_t sM, int dy, const double* variance, const double* length_scales, int nls,
-                     const double* noise, double* A, int64_t lda, int64_t sA, int32_t* info);
+                     const double* noise, double* A, int64_t lda, int64_t sA, int32_t* info, const int32_t* n_of = nullptr);
 
 // launch classes of the optional HIP-event profiler (profile.hip; bench.py's roofline legs)
 enum { PROF_GEMM = 0,         // rectangular contraction (in-panel updates, predict, VFE ...)

@@ -44,6 +44,9 @@ struct GradArgs {
   // at + z sAt and writes partial + z sPartial
   int64_t sX = 0, sG = 0, sAt = 0, sPartial = 0;
   int64_t sX2 = -1;     // stride of the second point set (-1: sX -- the symmetric case)
+  // ragged lock-step batch (gpn_lml_backward_ragged, LML mode): model z has n_of[z] <= n real points; the launch still covers the
+  // tiles of n, the tiles beyond a model's points write zero partial sums
+  const int32_t* n_of = nullptr;
 };
 
 __device__ __forceinline__ void select_model(GradArgs& p) {
@@ -52,6 +55,7 @@ __device__ __forceinline__ void select_model(GradArgs& p) {
     p.X2 += z * (p.sX2 < 0 ? p.sX : p.sX2); p.X += z * p.sX; p.variance += z; p.ls += z * p.nls;
     p.G += z * p.sG; p.at += z * p.sAt; p.partial += z * p.sPartial;
   }
+  if (p.n_of) p.n = p.m = p.n_of[blockIdx.y];
 }
 
 template <int KIND>
@@ -804,7 +808,7 @@ extern "C" int gpn_lml_grad_batched(void* stream, int kind, int batch, const dou
 int gpn::lml_grad_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d,
                           const double* variance, const double* length_scales, int nls,
                           const double* Kinv, int64_t ldk, int64_t sK, const double* at, int64_t ldat, int64_t sAt, int dy,
-                          double* work, int64_t sWork, double* out) {
+                          double* work, int64_t sWork, double* out, const int32_t* n_of) {
   if (batch < 1) return -3;
   if (!X) return -4;
   if (n <= 0) return -6;
@@ -827,6 +831,7 @@ int gpn::lml_grad_batched(hipStream_t s, int kind, int batch, const double* X, i
   a.tiles_m = a.tiles_n = (int)((n + GT - 1) / GT);
   const int64_t nblocks = (int64_t)a.tiles_m * (a.tiles_m + 1) / 2;
   a.sX = sX; a.sG = sK; a.sAt = sAt; a.sPartial = sWork > 0 ? sWork : nblocks * a.nout;
+  a.n_of = n_of;
   if (sWork > 0 && sWork < nblocks * a.nout) return -18;
   const int rc = dispatch_kind<true>(s, kind, a, nblocks, batch);
   if (rc != GPN_OK) return rc;

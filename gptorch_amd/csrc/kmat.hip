@@ -33,6 +33,9 @@ struct KmatArgs {
   int symmetric, lower, vec_ok;
   int64_t sX, sK;     // strided batch (gridDim.z problems): points and output at these strides, hyper-parameters consecutive
   int64_t sX2 = -1;   // ... of the second point set (-1: the first set's stride -- the symmetric case)
+  // ragged lock-step batch (gpn_lml_forward_ragged; symmetric lower only): model z has n_of[z] <= n real points; rows and columns
+  // from there to n are written as IDENTITY rows, so that the padded matrix factors to [L_z 0; 0 I]
+  const int32_t* n_of = nullptr;
   // gpn_lml_forward_saving: every entry is also stored here (same leading dimension) -- a pristine copy of Kyy for the refinement
   // step's residual pass, which otherwise re-computes every entry (the factorisation overwrites K in place)
   double* K2 = nullptr;
@@ -44,6 +47,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
   __shared__ __attribute__((aligned(16))) double ys[DC][KT];   // column points
 
   __shared__ double inv_ell[DC];
+  int nreal = p.n;                           // real points of this model (ragged batches: < p.n)
   if (gridDim.z > 1) {                       // problem z of a strided batch (gpn_lml_forward_batched)
     const int z = blockIdx.z;
     p.X2 += z * (p.sX2 < 0 ? p.sX : p.sX2); p.X += z * p.sX; p.K += z * p.sK;
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
     p.variance += z; p.ls += z * p.nls;
     if (p.noise) p.noise += z;
   }
+  if (p.n_of) nreal = p.n_of[blockIdx.z];
   int tj, ti;
   if (p.lower) {
     // only the tiles on/below the diagonal are launched (row-major over the triangle): no
@@ -135,6 +140,13 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
         if (row == col) v0 += noise;
         if (row == col + 1) v1 += noise;
       }
+      if (row >= nreal) {                      // identity row of a ragged batch (col <= row in the lower tiles that matter)
+        v0 = row == col ? 1.0 : 0.0;
+        v1 = row == col + 1 ? 1.0 : 0.0;
+      } else {
+        if (col >= nreal) v0 = 0.0;            // (upper part of a diagonal tile: never read)
+        if (col + 1 >= nreal) v1 = 0.0;
+      }
       if (p.vec_ok && col + 1 < p.m) {
         *reinterpret_cast<d2*>(krow + col) = d2{v0, v1};
         if (p.K2) *reinterpret_cast<d2*>(p.K2 + (int64_t)row * p.ldk + col) = d2{v0, v1};
@@ -154,13 +166,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
 // accumulates -alpha alpha^T during the factorisation) and the info word -- one launch instead of
 // this one plus two fills in gpn_lml_forward
 __global__ void pack_rhs_kernel(const double* Y, const double* M, int64_t n, int dy, double* E, int64_t lde,
-                                int corner, int32_t* info, int64_t sY = 0, int64_t sM = 0, int64_t sE = 0) {
+                                int corner, int32_t* info, int64_t sY = 0, int64_t sM = 0, int64_t sE = 0, const int32_t* n_of = nullptr) {
   if (gridDim.y > 1) {                       // problem y of a strided batch
     Y += blockIdx.y * sY;
     if (M) M += blockIdx.y * sM;
     E += blockIdx.y * sE;
     if (info) info += blockIdx.y;
   }
+  if (n_of) n = n_of[blockIdx.y];            // ragged batch: the right-hand sides of the identity rows are zero (corner != 0 clears them)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (corner) {
     if (i == 0 && info) *info = 0;
@@ -213,8 +226,9 @@ int assemble_lower_saving(hipStream_t s, int kind, const double* X, int64_t n, i
 // symmetric K(X_b) + noise_b I, lower tiles, for `batch` models in one launch (+ their right-hand sides and info words)
 int assemble_batched(hipStream_t s, int kind, int batch, const double* X, int64_t sX, int64_t n, int d, const double* Y, int64_t sY,
                      const double* M, int64_t sM, int dy, const double* variance, const double* length_scales, int nls,
-                     const double* noise, double* A, int64_t lda, int64_t sA, int32_t* info) {
+                     const double* noise, double* A, int64_t lda, int64_t sA, int32_t* info, const int32_t* n_of) {
   KmatArgs a;
+  a.n_of = n_of;
   a.X = X; a.X2 = X;
   a.variance = variance; a.ls = length_scales; a.noise = noise;
   a.K = A; a.ldk = lda;
@@ -237,7 +251,7 @@ int assemble_batched(hipStream_t s, int kind, int batch, const double* X, int64_
   if (rec >= 0) profile_end(s, rec);
   GPN_LAUNCH_CHECK();
   hipLaunchKernelGGL(pack_rhs_kernel, dim3((unsigned)((lda + 255) / 256), (unsigned)batch), dim3(256), 0, s, Y, M, n, dy,
-                     A + n * lda, lda, 1, info, sY, sM, sA);
+                     A + n * lda, lda, 1, info, sY, sM, sA, n_of);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

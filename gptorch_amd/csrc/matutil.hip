@@ -6,7 +6,7 @@ namespace gpn {
 
 // ---- reductions / utilities -------------------------------------------------
 __global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* A, int64_t n, int64_t e, int64_t lda,
-                                                          double* out3, int64_t sA) {
+                                                          double* out3, int64_t sA, const int32_t* n_of = nullptr) {
   A += (int64_t)blockIdx.x * sA;                 // `gridDim.x` problems at stride sA, results 3 apart
   out3 += 3 * blockIdx.x;
   // single workgroup: sums are O(N) work.  The diagonal is one cache line per element, so the
@@ -54,7 +54,9 @@ __global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* A, int64
     out3[0] = logdet;
     out3[1] = quad;
     // gpr.py:63-67
-    out3[2] = -0.5 * quad - (double)e * logdet - 0.5 * (double)e * (double)n * 1.8378770664093454836;
+    // (ragged batch: the identity rows of a padded model add log 1 and 0^2 to the sums above; its constant counts its own points)
+    const double npts = n_of ? (double)n_of[blockIdx.x] : (double)n;
+    out3[2] = -0.5 * quad - (double)e * logdet - 0.5 * (double)e * npts * 1.8378770664093454836;
   }
 }
 
@@ -135,6 +137,14 @@ extern "C" int gpn_lml_reduce_batched(void* stream, const double* A, int64_t n, 
   if (!out3) return -7;
   if (batch < 1) return -8;
   hipLaunchKernelGGL(lml_reduce_kernel, dim3((unsigned)batch), dim3(1024), 0, static_cast<hipStream_t>(stream), A, n, e, lda, out3, sA);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// gpn_lml_reduce_batched for a ragged batch (gpn_lml_forward_ragged): the padded factors' sums, each model's constant with its own n_of[b]
+int gpn::lml_reduce_ragged(hipStream_t s, const double* A, int64_t n, int64_t e, int64_t lda, int64_t sA, double* out3, int batch,
+                           const int32_t* n_of) {
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3((unsigned)batch), dim3(1024), 0, s, A, n, e, lda, out3, sA, n_of);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

@@ -196,6 +196,44 @@ extern "C" int gpn_lml_forward_batched(void* stream, int kind, int batch, const 
   return gpn_lml_reduce_batched(stream, A, n, dy, lda, sA, out3, batch);
 }
 
+// gpn_lml_forward_batched for models of DIFFERENT sizes (k-fold folds of unequal length, learning curves): model b has n_of[b] <= n
+// points (256 < n_of[b]; its points X + b sX, its right-hand sides Y + b sY, both padded to n rows) and is evaluated as the n x n
+// problem [Kyy_b 0; 0 I] -- identity rows, zero right-hand sides -- by the SAME launches as the equal-size batch.  The identity
+// block factors to itself, adds log 1 to the log-determinant and 0 to the quadratic form, and every launch of the drivers treats
+// an entry by its POSITION (panel boundaries are multiples of the panel widths from the top-left corner): each model's factor,
+// alpha and out3 are BIT-IDENTICAL to gpn_lml_forward on its own n_of[b] points, provided n and every n_of[b] select the same
+// panel levels (gpn_potrf_panel_levels) -- the caller groups accordingly.  n_of: device array of int32.
+extern "C" int gpn_lml_forward_ragged(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, const int32_t* n_of, int d,
+                                      const double* Y, int64_t sY, int dy,
+                                      const double* variance, const double* length_scales, int nls, const double* noise,
+                                      double* A, int64_t lda, int64_t sA, double* winv, int64_t sW, int32_t* info, double* out3) {
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
+  if (batch < 1) return -3;
+  if (!X) return -4;
+  if (n <= 2 * 128) return -6;
+  if (!n_of) return -7;
+  if (d <= 0) return -8;
+  if (!Y) return -9;
+  if (dy <= 0) return -11;
+  if (!variance) return -12;
+  if (!length_scales) return -13;
+  if (nls != 1 && nls != d) return -14;
+  if (!noise) return -15;
+  if (!A) return -16;
+  if (lda != gpn_factor_ld(n, dy)) return -17;
+  if (batch > 1 && (sA < gpn_factor_rows(n, dy) * lda || (sA & 1))) return -18;
+  if (!winv) return -19;
+  if (batch > 1 && sW < gpn_winv_bytes(n) / (int64_t)sizeof(double)) return -20;
+  if (!info) return -21;
+  if (!out3) return -22;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = assemble_batched(s, kind, batch, X, sX, n, d, Y, sY, nullptr, 0, dy, variance, length_scales, nls, noise, A, lda, sA, info, n_of);
+  if (rc != GPN_OK) return rc;
+  rc = gpn_potrf_lower_batched(stream, A, n, dy, lda, sA, winv, sW, info, batch);
+  if (rc != GPN_OK) return rc;
+  return lml_reduce_ragged(s, A, n, dy, lda, sA, out3, batch, n_of);
+}
+
 extern "C" int64_t gpn_lml_backward_work_bytes(int64_t n, int dy, int nls) {
   if (n < 0 || dy <= 0 || nls <= 0) return 0;
   return backward_layout(n, dy, nls).total * (int64_t)sizeof(double);
@@ -392,6 +430,49 @@ extern "C" int gpn_lml_backward_batched(void* stream, int kind, int batch, const
     hipLaunchKernelGGL(neg_transpose_small_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, s, at, b.ld, n, dy,
                        grad_resid, sWk);
     GPN_LAUNCH_CHECK();
+  }
+  return GPN_OK;
+}
+
+// The backward of a gpn_lml_forward_ragged call: gpn_lml_backward_batched on the padded factors, the gradient sweep masked to every
+// model's own points.  The inversion tree of n restricted to a model's points IS the tree of n_of[b] (a node splits at the largest
+// power-of-two multiple of 128 below its size: the same point whether the node ends at n or earlier), the identity block inverts to
+// itself and adds zeros to every sum over k: grads + b (2 + nls) is BIT-IDENTICAL to gpn_lml_backward on model b's own points.
+// work: gpn_lml_backward_batched_work_bytes(n, dy, nls, batch).
+extern "C" int gpn_lml_backward_ragged(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, const int32_t* n_of, int d,
+                                       const double* variance, const double* length_scales, int nls,
+                                       const double* A, int64_t lda, int64_t sA, const double* winv, int64_t sW, int dy,
+                                       double* work, double* grads) {
+  if (kind < GPN_RBF || kind > GPN_PERIODIC) return -2;
+  if (batch < 1) return -3;
+  if (!X) return -4;
+  if (n <= 2 * 128) return -6;
+  if (!n_of) return -7;
+  if (d <= 0) return -8;
+  if (!variance) return -9;
+  if (!length_scales) return -10;
+  if (nls != 1 && nls != d) return -11;
+  if (!A) return -12;
+  if (lda != gpn_factor_ld(n, dy)) return -13;
+  if (batch > 1 && (sA < gpn_factor_rows(n, dy) * lda || (sA & 1))) return -14;
+  if (!winv) return -15;
+  if (batch > 1 && sW < gpn_winv_bytes(n) / (int64_t)sizeof(double)) return -16;
+  if (dy <= 0) return -17;
+  if (!work) return -18;
+  if (!grads) return -19;
+  const BackwardLayout b = backward_layout(n, dy, nls);
+  const int64_t sWk = round_up(b.total, 2);
+  const int64_t max_models = std::max<int64_t>(2, 65535 / std::max<int64_t>(1, n / 256 + 1));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int z0 = 0; z0 < batch; z0 += (int)max_models) {
+    int nb = (int)std::min<int64_t>(max_models, batch - z0);
+    double* wk = work + z0 * sWk;
+    // (kinv_batched_impl runs a single model through the single-model entry points: the same launches)
+    int rc = kinv_batched_impl(s, nb, n, A + z0 * sA, lda, sA, winv + z0 * sW, sW, dy, wk, sWk, b);
+    if (rc != GPN_OK) return rc;
+    rc = lml_grad_batched(s, kind, nb, X + z0 * sX, sX, n, d, variance + z0, length_scales + (int64_t)z0 * nls, nls, wk + b.s, b.ld, sWk,
+                          wk + b.at, b.ld, sWk, dy, wk + b.sweep, sWk, grads + (int64_t)z0 * (2 + nls), n_of + z0);
+    if (rc != GPN_OK) return rc;
   }
   return GPN_OK;
 }

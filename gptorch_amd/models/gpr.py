@@ -191,10 +191,24 @@ def _group_key(m):
     return (k._kind, tuple(m.X.shape), m.Y.shape[1], int(k.length_scales.numel()), m.X.device)
 
 
+RAGGED_MIN_FRACTION = 0.75      # a ragged group's smallest model has at least this fraction of its largest model's rows
+
+
+def _panel_regime(n):
+    """models whose sizes select the same panel levels of the factorisation (gpn_potrf_panel_levels) -- and none of which is refined --
+    can be padded into one ragged lock-step group; None: no ragged group for this size"""
+    if n <= 2 * _ops.LEAF or n >= _ops.refine_min_n():
+        return None
+    return 0 if n <= 2048 else 1 if n < 20480 else 2
+
+
 def _lockstep_groups(models, for_grad=False):
     """[(key, indices)] of the models that can share one lock-step call, grouped by (kernel kind, n, d, dy, ARD, device):
     GPR over a native stationary kernel.  for_grad (the stacked-parameter
-    optimiser loop of multi_start_optimize): also no priors (loss() = -(LML + log prior), model.py:158-197, is formed per model)."""
+    optimiser loop of multi_start_optimize): also no priors (loss() = -(LML + log prior), model.py:158-197, is formed per model).
+    Models left alone by that (cross-validation folds of unequal length, learning curves) form RAGGED groups: same kind / d / dy / ARD,
+    zero mean, different n within one panel regime, each padded to the group's largest model with identity rows
+    (_ops.lml_forward_batched(n_of=...)); their key carries the sizes as a sixth entry."""
     groups = {}
     for i, m in enumerate(models):
         # GPR's own log_likelihood only: other GPModels (VFE), and subclasses that evaluate differently (DistGPR: collective, on the
@@ -207,7 +221,7 @@ def _lockstep_groups(models, for_grad=False):
         if for_grad and any(getattr(p, "prior", None) is not None for p in m.parameters()):
             continue
         groups.setdefault(_group_key(m), []).append(i)
-    out = []
+    out, singles = [], {}
     for key, g in groups.items():
         # a lock-step group holds B factor buffers AND (with gradients) a backward workspace of two more N x N matrices per model at
         # once: groups that would not fit the device's free memory are split into chunks that do (singletons fall to the sequential path)
@@ -216,6 +230,21 @@ def _lockstep_groups(models, for_grad=False):
             chunk = g[at:at + cap]
             if len(chunk) >= 2:
                 out.append((key, chunk))
+            elif not for_grad and type(models[chunk[0]].mean_function) is mean_functions.Zero and _panel_regime(key[1][0]) is not None:
+                singles.setdefault((key[0], key[1][1], key[2], key[3], key[4], _panel_regime(key[1][0])), []).append(chunk[0])
+    for (kind, d, dy, nls, dev, _regime), g in singles.items():
+        g = sorted(g, key=lambda i: -models[i].X.shape[0])
+        at = 0
+        while at < len(g):
+            nmax = models[g[at]].X.shape[0]
+            end = at + 1
+            cap = _lockstep_capacity((kind, (nmax, d)), dev)
+            while end < len(g) and end - at < cap and models[g[end]].X.shape[0] >= RAGGED_MIN_FRACTION * nmax:
+                end += 1
+            if end - at >= 2:
+                chunk = sorted(g[at:end])
+                out.append(((kind, (nmax, d), dy, nls, dev, tuple(models[i].X.shape[0] for i in chunk)), chunk))
+            at = end
     return out
 
 
@@ -306,9 +335,19 @@ def _vfe_group_bound(ms, key, differentiable):
     return _vfe_lockstep.BatchedVFEBound.apply(stacks[0].reshape(B), stacks[1].reshape(B, -1), stacks[2].reshape(B), Z, key[1], X, Y)
 
 
-def _group_data(ms, differentiable=False):
-    """(X, R) of a lock-step group: shared [n, d] / [n, dy] when every model holds the same tensors (restarts on one data
-    set), else stacked [B, ...].  differentiable: R keeps the autograd graph of trainable mean functions."""
+def _group_data(ms, differentiable=False, key=None):
+    """(X, R, n_of) of a lock-step group: shared [n, d] / [n, dy] when every model holds the same tensors (restarts on one data
+    set), else stacked [B, ...].  differentiable: R keeps the autograd graph of trainable mean functions.
+    A ragged group (key with a sixth entry: the sizes): X, R padded to the largest model, n_of = the sizes on the device (int32);
+    otherwise n_of is None."""
+    if key is not None and len(key) > 5:
+        nmax, B = key[1][0], len(ms)
+        X = torch.zeros(B, nmax, key[1][1], dtype=torch.float64, device=key[4])
+        R = torch.zeros(B, nmax, key[2], dtype=torch.float64, device=key[4])
+        for b, m in enumerate(ms):
+            X[b, :m.X.shape[0]] = m.X
+            R[b, :m.X.shape[0]] = m.Y
+        return X, R, torch.tensor(key[5], dtype=torch.int32, device=key[4])
     m0 = ms[0]
     same_x = all(m.X.data_ptr() == m0.X.data_ptr() for m in ms)
     zero_mean = all(type(m.mean_function) is mean_functions.Zero for m in ms)
@@ -323,7 +362,7 @@ def _group_data(ms, differentiable=False):
     else:
         with torch.no_grad():
             R = torch.stack([m.Y - m.mean_function(m.X) for m in ms])
-    return X, R
+    return X, R, None
 
 
 def batched_log_likelihood(models, streams=None):
@@ -350,12 +389,13 @@ def batched_log_likelihood(models, streams=None):
             ms = [models[i] for i in g]
             # host side: a handful of launches per GROUP, none per model (a per-model exp / subtraction / comparison costs
             # more than the model's share of the batch at N = 512)
-            X, R = _group_data(ms)
+            X, R, n_of = _group_data(ms, key=key)
             var = _stacked_values([m._stationary().variance for m in ms]).reshape(len(ms))
             ls = _stacked_values([m._stationary().length_scales for m in ms]).reshape(len(ms), -1)
             nz = _stacked_values([m.likelihood.variance for m in ms]).reshape(len(ms))
             holder = _batch_holder((key, len(ms)))
-            fb, terms = _ops.lml_forward_batched(key[0], X, R, var, ls, nz, fb=holder.get("fb"), refine=ms[0].X.shape[0] >= _ops.refine_min_n())
+            fb, terms = _ops.lml_forward_batched(key[0], X, R, var, ls, nz, fb=holder.get("fb"),
+                                                 refine=n_of is None and ms[0].X.shape[0] >= _ops.refine_min_n(), n_of=n_of)
             holder["fb"] = fb
             pending.append((g, fb, terms))
         for g, fb, terms in pending:
@@ -366,7 +406,7 @@ def batched_log_likelihood(models, streams=None):
                     # (the per-model factor cache is NOT pointed at the shared buffer: the next batched call overwrites it)
         for key, g, progs in _expression_groups(models):
             ms = [models[i] for i in g]
-            X, R = _group_data(ms)
+            X, R, _ = _group_data(ms)
             nz = _stacked_values([m.likelihood.variance for m in ms]).reshape(len(ms))
             flat = [p for prog in progs for p in prog.params()]
             lml = _expr.BatchedExprLogLik.apply(X, R, nz, progs, _batch_holder((key, len(ms))), *flat)
@@ -409,7 +449,7 @@ def batched_loss_and_grad(models):
     for key, g in _lockstep_groups(models):
         ms = [models[i] for i in g]
         B = len(ms)
-        X, R = _group_data(ms, differentiable=True)
+        X, R, n_of = _group_data(ms, differentiable=True, key=key)
         stacks = []
         for plist in _group_param_lists(ms):
             t0 = _shared_transform(plist)
@@ -418,7 +458,10 @@ def batched_loss_and_grad(models):
             else:
                 stacks.append(torch.stack([p.transform() for p in plist]))
         var, ls, nz = stacks[0].reshape(B), stacks[1].reshape(B, -1), stacks[2].reshape(B)
-        lml = _ops.BatchedGPRLogLik.apply(X, R, var, ls, nz, key[0], _batch_holder((key, B)))
+        holder = _batch_holder((key, B))
+        if n_of is not None:
+            holder["sizes"] = key[5]
+        lml = _ops.BatchedGPRLogLik.apply(X, R, var, ls, nz, key[0], holder, n_of)
         if any(getattr(p, "prior", None) is not None for m in ms for p in m.parameters()):
             # parameters with priors (model.py:158-197: loss = -(LML + log prior)): each model's own log_prior(), added to its
             # entry of the lock-step LML exactly as Model._loss adds it
@@ -435,7 +478,7 @@ def batched_loss_and_grad(models):
         # the expression's assembly and sweeps per model, everything kernel-independent once over the group
         ms = [models[i] for i in g]
         B = len(ms)
-        X, R = _group_data(ms, differentiable=True)
+        X, R, _ = _group_data(ms, differentiable=True)
         plist = [m.likelihood.variance for m in ms]
         t0 = _shared_transform(plist)
         nz = (t0(torch.stack(list(plist))) if t0 is not None else torch.stack([p.transform() for p in plist])).reshape(B)
@@ -741,7 +784,7 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
         mean_trainable = any(p.requires_grad for m in ms for p in m.mean_function.parameters())
         if any(t is None for t in transforms) or any(len(f) != 1 for f in flags) or mean_trainable:
             continue
-        X, R = _group_data(ms)
+        X, R, _ = _group_data(ms)
         raws = [torch.nn.Parameter(torch.stack([p.data for p in pl]), requires_grad=f.pop()) for pl, f in zip(plists, flags)]
         trainable = [r for r in raws if r.requires_grad]
         if not trainable:

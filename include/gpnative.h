@@ -382,6 +382,23 @@ int gpn_lml_forward_batched(void* stream, int kind, int batch, const double* X, 
  * r^T Kyy^-1 r = O(|E|^2)) and out3[2] by the LML with it; out3[0] (log-det) is kept.  Cost: one pass over L in
  * n/128 dependent launches + one pass of kernel evaluations (about 3 % of an evaluation at N = 32768); pointless
  * below N of about 10^4, where the plain value is already within 1e-9.  work: gpn_lml_refine_work_bytes(n, dy). */
+/* gpn_lml_forward_batched / gpn_lml_backward_batched for models of DIFFERENT sizes (round 6: cross-validation folds of unequal
+ * length, learning curves; the reference evaluates one model at a time, models/base.py:260-269).  Model b has n_of[b] <= n points
+ * (n_of: DEVICE array of int32, every entry > 256), its points at X + b sX and right-hand sides at Y + b sY, both padded to n rows
+ * (the padding is not read into any result).  It is evaluated as the n x n problem [Kyy_b 0; 0 I] with zero right-hand sides on
+ * the identity rows, by the same launches as an equal-size batch: factor, alpha, out3 and gradients are BIT-IDENTICAL to
+ * gpn_lml_forward / gpn_lml_backward on the model's own n_of[b] points, provided n and all n_of[b] select the same panel levels
+ * (gpn_potrf_panel_levels; both sides of 2048 rows differ) and stay below the refinement threshold.  Zero mean only (M = NULL).
+ * backward work: gpn_lml_backward_batched_work_bytes(n, dy, nls, batch). */
+int gpn_lml_forward_ragged(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, const int32_t* n_of, int d,
+                           const double* Y, int64_t sY, int dy,
+                           const double* variance, const double* length_scales, int nls, const double* noise,
+                           double* A, int64_t lda, int64_t sA, double* winv, int64_t sW, int32_t* info, double* out3);
+int gpn_lml_backward_ragged(void* stream, int kind, int batch, const double* X, int64_t sX, int64_t n, const int32_t* n_of, int d,
+                            const double* variance, const double* length_scales, int nls,
+                            const double* A, int64_t lda, int64_t sA, const double* winv, int64_t sW, int dy,
+                            double* work, double* grads);
+
 int64_t gpn_lml_refine_work_bytes(int64_t n, int dy);
 int gpn_lml_refine(void* stream, int kind, const double* X, int64_t n, int d,
                    const double* Y, const double* M, int dy,
