@@ -748,7 +748,7 @@ def run_single(args, device):
                             "batch": B, "ms_lock_step": t_l * 1e3, "ms_one_after_the_other": t_s * 1e3, "speedup": t_s / t_l,
                             "bit_identical_to_sequential": bool(same)}
                 return run
-            def kfold_lockstep(key, folds):
+            def kfold_lockstep(key, folds, ragged=False):
                 # k-fold cross-validation of one model (equal folds: every fold's training set has N (k-1)/k rows of its OWN): the k
                 # training evaluations `loss(); backward()` in lock step against one after the other (base.py:260-269 per fold)
                 def run():
@@ -761,6 +761,8 @@ def run_single(args, device):
                     ms_ = []
                     for f_ in range(folds):
                         keep = torch.cat([torch.arange(0, f_ * per, device=device), torch.arange((f_ + 1) * per, per * folds, device=device)])
+                        if ragged:                 # folds of unequal length: fold f_ trains on 3 f_ rows fewer (one ragged lock-step group)
+                            keep = keep[:keep.numel() - 3 * f_]
                         k_ = type(m0.kernel)(ww["d"], variance=ww["variance"], length_scales=ww["length_scales"])
                         mf = GPR(m0.X[keep].contiguous(), m0.Y[keep].contiguous(), k_, likelihood=likelihoods.Gaussian(variance=ww["noise"]))
                         mf.cuda()
@@ -785,12 +787,15 @@ def run_single(args, device):
                     same = all(torch.equal(u.reshape(-1), w.reshape(-1)) for u, w in zip(a, b_)) and \
                         all(torch.equal(u, w) for gs, v in zip(ga, ms_) for u, w in zip(gs, [p_.grad for p_ in v.parameters() if p_.grad is not None]))
                     nf = float(per * (folds - 1))
-                    return {"config": "%s: %d-fold cross-validation, the %d training evaluations (N = %d rows each, own data) loss(); backward() in lock step"
-                                      % (ww["name"].replace(" LML eval", ""), folds, folds, int(nf)),
+                    return {"config": "%s: %d-fold cross-validation, the %d training evaluations (N = %s rows, own data) loss(); backward() in lock step%s"
+                                      % (ww["name"].replace(" LML eval", ""), folds, folds,
+                                         "%d ... %d" % (int(nf) - 3 * (folds - 1), int(nf)) if ragged else "%d each" % int(nf),
+                                         " as ONE ragged group (padded to the largest fold with identity rows)" if ragged else ""),
                             "folds": folds, "ms_lock_step": t_l * 1e3, "ms_one_after_the_other": t_s * 1e3, "speedup": t_s / t_l,
                             "frac_of_fp64_peak_on_N3": folds * nf ** 3 / t_l / 1e12 / PEAK_FP64_MFMA_TFLOPS, "bit_identical_to_sequential": bool(same)}
                 return run
             leg("c2_kfold_batched", kfold_lockstep("c2", 8))
+            leg("c2_kfold_ragged", kfold_lockstep("c2", 8, ragged=True))
             leg("vfe_lockstep_n512", vfe_lockstep(512, 64, 2, 64))
             leg("vfe_lockstep_n8192", vfe_lockstep(8192, 512, 8, 8))
             leg("c2_batched", lockstep("c2", 8))
