@@ -140,12 +140,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs p) {
         if (row == col) v0 += noise;
         if (row == col + 1) v1 += noise;
       }
-      if (row >= nreal) {                      // identity row of a ragged batch (col <= row in the lower tiles that matter)
-        v0 = row == col ? 1.0 : 0.0;
-        v1 = row == col + 1 ? 1.0 : 0.0;
-      } else {
-        if (col >= nreal) v0 = 0.0;            // (upper part of a diagonal tile: never read)
-        if (col + 1 >= nreal) v1 = 0.0;
+      if (p.n_of) {                            // ragged batch (symmetric, lower tiles)
+        if (row >= nreal) {                    // an identity row (col <= row in the tiles that matter)
+          v0 = row == col ? 1.0 : 0.0;
+          v1 = row == col + 1 ? 1.0 : 0.0;
+        } else {
+          if (col >= nreal) v0 = 0.0;          // (upper part of a diagonal tile: never read)
+          if (col + 1 >= nreal) v1 = 0.0;
+        }
       }
       if (p.vec_ok && col + 1 < p.m) {
         *reinterpret_cast<d2*>(krow + col) = d2{v0, v1};
