@@ -192,6 +192,7 @@ def _group_key(m):
 
 
 RAGGED_MIN_FRACTION = 0.75      # a ragged group's smallest model has at least this fraction of its largest model's rows
+RAGGED_POOL_BELOW = 8            # equal-size groups of fewer models than this may merge with neighbouring sizes into one ragged group
 
 
 def _panel_regime(n):
@@ -221,8 +222,16 @@ def _lockstep_groups(models, for_grad=False):
         if for_grad and any(getattr(p, "prior", None) is not None for p in m.parameters()):
             continue
         groups.setdefault(_group_key(m), []).append(i)
-    out, singles = [], {}
+    out, pool = [], {}
     for key, g in groups.items():
+        # Small equal-size groups and singletons of ragged-eligible models are POOLED: folds of n and n - 1 rows make one ragged group
+        # of all of them rather than two small groups.  (Groups of RAGGED_POOL_BELOW models or more stay as they are -- multi-start
+        # restarts on one data set share its tensors --, and so does everything the stacked optimiser loop asks for.)
+        eligible = not for_grad and len(g) < RAGGED_POOL_BELOW and _panel_regime(key[1][0]) is not None and \
+            all(type(models[i].mean_function) is mean_functions.Zero for i in g)
+        if eligible:
+            pool.setdefault((key[0], key[1][1], key[2], key[3], key[4], _panel_regime(key[1][0])), []).extend(g)
+            continue
         # a lock-step group holds B factor buffers AND (with gradients) a backward workspace of two more N x N matrices per model at
         # once: groups that would not fit the device's free memory are split into chunks that do (singletons fall to the sequential path)
         cap = _lockstep_capacity(key, models[g[0]].X.device)
@@ -230,10 +239,8 @@ def _lockstep_groups(models, for_grad=False):
             chunk = g[at:at + cap]
             if len(chunk) >= 2:
                 out.append((key, chunk))
-            elif not for_grad and type(models[chunk[0]].mean_function) is mean_functions.Zero and _panel_regime(key[1][0]) is not None:
-                singles.setdefault((key[0], key[1][1], key[2], key[3], key[4], _panel_regime(key[1][0])), []).append(chunk[0])
-    for (kind, d, dy, nls, dev, _regime), g in singles.items():
-        g = sorted(g, key=lambda i: -models[i].X.shape[0])
+    for (kind, d, dy, nls, dev, _regime), g in pool.items():
+        g = sorted(g, key=lambda i: (-models[i].X.shape[0], i))
         at = 0
         while at < len(g):
             nmax = models[g[at]].X.shape[0]
@@ -243,7 +250,11 @@ def _lockstep_groups(models, for_grad=False):
                 end += 1
             if end - at >= 2:
                 chunk = sorted(g[at:end])
-                out.append(((kind, (nmax, d), dy, nls, dev, tuple(models[i].X.shape[0] for i in chunk)), chunk))
+                sizes = tuple(models[i].X.shape[0] for i in chunk)
+                if len(set(sizes)) == 1:                     # all of one size after all: the ordinary equal-size group
+                    out.append((_group_key(models[chunk[0]]), chunk))
+                else:
+                    out.append(((kind, (nmax, d), dy, nls, dev, sizes), chunk))
             at = end
     return out
 

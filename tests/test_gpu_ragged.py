@@ -106,15 +106,25 @@ def test_models_of_unequal_size_share_one_lockstep_evaluation(device):
 
 
 def test_ragged_groups_next_to_equal_groups_and_outliers(device):
-    """two models of one size (an ordinary lock-step group), three of nearby sizes (a ragged group), one far smaller and one on
-    the other side of the 2048-row panel regime (their own evaluations): every result as from the model's own loss(); backward()"""
-    ms = _gprs((1800, 1800, 1700, 1650, 1601, 600, 2100))
+    """eight models of one size (an ordinary lock-step group), two of another size with three of nearby sizes (small equal-size groups
+    are pooled with their neighbours: ONE ragged group of five), one far smaller and one on the other side of the 2048-row panel
+    regime (their own evaluations): every result as from the model's own loss(); backward()"""
+    ms = _gprs((1900,) * 8 + (1800, 1800, 1700, 1650, 1601, 600, 2100))
     groups = gpr_mod._lockstep_groups(ms)
-    assert sorted(len(g) for _, g in groups) == [2, 3]
-    assert [k[5] for k, g in groups if len(k) > 5] == [(1700, 1650, 1601)]
+    assert sorted(len(g) for _, g in groups) == [5, 8]
+    assert [k[5] for k, g in groups if len(k) > 5] == [(1800, 1800, 1700, 1650, 1601)]
     own = _own(ms)
     losses = batched_loss_and_grad(ms)
     for m, (l0, g0), l1 in zip(ms, own, losses):
+        assert torch.equal(l0.reshape(-1), l1.reshape(-1))
+        for a, b in zip(g0, [p.grad for p in m.parameters() if p.grad is not None]):
+            assert torch.equal(a, b)
+    # folds of n and n - 1 rows: one group of all of them
+    ms = _gprs((1000, 999, 1000, 999, 1000, 999))
+    groups = gpr_mod._lockstep_groups(ms)
+    assert len(groups) == 1 and groups[0][0][5] == (1000, 999, 1000, 999, 1000, 999)
+    own = _own(ms)
+    for m, (l0, g0), l1 in zip(ms, own, batched_loss_and_grad(ms)):
         assert torch.equal(l0.reshape(-1), l1.reshape(-1))
         for a, b in zip(g0, [p.grad for p in m.parameters() if p.grad is not None]):
             assert torch.equal(a, b)
