@@ -216,7 +216,7 @@ def _elbo(st):
     return elbo
 
 
-def _sandwich(U, W, m, st_uu):
+def _sandwich(U, W, m):
     B, rows, ld = U.shape
     kp = round_up(m, 16)
     dev = U.device
@@ -272,9 +272,9 @@ def _backward(st, var, ls, Z, X, Y):
     _gemm_b(_ptr(beta), pp, mp * pp, _ptr(beta), pp, mp * pp, _ptr(bbT), m, m * m, m, m, pp, B, dev=dev)
     W = torch.zeros_like(U)
     W[:, :m, :m] = p * (eye - Binv) - bbT
-    P = _sandwich(U, W, m, f_uu)                                           # s * dF/dKuf = P Kuf + gamma err^T
+    P = _sandwich(U, W, m)                                           # s * dF/dKuf = P Kuf + gamma err^T
     W[:, :m, :m] = 0.5 * p * (2.0 * eye - Binv - Bd) - 0.5 * bbT
-    Guu = _sandwich(U, W, m, f_uu)                                         # dF/dKuu
+    Guu = _sandwich(U, W, m)                                         # dF/dKuu
     gt = torch.empty(B, p, m, dtype=torch.float64, device=dev)
     _gemm_b(_ptr(bt), ld, pp * ld, _ptr(U), ld, rows * ld, _ptr(gt), m, p * m, p, m, mp, B, tri=_ops.TRI_B_UPPER, dev=dev)
 

@@ -48,6 +48,13 @@ M=$(ls $O/pmc_mfma_c3/*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$M" ] && python3 $R/tools/pmc_mfma.py $M $O/mfma_utilisation_c3.json c3 > /dev/null
 rm -rf $O/pmc_mfma_c3
 cd $R
+cd /tmp
+timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_valu_c4 -o v -- \
+    python3 $R/tools/backward_profile.py c4 1 > $O/pmc_valu_c4.log 2>&1
+V=$(ls $O/pmc_valu_c4/*counter_collection.csv 2>/dev/null | head -1)
+[ -n "$V" ] && python3 $R/tools/pmc_valu.py $V $O/valu_bound_c4.json c4 > /dev/null
+rm -rf $O/pmc_valu_c4
+cd $R
 python3 tools/persistent_ab.py 4096 6144 8192 12288 16384 --reps 4 > $O/persistent_ab.txt 2>&1
 PP_PATHS=2 PP_DEPTH=14 python3 tools/persistent_trace.py 8192 16 > $O/persistent_trace_c2.txt 2>&1
 python3 tools/capture_bench.py 512 1024 2048 4096 8192 --iters 100 > $O/capture_bench.txt 2>&1
@@ -55,4 +62,5 @@ python3 tools/fit_batched_bench.py c2 1 8 --parts > $O/fit_batched_c2.txt 2>&1
 python3 tools/kmat_bench.py c2 c3 c4 > $O/kmat_bench.txt 2>&1
 python3 tools/vfe_batched_bench.py --parts > $O/vfe_batched_bench.txt 2>&1
 python3 tools/vfe_fit_probe.py > $O/vfe_fit_probe.txt 2>&1
+python3 tools/fit_batched_bench.py c1 8 64 --capture --steps 400 > $O/capture_lockstep.txt 2>&1
 ls -la $O | head -60
