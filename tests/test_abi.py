@@ -92,6 +92,25 @@ def test_argument_validation_without_launch():
     r1, r8 = lib.gpn_dist_lml_refine_work_bytes(0, 1, 1, 65536, 32, 1, 2048), lib.gpn_dist_lml_refine_work_bytes(3, 2, 4, 65536, 32, 1, 2048)
     assert r8 % 256 == 0 and 0 < r8 < r1 / 3          # (the tile inverses and the residual share divide by the ranks)
     assert lib.gpn_dist_lml_refine(null, null, 0, 2, 4, 0, null, 100, 2, null, 1, null, null, 1, null, 128, null, null, 0, null) == -2   # no comm table
+    one_ = ctypes.c_double(0.0)
+    p_ = ctypes.cast(ctypes.pointer(one_), ctypes.c_void_p)
+    # round 6: the lock-step forms of the single-purpose entries, the ragged batch, the persistent factorisation
+    assert lib.gpn_kernel_matrix_batched(null, 9, 2, null, 0, 4, null, 0, 4, 2, null, null, 1, null, 0, null, 4, 16) == -2
+    assert lib.gpn_kernel_matrix_batched(null, 0, 0, null, 0, 4, null, 0, 4, 2, null, null, 1, null, 0, null, 4, 16) == -3
+    assert lib.gpn_kernel_matrix_batched(null, 0, 2, null, 0, 4, null, 0, 4, 2, null, null, 1, null, 0, null, 4, 16) == -4
+    assert lib.gpn_trsm_right_lt_batched(null, null, 4, 128, 0, null, 0, null, 1, 128, 0, 2) == -2
+    assert lib.gpn_trtri_upper_batched(null, null, 4, 128, 0, null, 0, null, 128, 0, null, 128, 0, 2) == -2
+    assert lib.gpn_gemm_nt_batched_scaled(null, 16, 16, 10, null, null, 16, 0, null, 16, 0, 0.0, null, 16, 0, 0, 0, 2) == -4      # K % 16
+    assert lib.gpn_gemm_nt_batched_scaled(null, 16, 16, 16, null, null, 16, 0, null, 16, 0, 0.0, null, 16, 0, 0, 0, 2) == -5      # no scales
+    assert lib.gpn_kernel_grad_batched(null, 0, 0, null, 0, 4, null, 0, 4, 2, null, null, 1, null, 4, 0, null, null) == -3
+    assert lib.gpn_kernel_grad_x2_batched(null, 0, 2, null, 0, 4, null, 0, 4, 2, null, null, 1, null, 4, 0, 1.0, 0, null, null) == -4
+    assert lib.gpn_dot2d_batched(null, null, 1, 0, null, 0, 0, 4, 1, null, 1) == -2
+    assert lib.gpn_lml_forward_ragged(null, 0, 2, null, 0, 1000, null, 2, null, 0, 1, null, null, 1, null, null, 1152, 0, null, 0, null, null) == -4
+    assert lib.gpn_lml_forward_ragged(null, 0, 2, p_, 0, 200, null, 2, null, 0, 1, null, null, 1, null, null, 256, 0, null, 0, null, null) == -6   # n <= 256
+    assert lib.gpn_lml_forward_ragged(null, 0, 2, p_, 0, 1000, null, 2, null, 0, 1, null, null, 1, null, null, 1152, 0, null, 0, null, null) == -7  # no sizes
+    assert lib.gpn_lml_backward_ragged(null, 0, 2, p_, 0, 1000, null, 2, null, null, 1, null, 1152, 0, null, 0, 1, null, null) == -7
+    assert lib.gpn_potrf_persistent_supported(8192, 1) == 1 and lib.gpn_potrf_persistent_supported(1000, 1) == 0
+    assert lib.gpn_potrf_persistent_supported(32768, 1) == 0 and lib.gpn_potrf_persistent_supported(8200, 1) == 0
     # zero-size problems are no-ops that succeed
     one = ctypes.c_double(0.0)
     p = ctypes.cast(ctypes.pointer(one), ctypes.c_void_p)
