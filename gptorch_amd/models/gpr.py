@@ -352,13 +352,22 @@ def _group_data(ms, differentiable=False, key=None):
     A ragged group (key with a sixth entry: the sizes): X, R padded to the largest model, n_of = the sizes on the device (int32);
     otherwise n_of is None."""
     if key is not None and len(key) > 5:
+        # (data and zero-mean right-hand sides do not change between the iterations of a search: the padded stacks are kept with
+        #  the group's lock-step buffers and rebuilt when a model's tensors are replaced or edited in place)
+        holder = _batch_holder((key, len(ms)))
+        stamp = tuple((id(m.X), m.X._version, id(m.Y), m.Y._version) for m in ms)
+        cached = holder.get("ragged_data")
+        if cached is not None and cached[0] == stamp:
+            return cached[1], cached[2], cached[3]
         nmax, B = key[1][0], len(ms)
         X = torch.zeros(B, nmax, key[1][1], dtype=torch.float64, device=key[4])
         R = torch.zeros(B, nmax, key[2], dtype=torch.float64, device=key[4])
         for b, m in enumerate(ms):
             X[b, :m.X.shape[0]] = m.X
             R[b, :m.X.shape[0]] = m.Y
-        return X, R, torch.tensor(key[5], dtype=torch.int32, device=key[4])
+        n_of = torch.tensor(key[5], dtype=torch.int32, device=key[4])
+        holder["ragged_data"] = (stamp, X, R, n_of, [(m.X, m.Y) for m in ms])     # (holds the tensors: an id() cannot be reused)
+        return X, R, n_of
     m0 = ms[0]
     same_x = all(m.X.data_ptr() == m0.X.data_ptr() for m in ms)
     zero_mean = all(type(m.mean_function) is mean_functions.Zero for m in ms)
