@@ -152,3 +152,32 @@ def test_ragged_group_replays_the_ladder_and_fits_bitwise(device):
         assert np.array_equal(np.asarray(mine[i]), losses[i])
         for p, q in zip(a[i].parameters(), b[i].parameters()):
             assert torch.equal(p.data, q.data)
+
+
+@pytest.mark.parametrize("seed", [201, 202])
+def test_fuzz_ragged_groups(device, seed):
+    """random size sets inside both panel regimes (ragged and full last blocks, sizes one apart, the regime's edges), all stationary
+    kinds, ARD / isotropic, dy 1..3: terms, factors and gradients of every member bit for bit"""
+    g = np.random.default_rng(seed)
+    for _rep in range(5):
+        lo, hi = (257, 2048) if g.integers(2) else (2049, 6000)
+        nmax = int(g.choice([hi, int(g.integers(lo + 64, hi)), (int(g.integers(lo + 128, hi)) // 128) * 128]))
+        sizes = [nmax] + [int(max(lo, nmax - g.integers(0, max(2, nmax // 4)))) for _ in range(int(g.integers(1, 4)))]
+        if g.integers(2):
+            sizes.append(nmax - 1)
+        sizes = tuple(int(v) for v in g.permutation(sizes))
+        d, dy = int(g.choice([1, 3, 8, 17])), int(g.choice([1, 2, 3]))
+        kind = str(g.choice(["Rbf", "Matern52", "Matern32", "Exp"]))
+        ard = bool(g.integers(2)) and d > 1
+        X, Y, var, ls, nz, n_of = _case(device, sizes, d, dy, kind, ard, seed=int(g.integers(1 << 30)))
+        fb, terms = _ops.lml_forward_batched(kind, X, Y, var, ls, nz, n_of=n_of)
+        assert fb.info.tolist() == [0] * len(sizes), (sizes, kind)
+        grads, _ = _ops.lml_backward_batched(kind, X, var, ls, fb, n_of=n_of)
+        A3 = fb.A.view(len(sizes), fb.rows, fb.ld)
+        for b, n in enumerate(sizes):
+            f, t = _ops.lml_forward(kind, X[b, :n], Y[b, :n], var[b:b + 1], ls[b], nz[b:b + 1], refine=False)
+            what = (sizes, b, d, dy, kind, ard)
+            assert torch.equal(t, terms[b]), what
+            assert torch.equal(torch.tril(f.A[:n, :n]), torch.tril(A3[b, :n, :n])), what
+            gv, gl, gn, _ = _backward.lml_backward(kind, X[b, :n], var[b:b + 1], ls[b], nz[b:b + 1], f)
+            assert torch.equal(grads[b], torch.cat([gv, gl, gn])), what

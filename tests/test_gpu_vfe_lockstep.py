@@ -305,3 +305,30 @@ def test_right_solve_inverse_and_scaled_contraction_batched_equal_single(device,
     for b in range(B):
         one = _ops.gemm_nt(Bm[b], Bm[b], rows, rows, kp, alpha=float(al[b].item()), lower=True)
         assert torch.equal(torch.tril(C[b]), torch.tril(one))
+
+
+@pytest.mark.parametrize("seed", [101, 102])
+def test_fuzz_lockstep_vfe(device, seed):
+    """random shapes on and around the blocking edges (16-row K padding, the 128 leaf, the 256-row recursion switch, the 8192-column
+    accumulation slice), all stationary kinds, ARD / isotropic, dy 1..3, shared / own data: bounds and gradients bit for bit"""
+    g = np.random.default_rng(seed)
+    for _rep in range(6):
+        n = int(g.choice([65, 128, 300, 511, 1024, 1500, 2049, 8200]))
+        m = int(min(n - 1, g.choice([1, 15, 16, 64, 127, 128, 129, 256, 257, 400])))
+        d, dy = int(g.choice([1, 2, 5, 9])), int(g.choice([1, 2, 3]))
+        kind = str(g.choice(["Rbf", "Matern52", "Matern32", "Exp"]))
+        ard, shared, B = bool(g.integers(2)) and d > 1, bool(g.integers(2)), int(g.choice([2, 3, 5]))
+        ms = _models(B, n, m, d, dy, kind, ard, shared, seed=int(g.integers(1 << 30)), noise=float(g.choice([0.01, 0.1])))
+        what = (n, m, d, dy, kind, ard, shared, B)
+        assert len(gpr_mod._vfe_groups(ms)) == 1, what
+        seq = []
+        for mdl in ms:
+            mdl.zero_grad()
+            loss = mdl.loss()
+            loss.backward()
+            seq.append((loss.detach().clone(), _grads(mdl)))
+            mdl.zero_grad()
+        for mdl, (l0, g0), l1 in zip(ms, seq, batched_loss_and_grad(ms)):
+            assert torch.equal(l0, l1), what
+            for a, b in zip(g0, _grads(mdl)):
+                assert torch.equal(a, b), what
