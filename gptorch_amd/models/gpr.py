@@ -442,6 +442,39 @@ def batched_log_likelihood(models, streams=None):
     return out
 
 
+def batched_factorise(models):
+    """The factorisations the predictions of several models start from -- chol(Kyy) with L^-1 (y - m) riding along, gpr.py:104-106 --
+    in LOCK STEP (cross-validation scoring: k fitted folds, each about to predict its held-out rows; the reference re-factorises
+    inside every _predict call, one model at a time).  Models of one shape (kind, N, D, dy, ARD) share ONE lock-step forward into
+    buffers of their own; every model's factor cache is then seeded with its slice, so its next predict_f / predict_y /
+    predict_*_samples goes straight to the solve -- with the factor, and therefore the predictions, bit-identical to what the model
+    would have computed alone.  A model whose factorisation needs the jitter ladder, and everything no group takes, is left to
+    its own _predict.  Returns the number of models seeded."""
+    _place_all(models)
+    seeded = 0
+    with torch.no_grad():
+        for key, g in _lockstep_groups(models):
+            if len(key) > 5:                         # ragged groups: a padded factor is not the layout _predict's entry points take
+                continue
+            ms = [models[i] for i in g]
+            X, R, _ = _group_data(ms)
+            var = _stacked_values([m._stationary().variance for m in ms]).reshape(len(ms))
+            ls = _stacked_values([m._stationary().length_scales for m in ms]).reshape(len(ms), -1)
+            nz = _stacked_values([m.likelihood.variance for m in ms]).reshape(len(ms))
+            fb, _terms = _ops.lml_forward_batched(key[0], X, R, var, ls, nz, fb=None)      # buffers of their own: the caches keep them
+            info = fb.info.cpu()
+            for b, m in enumerate(ms):
+                if int(info[b]) != 0:
+                    continue
+                k = m._stationary()
+                ckey = (m.X._version, tuple(m.X.shape), m.Y._version, k._kind)
+                params = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+                m._predict_cache = (ckey, fb.factor(b), params, m.X, m.Y)
+                m._predict_calls = 0
+                seeded += 1
+    return seeded
+
+
 def _group_param_lists(ms):
     return ([m._stationary().variance for m in ms], [m._stationary().length_scales for m in ms],
             [m.likelihood.variance for m in ms])

@@ -181,3 +181,29 @@ def test_fuzz_ragged_groups(device, seed):
             assert torch.equal(torch.tril(f.A[:n, :n]), torch.tril(A3[b, :n, :n])), what
             gv, gl, gn, _ = _backward.lml_backward(kind, X[b, :n], var[b:b + 1], ls[b], nz[b:b + 1], f)
             assert torch.equal(grads[b], torch.cat([gv, gl, gn])), what
+
+
+def test_batched_factorise_seeds_bit_identical_predictions(device):
+    """cross-validation scoring: the factorisations of k fitted folds in lock step (gpr.py:104-106 for all of them at once), then
+    every model's own predict_f / predict_y on its held-out rows -- bit-identical to the model predicting alone, factor not recomputed"""
+    from gptorch_amd.models import batched_factorise
+    a, b = _gprs((1300,) * 4, d=3), _gprs((1300,) * 4, d=3)
+    xs = [torch.as_tensor(rng.normal(50 + i, (37, 3))).to(device) for i in range(4)]
+    assert batched_factorise(b) == 4
+    for ma, mb, x in zip(a, b, xs):
+        f_seeded = mb._predict_cache[1]
+        for diag in (True, False):
+            m0, v0 = ma.predict_y(x, diag=diag)
+            m1, v1 = mb.predict_y(x, diag=diag)
+            assert torch.equal(m0, m1) and torch.equal(v0, v1)
+        assert mb._predict_cache[1] is f_seeded                       # the seeded factor served both predictions
+        mf0, vf0 = ma.predict_f(x)
+        mf1, vf1 = mb.predict_f(x)
+        assert torch.equal(mf0, mf1) and torch.equal(vf0, vf1)
+    # a parameter edit invalidates the seeded factor like any cached one
+    with torch.no_grad():
+        b[0].kernel.variance.data += 0.1
+        a[0].kernel.variance.data += 0.1
+    m0, v0 = a[0].predict_y(xs[0])
+    m1, v1 = b[0].predict_y(xs[0])
+    assert torch.equal(m0, m1) and torch.equal(v0, v1)
