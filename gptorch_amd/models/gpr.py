@@ -419,10 +419,11 @@ def batched_log_likelihood(models, streams=None):
             holder["fb"] = fb
             pending.append((g, fb, terms))
         for g, fb, terms in pending:
-            info = fb.info.cpu()                   # one read-back per group (synchronises the stream)
+            info = fb.info.cpu().tolist()          # one read-back per group (synchronises the stream)
+            vals = terms[:, 2:3].clone()           # ONE copy out of the shared buffers; every model gets its row of it
             for b, i in enumerate(g):
-                if int(info[b]) == 0:
-                    out[i] = terms[b, 2:3].clone()
+                if info[b] == 0:
+                    out[i] = vals[b]
                     # (the per-model factor cache is NOT pointed at the shared buffer: the next batched call overwrites it)
         for key, g, progs in _expression_groups(models):
             ms = [models[i] for i in g]
@@ -435,7 +436,7 @@ def batched_log_likelihood(models, streams=None):
         for key, g in _vfe_groups(models):
             elbo = _vfe_group_bound([models[i] for i in g], key, differentiable=False)
             for b, i in enumerate(g):
-                out[i] = elbo[b].clone()                                     # (VFE.log_likelihood returns a 0-dim tensor)
+                out[i] = elbo[b]                                             # (VFE.log_likelihood returns a 0-dim tensor)
         for i, m in enumerate(models):
             if out[i] is None:
                 out[i] = m.log_likelihood()
