@@ -772,7 +772,7 @@ class BatchedGPRLogLik(torch.autograd.Function):
         if _DEFERRED:
             # under hipGraph capture (multi_start_optimize(capture=True)): nothing may read `info` back -- it is OR-ed into the
             # capture's device flag, and a chunk of replays that saw a failure is repeated eagerly (through the ladder below)
-            _DEFERRED[-1].note(fb.info.max().reshape(1))
+            _DEFERRED[-1].note(fb.info.abs().max().reshape(1))
             info = None
         else:
             info = fb.info.cpu()                     # ONE read-back for the batch (the reference: one per model and step)
