@@ -207,3 +207,15 @@ def test_batched_factorise_seeds_bit_identical_predictions(device):
     m0, v0 = a[0].predict_y(xs[0])
     m1, v1 = b[0].predict_y(xs[0])
     assert torch.equal(m0, m1) and torch.equal(v0, v1)
+
+
+def test_cross_validation_example_runs(device):
+    """examples/cross_validation.py: five folds of unequal length fitted and scored in lock step"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "cross_validation.py"), "1503", "5", "6"], cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
+    assert "multi_start_optimize:" in out.stdout and "held-out RMSE per fold" in out.stdout
