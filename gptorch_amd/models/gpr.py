@@ -859,6 +859,9 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
             return loss
         if capture:
             optimizer = _captured_lockstep_loop(ms[0], method, trainable, learning_rate, step, dev_losses, max_iter)
+            if verbose:                                # (the replays print nothing: the lines of the ordinary loop, afterwards)
+                for idx, row in enumerate(dev_losses.tolist()):
+                    print("Iter: %d\tLoss: %s" % (idx, row))
         else:
             optimizer = ms[0]._make_optimizer(method, trainable, learning_rate)
             for idx in range(max_iter):
