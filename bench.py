@@ -838,6 +838,13 @@ def run_single(args, device):
                                                "count; the quarter-size case pinned in extended precision is tests/golden/vfe_extended_262144_2048.json")
                 except Exception:
                     pass
+                # predictions (sparse_gpr.py:155-195): the reference re-evaluates the bound inside every _predict; the state is kept here
+                xs_ = torch.as_tensor(rng.normal(7, (1024, d))).to(device)
+                mod._predict_cache = None
+                t_first, _ = timed(lambda: mod.predict_y(xs_), 1, 0)
+                t_next, _ = timed(lambda: mod.predict_y(xs_), 3, 0)
+                res["predict_1024_ms_first"] = t_first * 1e3
+                res["predict_1024_ms_state_kept"] = t_next * 1e3
                 return res
             leg("c5_vfe", vfe)
         else:

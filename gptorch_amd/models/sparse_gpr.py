@@ -498,12 +498,28 @@ class VFE(_InducingPointsGP):
             raise ValueError("X and Y must have same # data.")
         return self._bound(x)[0]
 
+    def _state_for_predict(self, x):
+        """the M-sized state of the bound (chol K(Z), chol B, c) that a prediction starts from.  The reference re-evaluates the bound
+        inside every _predict (sparse_gpr.py:155-170: two factorisations and the N-sized solves again); here it is kept between
+        predictions, like GPR's factor (models/gpr.py:_factor_for_predict): the cache HOLDS the tensors it was built from and
+        compares identity + version counters for the data and VALUES for every parameter (inducing points included) -- one
+        concatenation + one comparison per prediction."""
+        key = (x._version, tuple(x.shape), self.Y._version)
+        with torch.no_grad():
+            params = torch.cat([p.detach().reshape(-1) for p in self.parameters()])
+            c = getattr(self, "_predict_cache", None)
+            if c is None or c[0] != key or c[3] is not x or c[4] is not self.Y or c[2].shape != params.shape \
+                    or not torch.equal(c[2], params):
+                _, st = self._bound(x)
+                self._predict_cache = (key, st, params, x, self.Y)
+        return self._predict_cache[1]
+
     def _predict(self, x_new, diag=True, x=None):
         """sparse_gpr.py:155-195."""
         x = x if x is not None else self.X
         kern = self.kernel
         with torch.no_grad():
-            _, st = self._bound(x)
+            st = self._state_for_predict(x)
             f_uu, fB, s2 = st.f_uu, st.fB, st.s2
             ns, m, dy = x_new.shape[0], self.Z.shape[0], self.Y.shape[1]
             T1 = _ops.padded_like_factor(f_uu, ns)                                    # tmp1^T = K(x*, Z) L^-T

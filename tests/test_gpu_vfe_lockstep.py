@@ -332,3 +332,37 @@ def test_fuzz_lockstep_vfe(device, seed):
             assert torch.equal(l0, l1), what
             for a, b in zip(g0, _grads(mdl)):
                 assert torch.equal(a, b), what
+
+
+def test_vfe_prediction_state_is_kept_between_predictions(device):
+    """the reference re-evaluates the bound inside every _predict (sparse_gpr.py:155-170); the state it needs is kept here while data
+    and parameters are unchanged: same predictions bit for bit, the bound evaluated once; any parameter or data edit rebuilds it"""
+    from gptorch_amd.models import sparse_gpr
+    mdl = _models(1, 700, 48, 2, 1, "Matern52", seed=21)[0]
+    xs = torch.as_tensor(rng.normal(5, (33, 2))).to(device)
+    calls = []
+    orig = sparse_gpr._vfe_forward
+    sparse_gpr._vfe_forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        m0, v0 = mdl.predict_y(xs)
+        m1, c1 = mdl.predict_y(xs, diag=False)
+        m2, v2 = mdl.predict_f(xs)
+        assert len(calls) == 1
+        assert torch.equal(m0, m1) and torch.allclose(torch.diagonal(c1).reshape(-1), v0.reshape(-1), rtol=1e-9, atol=1e-12)
+        with torch.no_grad():
+            mdl.Z.data[3] += 0.05                                  # an inducing point moves: the state is rebuilt
+        m3, v3 = mdl.predict_y(xs)
+        assert len(calls) == 2 and not torch.equal(m3, m0)
+        with torch.no_grad():
+            mdl.Z.data[3] -= 0.05
+        mdl._predict_cache = None
+        m4, v4 = mdl.predict_y(xs)
+        assert len(calls) == 3
+        fresh = _models(1, 700, 48, 2, 1, "Matern52", seed=21)[0]
+        m5, v5 = fresh.predict_y(xs)
+        assert torch.equal(m5, m0) and torch.equal(v5, v0)         # (what a model that never cached anything computes)
+        mdl.Y = mdl.Y.clone()                                      # other data: rebuilt
+        mdl.predict_y(xs)
+        assert len(calls) == 5
+    finally:
+        sparse_gpr._vfe_forward = orig
