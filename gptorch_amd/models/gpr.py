@@ -98,7 +98,18 @@ class GPR(GPModel):
         native factorisation / right-solves / contractions."""
         with torch.no_grad():
             n, ns = x.shape[0], x_new.shape[0]
-            f = _ops.cholesky_factor(self._compute_kyy(x), rhs=self.Y - self.mean_function(x))
+            # the factor is kept between predictions exactly as for the native kinds (_factor_for_predict): data by identity +
+            # version, every parameter by value
+            key = (x._version, tuple(x.shape), self.Y._version, "dense")
+            params = torch.cat([p.detach().reshape(-1) for p in self.parameters()])
+            c = self._predict_cache
+            if c is None or c[0] != key or c[3] is not x or c[4] is not self.Y or c[2].shape != params.shape \
+                    or not torch.equal(c[2], params):
+                f = _ops.cholesky_factor(self._compute_kyy(x), rhs=self.Y - self.mean_function(x))
+                self._predict_cache = (key, f, params, x, self.Y)
+                self._predict_calls = 0
+            self._predict_calls += 1
+            f = self._predict_cache[1]
             Bt = _ops.padded_like_factor(f, ns)
             Bt[:ns, :n] = self.kernel.K(x_new, x)
             f.solve_right_lt(Bt, ns)                                        # A^T = K(x*, x) L^-T

@@ -219,3 +219,30 @@ def test_cross_validation_example_runs(device):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
     assert "multi_start_optimize:" in out.stdout and "held-out RMSE per fold" in out.stdout
+
+
+def test_composite_kernel_predictions_keep_their_factor(device):
+    """GPR over a composite kernel (the reference's example model, examples/regression_1d.py:34-53) predicts through the dense path:
+    its factor is kept between predictions like the native kinds' (the reference re-factorises inside every _predict, gpr.py:104-106)"""
+    x, y = rng.make_regression(400, 2, 1, seed=8)
+    m = GPR(x, y, kernels.Linear(2) + kernels.Rbf(2) + kernels.Constant(2), likelihood=likelihoods.Gaussian(variance=0.05))
+    m.cuda()
+    xs = torch.as_tensor(rng.normal(9, (21, 2))).to(device)
+    calls = []
+    orig = _ops.cholesky_factor
+    _ops.cholesky_factor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        m0, v0 = m.predict_y(xs)
+        m1, v1 = m.predict_y(xs)
+        _, c1 = m.predict_f(xs, diag=False)
+        assert len(calls) == 1 and torch.equal(m0, m1) and torch.equal(v0, v1)
+        with torch.no_grad():
+            m.likelihood.variance.data += 0.01
+        m2, _ = m.predict_y(xs)
+        assert len(calls) == 2 and not torch.equal(m2, m0)
+    finally:
+        _ops.cholesky_factor = orig
+    fresh = GPR(x, y, kernels.Linear(2) + kernels.Rbf(2) + kernels.Constant(2), likelihood=likelihoods.Gaussian(variance=0.05))
+    fresh.cuda()
+    m3, v3 = fresh.predict_y(xs)
+    assert torch.equal(m3, m0) and torch.equal(v3, v0)
