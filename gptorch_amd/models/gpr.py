@@ -497,7 +497,22 @@ def _shared_transform(params):
     return t0 if all(p._transform == t0 for p in params) else None
 
 
-def batched_loss_and_grad(models):
+def _has_priors(ms):
+    return any(getattr(p, "prior", None) is not None for m in ms for p in m.parameters())
+
+
+def _plan_groups(models):
+    """the grouping of batched_loss_and_grad for a list of models: [(lock-step groups), (expression groups), (sparse groups)] with each
+    group's "has priors" flag.  Shapes, kernels and priors do not change while a search runs: multi_start_optimize plans ONCE and
+    hands the plan to every iteration (the grouping walks every model's parameters and, for composite kernels, rebuilds their
+    expression programs: host time that a small-N iteration would spend several times over)."""
+    _place_all(models)
+    return ([(key, g, _has_priors([models[i] for i in g])) for key, g in _lockstep_groups(models)],
+            [(key, g, progs, _has_priors([models[i] for i in g])) for key, g, progs in _expression_groups(models)],
+            [(key, g, _has_priors([models[i] for i in g])) for key, g in _vfe_groups(models)])
+
+
+def batched_loss_and_grad(models, _plan=None):
     """`loss = m.loss(); loss.backward()` for several INDEPENDENT GPR models -- the body of the reference's optimiser step
     (gptorch/models/base.py:260-269: `closure()`), which the reference can only run one model at a time.  Gradients are
     ACCUMULATED into every trainable parameter's `.grad` exactly as backward() does; returns the list of detached (1,) loss
@@ -509,9 +524,9 @@ def batched_loss_and_grad(models):
     BIT-IDENTICAL to its own `loss(); backward()`; a model whose factorisation fails is replayed alone through the jitter
     ladder; parameters with priors add their model's own log_prior() (model.py:158-197); sizes that refine the quadratic
     form refine it per model.  Composite / dense-K kernels and singletons take the sequential path."""
-    _place_all(models)
+    plan = _plan if _plan is not None else _plan_groups(models)
     out = [None] * len(models)
-    for key, g in _lockstep_groups(models):
+    for key, g, priors in plan[0]:
         ms = [models[i] for i in g]
         B = len(ms)
         X, R, n_of = _group_data(ms, differentiable=True, key=key)
@@ -527,7 +542,7 @@ def batched_loss_and_grad(models):
         if n_of is not None:
             holder["sizes"] = key[5]
         lml = _ops.BatchedGPRLogLik.apply(X, R, var, ls, nz, key[0], holder, n_of)
-        if any(getattr(p, "prior", None) is not None for m in ms for p in m.parameters()):
+        if priors:
             # parameters with priors (model.py:158-197: loss = -(LML + log prior)): each model's own log_prior(), added to its
             # entry of the lock-step LML exactly as Model._loss adds it
             loss = torch.cat([-(lml[b:b + 1] + m.log_prior()) for b, m in enumerate(ms)])
@@ -538,7 +553,7 @@ def batched_loss_and_grad(models):
         ld = loss.detach()
         for b, i in enumerate(g):
             out[i] = ld[b:b + 1]
-    for key, g, progs in _expression_groups(models):
+    for key, g, progs, priors in plan[1]:
         # composite kernels of one structure (the reference's example model Linear + Rbf + Constant in a multi-start search):
         # the expression's assembly and sweeps per model, everything kernel-independent once over the group
         ms = [models[i] for i in g]
@@ -549,7 +564,7 @@ def batched_loss_and_grad(models):
         nz = (t0(torch.stack(list(plist))) if t0 is not None else torch.stack([p.transform() for p in plist])).reshape(B)
         flat = [p for prog in progs for p in prog.params()]
         lml = _expr.BatchedExprLogLik.apply(X, R, nz, progs, _batch_holder((key, B)), *flat)
-        if any(getattr(p, "prior", None) is not None for m in ms for p in m.parameters()):
+        if priors:
             loss = torch.cat([-(lml[b:b + 1] + m.log_prior()) for b, m in enumerate(ms)])
         else:
             loss = -(lml + 0.0)
@@ -558,12 +573,12 @@ def batched_loss_and_grad(models):
         ld = loss.detach()
         for b, i in enumerate(g):
             out[i] = ld[b:b + 1]
-    for key, g in _vfe_groups(models):
+    for key, g, priors in plan[2]:
         # sparse models of one shape (sparse_gpr.py:108-153 in a multi-start search over inducing points / hyper-parameters)
         ms = [models[i] for i in g]
         elbo = _vfe_group_bound(ms, key, differentiable=True)
         # Model.loss (model.py:158-197): -(bound + log prior), model by model as the sequential code forms it
-        if any(getattr(p, "prior", None) is not None for m in ms for p in m.parameters()):
+        if priors:
             loss = torch.stack([-(elbo[b] + m.log_prior()) for b, m in enumerate(ms)])
         else:
             loss = -(elbo + 0.0)
@@ -911,10 +926,11 @@ def multi_start_optimize(models, method="Adam", max_iter=2000, verbose=False, le
                 m.optimizer = m._make_optimizer(method, [p for p in m.parameters() if p.requires_grad], learning_rate)
                 opts.append(m.optimizer)
         print("multi_start_optimize: %d models, one lock-step evaluation per iteration, via %s" % (len(rest), method))
+        plan = _plan_groups(rest_models)              # (shapes, kernels and priors are fixed while the search runs)
         for idx in range(max_iter):
             for o in opts:
                 o.zero_grad()
-            out = batched_loss_and_grad(rest_models)
+            out = batched_loss_and_grad(rest_models, _plan=plan)
             for o in opts:
                 o.step()
             vals = torch.cat([l.reshape(-1) for l in out]).cpu().numpy()
