@@ -315,9 +315,19 @@ class BatchedExprLogLik(torch.autograd.Function):
         Xb = lambda b: X if X.dim() == 2 else X[b]
         Rb = lambda b: R if R.dim() == 2 else R[b]
         factors = [fb.factor(b) for b in range(batch)]
-        for b in range(batch):
-            kernel_matrix(progs[b], thetas[b], Xb(b), None, noise=nz[b:b + 1], out=factors[b].A, ldk=fb.ld, lower=True)
-            factors[b].pack_rhs(Rb(b))
+        # ONE assembly launch over the models (their programs have one structure: the term table of the first, every model its own
+        # row of parameter values), the right-hand sides as one copy (Factor.pack_rhs: (y - m)^T below the matrix, its corner cleared)
+        theta_all = torch.stack(thetas)
+        thetas = [theta_all[b] for b in range(batch)]
+        Xc, d = _c(X.detach()), X.shape[-1]
+        st = lib.gpn_kernel_matrix_expr_batched(_stream(X.device), progs[0].terms, len(progs[0].instances), progs[0].gstart, progs[0].ngroups, batch,
+                                                _ptr(theta_all), theta_all.shape[1], _ptr(Xc), 0 if X.dim() == 2 else n * d, n, d, _ptr(nz),
+                                                _ptr(fb.A), fb.ld, fb.sA)
+        _native.check(st, "gpn_kernel_matrix_expr_batched")
+        if e:
+            A3 = fb.A.view(batch, fb.rows, fb.ld)
+            A3[:, n:n + e, n:] = 0.0
+            A3[:, n:n + e, :n] = R.detach().transpose(-1, -2)
         fb.info.zero_()
         st = lib.gpn_potrf_lower_batched(_stream(X.device), _ptr(fb.A), n, e, fb.ld, fb.sA, _ptr(fb.winv), fb.sW, _ptr(fb.info), batch)
         _native.check(st, "gpn_potrf_lower_batched")
@@ -387,9 +397,34 @@ class BatchedExprLogLik(torch.autograd.Function):
                 ats[b] = _ops.gemm_nt(f.A[n:], U, dy, n, _ops.round_up(n, 16), tri=_ops.TRI_B_UPPER)
         go = grad_out.reshape(batch)
         g_params, g_noise, g_R = [], [], []
+        swept = None
+        if fb is not None and not ctx.replayed and batch > 1:
+            # the gradient sweeps in lock step: per leaf instance ONE sweep + one reduction launch over all models, reading every
+            # model's Kyy^-1 and a^T where gpn_lml_kinv_batched left them
+            prog0 = progs[0]
+            theta_all = torch.stack(list(thetas))
+            Xc, d = _c(X.detach()), X.shape[-1]
+            wk = fb._backward_work
+            work = torch.empty(max(1, batch * int(lib.gpn_kernel_expr_grad_work_bytes(n, n, d, 1)) // 8), dtype=torch.float64, device=X.device)
+            per_instance = []
+            for i, li in enumerate(prog0.instances):
+                _, nvar, _, nls = prog0.offsets[li]
+                want_trace = 1 if i == 0 else 0
+                o = torch.empty(batch, nvar + nls + want_trace, dtype=torch.float64, device=X.device)
+                st = lib.gpn_kernel_expr_grad_batched(_stream(X.device), prog0.terms, len(prog0.instances), prog0.gstart, prog0.ngroups, batch,
+                                                      _ptr(theta_all), theta_all.shape[1], i, _ptr(Xc), 0 if X.dim() == 2 else n * d, n, d,
+                                                      wk.data_ptr() + 8 * koff, ld, stride, wk.data_ptr() + 8 * aoff, ld, stride, dy, want_trace,
+                                                      _ptr(work), _ptr(o))
+                _native.check(st, "gpn_kernel_expr_grad_batched")
+                per_instance.append((o, nvar + nls))
+            swept = per_instance
         for b in range(batch):
             pb = params[b * npar:(b + 1) * npar]
-            outs, trace = _sweeps(progs[b], thetas[b], Xb(b), None, kinvs[b], kinvs[b].stride(0), at=ats[b], ldat=ats[b].stride(0), dy=dy)
+            if swept is not None:
+                outs = [o[b] for o, _ in swept]
+                trace = swept[0][0][b, swept[0][1]:swept[0][1] + 1]
+            else:
+                outs, trace = _sweeps(progs[b], thetas[b], Xb(b), None, kinvs[b], kinvs[b].stride(0), at=ats[b], ldat=ats[b].stride(0), dy=dy)
             g_params += [go[b] * g for g in progs[b].scatter(outs, pb)]
             g_noise.append(go[b] * trace)
             if ctx.needs_input_grad[1]:

@@ -126,6 +126,11 @@ SIGNATURES.update({
     "gpn_kernel_matrix_expr": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_void_p,
                                        c_int64, c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_int64]),
     "gpn_kernel_expr_grad_work_bytes": (c_int64, [c_int64, c_int64, c_int, c_int]),
+    "gpn_kernel_matrix_expr_batched": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_int, c_void_p,
+                                               c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int64]),
+    "gpn_kernel_expr_grad_batched": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_int, c_void_p,
+                                             c_int64, c_int, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p,
+                                             c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "gpn_kernel_expr_grad": (c_int, [c_void_p, ctypes.POINTER(ExprTerm), c_int, ctypes.POINTER(c_int), c_int, c_void_p, c_int,
                                      c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                                      c_void_p, c_void_p]),

@@ -175,12 +175,20 @@ struct ExprArgs {
   double* K;
   int64_t ldk;
   int n, m, d, symmetric, lower, tiles_n;
+  // lock-step batch (gridDim.y models of ONE program structure, gpn_kernel_matrix_expr_batched): model z reads X + z sX,
+  // theta + z sTheta, noise[z] and writes K + z sK
+  int64_t sX = 0, sTheta = 0, sK = 0;
 };
 
 __global__ __launch_bounds__(256) void kexpr_kernel(ExprArgs p, ExprProgram prog) {
   __shared__ __attribute__((aligned(16))) double xs[EDC][ET];
   __shared__ __attribute__((aligned(16))) double ys[EDC][ET];
   __shared__ double scale[EDC];
+  if (gridDim.y > 1) {
+    const int64_t z = blockIdx.y;
+    p.X += z * p.sX; p.X2 += z * p.sX; p.theta += z * p.sTheta; p.K += z * p.sK;
+    if (p.noise) p.noise += z;
+  }
   TileCtx c;
   c.X = p.X; c.X2 = p.X2; c.theta = p.theta; c.n = p.n; c.m = p.m; c.d = p.d; c.symmetric = p.symmetric;
   c.tid = threadIdx.x; c.tx = c.tid & 15; c.ty = c.tid >> 4;
@@ -297,6 +305,9 @@ struct ExprGradArgs {
   int target;               // index into prog.terms
   int group;                // its group: the other terms of the group multiply the weight
   int want_trace;           // LML mode: out[nout-1] = trace(G)  (d/d noise)
+  // lock-step batch (gridDim.y models of one program structure, gpn_kernel_expr_grad_batched): model z reads X + z sX,
+  // theta + z sTheta, G + z sG, at + z sAt and writes partial + z sPartial
+  int64_t sX = 0, sTheta = 0, sG = 0, sAt = 0, sPartial = 0;
 };
 
 // nout = (target's parameter count) + want_trace.  Parameter order of a target: stationary: variance, then the
@@ -306,6 +317,11 @@ __global__ __launch_bounds__(256) void kexpr_grad_kernel(ExprGradArgs p, ExprPro
   __shared__ __attribute__((aligned(16))) double ys[EDC][ET];
   __shared__ double scale[EDC];
   __shared__ double red[256];
+  if (gridDim.y > 1) {
+    const int64_t z = blockIdx.y;
+    p.X += z * p.sX; p.X2 += z * p.sX; p.theta += z * p.sTheta; p.G += z * p.sG; p.partial += z * p.sPartial;
+    if (p.at) p.at += z * p.sAt;
+  }
   TileCtx c;
   c.X = p.X; c.X2 = p.X2; c.theta = p.theta; c.n = p.n; c.m = p.m; c.d = p.d; c.symmetric = p.symmetric;
   c.tid = threadIdx.x; c.tx = c.tid & 15; c.ty = c.tid >> 4;
@@ -513,9 +529,12 @@ __global__ __launch_bounds__(256) void kexpr_grad_kernel(ExprGradArgs p, ExprPro
 }
 
 // out[k] = sum over blocks of partial[b * nout + k], in a fixed order
-__global__ __launch_bounds__(256) void kexpr_reduce_kernel(const double* partial, int64_t nblocks, int nout, double* out) {
+__global__ __launch_bounds__(256) void kexpr_reduce_kernel(const double* partial, int64_t nblocks, int nout, double* out,
+                                                           int64_t sPartial = 0) {
   __shared__ double red[256];
   const int k = blockIdx.x, tid = threadIdx.x;
+  partial += (int64_t)blockIdx.y * sPartial;       // gridDim.y models of a lock-step batch, outputs nout apart
+  out += (int64_t)blockIdx.y * nout;
   double s = 0.0;
   for (int64_t b = tid; b < nblocks; b += 256) s += partial[b * nout + k];
   red[tid] = s;
@@ -664,6 +683,89 @@ extern "C" int gpn_kernel_expr_grad(void* stream, const gpn_expr_term* terms, in
   if (rec >= 0) profile_end(s, rec);
   GPN_LAUNCH_CHECK();
   hipLaunchKernelGGL(kexpr_reduce_kernel, dim3((unsigned)a.nout), dim3(256), 0, s, work, nblocks, a.nout, out);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// gpn_kernel_matrix_expr (symmetric, lower tiles, noise on the diagonal: Kyy straight into the factor buffers) for `batch` models
+// whose expressions have ONE structure -- the same term table, every model its own parameter values theta + b sTheta -- in one
+// launch (gridDim.y): the reference's example model Linear + Rbf + Constant (examples/regression_1d.py:34-53) in a multi-start
+// search.  Model b reads X + b sX (0: shared points), noise[b] and writes K + b sK; per model bit-identical to
+// gpn_kernel_matrix_expr.
+extern "C" int gpn_kernel_matrix_expr_batched(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                                              int batch, const double* theta, int64_t sTheta, const double* X, int64_t sX, int64_t n, int d,
+                                              const double* noise, double* K, int64_t ldk, int64_t sK) {
+  if (d <= 0) return -12;
+  int rc = check_program(terms, nterms, group_start, ngroups, d, false);
+  if (rc != GPN_OK) return rc;
+  if (batch < 1 || batch > 65535) return -6;
+  if (!theta) return -7;
+  if (!X) return -9;
+  if (n < 0) return -11;
+  if (!K) return -14;
+  if (ldk < n) return -15;
+  if (batch > 1 && sK < n * ldk) return -16;
+  if (n == 0) return GPN_OK;
+  ExprArgs a;
+  a.X = X; a.X2 = X; a.theta = theta; a.noise = noise; a.K = K; a.ldk = ldk;
+  a.n = (int)n; a.m = (int)n; a.d = d; a.symmetric = 1; a.lower = 1;
+  const unsigned tm = (unsigned)((n + ET - 1) / ET);
+  a.tiles_n = (int)tm;
+  a.sX = sX; a.sTheta = sTheta; a.sK = sK;
+  ExprProgram P;
+  fill_program(P, terms, nterms, group_start, ngroups);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rec = -1;
+  if (profile_on()) rec = profile_begin(s, batch * 8.0 * (0.5 * n * (n + 1.0) + (double)n * d), PROF_KMAT);
+  hipLaunchKernelGGL(kexpr_kernel, dim3(tm * (tm + 1) / 2, (unsigned)batch), dim3(256), 0, s, a, P);
+  if (rec >= 0) profile_end(s, rec);
+  GPN_LAUNCH_CHECK();
+  return GPN_OK;
+}
+
+// gpn_kernel_expr_grad in LML mode (weights from Kyy^-1 and a^T) for `batch` models of one structure: ONE sweep launch + one
+// reduction launch per leaf instance instead of one pair per model.  Model b reads theta + b sTheta, X + b sX, G + b sG,
+// at + b sAt; out [batch, nout]; work: batch * gpn_kernel_expr_grad_work_bytes(n, n, d, 1).  Per model bit-identical to
+// gpn_kernel_expr_grad.
+extern "C" int gpn_kernel_expr_grad_batched(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                                            int batch, const double* theta, int64_t sTheta, int target, const double* X, int64_t sX,
+                                            int64_t n, int d, const double* G, int64_t ldg, int64_t sG, const double* at, int64_t ldat,
+                                            int64_t sAt, int dy, int want_trace, double* work, double* out) {
+  if (d <= 0) return -13;
+  int rc = check_program(terms, nterms, group_start, ngroups, d, true);
+  if (rc != GPN_OK) return rc;
+  if (batch < 1 || batch > 65535) return -6;
+  if (!theta) return -7;
+  if (target < 0 || target >= nterms) return -9;
+  if (!X) return -10;
+  if (n <= 0) return -12;
+  if (!G) return -14;
+  if (ldg < n) return -15;
+  if (!at || ldat < n || dy <= 0) return -17;
+  if (!work) return -22;
+  if (!out) return -23;
+  ExprGradArgs a;
+  a.X = X; a.X2 = X; a.theta = theta; a.G = G; a.ldg = ldg; a.at = at; a.ldat = ldat; a.partial = work;
+  a.n = (int)n; a.m = (int)n; a.d = d; a.dy = dy; a.symmetric = 1; a.lml = 1; a.target = target; a.want_trace = want_trace ? 1 : 0;
+  a.group = 0;
+  for (int g = 0; g < ngroups; ++g) if (target >= group_start[g] && target < group_start[g + 1]) a.group = g;
+  const gpn_expr_term& T = terms[target];
+  const int nparam = T.type == GPN_TERM_STATIONARY ? 1 + T.nls : (T.type == GPN_TERM_LINEAR ? T.nvar : 1);
+  a.nout = nparam + a.want_trace;
+  const int64_t tm = (n + ET - 1) / ET;
+  a.tiles_n = (int)tm;
+  const int64_t nblocks = tm * (tm + 1) / 2;
+  a.sX = sX; a.sTheta = sTheta; a.sG = sG; a.sAt = sAt;
+  a.sPartial = gpn_kernel_expr_grad_work_bytes(n, n, d, 1) / (int64_t)sizeof(double);
+  ExprProgram P;
+  fill_program(P, terms, nterms, group_start, ngroups);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rec = -1;
+  if (profile_on()) rec = profile_begin(s, batch * 8.0 * 0.5 * n * (n + 1.0), PROF_GRAD);
+  hipLaunchKernelGGL(kexpr_grad_kernel, dim3((unsigned)nblocks, (unsigned)batch), dim3(256), 0, s, a, P);
+  if (rec >= 0) profile_end(s, rec);
+  GPN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kexpr_reduce_kernel, dim3((unsigned)a.nout, (unsigned)batch), dim3(256), 0, s, work, nblocks, a.nout, out, a.sPartial);
   GPN_LAUNCH_CHECK();
   return GPN_OK;
 }

@@ -327,6 +327,18 @@ int gpn_kernel_matrix_expr(void* stream, const gpn_expr_term* terms, int nterms,
  * appends trace(W) (= dLML/d noise) as one more output.  One launch reads W once; a kernel of T leaf instances costs T
  * launches.  Per-dimension parameters (ARD length-scales, Linear with one variance per input) need d <= 16
  * (GPN_E_UNSUPPORTED beyond).  work: gpn_kernel_expr_grad_work_bytes(n, m, d, lml) bytes. */
+/* Lock-step forms for `batch` models whose expressions have ONE structure (the same term table, every model its own parameter
+ * values theta + b sTheta) -- the reference's example model Linear + Rbf + Constant (examples/regression_1d.py:34-53) in a
+ * multi-start search: Kyy_b (symmetric, lower tiles, noise[b] on the diagonal) into K + b sK in one launch, and the gradient sweep
+ * of one leaf instance in LML mode (G + b sG = Kyy_b^-1, at + b sAt = a_b^T) over all models as one sweep + one reduction launch
+ * (out [batch, nout]; work: batch * gpn_kernel_expr_grad_work_bytes(n, n, d, 1)).  Per model bit-identical to the single forms. */
+int gpn_kernel_matrix_expr_batched(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                                   int batch, const double* theta, int64_t sTheta, const double* X, int64_t sX, int64_t n, int d,
+                                   const double* noise, double* K, int64_t ldk, int64_t sK);
+int gpn_kernel_expr_grad_batched(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
+                                 int batch, const double* theta, int64_t sTheta, int target, const double* X, int64_t sX,
+                                 int64_t n, int d, const double* G, int64_t ldg, int64_t sG, const double* at, int64_t ldat,
+                                 int64_t sAt, int dy, int want_trace, double* work, double* out);
 int64_t gpn_kernel_expr_grad_work_bytes(int64_t n, int64_t m, int d, int lml);
 int gpn_kernel_expr_grad(void* stream, const gpn_expr_term* terms, int nterms, const int* group_start, int ngroups,
                          const double* theta, int target, const double* X, int64_t n, const double* X2, int64_t m, int d,
