@@ -110,6 +110,8 @@ def test_argument_validation_without_launch():
     assert lib.gpn_lml_forward_ragged(null, 0, 2, p_, 0, 1000, null, 2, null, 0, 1, null, null, 1, null, null, 1152, 0, null, 0, null, null) == -7  # no sizes
     assert lib.gpn_lml_backward_ragged(null, 0, 2, p_, 0, 1000, null, 2, null, null, 1, null, 1152, 0, null, 0, 1, null, null) == -7
     assert lib.gpn_potrf_persistent_supported(8192, 1) == 1 and lib.gpn_potrf_persistent_supported(1000, 1) == 0
+    assert lib.gpn_kernel_matrix_expr_batched(null, None, 0, None, 0, 2, null, 0, null, 0, 4, 2, null, null, 4, 16) == -2     # no program
+    assert lib.gpn_kernel_expr_grad_batched(null, None, 0, None, 0, 2, null, 0, 0, null, 0, 4, 2, null, 4, 0, null, 4, 0, 1, 0, null, null) == -2
     assert lib.gpn_potrf_persistent_supported(32768, 1) == 0 and lib.gpn_potrf_persistent_supported(8200, 1) == 0
     # zero-size problems are no-ops that succeed
     one = ctypes.c_double(0.0)
