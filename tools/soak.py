@@ -122,5 +122,44 @@ for i in range(rounds):
         nb += 1
 print("N=4096 x 4 restarts, lock-step loss + backward: %d rounds, %d differ, %.1f s" % (rounds, nb, time.perf_counter() - t0), flush=True)
 bad += nb
+# round 6: sparse models in lock step (the batched kernel matrix / right-solve / inversion / sweeps, the fixed-order scalar sums) and
+# a ragged group (identity-padded assembly, masked sweeps)
+def soak_group(models_, rounds_, label):
+    ref_, nb_, t0_ = None, 0, time.perf_counter()
+    for _ in range(rounds_):
+        for mm in models_:
+            mm.zero_grad()
+        ls_ = batched_loss_and_grad(models_)
+        cur_ = torch.cat([l.reshape(-1) for l in ls_] + [p.grad.reshape(-1) for mm in models_ for p in mm.parameters() if p.grad is not None])
+        cur_ = cur_.cpu().numpy().tobytes()
+        if ref_ is None:
+            ref_ = cur_
+        elif cur_ != ref_:
+            nb_ += 1
+    print("%s: %d rounds, %d differ, %.1f s" % (label, rounds_, nb_, time.perf_counter() - t0_), flush=True)
+    return nb_
+
+
+from gptorch_amd import mean_functions  # noqa: E402
+from gptorch_amd.models import VFE  # noqa: E402
+import numpy as np  # noqa: E402
+xv, yv = rng.make_regression(2048, 4, 1, seed=12)
+gz = np.random.default_rng(1)
+sparse = []
+for r in range(8):
+    v = VFE(xv, yv, kernels.Rbf(4, variance=1.0 + 0.05 * r, length_scales=1.0 + 0.05 * r), inducing_points=xv[gz.choice(2048, 256, replace=False)],
+            likelihood=likelihoods.Gaussian(variance=0.05), mean_function=mean_functions.Zero(1))
+    v.cuda()
+    sparse.append(v)
+for v in sparse[1:]:
+    v.X, v.Y = sparse[0].X, sparse[0].Y
+bad += soak_group(sparse, max(1, n_big // 5), "N=2048 M=256 x 8 sparse restarts, lock-step loss + backward")
+folds = []
+for r, nn in enumerate((3000, 2999, 2950, 2800, 2501)):
+    xf, yf = rng.make_regression(nn, 5, 1, seed=30 + r)
+    mf = GPR(xf, yf, kernels.Matern52(5, variance=1.0, length_scales=2.0 + 0.1 * r), likelihood=likelihoods.Gaussian(variance=0.03))
+    mf.cuda()
+    folds.append(mf)
+bad += soak_group(folds, max(1, n_big // 5), "N=2501..3000 x 5 as one ragged group, lock-step loss + backward")
 print("SOAK", "OK" if bad == 0 else "MISMATCHES %d" % bad)
 sys.exit(0 if bad == 0 else 1)
